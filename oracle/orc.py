@@ -1,0 +1,196 @@
+"""oracle/orc.py — ctypes binding of the C++ CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+Builds oracle/build/liborc.so on demand (g++, seconds).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "build", "liborc.so")
+BIN = os.path.join(HERE, "build", "vsr_oracle")
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in ("vsr_oracle.cpp", "vsr_oracle_bfs.cpp", "vsr_oracle.hpp", "Makefile")]
+    stale = force or not (os.path.exists(LIB) and os.path.exists(BIN)) or any(
+        os.path.getmtime(s) > min(os.path.getmtime(LIB), os.path.getmtime(BIN)) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", HERE, "-s"], check=True)
+    return LIB
+
+
+ACTIONS = ["Initial predicate", "TimerSendSVC", "ReceiveHigherSVC", "ReceiveMatchingSVC", "SendDVC",
+           "ReceiveHigherDVC", "ReceiveMatchingDVC", "SendSV", "ReceiveSV", "ReceiveClientRequest",
+           "ReceivePrepareMsg", "ReceivePrepareOkMsg", "ExecuteOp", "SendGetState", "ReceiveGetState",
+           "ReceiveNewState"]   # action ids in Next order (VSR.tla:896-913)
+ACTION_NAMES = ACTIONS
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_bfs_create.restype = C.c_void_p
+        L.orc_bfs_create.argtypes = [C.c_void_p]
+        L.orc_bfs_destroy.argtypes = [C.c_void_p]
+        L.orc_bfs_step.restype = C.c_longlong
+        L.orc_bfs_step.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_bfs_level_seconds.restype = C.c_double
+        L.orc_bfs_level_seconds.argtypes = [C.c_void_p]
+        L.orc_bfs_level_fps.restype = C.c_longlong
+        L.orc_bfs_level_fps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+        L.orc_bfs_frontier.restype = C.c_longlong
+        L.orc_bfs_frontier.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
+        L.orc_bfs_trace_fps.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+class OracleError(Exception):
+    def __init__(self, code, msg):
+        Exception.__init__(self, "oracle error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params:
+    """Model constants in the order the C API expects."""
+
+    def __init__(self, R=3, C=1, n=2, L=2, restart_limit=0, assume_commit_number=False, symmetry=True,
+                 invariant_mask=1):
+        self.R, self.C, self.n, self.L = R, C, n, L
+        self.arr = np.array([R, C, n, L, restart_limit, int(assume_commit_number), int(symmetry), invariant_mask],
+                            dtype=np.int32)
+
+    @property
+    def ptr(self):
+        return self.arr.ctypes.data
+
+    def wpr(self):
+        return 1 + (self.R + 2) // 2
+
+    def fixed_words(self):
+        return 1 + self.R * self.wpr()
+
+
+def _err(code):
+    raise OracleError(code, lib().orc_last_error().decode())
+
+
+def init_record(P):
+    out = np.zeros(512, dtype=np.uint64)
+    n = lib().orc_init_record(C.c_void_p(P.ptr), C.c_void_p(out.ctypes.data), 512)
+    if n < 0:
+        _err(n)
+    return out[:n].copy()
+
+
+def fingerprint(P, rec):
+    rec = np.ascontiguousarray(rec, dtype=np.uint64)
+    fp = C.c_uint64()
+    ak = C.c_uint32()
+    r = lib().orc_fingerprint(C.c_void_p(P.ptr), C.c_void_p(rec.ctypes.data), C.byref(fp), C.byref(ak))
+    if r < 0:
+        _err(r)
+    return fp.value, ak.value
+
+
+def invariants(P, rec):
+    rec = np.ascontiguousarray(rec, dtype=np.uint64)
+    r = lib().orc_invariants(C.c_void_p(P.ptr), C.c_void_p(rec.ctypes.data))
+    if r < 0:
+        _err(r)
+    return r
+
+
+def normalise(P, rec):
+    rec = np.ascontiguousarray(rec, dtype=np.uint64)
+    out = np.zeros(512, dtype=np.uint64)
+    n = lib().orc_normalise(C.c_void_p(P.ptr), C.c_void_p(rec.ctypes.data), C.c_void_p(out.ctypes.data), 512)
+    if n < 0:
+        _err(n)
+    return out[:n].copy()
+
+
+def successors(P, rec):
+    """-> list of dict(action, fp, auxkey, inv, words=np.uint64 array) in Next order."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint64)
+    cap_w, cap_s = 1 << 16, 512
+    words = np.zeros(cap_w, dtype=np.uint64)
+    meta = np.zeros(5 * cap_s, dtype=np.uint64)
+    used = C.c_int()
+    n = lib().orc_successors(C.c_void_p(P.ptr), C.c_void_p(rec.ctypes.data), C.c_void_p(words.ctypes.data), cap_w,
+                             C.c_void_p(meta.ctypes.data), cap_s, C.byref(used))
+    if n < 0:
+        _err(n)
+    out, off = [], 0
+    for k in range(n):
+        a, fp, ak, nw, inv = (int(x) for x in meta[5 * k: 5 * k + 5])
+        out.append(dict(action=a, fp=fp, auxkey=ak, inv=inv, words=words[off: off + nw].copy()))
+        off += nw
+    return out
+
+
+class Bfs:
+    """Level-synchronous BFS handle (Init = level 1)."""
+    INFO = ["depth", "n_new", "generated", "ties", "deadlocks", "distinct", "total_generated", "viol_mask",
+            "viol_gid", "error_code", "max_bag", "frontier_words"]
+
+    def __init__(self, P):
+        self.P = P
+        self.h = lib().orc_bfs_create(C.c_void_p(P.ptr))
+        if not self.h:
+            _err(-2)
+        self.info = dict(depth=1, n_new=1, generated=0, ties=0, deadlocks=0, distinct=1, total_generated=0,
+                         viol_mask=0, viol_gid=2 ** 64 - 1, error_code=0, max_bag=0, frontier_words=0)
+
+    def step(self):
+        info = np.zeros(12, dtype=np.uint64)
+        nn = lib().orc_bfs_step(self.h, C.c_void_p(info.ctypes.data))
+        self.info = {k: int(v) for k, v in zip(self.INFO, info)}
+        if self.info["error_code"]:
+            code = self.info["error_code"] - (1 << 64)
+            raise OracleError(code, lib().orc_last_error().decode())
+        return nn
+
+    def level_seconds(self):
+        return lib().orc_bfs_level_seconds(self.h)
+
+    def level_fps(self, level, cap=None):
+        cap = cap or max(1, self.info["distinct"])
+        out = np.zeros(cap, dtype=np.uint64)
+        n = lib().orc_bfs_level_fps(self.h, level, C.c_void_p(out.ctypes.data), cap)
+        if n < 0:
+            raise OracleError(int(n), "level_fps")
+        return out[:n].copy()
+
+    def frontier(self):
+        """-> (words, offsets) of the newest level."""
+        nw = max(1, self.info["frontier_words"]) if self.info["depth"] > 1 else 512
+        ns = max(1, self.info["n_new"]) + 1
+        words = np.zeros(nw, dtype=np.uint64)
+        off = np.zeros(ns, dtype=np.uint64)
+        n = lib().orc_bfs_frontier(self.h, C.c_void_p(words.ctypes.data), nw, C.c_void_p(off.ctypes.data), ns)
+        if n < 0:
+            raise OracleError(int(n), "frontier buffers too small")
+        return words[: int(off[n])].copy(), off[: n + 1].copy()
+
+    def trace_fps(self, gid):
+        out = np.zeros(4096, dtype=np.uint64)
+        n = lib().orc_bfs_trace_fps(self.h, C.c_uint64(gid), C.c_void_p(out.ctypes.data), 4096)
+        return out[:n].copy()
+
+    def close(self):
+        if self.h:
+            lib().orc_bfs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

@@ -138,6 +138,12 @@ struct Bfs {
       error = e.what();
       error_code = -2;
     }
+    if (error_code) {   // a TLC evaluation error aborts the run; the partial level is not committed
+      generated = gen;
+      n_new = 0;
+      level_seconds = now_s() - t0;
+      return 0;
+    }
     // invariants are evaluated on the survivors of the level (B7: on each new state)
     size_t nn = nx_off.size() - 1;
     for (size_t k = 0; k < nn && error_code == 0; k++) {
