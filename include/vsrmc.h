@@ -1,0 +1,144 @@
+/* vsrmc.h — C ABI of libvsrmc.so, the MI355X-native explicit-state checker for VSR.tla.
+ *
+ * Drop-in boundary for the BFS hot path of TLC when it checks
+ *   /root/reference/vsr-revisited/paper/VSR.tla  under  /root/reference/vsr-revisited/paper/VSR.cfg.
+ * The reference repository holds no code of its own: the interfaces replaced are those of the TLC
+ * classes the north star names — tlc2.tool.fp.FPSet, tlc2.tool.queue.StateQueue, tlc2.tool.Worker /
+ * tlc2.tool.ModelChecker, tlc2.tool.impl.Tool, tlc2.tool.TLCTrace (recalled from TLC's public API) —
+ * parameterised by VSR.cfg:3-37 (CONSTANTS / INIT / NEXT / VIEW / SYMMETRY / INVARIANT).
+ *
+ * Conventions: every entry point returns 0 on success and a negative VSRMC_E_* code on failure, with a text in
+ * vsrmc_last_error() (thread-local).  Plain pointers and sizes only; the caller owns every buffer it passes, the
+ * library copies in/out; handles are library-owned until *_destroy.  One host thread per handle.
+ * "Wire layout" of a state record = 64-bit words [header][R replica blocks][bag words], documented in DESIGN.md
+ * ("Packed record"); `off` arrays hold n+1 word offsets.
+ */
+#ifndef VSRMC_H
+#define VSRMC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSRMC_E_ARG (-1)         /* bad argument / buffer too small */
+#define VSRMC_E_CFG (-2)         /* .cfg / .tla not accepted by the lowering (names the line) */
+#define VSRMC_E_HIP (-3)         /* HIP runtime failure or no GPU */
+#define VSRMC_E_EVAL (-4)        /* TLC-style evaluation error inside the spec (e.g. VSR.tla:421) */
+#define VSRMC_E_REP (-5)         /* a state left the range of the packed record / a capacity was exceeded */
+#define VSRMC_E_STATE (-6)       /* call not valid in the handle's current state */
+
+typedef struct vsrmc_model vsrmc_model;
+typedef struct vsrmc_fpset vsrmc_fpset;
+typedef struct vsrmc_checker vsrmc_checker;
+
+const char* vsrmc_last_error(void);
+int32_t vsrmc_version(void);
+/* number of visible HIP devices (0 when there is no GPU; never an error) */
+int32_t vsrmc_device_count(void);
+
+/* ---- model = (VSR.tla, VSR.cfg) lowered to a record layout + action table ------------------------------------
+ * vsrmc_model_load ≙ tlc2.TLC reading `-config VSR.cfg VSR.tla` (ModelConfig + SpecProcessor); grammar accepted:
+ * VSR.cfg:3-37.  tla_path may be NULL (then only the cfg is read); if given, its SHA-256 must be the VSR.tla this
+ * build lowers, any other module is refused. */
+typedef struct vsrmc_layout {
+  int32_t replica_count, client_count, value_count, start_view_on_timer_limit;
+  int32_t symmetry, invariant_mask, assume_commit_number, check_deadlock;
+  int32_t words_per_replica;     /* wire layout */
+  int32_t fixed_words;           /* wire layout: index of the first bag word */
+  int32_t permutations;          /* |Permutations(Values)| hashed per state */
+  int32_t max_bag;               /* largest message bag a record may hold */
+  int32_t max_record_words;      /* wire layout upper bound */
+  int32_t reserved[3];
+} vsrmc_layout;
+
+int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model** out);
+int32_t vsrmc_model_from_constants(int32_t replica_count, int32_t client_count, int32_t value_count,
+                                   int32_t start_view_on_timer_limit, int32_t restart_empty_limit, int32_t symmetry,
+                                   int32_t invariant_mask, int32_t assume_commit_number, vsrmc_model** out);
+int32_t vsrmc_model_info(const vsrmc_model* m, vsrmc_layout* out);
+/* Init (VSR.tla:323-348) in wire layout */
+int32_t vsrmc_model_init_state(const vsrmc_model* m, uint64_t* rec, int32_t cap_words, int32_t* n_words);
+/* TLC-syntax text of one state (the format of state_transfer_violation_trace.txt); returns needed size in *n */
+int32_t vsrmc_model_format_state(const vsrmc_model* m, const uint64_t* rec, char* buf, int64_t cap, int64_t* n);
+const char* vsrmc_action_name(int32_t action_id);
+void vsrmc_model_destroy(vsrmc_model* m);
+
+/* ---- FPSet ≙ tlc2.tool.fp.FPSet (init / putBlock / containsBlock / size / close) ---------------------------------
+ * Open-addressing table of 2^log2_slots 16-byte slots in HBM.  put: was_present[i] = 1 iff fp[i] was already in the
+ * set (FPSet.put's return value); equal fingerprints inside one batch: exactly one reports 0. */
+int32_t vsrmc_fpset_create(int32_t device, int32_t log2_slots, vsrmc_fpset** out);
+int32_t vsrmc_fpset_put_batch(vsrmc_fpset* s, const uint64_t* fps, uint64_t n, uint8_t* was_present);
+int32_t vsrmc_fpset_contains_batch(vsrmc_fpset* s, const uint64_t* fps, uint64_t n, uint8_t* present);
+/* same, buffers already in HBM (device pointers), enqueued on `hip_stream` (a hipStream_t, may be NULL) */
+int32_t vsrmc_fpset_put_batch_device(vsrmc_fpset* s, const uint64_t* d_fps, uint64_t n, uint8_t* d_was_present,
+                                     void* hip_stream);
+int32_t vsrmc_fpset_contains_batch_device(vsrmc_fpset* s, const uint64_t* d_fps, uint64_t n, uint8_t* d_present,
+                                          void* hip_stream);
+int32_t vsrmc_fpset_size(vsrmc_fpset* s, uint64_t* size);
+void vsrmc_fpset_destroy(vsrmc_fpset* s);
+
+/* ---- Tool.getNextStates over all actions, for a batch of states (≙ tlc2.tool.impl.Tool.getNextStates) ------------
+ * in: n records (wire layout).  out: successors in (parent, ordinal) order, wire layout, plus 8 words of meta each:
+ * [parent index, ordinal, action id, fingerprint, auxkey, violated-invariant mask, error code, word offset]. */
+int32_t vsrmc_expand_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off, uint64_t n,
+                           uint64_t* out_words, uint64_t out_words_cap, uint64_t* out_meta, uint64_t out_cap,
+                           uint64_t* n_out, uint64_t* words_out);
+/* canonical VIEW fingerprints (TLCState.fingerPrint with VIEW + SYMMETRY) of n records */
+int32_t vsrmc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off,
+                                uint64_t n, uint64_t* fps, uint32_t* auxkeys);
+
+/* ---- the checker ≙ tlc2.tool.ModelChecker + Worker.run + StateQueue + TLCTrace ---------------------------------- */
+typedef struct vsrmc_options {
+  int32_t device;                /* HIP device ordinal */
+  int32_t table_log2;            /* seen-set slots = 2^table_log2 (16 B each) */
+  uint64_t frontier_words;       /* capacity of each of the two frontier buffers, in 8-byte words */
+  uint64_t frontier_states;      /* capacity of each frontier in states */
+  uint64_t pending_entries;      /* capacity of the per-level pending list (16 B each) */
+  int32_t keep_trace;            /* 1 = keep (parent, ordinal) per state on the host for counter-examples */
+  int32_t rank, world;           /* shard of the seen-set owned by this process (world = 1: everything) */
+  int32_t reserved[8];
+} vsrmc_options;
+
+typedef struct vsrmc_level_info {
+  int32_t level;                 /* level just completed (Init = 1) */
+  int32_t error_code;            /* 0 or a device ERR_* code */
+  uint64_t frontier;             /* states expanded in this step */
+  uint64_t generated;            /* successors generated (TLC "states generated") */
+  uint64_t n_new;                /* new distinct states = size of the next frontier */
+  uint64_t distinct;             /* total distinct states so far */
+  uint64_t total_generated;
+  uint64_t deadlocks;            /* expanded states without successor */
+  uint64_t pending;              /* candidates that raced for a slot claimed in this level */
+  uint64_t probes;               /* seen-set slots inspected */
+  uint64_t words_new;            /* words of the next frontier (device layout) */
+  uint64_t max_bag;
+  uint64_t viol_fp;              /* smallest fingerprint of a violating new state, ~0 if none */
+  uint64_t viol_index;           /* its index in the next frontier */
+  int32_t viol_mask;
+  int32_t reserved0;
+  double seconds;                /* host wall time of the step */
+  double expand_ms;              /* HIP-event time of k_expand (on the checker's stream) */
+  double materialize_ms;         /* HIP-event time of k_materialize */
+  uint64_t act_generated[16];    /* generated successors per action id */
+} vsrmc_level_info;
+
+void vsrmc_options_default(vsrmc_options* o);
+int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc_checker** out);
+/* expand the newest level by one BFS step; info->n_new == 0 means the search is exhausted */
+int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info);
+/* sorted fingerprints of the newest level */
+int32_t vsrmc_checker_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, uint64_t* n);
+/* the newest level in wire layout (≙ StateQueue.sDequeue(int) without removal) */
+int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, uint64_t cap_states,
+                               uint64_t* n);
+/* ≙ TLCTrace.getTrace: the path Init .. state `index` of level `level`; records in wire layout, one action id per
+ * state (0 = Initial predicate) */
+int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words,
+                            uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
+void vsrmc_checker_destroy(vsrmc_checker* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

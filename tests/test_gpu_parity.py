@@ -1,0 +1,276 @@
+"""Parity tests proper (`-m gpu`): the HIP path, called through the C ABI (libvsrmc.so), against the CPU oracle and the
+committed golden fixtures.  Integer / byte work throughout: the bar is bit-exact (fingerprints, records, counts).
+
+Nothing here reads /root/reference (it does not exist on the GPU box); the reference's golden vector travels as
+tests/golden/state_transfer_trace.json.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M64 = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def vt():
+    import vsr_tlaplus_amd as vt
+    assert vt.load().vsrmc_device_count() >= 1, "no HIP device visible"
+    return vt
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import orc
+    return orc
+
+
+def _norm(orc, P, words):
+    return tuple(int(x) for x in orc.normalise(P, words))
+
+
+def _succ_multiset_oracle(orc, P, rec):
+    return sorted((s["action"], s["fp"], s["auxkey"], s["inv"], _norm(orc, P, s["words"])) for s in orc.successors(P, rec))
+
+
+def _succ_multiset_gpu(orc, P, succs):
+    return sorted((s["action"], s["fp"], s["auxkey"], s["inv"], _norm(orc, P, s["words"])) for s in succs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FPSet (tlc2.tool.fp.FPSet semantics)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_fpset_put_contains_semantics(vt):
+    rng = np.random.default_rng(0x5EED)
+    s = vt.FPSet(log2_slots=16)
+    a = rng.integers(1, M64, size=20000, dtype=np.uint64)
+    assert not s.contains_block(a).any()
+    assert not s.put_block(a).any() or len(np.unique(a)) < len(a)
+    assert s.size() == len(np.unique(a))
+    assert s.contains_block(a).all()
+    assert s.put_block(a).all()                        # second put: all already present
+    b = rng.integers(1, M64, size=5000, dtype=np.uint64)
+    mixed = np.concatenate([a[:5000], b])
+    was = s.put_block(mixed)
+    assert was[:5000].all() and not was[5000:].any()
+    assert s.size() == len(np.unique(np.concatenate([a, b])))
+    # duplicates inside one batch: exactly one of each group reports "new"
+    d = np.repeat(rng.integers(1, M64, size=100, dtype=np.uint64), 7)
+    was = s.put_block(d)
+    assert int((was == 0).sum()) == 100
+    assert s.put(12345) is False and s.put(12345) is True and s.contains(12345) and not s.contains(54321)
+    s.close()
+
+
+def test_fpset_empty_batch_and_zero_fp(vt):
+    s = vt.FPSet(log2_slots=8)
+    assert len(s.put_block(np.zeros(0, dtype=np.uint64))) == 0
+    assert s.put(0) is False and s.put(0) is True      # fingerprint 0 is remapped, not lost
+    s.close()
+
+
+def test_fpset_full_table_is_an_error(vt):
+    s = vt.FPSet(log2_slots=4)
+    with pytest.raises(vt.VsrmcError):
+        s.put_block(np.arange(1, 40, dtype=np.uint64))
+    s.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tool.getNextStates + fingerprint + invariant: golden trace states (README defect config)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_successors_of_every_golden_trace_state(vt, orc, golden_trace):
+    p = golden_trace["params"]
+    P = orc.Params(p["R"], p["C"], len(p["values"]), p["L"])
+    m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=len(p["values"]), L=p["L"])
+    recs = [np.array([int(w, 16) for w in st["words"]], dtype=np.uint64) for st in golden_trace["states"]]
+    words = np.concatenate(recs)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    fps, aks = m.fingerprints(words, off)
+    for i, st in enumerate(golden_trace["states"]):
+        assert "%016x" % int(fps[i]) == st["fp"] and int(aks[i]) == st["auxkey"]
+    succ = m.get_next_states(words, off)
+    by_parent = {}
+    for s in succ:
+        assert s["err"] == 0
+        by_parent.setdefault(s["parent"], []).append(s)
+    for i, rec in enumerate(recs):
+        assert _succ_multiset_gpu(orc, P, by_parent.get(i, [])) == _succ_multiset_oracle(orc, P, rec), i
+    # the reference trace itself: step i+1 is among the successors of step i, produced by the named action, and the
+    # invariant verdict flips exactly at state 24 (trace:555-577)
+    for i in range(len(recs) - 1):
+        nxt = _norm(orc, P, recs[i + 1])
+        hits = [s for s in by_parent[i] if _norm(orc, P, s["words"]) == nxt]
+        assert len(hits) == 1
+        assert vt.ACTION_NAMES[hits[0]["action"]] == golden_trace["states"][i + 1]["action"]
+        assert hits[0]["inv"] == golden_trace["states"][i + 1]["inv_mask"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# every reachable state of a small space: successor multisets agree state by state
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,C,n,L,sym,assume", [(2, 1, 2, 2, True, False), (2, 2, 2, 1, True, True), (3, 1, 1, 1, True, False)])
+def test_successors_of_every_state_of_a_small_space(vt, orc, R, C, n, L, sym, assume):
+    P = orc.Params(R, C, n, L, symmetry=sym, assume_commit_number=assume)
+    m = vt.Model.from_constants(R=R, C_=C, n=n, L=L, symmetry=sym, assume_commit_number=assume)
+    b = orc.Bfs(P)
+    checked = 0
+    while True:
+        words, off = b.frontier() if b.info["depth"] > 1 else (orc.init_record(P), np.array([0, len(orc.init_record(P))], dtype=np.uint64))
+        succ = m.get_next_states(words, off)
+        by_parent = {}
+        for s in succ:
+            by_parent.setdefault(s["parent"], []).append(s)
+        for i in range(len(off) - 1):
+            rec = words[int(off[i]): int(off[i + 1])]
+            assert _succ_multiset_gpu(orc, P, by_parent.get(i, [])) == _succ_multiset_oracle(orc, P, rec)
+            checked += 1
+        if b.step() == 0 or checked > 6000:
+            break
+    assert checked > 50
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the BFS: per-level fingerprint sets, generated / new / deadlock counts
+# ---------------------------------------------------------------------------------------------------------------------
+def _compare_levels(vt, orc, params, max_depth, sizes=None, **kw):
+    R, C, n, L = params
+    P = orc.Params(R, C, n, L, **kw)
+    m = vt.Model.from_constants(R=R, C_=C, n=n, L=L, symmetry=kw.get("symmetry", True),
+                                assume_commit_number=kw.get("assume_commit_number", False))
+    mc = vt.ModelChecker(m, **(sizes or dict(table_log2=22, frontier_words=1 << 24, frontier_states=1 << 19,
+                                             pending_entries=1 << 21)))
+    ob = orc.Bfs(P)
+    level = 1
+    while level < max_depth:
+        assert np.array_equal(mc.level_fps(), ob.level_fps(level)), "fingerprint sets differ at level %d" % level
+        d = mc.step()
+        nn = ob.step()
+        assert d["n_new"] == nn, (level, d["n_new"], nn)
+        assert d["generated"] == ob.info["generated"], level
+        assert d["deadlocks"] == ob.info["deadlocks"], level
+        assert d["distinct"] == ob.info["distinct"]
+        assert ob.info["ties"] == 0
+        if nn == 0:
+            break
+        assert d["max_bag"] <= ob.info["max_bag"]
+        level += 1
+    total = mc.distinct
+    mc.close()
+    ob.close()
+    return total, level
+
+
+def test_bfs_config1_whole_space(vt, orc):
+    assert _compare_levels(vt, orc, (2, 1, 1, 1), 100) == (76, 14)               # BASELINE config 1
+
+
+def test_bfs_two_replicas_two_values_whole_space(vt, orc):
+    assert _compare_levels(vt, orc, (2, 1, 2, 2), 100) == (2073, 27)
+    assert _compare_levels(vt, orc, (2, 1, 2, 2), 100, symmetry=False) == (4034, 27)
+
+
+def test_bfs_three_replicas_one_value_whole_space(vt, orc):
+    assert _compare_levels(vt, orc, (3, 1, 1, 1), 100) == (43941, 24)
+
+
+def test_bfs_config2_prefix(vt, orc):
+    total, level = _compare_levels(vt, orc, (3, 1, 2, 2), 13)                    # BASELINE config 2 = shipped VSR.cfg
+    assert (total, level) == (163346 + 161457, 13)
+
+
+def test_bfs_config3_prefix(vt, orc):
+    total, level = _compare_levels(vt, orc, (3, 1, 3, 3), 11)                    # README defect config, 6 permutations
+    assert level == 11 and total == 80646 + 154410
+
+
+def test_bfs_config5_prefix(vt, orc):
+    total, level = _compare_levels(vt, orc, (5, 1, 2, 2), 7)                     # five replicas
+    assert level == 7
+
+
+def test_bfs_config4_assume_commit_number_prefix(vt, orc):
+    _compare_levels(vt, orc, (3, 2, 3, 3), 7, assume_commit_number=True)
+
+
+def test_config4_strict_raises_the_tlc_evaluation_error(vt, orc):
+    """VSR.tla:421 reads the nonexistent field `m.commit`: with ClientCount = 2 TLC aborts; so do we, at the
+    same BFS level as the oracle, without committing the partial level."""
+    m = vt.Model.from_constants(R=3, C_=2, n=3, L=3)
+    mc = vt.ModelChecker(m, table_log2=16, frontier_words=1 << 16, frontier_states=1 << 12, pending_entries=1 << 14)
+    ob = orc.Bfs(orc.Params(3, 2, 3, 3))
+    with pytest.raises(vt.VsrmcError) as ei:
+        for _ in range(10):
+            mc.step()
+    assert ei.value.code == -4 and "VSR.tla:421" in ei.value.message
+    with pytest.raises(orc.OracleError):
+        for _ in range(10):
+            ob.step()
+    assert mc.level == ob.info["depth"] == 2 and mc.distinct == ob.info["distinct"] == 5
+
+
+def test_golden_level_checksums(vt, golden_counts):
+    """Per-level xor / sum of all fingerprints against tests/golden/bfs_counts.json — deeper than the tests above run
+    the oracle live."""
+    for label, depth in (("config2 (3,1,{v1,v2},2)", 16), ("config3 (3,1,{v1,v2,v3},3)", 12), ("config5 (5,1,{v1,v2},2)", 8)):
+        g = golden_counts[label]
+        p = g["params"]
+        m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=p["n"], L=p["L"], symmetry=p["symmetry"])
+        mc = vt.ModelChecker(m, table_log2=24, frontier_words=1 << 26, frontier_states=1 << 21, pending_entries=1 << 23,
+                             keep_trace=False)
+        for lv in g["levels"][:depth]:
+            fps = mc.level_fps()
+            assert len(fps) == lv["new"], (label, lv["level"])
+            assert "%016x" % int(np.bitwise_xor.reduce(fps)) == lv["fp_xor"], (label, lv["level"])
+            assert "%016x" % (int(fps.astype(object).sum()) & M64) == lv["fp_sum"], (label, lv["level"])
+            if lv["level"] > 1:
+                assert d["generated"] == lv["generated"] and d["deadlocks"] == lv["deadlocks"]
+            d = mc.step()
+        mc.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# TLCTrace.getTrace
+# ---------------------------------------------------------------------------------------------------------------------
+def test_trace_reconstruction_is_a_valid_shortest_path(vt, orc):
+    P = orc.Params(2, 1, 2, 2)
+    m = vt.Model.from_constants(R=2, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=16, frontier_words=1 << 18, frontier_states=1 << 13, pending_entries=1 << 15)
+    while mc.level < 20:
+        mc.step()
+    fps = mc.level_fps()
+    words, off = mc.frontier()
+    ffp, _ = m.fingerprints(words, off)
+    for index in (0, len(off) // 2, len(off) - 2):
+        tr = mc.trace(mc.level, index)
+        assert len(tr) == mc.level and tr[0][0] == "Initial predicate"
+        assert _norm(orc, P, tr[0][1]) == _norm(orc, P, orc.init_record(P))
+        for t in range(len(tr) - 1):
+            nxt = _norm(orc, P, tr[t + 1][1])
+            hits = [s for s in orc.successors(P, tr[t][1]) if _norm(orc, P, s["words"]) == nxt]
+            assert len(hits) >= 1 and orc.ACTIONS[hits[0]["action"]] == tr[t + 1][0]
+        assert _norm(orc, P, tr[-1][1]) == _norm(orc, P, words[int(off[index]): int(off[index + 1])])
+        assert int(ffp[index]) in set(int(x) for x in fps)
+    mc.close()
+
+
+def test_frontier_export_matches_oracle_states(vt, orc):
+    """StateQueue contents: every record of a level is a record the oracle also reached (up to the value permutation
+    the fingerprint canonicalises), i.e. same canonical fingerprints and same auxkeys."""
+    P = orc.Params(3, 1, 2, 2)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=18, frontier_words=1 << 20, frontier_states=1 << 14, pending_entries=1 << 16)
+    ob = orc.Bfs(P)
+    for _ in range(7):
+        mc.step()
+        ob.step()
+    words, off = mc.frontier()
+    fps, aks = m.fingerprints(words, off)
+    ow, oo = ob.frontier()
+    ofp = {}
+    for i in range(len(oo) - 1):
+        fp, ak = orc.fingerprint(P, ow[int(oo[i]): int(oo[i + 1])])
+        ofp[fp] = ak
+    assert len(ofp) == len(fps)
+    for fp, ak in zip(fps, aks):
+        assert ofp[int(fp)] == int(ak)

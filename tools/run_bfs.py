@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Exploratory driver: run the GPU BFS on one config and print one JSON line per level."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vsr_tlaplus_amd as vt  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("R", type=int); ap.add_argument("C", type=int); ap.add_argument("n", type=int); ap.add_argument("L", type=int)
+ap.add_argument("--table-log2", type=int, default=30)
+ap.add_argument("--frontier-words-log2", type=int, default=31)
+ap.add_argument("--frontier-states-log2", type=int, default=27)
+ap.add_argument("--pending-log2", type=int, default=28)
+ap.add_argument("--max-seconds", type=float, default=120)
+ap.add_argument("--max-depth", type=int, default=10 ** 6)
+ap.add_argument("--inv-mask", type=int, default=1)
+ap.add_argument("--no-symmetry", action="store_true")
+ap.add_argument("--assume-commit-number", action="store_true")
+ap.add_argument("--no-trace", action="store_true")
+a = ap.parse_args()
+m = vt.Model.from_constants(R=a.R, C_=a.C, n=a.n, L=a.L, symmetry=not a.no_symmetry, invariant_mask=a.inv_mask,
+                            assume_commit_number=a.assume_commit_number)
+t0 = time.time()
+mc = vt.ModelChecker(m, table_log2=a.table_log2, frontier_words=1 << a.frontier_words_log2,
+                     frontier_states=1 << a.frontier_states_log2, pending_entries=1 << a.pending_log2,
+                     keep_trace=not a.no_trace)
+print(json.dumps(dict(setup_seconds=round(time.time() - t0, 3))))
+t0 = time.time()
+why = "exhausted"
+try:
+    while True:
+        if mc.level >= a.max_depth:
+            why = "max-depth"; break
+        if time.time() - t0 > a.max_seconds:
+            why = "max-seconds"; break
+        d = mc.step()
+        if d["n_new"]:
+            d.pop("act_generated")
+            print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()
+                              if k in ("level", "frontier", "generated", "n_new", "distinct", "deadlocks", "pending", "probes",
+                                       "words_new", "max_bag", "seconds", "expand_ms", "materialize_ms", "viol_mask")}), flush=True)
+        if d["n_new"] == 0:
+            break
+        if mc.violation:
+            why = "violation"; break
+except vt.VsrmcError as e:
+    why = "error: %s" % e
+dt = time.time() - t0
+print(json.dumps(dict(summary=True, stop=why, depth=mc.level, distinct=mc.distinct, seconds=round(dt, 3),
+                      states_per_s=round(mc.distinct / dt, 1), violation=mc.violation)))
+if mc.violation:
+    tr = mc.trace(mc.violation["level"], mc.violation["index"])
+    print("trace length", len(tr), [t[0] for t in tr])
+    print(m.format_state(tr[-1][1]))

@@ -1,0 +1,99 @@
+"""ctypes binding of libvsrmc.so (include/vsrmc.h).  No fallback: if the library is missing, loading raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvsrmc.so")
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "replica_count", "client_count", "value_count", "start_view_on_timer_limit", "symmetry", "invariant_mask",
+        "assume_commit_number", "check_deadlock", "words_per_replica", "fixed_words", "permutations", "max_bag",
+        "max_record_words")] + [("reserved", C.c_int32 * 3)]
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("table_log2", C.c_int32), ("frontier_words", C.c_uint64),
+                ("frontier_states", C.c_uint64), ("pending_entries", C.c_uint64), ("keep_trace", C.c_int32),
+                ("rank", C.c_int32), ("world", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class LevelInfo(C.Structure):
+    _fields_ = [("level", C.c_int32), ("error_code", C.c_int32), ("frontier", C.c_uint64), ("generated", C.c_uint64),
+                ("n_new", C.c_uint64), ("distinct", C.c_uint64), ("total_generated", C.c_uint64),
+                ("deadlocks", C.c_uint64), ("pending", C.c_uint64), ("probes", C.c_uint64), ("words_new", C.c_uint64),
+                ("max_bag", C.c_uint64), ("viol_fp", C.c_uint64), ("viol_index", C.c_uint64), ("viol_mask", C.c_int32),
+                ("reserved0", C.c_int32), ("seconds", C.c_double), ("expand_ms", C.c_double),
+                ("materialize_ms", C.c_double), ("act_generated", C.c_uint64 * 16)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("act_generated", "reserved0")}
+        d["act_generated"] = list(self.act_generated)
+        return d
+
+
+# every symbol include/vsrmc.h declares: name -> (restype, argtypes)
+V = C.c_void_p
+SYMBOLS = {
+    "vsrmc_last_error": (C.c_char_p, []),
+    "vsrmc_version": (C.c_int32, []),
+    "vsrmc_device_count": (C.c_int32, []),
+    "vsrmc_model_load": (C.c_int32, [C.c_char_p, C.c_char_p, C.POINTER(V)]),
+    "vsrmc_model_from_constants": (C.c_int32, [C.c_int32] * 8 + [C.POINTER(V)]),
+    "vsrmc_model_info": (C.c_int32, [V, C.POINTER(Layout)]),
+    "vsrmc_model_init_state": (C.c_int32, [V, V, C.c_int32, C.POINTER(C.c_int32)]),
+    "vsrmc_model_format_state": (C.c_int32, [V, V, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "vsrmc_action_name": (C.c_char_p, [C.c_int32]),
+    "vsrmc_model_destroy": (None, [V]),
+    "vsrmc_fpset_create": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(V)]),
+    "vsrmc_fpset_put_batch": (C.c_int32, [V, V, C.c_uint64, V]),
+    "vsrmc_fpset_contains_batch": (C.c_int32, [V, V, C.c_uint64, V]),
+    "vsrmc_fpset_put_batch_device": (C.c_int32, [V, V, C.c_uint64, V, V]),
+    "vsrmc_fpset_contains_batch_device": (C.c_int32, [V, V, C.c_uint64, V, V]),
+    "vsrmc_fpset_size": (C.c_int32, [V, C.POINTER(C.c_uint64)]),
+    "vsrmc_fpset_destroy": (None, [V]),
+    "vsrmc_expand_batch": (C.c_int32, [V, C.c_int32, V, V, C.c_uint64, V, C.c_uint64, V, C.c_uint64,
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vsrmc_fingerprint_batch": (C.c_int32, [V, C.c_int32, V, V, C.c_uint64, V, V]),
+    "vsrmc_options_default": (None, [C.POINTER(Options)]),
+    "vsrmc_checker_create": (C.c_int32, [V, C.POINTER(Options), C.POINTER(V)]),
+    "vsrmc_checker_step": (C.c_int32, [V, C.POINTER(LevelInfo)]),
+    "vsrmc_checker_level_fps": (C.c_int32, [V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_frontier": (C.c_int32, [V, V, C.c_uint64, V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_trace": (C.c_int32, [V, C.c_int32, C.c_uint64, V, C.c_uint64, V, V, C.c_uint64,
+                                        C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_destroy": (None, [V]),
+}
+
+_lib = None
+
+
+class VsrmcError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "vsrmc error %d: %s" % (code, msg))
+        self.code = code
+        self.message = msg
+
+
+def load():
+    """Load libvsrmc.so and declare every exported symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python vsr-tlaplus_amd/build.py` (hipcc, gfx950); "
+                              "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise VsrmcError(rc, load().vsrmc_last_error().decode())

@@ -1,0 +1,244 @@
+"""Host-side mirror of the TLC interfaces this path replaces, over the C ABI (include/vsrmc.h):
+
+    Model         tlc2.tool.impl.Tool / ModelConfig   — (VSR.tla, VSR.cfg) lowered; getNextStates(batch)
+    FPSet         tlc2.tool.fp.FPSet                  — put / contains / putBlock / containsBlock / size / close
+    ModelChecker  tlc2.tool.ModelChecker + Worker.run + StateQueue + TLCTrace — level-synchronous BFS on the GPU
+
+Everything below is plumbing: all model semantics, hashing and set operations run in the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import VsrmcError, check
+
+ACTION_NAMES = ["Initial predicate", "TimerSendSVC", "ReceiveHigherSVC", "ReceiveMatchingSVC", "SendDVC",
+                "ReceiveHigherDVC", "ReceiveMatchingDVC", "SendSV", "ReceiveSV", "ReceiveClientRequest",
+                "ReceivePrepareMsg", "ReceivePrepareOkMsg", "ExecuteOp", "SendGetState", "ReceiveGetState",
+                "ReceiveNewState"]          # Next order, VSR.tla:896-913
+
+INV_ACK_NOT_LOST = 1           # AcknowledgedWriteNotLost           VSR.tla:945-950
+INV_ACK_ON_MAJORITY = 2        # AcknowledgedWritesExistOnMajority  VSR.tla:937-943
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Model:
+    """The lowered (VSR.tla, VSR.cfg) pair."""
+
+    def __init__(self, handle):
+        self._h = handle
+        lay = capi.Layout()
+        check(capi.load().vsrmc_model_info(self._h, C.byref(lay)))
+        self.layout = lay
+
+    @classmethod
+    def load(cls, cfg_path, tla_path=None):
+        """≙ `tlc2.TLC -config VSR.cfg VSR.tla`: reads the cfg grammar of VSR.cfg:1-39."""
+        h = C.c_void_p()
+        check(capi.load().vsrmc_model_load(tla_path.encode() if tla_path else None, cfg_path.encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_constants(cls, R=3, C_=1, n=2, L=2, restart_limit=0, symmetry=True, invariant_mask=1,
+                       assume_commit_number=False):
+        h = C.c_void_p()
+        check(capi.load().vsrmc_model_from_constants(R, C_, n, L, restart_limit, int(symmetry), invariant_mask,
+                                                     int(assume_commit_number), C.byref(h)))
+        return cls(h)
+
+    def init_state(self):
+        out = np.zeros(256, dtype=np.uint64)
+        n = C.c_int32()
+        check(capi.load().vsrmc_model_init_state(self._h, _p(out), 256, C.byref(n)))
+        return out[: n.value].copy()
+
+    def format_state(self, rec):
+        rec = np.ascontiguousarray(rec, dtype=np.uint64)
+        n = C.c_int64()
+        check(capi.load().vsrmc_model_format_state(self._h, _p(rec), None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        check(capi.load().vsrmc_model_format_state(self._h, _p(rec), buf, n.value, C.byref(n)))
+        return buf.value.decode()
+
+    def get_next_states(self, words, off, device=0, cap_succ=None, cap_words=None):
+        """Tool.getNextStates over all actions for a batch of states.
+        -> list of dict(parent, ordinal, action, fp, auxkey, inv, err, words)."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        cap_succ = cap_succ or max(64, 48 * n)
+        cap_words = cap_words or cap_succ * int(self.layout.max_record_words)
+        ow = np.zeros(cap_words, dtype=np.uint64)
+        om = np.zeros(8 * cap_succ, dtype=np.uint64)
+        n_out, w_out = C.c_uint64(), C.c_uint64()
+        check(capi.load().vsrmc_expand_batch(self._h, device, _p(words), _p(off), n, _p(ow), cap_words, _p(om), cap_succ,
+                                             C.byref(n_out), C.byref(w_out)))
+        out = []
+        offs = [int(om[8 * k + 7]) for k in range(n_out.value)] + [w_out.value]
+        for k in range(n_out.value):
+            m = om[8 * k: 8 * k + 8]
+            out.append(dict(parent=int(m[0]), ordinal=int(m[1]), action=int(m[2]), fp=int(m[3]), auxkey=int(m[4]),
+                            inv=int(m[5]), err=int(m[6]), words=ow[offs[k]: offs[k + 1]].copy()))
+        return out
+
+    def fingerprints(self, words, off, device=0):
+        """TLCState.fingerPrint (VIEW + SYMMETRY) of a batch of states -> (fps, auxkeys)."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        fps = np.zeros(n, dtype=np.uint64)
+        aks = np.zeros(n, dtype=np.uint32)
+        check(capi.load().vsrmc_fingerprint_batch(self._h, device, _p(words), _p(off), n, _p(fps), _p(aks)))
+        return fps, aks
+
+    def close(self):
+        if self._h:
+            capi.load().vsrmc_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FPSet:
+    """≙ tlc2.tool.fp.FPSet: an open-addressing set of 64-bit fingerprints in HBM."""
+
+    def __init__(self, log2_slots=20, device=0):
+        self._h = C.c_void_p()
+        check(capi.load().vsrmc_fpset_create(device, log2_slots, C.byref(self._h)))
+
+    def put_block(self, fps):
+        """-> uint8 array: 1 where the fingerprint was already present (FPSet.put's return value)."""
+        fps = np.ascontiguousarray(fps, dtype=np.uint64)
+        out = np.zeros(len(fps), dtype=np.uint8)
+        check(capi.load().vsrmc_fpset_put_batch(self._h, _p(fps), len(fps), _p(out)))
+        return out
+
+    def contains_block(self, fps):
+        fps = np.ascontiguousarray(fps, dtype=np.uint64)
+        out = np.zeros(len(fps), dtype=np.uint8)
+        check(capi.load().vsrmc_fpset_contains_batch(self._h, _p(fps), len(fps), _p(out)))
+        return out
+
+    def put(self, fp):
+        return bool(self.put_block(np.array([fp], dtype=np.uint64))[0])
+
+    def contains(self, fp):
+        return bool(self.contains_block(np.array([fp], dtype=np.uint64))[0])
+
+    def put_block_device(self, d_fps_ptr, n, d_out_ptr, stream=None):
+        check(capi.load().vsrmc_fpset_put_batch_device(self._h, C.c_void_p(d_fps_ptr), n, C.c_void_p(d_out_ptr),
+                                                       C.c_void_p(stream or 0)))
+
+    def contains_block_device(self, d_fps_ptr, n, d_out_ptr, stream=None):
+        check(capi.load().vsrmc_fpset_contains_batch_device(self._h, C.c_void_p(d_fps_ptr), n, C.c_void_p(d_out_ptr),
+                                                            C.c_void_p(stream or 0)))
+
+    def size(self):
+        n = C.c_uint64()
+        check(capi.load().vsrmc_fpset_size(self._h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            capi.load().vsrmc_fpset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ModelChecker:
+    """≙ tlc2.tool.ModelChecker: level-synchronous BFS; `step()` = every Worker draining one level of the StateQueue."""
+
+    def __init__(self, model, device=0, table_log2=24, frontier_words=1 << 25, frontier_states=1 << 20,
+                 pending_entries=1 << 21, keep_trace=True):
+        self.model = model
+        o = capi.Options()
+        capi.load().vsrmc_options_default(C.byref(o))
+        o.device, o.table_log2 = device, table_log2
+        o.frontier_words, o.frontier_states, o.pending_entries = frontier_words, frontier_states, pending_entries
+        o.keep_trace = int(keep_trace)
+        self.options = o
+        self._h = C.c_void_p()
+        check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))
+        self.level = 1
+        self.n_frontier = 1
+        self.distinct = 1
+        self.levels = [dict(level=1, n_new=1, generated=0, deadlocks=0)]
+        self.violation = None
+
+    def step(self):
+        info = capi.LevelInfo()
+        check(capi.load().vsrmc_checker_step(self._h, C.byref(info)))
+        d = info.as_dict()
+        self.level, self.n_frontier, self.distinct = d["level"], d["n_new"], d["distinct"]
+        if d["n_new"]:
+            self.levels.append(d)
+        if d["viol_mask"] and self.violation is None:
+            self.violation = dict(level=d["level"], index=d["viol_index"], fp=d["viol_fp"], mask=d["viol_mask"])
+        return d
+
+    def run(self, max_depth=None, max_seconds=None, stop_on_violation=True):
+        """Worker.run until the queue is empty, an invariant is violated, or a bound is hit."""
+        import time
+        t0 = time.time()
+        while True:
+            if max_depth is not None and self.level >= max_depth:
+                return "max-depth"
+            if max_seconds is not None and time.time() - t0 > max_seconds:
+                return "max-seconds"
+            d = self.step()
+            if d["n_new"] == 0:
+                return "exhausted"
+            if self.violation is not None and stop_on_violation:
+                return "violation"
+
+    def level_fps(self):
+        out = np.zeros(max(1, self.n_frontier), dtype=np.uint64)
+        n = C.c_uint64()
+        check(capi.load().vsrmc_checker_level_fps(self._h, _p(out), len(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def frontier(self):
+        """The newest level in wire layout -> (words, offsets)."""
+        lay = self.model.layout
+        cap_w = max(1, self.n_frontier) * int(lay.max_record_words)
+        words = np.zeros(cap_w, dtype=np.uint64)
+        off = np.zeros(self.n_frontier + 1, dtype=np.uint64)
+        n = C.c_uint64()
+        check(capi.load().vsrmc_checker_frontier(self._h, _p(words), cap_w, _p(off), len(off), C.byref(n)))
+        return words[: int(off[n.value])].copy(), off[: n.value + 1].copy()
+
+    def trace(self, level, index):
+        """TLCTrace.getTrace -> list of (action name, record words) from Init to the given state."""
+        lay = self.model.layout
+        cap_w = (level + 1) * int(lay.max_record_words)
+        words = np.zeros(cap_w, dtype=np.uint64)
+        off = np.zeros(level + 2, dtype=np.uint64)
+        acts = np.zeros(level + 2, dtype=np.int32)
+        n = C.c_uint64()
+        check(capi.load().vsrmc_checker_trace(self._h, level, index, _p(words), cap_w, _p(off), _p(acts), len(off),
+                                              C.byref(n)))
+        return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(n.value)]
+
+    def close(self):
+        if self._h:
+            capi.load().vsrmc_checker_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

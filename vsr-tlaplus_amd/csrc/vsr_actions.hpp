@@ -1,0 +1,485 @@
+// vsr_actions.hpp — the guarded-update action table of VSR.tla, lowered onto the packed record.
+//
+// Replaces tlc2.tool.impl.Tool.getNextStates for this one model.
+// One call = one (action, binding) instance, identified by an ordinal `ord` relative to the parent record:
+//   [0,R)            TimerSendSVC(r)                    VSR.tla:578-590
+//   [R,2R)           SendDVC(r)                         VSR.tla:648-669
+//   [2R,3R)          SendSV(r)                          VSR.tla:735-760
+//   [3R,4R)          ExecuteOp(r)                       VSR.tla:462-476
+//   [4R,m0)          ReceiveClientRequest(r,c,v)        VSR.tla:366-394
+//   m0 + j*(R+1) + k the action that receives bag entry j (r = its dest, VSR.tla:272-275):
+//        k = 0       by message type: ReceiveHigherSVC 602-613 / ReceiveMatchingSVC 625-634 /
+//                    ReceiveHigherDVC 677-688 / ReceiveMatchingDVC 696-703 / ReceiveSV 773-793 /
+//                    ReceivePrepareMsg 405-428 / ReceivePrepareOkMsg 437-447 / ReceiveGetState 526-543 /
+//                    ReceiveNewState 551-567
+//        k = rDest   SendGetState(r, rDest, m)          VSR.tla:496-516   (Prepare entries only)
+// The four recovery actions (VSR.tla:813-894) are dead at RestartEmptyLimit = 0 and are rejected at model load.
+//
+// gen<true>  evaluates the guards only (used by frontier enumeration);
+// gen<false> additionally produces the Delta: new header, new replica block, and the bag patches.
+#pragma once
+#include "vsr_model.hpp"
+
+namespace vsr {
+
+#define VSR_MAXPATCH 5    // 1 discard + (R-1 <= 4) broadcasts
+
+struct Delta {
+  u64 hdr;                 // new header (nmsg already updated)
+  u64 rep[4];              // new replica block of replica r (wpr <= 4 words)
+  int r;                   // the one replica an action updates
+  int action;              // A_* id (for traces)
+  int npatch;
+  int pj[VSR_MAXPATCH];    // bag index patched, or -1 = appended entry
+  u64 pold[VSR_MAXPATCH];  // previous word (0 for appended entries)
+  u64 pnew[VSR_MAXPATCH];
+  int err;
+};
+
+// ---- x-slot access inside a replica block held in D.rep -------------------------------------------------------
+VSR_HD u32 blk_x(const u64* b, int i) { return (u32)(b[1 + (i >> 1)] >> (32 * (i & 1))); }
+VSR_HD void blk_setx(u64* b, int i, u32 x) {
+  int w = 1 + (i >> 1), sh = 32 * (i & 1);
+  b[w] = (b[w] & ~((u64)0xFFFFFFFFu << sh)) | ((u64)x << sh);
+}
+VSR_HD void blk_clear_dvc(const Model& M, u64* b) {           // rep_dvc_recv[r] = {}  (keeps x0 = own log)
+  b[1] &= 0xFFFFFFFFull;
+  for (int k = 2; k < M.wpr; k++) b[k] = 0;
+}
+VSR_HD int blk_dvc_count(const Model& M, const u64* b) {
+  int c = 0;
+  for (int s = 1; s <= M.R; s++) c += (int)(blk_x(b, s) & 1);
+  return c;
+}
+
+// ---- bag algebra (VSR.tla:228-270) on parent bag + patch list ---------------------------------------------------
+// DiscardFunc (VSR.tla:244-245): count - 1, the key stays in the domain.
+VSR_HD void bag_discard(Delta& D, int j, u64 w) {
+  int k = D.npatch++;
+  D.pj[k] = j;
+  D.pold[k] = w;
+  D.pnew[k] = m_set_count(w, m_count(w) - 1);
+}
+// SendFunc (VSR.tla:228-231): existing key -> count + 1 (even from 0), new key -> count 1.
+template <typename PTR>
+VSR_HD void bag_send(const Model& M, PTR bag, int nmsg, Delta& D, u64 key) {
+  for (int k = 0; k < D.npatch; k++)
+    if ((D.pnew[k] & KEYMASK) == key) {                        // key touched earlier in this action
+      int c = m_count(D.pnew[k]) + 1;
+      if (c > 3) { D.err = ERR_REP_COUNT; return; }
+      D.pnew[k] = m_set_count(D.pnew[k], c);
+      return;
+    }
+  int k = D.npatch++;
+  for (int j = 0; j < nmsg; j++) {
+    u64 w = bag[j];
+    if ((w & KEYMASK) == key) {
+      int c = m_count(w) + 1;
+      if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
+      D.pj[k] = j;
+      D.pold[k] = w;
+      D.pnew[k] = m_set_count(w, c);
+      return;
+    }
+  }
+  D.pj[k] = -1;
+  D.pold[k] = 0;
+  D.pnew[k] = m_set_count(key, 1);
+}
+// BroadcastFunc (VSR.tla:233-240): one copy per replica other than the source, dest overwritten.
+template <typename PTR>
+VSR_HD void bag_broadcast(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, int source) {
+  for (int d = 1; d <= M.R; d++)
+    if (d != source) bag_send(M, bag, nmsg, D, m_set_dest(key, d));
+}
+template <typename PTR>
+VSR_HD bool bag_has_key(PTR bag, int nmsg, u64 key) {          // key \in DOMAIN messages (any count)
+  for (int j = 0; j < nmsg; j++)
+    if ((bag[j] & KEYMASK) == key) return true;
+  return false;
+}
+
+// ResetRecvMsgs + ResetSentVars (VSR.tla:299-305) on a replica block
+VSR_HD void blk_reset_recv(const Model& M, u64* b) {
+  b[0] = a_set_svcmask(b[0], 0);
+  blk_clear_dvc(M, b);
+}
+VSR_HD void blk_reset_sent(u64* b) { b[0] = a_set_sent_sv(a_set_sent_dvc(b[0], 0), 0); }
+
+// Decode an ordinal into (group, r, c, v, j, k).  group: 0 timer, 1 sendDVC, 2 sendSV, 3 execute, 4 client, 5 message.
+struct Ord { int group, r, c, v, j, k; };
+VSR_HD Ord ord_decode(const Model& M, int ord) {
+  Ord o;
+  o.group = 5; o.r = 0; o.c = 0; o.v = 0; o.j = 0; o.k = 0;
+  if (ord < 4 * M.R) {
+    o.group = ord / M.R;
+    o.r = ord % M.R + 1;
+  } else if (ord < M.m0) {
+    int idx = ord - 4 * M.R;
+    o.group = 4;
+    o.r = idx / (M.C * M.n) + 1;
+    o.c = (idx / M.n) % M.C + 1;
+    o.v = idx % M.n;
+  } else {
+    int q = ord - M.m0;
+    o.j = q / (M.R + 1);
+    o.k = q % (M.R + 1);
+  }
+  return o;
+}
+
+// The action table.  `rec` is the parent record (device layout).  Returns true iff the instance is enabled.
+template <bool GUARD_ONLY, typename PTR>
+VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
+  const u64 hdr = rec[0];
+  const int nmsg = hdr_nmsg(hdr);
+  PTR bag = rec + M.fixed;
+  Ord o = ord_decode(M, ord);
+  int r = o.r;
+  u64 mw = 0;
+  if (o.group == 5) {
+    if (o.j >= nmsg) return false;
+    mw = bag[o.j];
+    if (m_count(mw) == 0) return false;                        // ReceivableMsg: messages[m] > 0   VSR.tla:275
+    r = m_dest(mw);                                            //                m.dest = r        VSR.tla:274
+    if (o.k != 0 && (m_type(mw) != T_PREPARE || o.k == r)) return false;
+  }
+  PTR pb = rec + 1 + (r - 1) * M.wpr;
+  const u64 A = pb[0];
+  const int view = a_view(A), status = a_status(A), op = a_op(A), commit = a_commit(A);
+  const bool is_primary = primary_of(M, view) == r;           // IsPrimary VSR.tla:290-291
+
+  if (!GUARD_ONLY) {
+    D.hdr = hdr;
+    D.r = r;
+    D.npatch = 0;
+    D.err = 0;
+    D.action = 0;
+    for (int k = 0; k < M.wpr; k++) D.rep[k] = pb[k];
+  }
+  u64* nb = D.rep;
+
+  switch (o.group) {
+    case 0: {  // ---- TimerSendSVC (VSR.tla:578-590)
+      if (!(hdr_aux_svc(hdr) < M.L)) return false;             // :579
+      if (is_primary) return false;                            // :581
+      if (GUARD_ONLY) return true;
+      D.action = A_TimerSendSVC;
+      if (view + 1 > 7) { D.err = ERR_REP_RANGE; return true; }
+      nb[0] = a_set_view(nb[0], view + 1);                     // :582
+      nb[0] = a_set_status(nb[0], ST_VIEWCHANGE);              // :583
+      blk_reset_recv(M, nb);                                   // :584
+      blk_reset_sent(nb);                                      // :585
+      D.hdr = (hdr & ~((u64)7 << 8)) | ((u64)(hdr_aux_svc(hdr) + 1) << 8);   // :586
+      bag_broadcast(M, bag, nmsg, D, m_make(T_SVC, view + 1, 0, r, 0, 0, 0, 0, 0), r);   // :587
+      break;
+    }
+    case 1: {  // ---- SendDVC (VSR.tla:648-669)
+      if (status != ST_VIEWCHANGE) return false;               // :650
+      if (a_sent_dvc(A)) return false;                         // :651
+      if (!(__builtin_popcount(a_svcmask(A)) >= M.R / 2)) return false;      // :652
+      if (GUARD_ONLY) return true;
+      D.action = A_SendDVC;
+      nb[0] = a_set_sent_dvc(nb[0], 1);                        // :653
+      u32 lg = blk_x(pb, 0);
+      int prim = primary_of(M, view);
+      if (prim == r) {                                         // :662-664  rep_dvc_recv[r] \union {msg}
+        u32 slot = dvc_make(a_lnv(A), op, commit, lg);
+        u32 cur = blk_x(pb, r);
+        if ((cur & 1) && cur != slot) { D.err = ERR_REP_I2; return true; }
+        blk_setx(nb, r, slot);
+      } else {                                                 // :665-667
+        bag_send(M, bag, nmsg, D, m_make(T_DVC, view, prim, r, op, commit, a_lnv(A), 0, lg));
+      }
+      break;
+    }
+    case 2: {  // ---- SendSV (VSR.tla:735-760)
+      if (status != ST_VIEWCHANGE) return false;               // :737
+      if (a_sent_sv(A)) return false;                          // :738
+      if (!(blk_dvc_count(M, pb) >= M.R / 2 + 1)) return false;   // :739
+      if (GUARD_ONLY) return true;
+      D.action = A_SendSV;
+      // HighestLog (VSR.tla:716-722): CHOOSE among the DVCs maximal in (last_normal_vn, op_number); TLC's CHOOSE
+      // takes the first such record in its value order [view, type, op, commit, dest, source, log, lnv]
+      //  = smallest (commit_number, source).  HighestCommitNumber (VSR.tla:729-733) = max commit.
+      int best_s = 0, best_lnv = -1, best_op = -1, best_commit = 0, max_commit = -1;
+      for (int s = 1; s <= M.R; s++) {
+        u32 x = blk_x(pb, s);
+        if (!(x & 1)) continue;
+        int l = dvc_lnv(x), o2 = dvc_op(x), c2 = dvc_commit(x);
+        if (c2 > max_commit) max_commit = c2;
+        bool better = (l > best_lnv) || (l == best_lnv && o2 > best_op) ||
+                      (l == best_lnv && o2 == best_op && c2 < best_commit);
+        if (better) { best_s = s; best_lnv = l; best_op = o2; best_commit = c2; }
+      }
+      if (!best_s) { D.err = ERR_EVAL_CHOOSE; return true; }
+      u32 new_log = dvc_log(blk_x(pb, best_s));                // :740
+      int new_on = log_len(new_log);                           // :741  Len(HighestLog(r))
+      nb[0] = a_set_status(nb[0], ST_NORMAL);                  // :744
+      blk_setx(nb, 0, new_log);                                // :746
+      nb[0] = a_set_op(nb[0], new_on);                         // :747
+      for (int p = 1; p <= M.R; p++) nb[0] = a_set_peer(nb[0], p, 0);   // :748
+      nb[0] = a_set_commit(nb[0], max_commit);                 // :749
+      nb[0] = a_set_sent_sv(nb[0], 1);                         // :750
+      nb[0] = a_set_lnv(nb[0], view);                          // :751
+      bag_broadcast(M, bag, nmsg, D, m_make(T_SV, view, 0, r, new_on, max_commit, 0, 0, new_log), r);   // :752-758
+      break;
+    }
+    case 3: {  // ---- ExecuteOp (VSR.tla:462-476)
+      if (!is_primary) return false;                           // :464
+      if (status != ST_NORMAL) return false;                   // :465
+      if (!(commit < op)) return false;                        // :466
+      int q = 0;                                               // IsCommitted :457-460
+      for (int p = 1; p <= M.R; p++) q += a_peer(A, p) >= commit + 1 ? 1 : 0;
+      if (!(q >= M.R / 2)) return false;                       // :467
+      if (GUARD_ONLY) return true;
+      D.action = A_ExecuteOp;
+      int opn = commit + 1;                                    // :468
+      int e = log_byte(blk_x(pb, 0), opn);                     // :469
+      if (!e) { D.err = ERR_EVAL_DOMAIN; return true; }
+      nb[0] = a_set_commit(nb[0], opn);                        // :471
+      int c = entry_client(e);
+      if (c > M.C) { D.err = ERR_EVAL_DOMAIN; return true; }
+      nb[0] = a_set_ctrow(nb[0], c, a_ctrow(A, c) | 16);       // :472  executed = TRUE
+      if (hdr_acked(hdr, entry_val(e)) == 0) { D.err = ERR_EVAL_DOMAIN; return true; }
+      D.hdr = hdr_set_acked(hdr, entry_val(e), 2);             // :473
+      break;
+    }
+    case 4: {  // ---- ReceiveClientRequest (VSR.tla:366-394)
+      if (!is_primary) return false;                           // :368
+      if (status != ST_NORMAL) return false;                   // :369
+      if (hdr_acked(hdr, o.v) != 0) return false;              // :370
+      int row = a_ctrow(A, o.c);
+      if (!ct_exec(row)) return false;                         // :371
+      if (GUARD_ONLY) return true;
+      D.action = A_ReceiveClientRequest;
+      int req = ct_req(row) + 1;                               // :372
+      u32 lg = blk_x(pb, 0);
+      int opn = log_len(lg) + 1;                               // :373
+      if (req > 3 || opn > 3) { D.err = ERR_REP_RANGE; return true; }
+      int e = entry_make(view, o.v, o.c, req);                 // :374-377
+      blk_setx(nb, 0, lg | ((u32)e << (8 * (opn - 1))));       // :379
+      nb[0] = a_set_op(nb[0], opn);                            // :380
+      nb[0] = a_set_ctrow(nb[0], o.c, ct_make(req, opn, 0));   // :381-384
+      bag_broadcast(M, bag, nmsg, D, m_make(T_PREPARE, view, 0, r, opn, commit, 0, 0, (u32)e), r);   // :385-391
+      D.hdr = hdr_set_acked(hdr, o.v, 1);                      // :392
+      break;
+    }
+    default: {  // ---- message-bound actions
+      const int mt = m_type(mw), mview = m_view(mw), msrc = m_source(mw), mop = m_op(mw), mcommit = m_commit(mw);
+      if (o.k != 0) {  // ---- SendGetState (VSR.tla:496-516), m is a Prepare addressed to r, rDest = k
+        if (is_primary) return false;                          // :498
+        if (status != ST_NORMAL) return false;                 // :501
+        if (!(mview > view)) return false;                     // :502
+        if (!(mop > op + 1)) return false;                     // :503
+        u32 lg = blk_x(pb, 0);
+        int t = commit < log_len(lg) ? commit : log_len(lg);   // :504 MinVal
+        u64 gs = m_make(T_GETSTATE, mview, o.k, r, t, 0, 0, 0, 0);   // :510-514
+        if (bag_has_key(bag, nmsg, gs)) return false;          // SendOnce :250-251
+        if (GUARD_ONLY) return true;
+        D.action = A_SendGetState;
+        // the mask/slot forms of rep_svc_recv / rep_dvc_recv assume records of the replica's own view
+        if (a_svcmask(A) || blk_dvc_count(M, pb)) { D.err = ERR_REP_I1; return true; }
+        blk_setx(nb, 0, log_prefix(lg, t));                    // :506
+        nb[0] = a_set_op(nb[0], t);                            // :507
+        nb[0] = a_set_view(nb[0], mview);                      // :508
+        nb[0] = a_set_lnv(nb[0], mview);                       // :509
+        bag_send(M, bag, nmsg, D, gs);                         // :252
+        break;
+      }
+      switch (mt) {
+        case T_SVC: {
+          if (mview > view) {  // ---- ReceiveHigherSVC (VSR.tla:602-613)
+            if (GUARD_ONLY) return true;
+            D.action = A_ReceiveHigherSVC;
+            nb[0] = a_set_view(nb[0], mview);                  // :606
+            nb[0] = a_set_status(nb[0], ST_VIEWCHANGE);        // :607
+            nb[0] = a_set_svcmask(nb[0], 1 << (msrc - 1));     // :608
+            blk_clear_dvc(M, nb);                              // :609
+            blk_reset_sent(nb);                                // :610
+            bag_discard(D, o.j, mw);                           // :611
+            bag_broadcast(M, bag, nmsg, D, m_make(T_SVC, mview, 0, r, 0, 0, 0, 0, 0), r);
+          } else if (mview == view && status == ST_VIEWCHANGE) {   // ---- ReceiveMatchingSVC (VSR.tla:625-634)
+            if (GUARD_ONLY) return true;
+            D.action = A_ReceiveMatchingSVC;
+            nb[0] = a_set_svcmask(nb[0], a_svcmask(A) | (1 << (msrc - 1)));   // :631
+            bag_discard(D, o.j, mw);                           // :632
+          } else {
+            return false;
+          }
+          break;
+        }
+        case T_DVC: {
+          u32 slot = dvc_make(m_lnv(mw), mop, mcommit, m_lg(mw) & 0xFFFFFF);
+          if (mview > view) {  // ---- ReceiveHigherDVC (VSR.tla:677-688)
+            if (GUARD_ONLY) return true;
+            D.action = A_ReceiveHigherDVC;
+            nb[0] = a_set_view(nb[0], mview);                  // :681
+            nb[0] = a_set_status(nb[0], ST_VIEWCHANGE);        // :682
+            nb[0] = a_set_svcmask(nb[0], 0);                   // :683
+            blk_clear_dvc(M, nb);                              // :684
+            blk_setx(nb, msrc, slot);
+            blk_reset_sent(nb);                                // :685
+            bag_discard(D, o.j, mw);                           // :686
+            bag_broadcast(M, bag, nmsg, D, m_make(T_SVC, mview, 0, r, 0, 0, 0, 0, 0), r);
+          } else if (mview == view) {  // ---- ReceiveMatchingDVC (VSR.tla:696-703)
+            if (GUARD_ONLY) return true;
+            D.action = A_ReceiveMatchingDVC;
+            u32 cur = blk_x(pb, msrc);
+            if ((cur & 1) && cur != slot) { D.err = ERR_REP_I2; return true; }
+            blk_setx(nb, msrc, slot);                          // :700
+            bag_discard(D, o.j, mw);                           // :701
+          } else {
+            return false;
+          }
+          break;
+        }
+        case T_SV: {  // ---- ReceiveSV (VSR.tla:773-793)
+          if (!(mview >= view)) return false;                  // :776
+          if (GUARD_ONLY) return true;
+          D.action = A_ReceiveSV;
+          nb[0] = a_set_status(nb[0], ST_NORMAL);              // :777
+          nb[0] = a_set_view(nb[0], mview);                    // :778
+          blk_setx(nb, 0, m_lg(mw) & 0xFFFFFF);                // :779
+          nb[0] = a_set_op(nb[0], mop);                        // :780
+          nb[0] = a_set_commit(nb[0], mcommit);                // :781
+          nb[0] = a_set_lnv(nb[0], mview);                     // :782
+          blk_reset_recv(M, nb);                               // :783
+          blk_reset_sent(nb);                                  // :784
+          bag_discard(D, o.j, mw);
+          if (commit < mop)                                    // :785 (old commit number)
+            bag_send(M, bag, nmsg, D, m_make(T_PREPAREOK, mview, primary_of(M, mview), r, mop, 0, 0, 0, 0));   // :786-790
+          break;
+        }
+        case T_PREPARE: {  // ---- ReceivePrepareMsg (VSR.tla:405-428)
+          if (status != ST_NORMAL) return false;               // :408
+          if (mview != view) return false;                     // :409
+          if (mop != op + 1) return false;                     // :410
+          if (GUARD_ONLY) return true;
+          D.action = A_ReceivePrepareMsg;
+          int e = (int)(m_lg(mw) & 0xFF);
+          u32 lg = blk_x(pb, 0);
+          int pos = log_len(lg) + 1;                           // Append :411
+          if (pos > 3) { D.err = ERR_REP_RANGE; return true; }
+          blk_setx(nb, 0, lg | ((u32)e << (8 * (pos - 1))));
+          nb[0] = a_set_op(nb[0], mop);                        // :412
+          nb[0] = a_set_commit(nb[0], mcommit);                // :413
+          for (int c = 1; c <= M.C; c++) {                     // :414-421
+            if (c == entry_client(e)) {
+              nb[0] = a_set_ctrow(nb[0], c, ct_make(entry_req(e), mop, mop <= mcommit ? 1 : 0));
+            } else {
+              // VSR.tla:421 reads `m.commit`, a field PrepareMsg does not have: TLC evaluation error
+              if (!M.assume_commit) { D.err = ERR_EVAL_421; return true; }
+              int row = a_ctrow(A, c);
+              nb[0] = a_set_ctrow(nb[0], c, ct_make(ct_req(row), ct_op(row), ct_op(row) <= mcommit ? 1 : 0));
+            }
+          }
+          bag_discard(D, o.j, mw);
+          bag_send(M, bag, nmsg, D, m_make(T_PREPAREOK, view, msrc, r, mop, 0, 0, 0, 0));   // :422-426
+          break;
+        }
+        case T_PREPAREOK: {  // ---- ReceivePrepareOkMsg (VSR.tla:437-447)
+          if (!is_primary) return false;                       // :440
+          if (status != ST_NORMAL) return false;               // :441
+          if (mview != view) return false;                     // :442
+          if (!(mop > a_peer(A, msrc))) return false;          // :443
+          if (GUARD_ONLY) return true;
+          D.action = A_ReceivePrepareOkMsg;
+          nb[0] = a_set_peer(nb[0], msrc, mop);                // :444
+          bag_discard(D, o.j, mw);                             // :445
+          break;
+        }
+        case T_GETSTATE: {  // ---- ReceiveGetState (VSR.tla:526-543)
+          if (view != mview) return false;                     // :529
+          if (status != ST_NORMAL) return false;               // :530
+          if (!(op > mop)) return false;                       // :531
+          if (GUARD_ONLY) return true;
+          D.action = A_ReceiveGetState;
+          u32 lg = blk_x(pb, 0);
+          u32 part = log_prefix(lg, op) & ~log_prefix(0xFFFFFF, mop);   // entries mop+1 .. op   :535-536
+          for (int on = mop + 1; on <= op; on++)
+            if (!log_byte(lg, on)) { D.err = ERR_EVAL_DOMAIN; return true; }
+          bag_discard(D, o.j, mw);
+          bag_send(M, bag, nmsg, D, m_make(T_NEWSTATE, view, msrc, r, op, commit, 0, mop + 1, part));   // :533-541
+          break;
+        }
+        case T_NEWSTATE: {  // ---- ReceiveNewState (VSR.tla:551-567)
+          if (view != mview) return false;                     // :554
+          if (status != ST_NORMAL) return false;               // :555
+          if (!(op == m_first_op(mw) - 1)) return false;       // :556
+          if (GUARD_ONLY) return true;
+          D.action = A_ReceiveNewState;
+          u32 lg = blk_x(pb, 0), ml = m_lg(mw) & 0xFFFFFF;
+          u32 nl = log_prefix(lg, op) | (log_prefix(ml, mop) & ~log_prefix(0xFFFFFF, op));   // :557-561
+          for (int on = 1; on <= mop; on++)
+            if (!log_byte(nl, on)) { D.err = ERR_EVAL_DOMAIN; return true; }
+          blk_setx(nb, 0, nl);
+          nb[0] = a_set_op(nb[0], mop);                        // :562
+          bag_discard(D, o.j, mw);                             // :564 (client table untouched, :563)
+          break;
+        }
+        default:
+          return false;
+      }
+      break;
+    }
+  }
+  if (!GUARD_ONLY) {
+    int na = 0;
+    for (int k = 0; k < D.npatch; k++) na += D.pj[k] < 0 ? 1 : 0;
+    if (nmsg + na > M.max_bag) D.err = D.err ? D.err : ERR_REP_BAG;
+    D.hdr = hdr_set_nmsg(D.hdr, nmsg + na);
+  }
+  return true;
+}
+
+// Incremental view hashes of the child: Hc[i] = Hp[i] - hash(old replica block) + hash(new) + bag patch deltas.
+template <typename PTR>
+VSR_HD void hash_child(const Model& M, PTR rec, const Delta& D, u64* Hc) {
+  PTR pb = rec + 1 + (D.r - 1) * M.wpr;
+  bool rep_changed = false;
+  for (int k = 0; k < M.wpr; k++) rep_changed |= (pb[k] != D.rep[k]);
+  u64 ha_old = 0, ha_new = 0;
+  if (rep_changed) {
+    ha_old = fmix64(pb[0] ^ M.salt_rep[D.r]);
+    ha_new = fmix64(D.rep[0] ^ M.salt_rep[D.r]);
+  }
+  for (int i = 0; i < M.np; i++) {
+    u32 pt = M.pitab[i];
+    u64 h = rec[M.h0 + i];
+    if (rep_changed) h += hash_rep_tail(M, ha_new, D.rep, pt) - hash_rep_tail(M, ha_old, pb, pt);
+    for (int k = 0; k < D.npatch; k++) {
+      h += hash_msg(D.pnew[k], pt);
+      if (D.pj[k] >= 0) h -= hash_msg(D.pold[k], pt);
+    }
+    Hc[i] = h;
+  }
+}
+
+// Invariants on the child (VSR.tla:933-950).  Returns the mask of VIOLATED invariants.
+template <typename PTR>
+VSR_HD int check_invariants_child(const Model& M, PTR rec, const Delta& D) {
+  if (!(M.inv_mask & 3)) return 0;
+  int bad = 0;
+  for (int v = 0; v < M.n; v++) {
+    if (hdr_acked(D.hdr, v) != 2) continue;                    // aux_client_acked[v] = TRUE   :940, :948
+    int holders = 0;
+    for (int r = 1; r <= M.R; r++) {
+      u32 lg = (r == D.r) ? blk_x(D.rep, 0) : (u32)rec[1 + (r - 1) * M.wpr + 1];
+      bool has = false;                                        // ReplicaHasOp :933-935
+      for (int i = 1; i <= 3; i++) {
+        int e = log_byte(lg, i);
+        if (e && entry_val(e) == v) has = true;
+      }
+      holders += has ? 1 : 0;
+    }
+    if ((M.inv_mask & 1) && holders == 0) bad |= 1;            // AcknowledgedWriteNotLost :945-950
+    if ((M.inv_mask & 2) && !(holders >= M.R / 2 + 1)) bad |= 2;   // AcknowledgedWritesExistOnMajority :937-943
+  }
+  return bad;
+}
+
+// Number of ordinals to scan for a parent record.
+VSR_HD int ord_count(const Model& M, int nmsg) { return M.m0 + nmsg * (M.R + 1); }
+
+}  // namespace vsr

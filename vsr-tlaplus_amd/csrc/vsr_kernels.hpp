@@ -1,0 +1,474 @@
+// vsr_kernels.hpp — CDNA4 (gfx950, wave64) kernels of the BFS hot path.
+//
+// TLC roles replaced:
+//   k_expand       Worker.run -> ModelChecker.doNext -> Tool.getNextStates + TLCState.fingerPrint + FPSet.put
+//                  (rows a7, a10, a11): stage a tile of frontier records in LDS, enumerate the enabled
+//                  (action, binding) instances, apply each one, hash incrementally, probe/insert the seen-set.
+//   k_materialize  StateQueue.sEnqueue + TLCTrace.writeState + invariant check (rows a9, a12, a13): the winner of
+//                  every newly claimed slot rebuilds its successor and appends it to the next frontier.
+//   k_fpset_*      FPSet.putBlock / containsBlock (row a11) as a standalone batch API.
+//   k_successors   Tool.getNextStates over all actions for a batch of states (boundary / parity-test entry).
+//   k_replay       TLCTrace.getTrace: re-executes a path of ordinals from Init.
+// No floating point, no MFMA: integer compare/shift/multiply, LDS staging, 64-bit atomics in HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vsr_actions.hpp"
+
+namespace vsr {
+
+struct Slot {       // one seen-set slot: 16 bytes, fp == 0 means empty
+  u64 fp;
+  u64 meta;
+};
+
+struct LevelCtl {   // device-resident counters of one BFS level
+  u64 generated;    // enabled (action, binding) instances = successors generated (TLC "states generated")
+  u64 deadlocks;    // frontier states without any successor
+  u64 n_pending;    // candidates that hit a slot claimed during this level
+  u64 n_new;        // successors appended to the next frontier = new distinct states
+  u64 words_new;    // words used in the next frontier
+  u64 viol_fp;      // smallest fingerprint among new states violating an invariant (~0 = none)
+  u64 probes;       // seen-set slots inspected
+  u64 max_bag;      // largest bag among the new states
+  u32 viol_mask;
+  u32 err;          // first ERR_* raised
+  u64 err_info;     // (parent index << 16) | ordinal of the instance that raised it
+  u64 act_generated[16];   // generated successors per action id
+};
+
+#define VSR_TILE 64          // frontier records staged per block iteration
+#define VSR_BLOCK 256
+#define VSR_CAND_CAP 3072    // enabled instances per tile the LDS work list can hold
+
+__device__ __forceinline__ void raise_error(LevelCtl* ctl, int code, u64 info) {
+  if (atomicCAS(&ctl->err, 0u, (u32)code) == 0u) ctl->err_info = info;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// One atomic per wave: returns base + rank of this lane among the lanes that call it (all callers must pass the
+// same counter).  Lanes call this from inside a divergent branch; the ballot only sees the active ones.
+__device__ __forceinline__ u64 wave_alloc(u64* counter, u64 amount_per_lane_one) {
+  (void)amount_per_lane_one;
+  u64 active = __ballot(1);
+  int lane = lane_id();
+  int leader = __ffsll((long long)active) - 1;
+  u64 base = 0;
+  if (lane == leader) base = atomicAdd((unsigned long long*)counter, (unsigned long long)__popcll(active));
+  base = __shfl(base, leader);
+  return base + (u64)__popcll(active & (((u64)1 << lane) - 1));
+}
+
+// Seen-set probe.  Returns the slot index; *found_old = true when the fingerprint was inserted at an earlier level
+// (nothing else to do), otherwise the caller's key has been min-merged into the slot's meta word.
+__device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 key, int level, bool* found_old,
+                                           u32* nprobe, bool* full) {
+  u64 i = fp & mask;
+  *full = false;
+  for (u64 step = 0; step <= mask; step++, i = (i + 1) & mask) {
+    (*nprobe)++;
+    u64 cur = __hip_atomic_load(&table[i].fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) {
+      cur = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
+      if (cur == 0) cur = fp;                                  // claimed by this lane
+    }
+    if (cur == fp) {
+      u64 m = __hip_atomic_load(&table[i].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (meta_level(m) < level) {                             // inserted at an earlier level: plain duplicate
+        *found_old = true;
+        return i;
+      }
+      atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
+      *found_old = false;
+      return i;
+    }
+    if (step > 4096) break;
+  }
+  *full = true;
+  *found_old = true;
+  return 0;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_expand
+// -----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(VSR_BLOCK)
+k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
+         Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride) {
+  extern __shared__ u64 smem[];
+  u64* s_rec = smem;                                           // VSR_TILE * stride words
+  u32* s_cand = (u32*)(smem + VSR_TILE * stride);              // VSR_CAND_CAP entries: parent << 16 | ord
+  __shared__ u32 s_ncand, s_dead;
+  __shared__ u32 s_pcount[VSR_TILE];
+  __shared__ u32 s_act[16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 ntiles = (n_parents + VSR_TILE - 1) / VSR_TILE;
+
+  for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const u64 p_base = tile * VSR_TILE;
+    const int np_tile = (int)((n_parents - p_base) < VSR_TILE ? (n_parents - p_base) : VSR_TILE);
+    if (tid == 0) { s_ncand = 0; s_dead = 0; }
+    if (tid < VSR_TILE) s_pcount[tid] = 0;
+    if (tid < 16) s_act[tid] = 0;
+
+    // ---- stage the tile: one wave per record, lane k copies word k (coalesced 8-byte loads)
+    for (int p = wave; p < np_tile; p += VSR_BLOCK / 64) {
+      u64 off = fr_off[p_base + p];
+      u64 hdr = fr_words[off];
+      int len = M.fixed + hdr_nmsg(hdr);
+      if (len > stride) len = stride;                          // cannot happen: max_bag is enforced at creation
+      for (int k = lane; k < len; k += 64) s_rec[p * stride + k] = fr_words[off + k];
+    }
+    __syncthreads();
+
+    // ---- enumerate enabled instances: 4 threads per record (replica-bound ordinals, and the bag split 3 ways)
+    {
+      const int p = tid >> 2, part = tid & 3;
+      if (p < np_tile) {
+        const u64* rec = s_rec + p * stride;
+        const int nmsg = hdr_nmsg(rec[0]);
+        Delta dummy;
+        u32 mine = 0;
+        if (part == 0) {
+          for (int ord = 0; ord < M.m0; ord++)
+            if (gen<true>(M, rec, ord, dummy)) {
+              u32 idx = atomicAdd(&s_ncand, 1u);
+              if (idx < VSR_CAND_CAP) s_cand[idx] = ((u32)p << 16) | (u32)ord;
+              mine++;
+            }
+        } else {
+          for (int j = part - 1; j < nmsg; j += 3) {
+            u64 mw = rec[M.fixed + j];
+            if (m_count(mw) == 0) continue;
+            int kmax = (m_type(mw) == T_PREPARE) ? M.R : 0;
+            for (int k = 0; k <= kmax; k++) {
+              int ord = M.m0 + j * (M.R + 1) + k;
+              if (gen<true>(M, rec, ord, dummy)) {
+                u32 idx = atomicAdd(&s_ncand, 1u);
+                if (idx < VSR_CAND_CAP) s_cand[idx] = ((u32)p << 16) | (u32)ord;
+                mine++;
+              }
+            }
+          }
+        }
+        if (mine) atomicAdd(&s_pcount[p], mine);
+      }
+    }
+    __syncthreads();
+    if (tid < np_tile && s_pcount[tid] == 0) atomicAdd(&s_dead, 1u);
+    u32 ncand = s_ncand;
+    if (ncand > VSR_CAND_CAP) {
+      if (tid == 0) raise_error(ctl, ERR_FRONTIER_FULL, p_base);
+      ncand = VSR_CAND_CAP;
+    }
+
+    // ---- apply + fingerprint + seen-set claim: one lane per enabled instance
+    u32 my_probes = 0;
+    for (u32 c = tid; c < ncand; c += VSR_BLOCK) {
+      const u32 code = s_cand[c];
+      const int p = (int)(code >> 16), ord = (int)(code & 0xFFFF);
+      const u64* rec = s_rec + p * stride;
+      Delta D;
+      gen<false>(M, rec, ord, D);
+      atomicAdd(&s_act[D.action & 15], 1u);
+      if (D.err) {
+        raise_error(ctl, D.err, ((p_base + (u64)p) << 16) | (u64)ord);
+        continue;
+      }
+      u64 Hc[6];
+      hash_child(M, rec, D, Hc);
+      u64 fp;
+      u32 ak;
+      canonical_fp(M, D.hdr, Hc, &fp, &ak);
+      const u64 key = meta_make(level, ak, rank, p_base + (u64)p, ord);
+      bool found_old, full;
+      u64 slot = table_claim(table, tmask, fp, key, level, &found_old, &my_probes, &full);
+      if (full) {
+        raise_error(ctl, ERR_TABLE_FULL, fp);
+        continue;
+      }
+      if (!found_old) {
+        u64 i = wave_alloc(&ctl->n_pending, 1);
+        if (i < pending_cap) {
+          pending[2 * i] = slot;
+          pending[2 * i + 1] = key;
+        } else {
+          raise_error(ctl, ERR_FRONTIER_FULL, i);
+        }
+      }
+    }
+    // wave-level reduction of the probe statistic
+    for (int o = 32; o > 0; o >>= 1) my_probes += __shfl_down(my_probes, o);
+    if (lane == 0 && my_probes) atomicAdd((unsigned long long*)&ctl->probes, (unsigned long long)my_probes);
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd((unsigned long long*)&ctl->generated, (unsigned long long)s_ncand);
+      if (s_dead) atomicAdd((unsigned long long*)&ctl->deadlocks, (unsigned long long)s_dead);
+    }
+    if (tid < 16 && s_act[tid]) atomicAdd((unsigned long long*)&ctl->act_generated[tid], (unsigned long long)s_act[tid]);
+    __syncthreads();
+  }
+}
+
+// Write the child record: copy of the parent with the Delta applied.  Single-lane version (k_successors, k_replay).
+__device__ __forceinline__ void write_child_serial(const Model& M, const u64* rec, const Delta& D, const u64* Hc, u64* dst) {
+  int nmsg = hdr_nmsg(rec[0]);
+  int len = M.fixed + nmsg;
+  for (int k = 0; k < len; k++) dst[k] = rec[k];
+  dst[0] = D.hdr;
+  for (int k = 0; k < M.wpr; k++) dst[1 + (D.r - 1) * M.wpr + k] = D.rep[k];
+  for (int i = 0; i < M.np; i++) dst[M.h0 + i] = Hc[i];
+  int a = 0;
+  for (int k = 0; k < D.npatch; k++) {
+    if (D.pj[k] >= 0) dst[M.fixed + D.pj[k]] = D.pnew[k];
+    else dst[M.fixed + nmsg + (a++)] = D.pnew[k];
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_materialize: one lane per pending entry; winners (slot meta == own key) append their successor.
+// -----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(VSR_BLOCK)
+k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, const u64* __restrict__ pending,
+              u64 n_pending, const Slot* __restrict__ table, u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap,
+              u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl) {
+  const int lane = threadIdx.x & 63;
+  const u64 nthreads = (u64)gridDim.x * blockDim.x;
+  const u64 rounds = (n_pending + nthreads - 1) / nthreads;
+  for (u64 it = 0; it < rounds; it++) {
+    const u64 i = it * nthreads + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool win = false;
+    u64 key = 0, src = 0, fp = 0;
+    int plen = 0, clen = 0, bad = 0;
+    Delta D;
+    u64 Hc[6];
+    D.npatch = 0;
+    D.err = 0;
+    if (i < n_pending) {
+      u64 slot = pending[2 * i];
+      key = pending[2 * i + 1];
+      win = (table[slot].meta == key);
+    }
+    if (win) {
+      src = fr_off[meta_pidx(key)];
+      const u64* rec = fr_words + src;
+      gen<false>(M, rec, meta_ord(key), D);
+      hash_child(M, rec, D, Hc);
+      u32 ak;
+      canonical_fp(M, D.hdr, Hc, &fp, &ak);
+      plen = M.fixed + hdr_nmsg(rec[0]);
+      clen = M.fixed + hdr_nmsg(D.hdr);
+      bad = check_invariants_child(M, rec, D);
+    }
+    // wave-wide allocation: state indices and word ranges
+    const u64 wmask = __ballot(win);
+    if (wmask == 0) continue;
+    const int nwin = __popcll(wmask);
+    int incl = clen;                                           // inclusive scan of child lengths over the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    u64 idx_base = 0, word_base = 0;
+    if (lane == 0) {
+      idx_base = atomicAdd((unsigned long long*)&ctl->n_new, (unsigned long long)nwin);
+      word_base = atomicAdd((unsigned long long*)&ctl->words_new, (unsigned long long)total);
+    }
+    idx_base = __shfl(idx_base, 0);
+    word_base = __shfl(word_base, 0);
+    if (idx_base + (u64)nwin > nx_cap || word_base + (u64)total > nx_words_cap) {
+      if (lane == 0) raise_error(ctl, ERR_FRONTIER_FULL, idx_base);
+      continue;
+    }
+    const u64 dst = word_base + (u64)(incl - clen);
+    const u64 idx = idx_base + (u64)__popcll(wmask & (((u64)1 << lane) - 1));
+    // cooperative copy parent -> child, one winner at a time, lane k moves word k
+    for (u64 rest = wmask; rest; rest &= rest - 1) {
+      const int w = __ffsll((long long)rest) - 1;
+      const u64 s = __shfl(src, w), d = __shfl(dst, w);
+      const int n = __shfl(plen, w);
+      for (int k = lane; k < n; k += 64) nx_words[d + k] = fr_words[s + k];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the copies land before the patches overwrite them
+    if (win) {
+      u64* out = nx_words + dst;
+      out[0] = D.hdr;
+      for (int k = 0; k < M.wpr; k++) out[1 + (D.r - 1) * M.wpr + k] = D.rep[k];
+      for (int k = 0; k < M.np; k++) out[M.h0 + k] = Hc[k];
+      int a = 0;
+      for (int k = 0; k < D.npatch; k++) {
+        if (D.pj[k] >= 0) out[M.fixed + D.pj[k]] = D.pnew[k];
+        else out[plen + (a++)] = D.pnew[k];
+      }
+      nx_off[idx] = dst;
+      lvl_fp[idx] = fp;
+      lvl_tr[idx] = key;
+      if (bad) {
+        atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
+        atomicOr(&ctl->viol_mask, (u32)bad);
+      }
+      atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)hdr_nmsg(D.hdr));
+    }
+  }
+}
+
+// empty seen-set: fp = 0, meta = all ones
+__global__ void k_table_init(Slot* table, u64 slots) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (u64)gridDim.x * blockDim.x) {
+    table[i].fp = 0;
+    table[i].meta = META_EMPTY;
+  }
+}
+
+// Seed the search with the initial state (ModelChecker.doInit): record already in frontier slot 0.
+__global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl) {
+  if (threadIdx.x || blockIdx.x) return;
+  u64 fp;
+  u32 ak;
+  canonical_fp(M, rec[0], rec + M.h0, &fp, &ak);
+  u64 key = meta_make(1, ak, 0, 0, 0);
+  bool found_old, full;
+  u32 np = 0;
+  table_claim(table, tmask, fp, key, 1, &found_old, &np, &full);
+  lvl_fp[0] = fp;
+  lvl_tr[0] = key;
+  ctl->n_new = 1;
+  ctl->words_new = (u64)(M.fixed + hdr_nmsg(rec[0]));
+}
+
+// index of the record of the newest level whose fingerprint is `fp`
+__global__ void k_find_fp(const u64* lvl_fp, u64 n, u64 fp, u64* out_idx) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && lvl_fp[i] == fp) atomicMin((unsigned long long*)out_idx, (unsigned long long)i);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// Standalone FPSet batch operations (tlc2.tool.fp.FPSet.putBlock / containsBlock)
+// -----------------------------------------------------------------------------------------------------------------
+__global__ void k_fpset_put(Slot* table, u64 tmask, const u64* fps, u64 n, uint8_t* was_present, u64* size, u32* err) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  u64 fp = fps[t] ? fps[t] : 1;
+  u64 i = fp & tmask;
+  for (u64 step = 0; step <= tmask; step++, i = (i + 1) & tmask) {
+    u64 cur = __hip_atomic_load(&table[i].fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) {
+      cur = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
+      if (cur == 0) {
+        // first claimer of a batch wins: later equal keys in the same batch report "present"
+        table[i].meta = 0;
+        was_present[t] = 0;
+        atomicAdd((unsigned long long*)size, 1ull);
+        return;
+      }
+    }
+    if (cur == fp) {
+      was_present[t] = 1;
+      return;
+    }
+  }
+  was_present[t] = 1;
+  atomicExch(err, (u32)ERR_TABLE_FULL);
+}
+
+__global__ void k_fpset_contains(const Slot* table, u64 tmask, const u64* fps, u64 n, uint8_t* present) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  u64 fp = fps[t] ? fps[t] : 1;
+  u64 i = fp & tmask;
+  for (u64 step = 0; step <= tmask; step++, i = (i + 1) & tmask) {
+    u64 cur = table[i].fp;
+    if (cur == fp) { present[t] = 1; return; }
+    if (cur == 0) break;
+  }
+  present[t] = 0;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_successors: all successors of a batch of records in ordinal order (Tool.getNextStates over every action).
+// One lane per parent; out_meta has 8 words per successor:
+//   [parent index, ordinal, action id, fingerprint, auxkey, violated-invariant mask, error code, word offset]
+// -----------------------------------------------------------------------------------------------------------------
+__global__ void k_successors(Model M, const u64* words, const u64* off, u64 n, u64* out_words, u64 out_words_cap,
+                             u64* out_meta, u64 out_cap, u64* counters /* [0] successors, [1] words, [2] overflow */) {
+  u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const u64* rec = words + off[p];
+  int nords = ord_count(M, hdr_nmsg(rec[0]));
+  for (int ord = 0; ord < nords; ord++) {
+    Delta D;
+    if (!gen<true>(M, rec, ord, D)) continue;
+    gen<false>(M, rec, ord, D);
+    u64 Hc[6];
+    hash_child(M, rec, D, Hc);
+    u64 fp;
+    u32 ak;
+    canonical_fp(M, D.hdr, Hc, &fp, &ak);
+    int clen = M.fixed + hdr_nmsg(D.hdr);
+    u64 k = atomicAdd((unsigned long long*)&counters[0], 1ull);
+    u64 w = atomicAdd((unsigned long long*)&counters[1], (unsigned long long)clen);
+    if (k >= out_cap || w + clen > out_words_cap) {
+      counters[2] = 1;
+      continue;
+    }
+    if (!D.err) write_child_serial(M, rec, D, Hc, out_words + w);
+    else for (int q = 0; q < clen; q++) out_words[w + q] = 0;
+    u64* m = out_meta + 8 * k;
+    m[0] = p;
+    m[1] = (u64)ord;
+    m[2] = (u64)D.action;
+    m[3] = fp;
+    m[4] = ak;
+    m[5] = D.err ? 0 : (u64)check_invariants_child(M, rec, D);
+    m[6] = (u64)D.err;
+    m[7] = w;
+  }
+}
+
+// k_hash_records: fill in the H words of device-layout records (used when records enter through the C ABI)
+__global__ void k_hash_records(Model M, u64* words, const u64* off, u64 n) {
+  u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  u64* rec = words + off[p];
+  u64 H[6];
+  hash_full(M, (const u64*)rec, H);
+  for (int i = 0; i < M.np; i++) rec[M.h0 + i] = H[i];
+}
+
+// k_replay: re-execute a path of ordinals starting from the record at out_words[0..).  Record t+1 = ord[t] applied
+// to record t.  out_meta per step: [action id, fingerprint, invariant mask, error].
+__global__ void k_replay(Model M, u64* out_words, u64* out_off, const u32* ords, int nsteps, u64* out_meta) {
+  if (threadIdx.x || blockIdx.x) return;
+  u64 pos = 0;
+  out_off[0] = 0;
+  for (int t = 0; t < nsteps; t++) {
+    const u64* rec = out_words + pos;
+    u64 next = pos + (u64)(M.fixed + hdr_nmsg(rec[0]));
+    Delta D;
+    bool en = gen<true>(M, rec, (int)ords[t], D);
+    if (!en) {
+      out_meta[4 * t + 3] = 0xFFFF;
+      out_off[t + 1] = next;
+      for (int k = t + 1; k < nsteps; k++) out_off[k + 1] = next;
+      return;
+    }
+    gen<false>(M, rec, (int)ords[t], D);
+    u64 Hc[6];
+    hash_child(M, rec, D, Hc);
+    u64 fp;
+    u32 ak;
+    canonical_fp(M, D.hdr, Hc, &fp, &ak);
+    write_child_serial(M, rec, D, Hc, out_words + next);
+    out_meta[4 * t + 0] = (u64)D.action;
+    out_meta[4 * t + 1] = fp;
+    out_meta[4 * t + 2] = (u64)check_invariants_child(M, rec, D);
+    out_meta[4 * t + 3] = (u64)D.err;
+    out_off[t + 1] = next;
+    pos = next;
+  }
+}
+
+}  // namespace vsr

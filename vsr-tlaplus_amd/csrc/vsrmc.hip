@@ -1,0 +1,892 @@
+// vsrmc.hip — host side of libvsrmc.so: cfg reader, model lowering, FPSet / expand / checker handles (include/vsrmc.h).
+// Mirrors tlc2.TLC (config reading), tlc2.tool.ModelChecker + Worker.run (level loop), StateQueue (frontier double
+// buffer), FPSet (seen-set) and TLCTrace (parent/ordinal log) for VSR.tla — see SURVEY.md §3.1 for the TLC loop.
+// All model semantics run on the GPU (vsr_kernels.hpp); there is no CPU fallback: without a HIP device every
+// compute entry point fails with VSRMC_E_HIP.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/vsrmc.h"
+#include "vsr_format.hpp"
+#include "vsr_kernels.hpp"
+
+using namespace vsr;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(VSRMC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// SHA-256 (FIPS 180-4), used to refuse any module other than the VSR.tla this build lowers.
+// ---------------------------------------------------------------------------------------------------------------
+std::string sha256_hex(const std::string& data) {
+  static const uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+      0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  std::string msg = data;
+  uint64_t bitlen = (uint64_t)data.size() * 8;
+  msg.push_back((char)0x80);
+  while (msg.size() % 64 != 56) msg.push_back((char)0);
+  for (int i = 7; i >= 0; i--) msg.push_back((char)((bitlen >> (8 * i)) & 0xFF));
+  auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+  for (size_t blk = 0; blk < msg.size(); blk += 64) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+      w[i] = ((uint32_t)(uint8_t)msg[blk + 4 * i] << 24) | ((uint32_t)(uint8_t)msg[blk + 4 * i + 1] << 16) |
+             ((uint32_t)(uint8_t)msg[blk + 4 * i + 2] << 8) | (uint32_t)(uint8_t)msg[blk + 4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+      uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+      uint32_t ch = (e & f) ^ (~e & g);
+      uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+      uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+      uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+      uint32_t t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  char buf[65];
+  for (int i = 0; i < 8; i++) std::snprintf(buf + 8 * i, 9, "%08x", h[i]);
+  return std::string(buf, 64);
+}
+
+// SHA-256 of the one module this build lowers: /root/reference/vsr-revisited/paper/VSR.tla (970 lines)
+const char* const VSR_TLA_SHA256 = "f37efb7b055316624c885e2805550097fa609864b1b7a782279c189f8e2dbf22";
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------------------------
+struct vsrmc_model {
+  Model M;
+  int symmetry = 1;
+  int check_deadlock = 0;
+  std::vector<std::string> value_names;
+};
+
+namespace {
+
+int build_model(int R, int C, int n, int L, int restart, int symmetry, int inv_mask, int assume_commit, vsrmc_model* out) {
+  if (R < 2 || R > 5 || C < 1 || C > 2 || n < 1 || n > 3 || L < 0 || L > 6)
+    return fail(VSRMC_E_CFG, "model constants outside the supported bounds (ReplicaCount 2..5, ClientCount 1..2, "
+                             "|Values| 1..3, StartViewOnTimerLimit 0..6)");
+  if (restart != 0)
+    return fail(VSRMC_E_CFG, "RestartEmptyLimit > 0 is not supported: the recovery actions (VSR.tla:813-894) are not lowered");
+  Model& M = out->M;
+  std::memset(&M, 0, sizeof(M));
+  M.R = R; M.C = C; M.n = n; M.L = L;
+  M.wpr = 1 + (R + 2) / 2;
+  M.h0 = 1 + R * M.wpr;
+  int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+  int np = 0;
+  for (int i = 0; i < 6; i++) {
+    bool ok = true;                       // a permutation of {0..n-1}: fixes every index >= n
+    for (int v = n; v < 3; v++) ok = ok && perms[i][v] == v;
+    if (!ok) continue;
+    if (!symmetry && np >= 1) break;
+    M.pitab[np++] = (u32)perms[i][0] | ((u32)perms[i][1] << 2) | ((u32)perms[i][2] << 4);
+  }
+  M.np = np;
+  M.fixed = M.h0 + M.np;
+  M.assume_commit = assume_commit ? 1 : 0;
+  M.inv_mask = inv_mask;
+  M.max_bag = 64 - (M.fixed + 1);        // LDS stride of one staged record = 65 words (odd: conflict-free columns)
+  M.m0 = 4 * R + R * C * n;
+  for (int r = 0; r < 6; r++) M.salt_rep[r] = fmix64(0xA0761D6478BD642FULL + (u64)r);
+  out->symmetry = symmetry ? 1 : 0;
+  out->value_names.clear();
+  for (int v = 0; v < n; v++) out->value_names.push_back("v" + std::to_string(v + 1));
+  return 0;
+}
+
+std::string strip(const std::string& s) {
+  size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+  return a == std::string::npos ? "" : s.substr(a, b - a + 1);
+}
+
+// wire layout -> device layout (insert np zero H words); returns device length
+int wire_to_device(const Model& M, const u64* wire, u64* dev) {
+  int nmsg = hdr_nmsg(wire[0]);
+  for (int k = 0; k < M.h0; k++) dev[k] = wire[k];
+  for (int i = 0; i < M.np; i++) dev[M.h0 + i] = 0;
+  for (int j = 0; j < nmsg; j++) dev[M.fixed + j] = wire[M.h0 + j];
+  return M.fixed + nmsg;
+}
+int device_to_wire(const Model& M, const u64* dev, u64* wire) {
+  int nmsg = hdr_nmsg(dev[0]);
+  for (int k = 0; k < M.h0; k++) wire[k] = dev[k];
+  for (int j = 0; j < nmsg; j++) wire[M.h0 + j] = dev[M.fixed + j];
+  return M.h0 + nmsg;
+}
+
+void init_record_wire(const Model& M, std::vector<u64>& rec) {   // Init, VSR.tla:323-348
+  rec.assign(M.h0, 0);
+  for (int r = 1; r <= M.R; r++) {
+    u64 A = 0;
+    A = a_set_status(A, ST_NORMAL);        // rep_status = Normal            :328
+    A = a_set_view(A, 1);                  // rep_view_number = 1            :330
+    for (int c = 1; c <= M.C; c++) A = a_set_ctrow(A, c, ct_make(0, 0, 1));   // EmptyClientTableRow :318-321
+    rec[1 + (r - 1) * M.wpr] = A;          // everything else 0 / empty      :329-343
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vsrmc_last_error(void) { return g_err.c_str(); }
+int32_t vsrmc_version(void) { return 100; }
+int32_t vsrmc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t vsrmc_model_from_constants(int32_t R, int32_t C, int32_t n, int32_t L, int32_t restart, int32_t symmetry,
+                                   int32_t inv_mask, int32_t assume_commit, vsrmc_model** out) {
+  if (!out) return fail(VSRMC_E_ARG, "out is NULL");
+  vsrmc_model* m = new vsrmc_model();
+  int rc = build_model(R, C, n, L, restart, symmetry, inv_mask, assume_commit, m);
+  if (rc) { delete m; return rc; }
+  *out = m;
+  return 0;
+}
+
+// The TLC cfg grammar as used by VSR.cfg:1-39: CONSTANTS (name = int | name = {mv, ...} | name = mv), INIT, NEXT,
+// VIEW, SYMMETRY, INVARIANT[S] (multi-line list), CHECK_DEADLOCK, `\*` comments.  SPECIFICATION / PROPERTY are refused.
+int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model** out) {
+  if (!cfg_path || !out) return fail(VSRMC_E_ARG, "cfg_path / out is NULL");
+  if (tla_path) {
+    std::ifstream f(tla_path, std::ios::binary);
+    if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + tla_path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::string dig = sha256_hex(ss.str());
+    if (dig != VSR_TLA_SHA256)
+      return fail(VSRMC_E_CFG, std::string(tla_path) + ": sha256 " + dig + " is not the VSR.tla this build lowers (" +
+                                   VSR_TLA_SHA256 + "); refusing to check a module the action table was not derived from");
+  }
+  std::ifstream f(cfg_path);
+  if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + cfg_path);
+  std::map<std::string, std::string> consts;
+  std::vector<std::string> invariants;
+  std::string init, next, view, symmetry, line, section;
+  int check_deadlock = 0;   // TLC's default is TRUE; the BASELINE runs use -deadlock, see DESIGN.md
+  int lineno = 0;
+  static const char* KW[] = {"CONSTANTS", "CONSTANT", "INIT", "NEXT", "VIEW", "SYMMETRY", "INVARIANTS", "INVARIANT",
+                             "SPECIFICATION", "PROPERTIES", "PROPERTY", "CHECK_DEADLOCK", "CONSTRAINT", "CONSTRAINTS",
+                             "ACTION_CONSTRAINT", "ACTION_CONSTRAINTS", "ALIAS", "POSTCONDITION"};
+  while (std::getline(f, line)) {
+    lineno++;
+    size_t cpos = line.find("\\*");
+    if (cpos != std::string::npos) line = line.substr(0, cpos);
+    std::string rest = strip(line);
+    while (!rest.empty()) {
+      // leading keyword?
+      std::string tok = rest.substr(0, rest.find_first_of(" \t"));
+      bool is_kw = false;
+      for (const char* k : KW)
+        if (tok == k) is_kw = true;
+      if (is_kw) {
+        section = tok;
+        rest = strip(rest.substr(tok.size()));
+        if (section == "SPECIFICATION" || section == "PROPERTY" || section == "PROPERTIES" || section == "CONSTRAINT" ||
+            section == "CONSTRAINTS" || section == "ACTION_CONSTRAINT" || section == "ACTION_CONSTRAINTS" ||
+            section == "ALIAS" || section == "POSTCONDITION")
+          return fail(VSRMC_E_CFG, std::string(cfg_path) + ":" + std::to_string(lineno) + ": " + section +
+                                       " is not supported (only INIT/NEXT safety checking of VSR.tla is lowered)");
+        continue;
+      }
+      if (section == "CONSTANTS" || section == "CONSTANT") {
+        size_t eq = rest.find('=');
+        if (eq == std::string::npos)
+          return fail(VSRMC_E_CFG, std::string(cfg_path) + ":" + std::to_string(lineno) + ": expected `name = value`");
+        std::string name = strip(rest.substr(0, eq)), val = strip(rest.substr(eq + 1));
+        consts[name] = val;
+        rest.clear();
+      } else if (section == "INIT") { init = tok; rest = strip(rest.substr(tok.size())); }
+      else if (section == "NEXT") { next = tok; rest = strip(rest.substr(tok.size())); }
+      else if (section == "VIEW") { view = tok; rest = strip(rest.substr(tok.size())); }
+      else if (section == "SYMMETRY") { symmetry = tok; rest = strip(rest.substr(tok.size())); }
+      else if (section == "INVARIANT" || section == "INVARIANTS") { invariants.push_back(tok); rest = strip(rest.substr(tok.size())); }
+      else if (section == "CHECK_DEADLOCK") { check_deadlock = (tok == "TRUE"); rest = strip(rest.substr(tok.size())); }
+      else
+        return fail(VSRMC_E_CFG, std::string(cfg_path) + ":" + std::to_string(lineno) + ": unexpected text `" + rest + "`");
+    }
+  }
+  auto need_int = [&](const char* name, int* v) -> bool {
+    auto it = consts.find(name);
+    if (it == consts.end()) return false;
+    char* end = nullptr;
+    long x = std::strtol(it->second.c_str(), &end, 10);
+    if (end == it->second.c_str() || *end) return false;
+    *v = (int)x;
+    return true;
+  };
+  int R, C, L, restart;
+  if (!need_int("ReplicaCount", &R) || !need_int("ClientCount", &C) || !need_int("StartViewOnTimerLimit", &L) ||
+      !need_int("RestartEmptyLimit", &restart))
+    return fail(VSRMC_E_CFG, std::string(cfg_path) + ": CONSTANTS must bind ReplicaCount, ClientCount, "
+                                 "StartViewOnTimerLimit, RestartEmptyLimit to integers (VSR.cfg:4-8)");
+  std::vector<std::string> values;
+  {
+    auto it = consts.find("Values");
+    if (it == consts.end() || it->second.size() < 2 || it->second.front() != '{' || it->second.back() != '}')
+      return fail(VSRMC_E_CFG, std::string(cfg_path) + ": CONSTANTS must bind Values to a set of model values (VSR.cfg:6)");
+    std::string body = it->second.substr(1, it->second.size() - 2), item;
+    std::stringstream ss(body);
+    while (std::getline(ss, item, ',')) {
+      item = strip(item);
+      if (!item.empty()) values.push_back(item);
+    }
+  }
+  // the self-named model values of VSR.cfg:9-24
+  static const char* SELF[] = {"Normal", "ViewChange", "Recovering", "RequestMsg", "ReplyMsg", "PrepareMsg", "PrepareOkMsg",
+                               "CommitMsg", "StartViewChangeMsg", "DoViewChangeMsg", "StartViewMsg", "GetStateMsg",
+                               "NewStateMsg", "RecoveryMsg", "RecoveryResponseMsg", "Nil"};
+  for (const char* s : SELF) {
+    auto it = consts.find(s);
+    if (it == consts.end() || it->second != s)
+      return fail(VSRMC_E_CFG, std::string(cfg_path) + ": constant " + s + " must be bound to the model value " + s +
+                                   " (VSR.cfg:9-24)");
+  }
+  if (init != "Init" || next != "Next")
+    return fail(VSRMC_E_CFG, std::string(cfg_path) + ": expected INIT Init / NEXT Next (VSR.cfg:26-27)");
+  if (view != "view")
+    return fail(VSRMC_E_CFG, std::string(cfg_path) + ": expected VIEW view (VSR.cfg:29); state identity without the view is not lowered");
+  if (!symmetry.empty() && symmetry != "symmValues")
+    return fail(VSRMC_E_CFG, std::string(cfg_path) + ": SYMMETRY must be symmValues (VSR.cfg:31)");
+  int inv_mask = 0;
+  for (const std::string& iv : invariants) {
+    if (iv == "AcknowledgedWriteNotLost") inv_mask |= 1;            // VSR.tla:945-950
+    else if (iv == "AcknowledgedWritesExistOnMajority") inv_mask |= 2;   // VSR.tla:937-943
+    else if (iv == "NoLogDivergence") inv_mask |= 4;                // VSR.tla:926-931 (vacuous)
+    else if (iv == "TestInv") inv_mask |= 8;                        // VSR.tla:952
+    else return fail(VSRMC_E_CFG, std::string(cfg_path) + ": unknown INVARIANT " + iv);
+  }
+  vsrmc_model* m = new vsrmc_model();
+  int rc = build_model(R, C, (int)values.size(), L, restart, symmetry.empty() ? 0 : 1, inv_mask, 0, m);
+  if (rc) { delete m; return rc; }
+  m->value_names = values;
+  m->check_deadlock = check_deadlock;
+  *out = m;
+  return 0;
+}
+
+int32_t vsrmc_model_info(const vsrmc_model* m, vsrmc_layout* out) {
+  if (!m || !out) return fail(VSRMC_E_ARG, "NULL argument");
+  std::memset(out, 0, sizeof(*out));
+  const Model& M = m->M;
+  out->replica_count = M.R; out->client_count = M.C; out->value_count = M.n; out->start_view_on_timer_limit = M.L;
+  out->symmetry = m->symmetry; out->invariant_mask = M.inv_mask; out->assume_commit_number = M.assume_commit;
+  out->check_deadlock = m->check_deadlock;
+  out->words_per_replica = M.wpr; out->fixed_words = M.h0; out->permutations = M.np; out->max_bag = M.max_bag;
+  out->max_record_words = M.h0 + M.max_bag;
+  return 0;
+}
+
+int32_t vsrmc_model_init_state(const vsrmc_model* m, uint64_t* rec, int32_t cap, int32_t* n_words) {
+  if (!m || !rec || !n_words) return fail(VSRMC_E_ARG, "NULL argument");
+  std::vector<u64> r;
+  init_record_wire(m->M, r);
+  if ((int)r.size() > cap) return fail(VSRMC_E_ARG, "buffer too small");
+  std::copy(r.begin(), r.end(), rec);
+  *n_words = (int32_t)r.size();
+  return 0;
+}
+
+int32_t vsrmc_model_format_state(const vsrmc_model* m, const uint64_t* rec, char* buf, int64_t cap, int64_t* n) {
+  if (!m || !rec || !n) return fail(VSRMC_E_ARG, "NULL argument");
+  std::string s = format_state_tlc(m->M, m->value_names, rec);
+  *n = (int64_t)s.size() + 1;
+  if (buf && cap >= *n) std::memcpy(buf, s.c_str(), s.size() + 1);
+  else if (buf && cap > 0) return fail(VSRMC_E_ARG, "buffer too small");
+  return 0;
+}
+
+const char* vsrmc_action_name(int32_t a) {
+  static const char* const NAMES[16] = {"Initial predicate", "TimerSendSVC", "ReceiveHigherSVC", "ReceiveMatchingSVC",
+                                        "SendDVC", "ReceiveHigherDVC", "ReceiveMatchingDVC", "SendSV", "ReceiveSV",
+                                        "ReceiveClientRequest", "ReceivePrepareMsg", "ReceivePrepareOkMsg", "ExecuteOp",
+                                        "SendGetState", "ReceiveGetState", "ReceiveNewState"};   // VSR.tla:896-913
+  return (a >= 0 && a < 16) ? NAMES[a] : "?";
+}
+
+void vsrmc_model_destroy(vsrmc_model* m) { delete m; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// FPSet
+// ---------------------------------------------------------------------------------------------------------------
+struct vsrmc_fpset {
+  int device = 0;
+  u64 slots = 0;
+  Slot* table = nullptr;
+  u64* d_size = nullptr;
+  u32* d_err = nullptr;
+};
+
+namespace {
+int check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(VSRMC_E_HIP, "no HIP device: libvsrmc has no CPU fallback (the GPU path is the product)");
+  if (device < 0 || device >= n) return fail(VSRMC_E_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t vsrmc_fpset_create(int32_t device, int32_t log2_slots, vsrmc_fpset** out) {
+  if (!out || log2_slots < 4 || log2_slots > 36) return fail(VSRMC_E_ARG, "bad argument");
+  int rc = check_device(device);
+  if (rc) return rc;
+  vsrmc_fpset* s = new vsrmc_fpset();
+  s->device = device;
+  s->slots = (u64)1 << log2_slots;
+  hipError_t e = hipMalloc((void**)&s->table, s->slots * sizeof(Slot));
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_size, 16);
+  if (e != hipSuccess) { delete s; return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  s->d_err = (u32*)(s->d_size + 1);
+  HIPCHK(hipMemset(s->table, 0, s->slots * sizeof(Slot)));
+  HIPCHK(hipMemset(s->d_size, 0, 16));
+  *out = s;
+  return 0;
+}
+
+int32_t vsrmc_fpset_put_batch_device(vsrmc_fpset* s, const uint64_t* d_fps, uint64_t n, uint8_t* d_was, void* stream) {
+  if (!s) return fail(VSRMC_E_ARG, "NULL handle");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_fpset_put, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->table, s->slots - 1,
+                     d_fps, n, d_was, s->d_size, s->d_err);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int32_t vsrmc_fpset_contains_batch_device(vsrmc_fpset* s, const uint64_t* d_fps, uint64_t n, uint8_t* d_present, void* stream) {
+  if (!s) return fail(VSRMC_E_ARG, "NULL handle");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_fpset_contains, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->table,
+                     s->slots - 1, d_fps, n, d_present);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int fpset_host_batch(vsrmc_fpset* s, const uint64_t* fps, uint64_t n, uint8_t* res, bool put) {
+  if (!s || (n && (!fps || !res))) return fail(VSRMC_E_ARG, "NULL argument");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(s->device));
+  u64* d_fps = nullptr;
+  uint8_t* d_res = nullptr;
+  HIPCHK(hipMalloc((void**)&d_fps, n * 8));
+  hipError_t e = hipMalloc((void**)&d_res, n);
+  if (e != hipSuccess) { (void)hipFree(d_fps); return fail(VSRMC_E_HIP, "hipMalloc"); }
+  int rc = 0;
+  e = hipMemcpy(d_fps, fps, n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = put ? vsrmc_fpset_put_batch_device(s, d_fps, n, d_res, nullptr) : vsrmc_fpset_contains_batch_device(s, d_fps, n, d_res, nullptr);
+    if (!rc) e = hipMemcpy(res, d_res, n, hipMemcpyDeviceToHost);
+  }
+  u32 err = 0;
+  if (e == hipSuccess) e = hipMemcpy(&err, s->d_err, 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d_fps);
+  (void)hipFree(d_res);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(VSRMC_E_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+  if (err) return fail(VSRMC_E_REP, "fingerprint set is full");
+  return 0;
+}
+int32_t vsrmc_fpset_put_batch(vsrmc_fpset* s, const uint64_t* fps, uint64_t n, uint8_t* was_present) {
+  return fpset_host_batch(s, fps, n, was_present, true);
+}
+int32_t vsrmc_fpset_contains_batch(vsrmc_fpset* s, const uint64_t* fps, uint64_t n, uint8_t* present) {
+  return fpset_host_batch(s, fps, n, present, false);
+}
+int32_t vsrmc_fpset_size(vsrmc_fpset* s, uint64_t* size) {
+  if (!s || !size) return fail(VSRMC_E_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipMemcpy(size, s->d_size, 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+void vsrmc_fpset_destroy(vsrmc_fpset* s) {
+  if (!s) return;
+  if (s->table) (void)hipFree(s->table);
+  if (s->d_size) (void)hipFree(s->d_size);
+  delete s;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// expand_batch / fingerprint_batch
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// upload n wire records as device-layout records with their H words filled in
+int upload_records(const Model& M, const u64* words, const u64* off, u64 n, u64** d_words, u64** d_off, u64* total_words) {
+  std::vector<u64> dev, doff(n + 1);
+  dev.reserve((size_t)(off[n] + n * M.np));
+  std::vector<u64> tmp(512);
+  for (u64 i = 0; i < n; i++) {
+    doff[i] = dev.size();
+    const u64* w = words + off[i];
+    int nmsg = hdr_nmsg(w[0]);
+    if ((u64)(M.h0 + nmsg) != off[i + 1] - off[i]) return fail(VSRMC_E_ARG, "record length does not match its header");
+    if (nmsg > M.max_bag) return fail(VSRMC_E_REP, "record bag larger than max_bag");
+    int len = wire_to_device(M, w, tmp.data());
+    dev.insert(dev.end(), tmp.begin(), tmp.begin() + len);
+  }
+  doff[n] = dev.size();
+  *total_words = dev.size();
+  HIPCHK(hipMalloc((void**)d_words, std::max<size_t>(dev.size(), 1) * 8));
+  HIPCHK(hipMalloc((void**)d_off, (n + 1) * 8));
+  HIPCHK(hipMemcpy(*d_words, dev.data(), dev.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(*d_off, doff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_hash_records, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, *d_words, *d_off, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vsrmc_expand_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off, uint64_t n,
+                           uint64_t* out_words, uint64_t out_words_cap, uint64_t* out_meta, uint64_t out_cap,
+                           uint64_t* n_out, uint64_t* words_out) {
+  if (!m || !words || !off || !out_words || !out_meta || !n_out || !words_out) return fail(VSRMC_E_ARG, "NULL argument");
+  int rc = check_device(device);
+  if (rc) return rc;
+  const Model& M = m->M;
+  *n_out = 0;
+  *words_out = 0;
+  if (n == 0) return 0;
+  u64 *d_words = nullptr, *d_off = nullptr, *d_ow = nullptr, *d_om = nullptr, *d_cnt = nullptr, total = 0;
+  rc = upload_records(M, words, off, n, &d_words, &d_off, &total);
+  if (rc) return rc;
+  u64 dev_words_cap = out_words_cap + out_cap * (u64)M.np;
+  HIPCHK(hipMalloc((void**)&d_ow, std::max<u64>(dev_words_cap, 1) * 8));
+  HIPCHK(hipMalloc((void**)&d_om, std::max<u64>(out_cap, 1) * 64));
+  HIPCHK(hipMalloc((void**)&d_cnt, 32));
+  HIPCHK(hipMemset(d_cnt, 0, 32));
+  hipLaunchKernelGGL(k_successors, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, d_words, d_off, n, d_ow, dev_words_cap,
+                     d_om, out_cap, d_cnt);
+  HIPCHK(hipGetLastError());
+  u64 cnt[4];
+  HIPCHK(hipMemcpy(cnt, d_cnt, 32, hipMemcpyDeviceToHost));
+  int ret = 0;
+  if (cnt[2]) {
+    ret = fail(VSRMC_E_ARG, "successor buffers too small");
+  } else {
+    std::vector<u64> hw(cnt[1]), hm(cnt[0] * 8);
+    HIPCHK(hipMemcpy(hw.data(), d_ow, cnt[1] * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hm.data(), d_om, cnt[0] * 64, hipMemcpyDeviceToHost));
+    // deterministic (parent, ordinal) order
+    std::vector<u64> order(cnt[0]);
+    for (u64 k = 0; k < cnt[0]; k++) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](u64 a, u64 b) {
+      if (hm[8 * a] != hm[8 * b]) return hm[8 * a] < hm[8 * b];
+      return hm[8 * a + 1] < hm[8 * b + 1];
+    });
+    u64 wpos = 0;
+    for (u64 k = 0; k < cnt[0] && !ret; k++) {
+      const u64* mm = &hm[8 * order[k]];
+      const u64* dev = &hw[mm[7]];
+      int evalerr = (int)mm[6];
+      int wl = evalerr ? 0 : M.h0 + hdr_nmsg(dev[0]);
+      if (wpos + (u64)wl > out_words_cap) { ret = fail(VSRMC_E_ARG, "successor word buffer too small"); break; }
+      if (!evalerr) device_to_wire(M, dev, out_words + wpos);
+      for (int q = 0; q < 7; q++) out_meta[8 * k + q] = mm[q];
+      out_meta[8 * k + 7] = wpos;
+      wpos += (u64)wl;
+    }
+    *n_out = cnt[0];
+    *words_out = wpos;
+  }
+  (void)hipFree(d_words); (void)hipFree(d_off); (void)hipFree(d_ow); (void)hipFree(d_om); (void)hipFree(d_cnt);
+  return ret;
+}
+
+int32_t vsrmc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off, uint64_t n,
+                                uint64_t* fps, uint32_t* auxkeys) {
+  if (!m || !words || !off || !fps) return fail(VSRMC_E_ARG, "NULL argument");
+  int rc = check_device(device);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  const Model& M = m->M;
+  u64 *d_words = nullptr, *d_off = nullptr, total = 0;
+  rc = upload_records(M, words, off, n, &d_words, &d_off, &total);
+  if (rc) return rc;
+  std::vector<u64> dev(total), doff(n + 1);
+  HIPCHK(hipMemcpy(dev.data(), d_words, total * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(doff.data(), d_off, (n + 1) * 8, hipMemcpyDeviceToHost));
+  for (u64 i = 0; i < n; i++) {   // the hashes were computed on the GPU (k_hash_records); only the final min is here
+    u64 fp;
+    u32 ak;
+    canonical_fp(M, dev[doff[i]], &dev[doff[i] + M.h0], &fp, &ak);
+    fps[i] = fp;
+    if (auxkeys) auxkeys[i] = ak;
+  }
+  (void)hipFree(d_words); (void)hipFree(d_off);
+  return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// checker
+// ---------------------------------------------------------------------------------------------------------------
+struct vsrmc_checker {
+  vsrmc_model model;
+  vsrmc_options opt;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  Slot* table = nullptr;
+  u64 tmask = 0;
+  u64* words[2] = {nullptr, nullptr};
+  u64* off[2] = {nullptr, nullptr};
+  u64* lvl_fp = nullptr;
+  u64* lvl_tr = nullptr;
+  u64* pending = nullptr;
+  LevelCtl* ctl = nullptr;
+  u64* d_find = nullptr;
+  int cur = 0;
+  int level = 0;
+  u64 n_frontier = 0;
+  u64 distinct = 0, total_generated = 0;
+  int num_cus = 256;
+  int lds_stride = 65;
+  int failed = 0;
+  std::vector<std::vector<u64>> trace;   // per level: meta key (parent index, ordinal) of every state
+};
+
+extern "C" {
+
+void vsrmc_options_default(vsrmc_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->device = 0;
+  o->table_log2 = 26;
+  o->frontier_words = (uint64_t)1 << 27;
+  o->frontier_states = (uint64_t)1 << 22;
+  o->pending_entries = (uint64_t)1 << 23;
+  o->keep_trace = 1;
+  o->rank = 0;
+  o->world = 1;
+}
+
+int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc_checker** out) {
+  if (!m || !o || !out) return fail(VSRMC_E_ARG, "NULL argument");
+  if (o->table_log2 < 8 || o->table_log2 > 36 || o->frontier_states < 1 || o->frontier_words < 256 || o->pending_entries < 1)
+    return fail(VSRMC_E_ARG, "bad options");
+  int rc = check_device(o->device);
+  if (rc) return rc;
+  vsrmc_checker* c = new vsrmc_checker();
+  c->model = *m;
+  c->opt = *o;
+  const Model& M = c->model.M;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, o->device));
+  c->num_cus = prop.multiProcessorCount;
+  c->lds_stride = (M.fixed + M.max_bag) | 1;
+  HIPCHK(hipStreamCreate(&c->stream));
+  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+  u64 slots = (u64)1 << o->table_log2;
+  c->tmask = slots - 1;
+  hipError_t e = hipMalloc((void**)&c->table, slots * sizeof(Slot));
+  for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    e = hipMalloc((void**)&c->words[b], o->frontier_words * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->off[b], (o->frontier_states + 1) * 8);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&c->lvl_fp, o->frontier_states * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->lvl_tr, o->frontier_states * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->pending, o->pending_entries * 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ctl, sizeof(LevelCtl));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_find, 8);
+  if (e != hipSuccess) {
+    vsrmc_checker_destroy(c);
+    return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  // empty table: fp = 0, meta = all ones
+  hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, slots);
+  HIPCHK(hipGetLastError());
+  // Init (ModelChecker.doInit)
+  std::vector<u64> wire, dev(512);
+  init_record_wire(M, wire);
+  int len = wire_to_device(M, wire.data(), dev.data());
+  u64 H[6];
+  hash_full(M, (const u64*)dev.data(), H);   // pure arithmetic on the constant Init record (same code as the kernels)
+  for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
+  u64 zero = 0;
+  HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->off[0], &zero, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(LevelCtl), c->stream));
+  hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->lvl_tr, c->ctl);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->cur = 0;
+  c->level = 1;
+  c->n_frontier = 1;
+  c->distinct = 1;
+  if (o->keep_trace) {
+    c->trace.emplace_back(1);
+    HIPCHK(hipMemcpy(c->trace[0].data(), c->lvl_tr, 8, hipMemcpyDeviceToHost));
+  }
+  *out = c;
+  return 0;
+}
+
+int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
+  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  std::memset(info, 0, sizeof(*info));
+  const Model& M = c->model.M;
+  HIPCHK(hipSetDevice(c->opt.device));
+  double t0 = now_s();
+  const int cur = c->cur, nxt = cur ^ 1;
+  const int new_level = c->level + 1;
+  if (new_level >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
+  LevelCtl h;
+  std::memset(&h, 0, sizeof(h));
+  h.viol_fp = ~(u64)0;
+  HIPCHK(hipMemcpyAsync(c->ctl, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  info->frontier = c->n_frontier;
+  if (c->n_frontier > 0) {
+    u64 ntiles = (c->n_frontier + VSR_TILE - 1) / VSR_TILE;
+    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 8);
+    size_t lds = (size_t)VSR_TILE * c->lds_stride * 8 + VSR_CAND_CAP * 4;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(k_expand, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[cur], c->off[cur], c->n_frontier,
+                       new_level, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, c->lds_stride);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(&h, c->ctl, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->n_frontier > 0) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    info->expand_ms = ms;
+  }
+  u64 n_pending = h.n_pending;
+  if (!h.err && n_pending > 0) {
+    if (n_pending > c->opt.pending_entries) n_pending = c->opt.pending_entries;
+    unsigned grid = (unsigned)std::min<u64>((n_pending + VSR_BLOCK - 1) / VSR_BLOCK, (u64)c->num_cus * 16);
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_materialize, dim3(grid), dim3(VSR_BLOCK), 0, c->stream, M, c->words[cur], c->off[cur], c->pending,
+                       n_pending, c->table, c->words[nxt], c->opt.frontier_words, c->off[nxt], c->opt.frontier_states, c->lvl_fp,
+                       c->lvl_tr, c->ctl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(hipMemcpyAsync(&h, c->ctl, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    info->materialize_ms = ms;
+  }
+  info->generated = h.generated;
+  info->deadlocks = h.deadlocks;
+  info->pending = h.n_pending;
+  info->probes = h.probes;
+  info->max_bag = h.max_bag;
+  for (int a = 0; a < 16; a++) info->act_generated[a] = h.act_generated[a];
+  info->error_code = (int32_t)h.err;
+  info->viol_fp = ~(u64)0;
+  info->viol_index = ~(u64)0;
+  if (h.err) {
+    // like a TLC evaluation error: the run aborts, the partial level is not committed
+    c->failed = 1;
+    info->level = c->level;
+    info->distinct = c->distinct;
+    info->total_generated = c->total_generated;
+    info->seconds = now_s() - t0;
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "device error %u at frontier index %llu ordinal %llu (level %d)", h.err,
+                  (unsigned long long)(h.err_info >> 16), (unsigned long long)(h.err_info & 0xFFFF), new_level);
+    std::string msg = buf;
+    if (h.err == ERR_EVAL_421) msg = "VSR.tla:421: record has no field 'commit' (ReceivePrepareMsg, ClientCount >= 2); " + msg;
+    return fail(h.err < ERR_REP_RANGE ? VSRMC_E_EVAL : VSRMC_E_REP, msg);
+  }
+  u64 n_new = h.n_new;
+  c->total_generated += h.generated;
+  info->n_new = n_new;
+  info->words_new = h.words_new;
+  if (n_new > 0) {
+    if (c->opt.keep_trace) {
+      c->trace.emplace_back(n_new);
+      HIPCHK(hipMemcpy(c->trace.back().data(), c->lvl_tr, n_new * 8, hipMemcpyDeviceToHost));
+    }
+    c->cur = nxt;
+    c->level = new_level;
+    c->distinct += n_new;
+  }
+  c->n_frontier = n_new;
+  if (h.viol_fp != ~(u64)0) {
+    info->viol_fp = h.viol_fp;
+    info->viol_mask = (int32_t)h.viol_mask;
+    u64 big = ~(u64)0;
+    HIPCHK(hipMemcpy(c->d_find, &big, 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_find_fp, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, c->stream, c->lvl_fp, n_new, h.viol_fp, c->d_find);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(&info->viol_index, c->d_find, 8, hipMemcpyDeviceToHost));
+  }
+  info->level = c->level;
+  info->distinct = c->distinct;
+  info->total_generated = c->total_generated;
+  info->seconds = now_s() - t0;
+  return 0;
+}
+
+int32_t vsrmc_checker_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return fail(VSRMC_E_ARG, "NULL argument");
+  *n = c->n_frontier;
+  if (!out || cap < c->n_frontier) return fail(VSRMC_E_ARG, "buffer too small");
+  HIPCHK(hipSetDevice(c->opt.device));
+  HIPCHK(hipMemcpy(out, c->lvl_fp, c->n_frontier * 8, hipMemcpyDeviceToHost));
+  std::sort(out, out + c->n_frontier);
+  return 0;
+}
+
+int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, uint64_t cap_states,
+                               uint64_t* n) {
+  if (!c || !n || !words || !off) return fail(VSRMC_E_ARG, "NULL argument");
+  const Model& M = c->model.M;
+  *n = c->n_frontier;
+  if (cap_states < c->n_frontier + 1) return fail(VSRMC_E_ARG, "offset buffer too small");
+  HIPCHK(hipSetDevice(c->opt.device));
+  std::vector<u64> doff(c->n_frontier);
+  HIPCHK(hipMemcpy(doff.data(), c->off[c->cur], c->n_frontier * 8, hipMemcpyDeviceToHost));
+  u64 hi = 0;
+  for (u64 o : doff) hi = std::max(hi, o);
+  std::vector<u64> dev(hi + (u64)M.fixed + 256);
+  u64 take = std::min<u64>(dev.size(), c->opt.frontier_words);
+  HIPCHK(hipMemcpy(dev.data(), c->words[c->cur], take * 8, hipMemcpyDeviceToHost));
+  u64 pos = 0;
+  for (u64 i = 0; i < c->n_frontier; i++) {
+    const u64* r = &dev[doff[i]];
+    u64 wl = (u64)M.h0 + hdr_nmsg(r[0]);
+    if (pos + wl > cap_words) return fail(VSRMC_E_ARG, "word buffer too small");
+    off[i] = pos;
+    device_to_wire(M, r, words + pos);
+    pos += wl;
+  }
+  off[c->n_frontier] = pos;
+  return 0;
+}
+
+int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words, uint64_t* off,
+                            int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
+  if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
+  if (!c->opt.keep_trace) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
+  if (level < 1 || level > (int)c->trace.size() || index >= c->trace[level - 1].size())
+    return fail(VSRMC_E_ARG, "no such state");
+  const Model& M = c->model.M;
+  if (cap_states < (u64)level + 1) return fail(VSRMC_E_ARG, "state buffers too small");
+  // walk the (parent index, ordinal) log back to Init (TLCTrace.getTrace), then re-execute forward on the GPU
+  std::vector<u32> ords(level > 1 ? level - 1 : 1);
+  u64 idx = index;
+  for (int l = level; l >= 2; l--) {
+    u64 key = c->trace[l - 1][idx];
+    ords[l - 2] = (u32)meta_ord(key);
+    idx = meta_pidx(key);
+  }
+  int nsteps = level - 1;
+  HIPCHK(hipSetDevice(c->opt.device));
+  u64 maxw = (u64)(M.fixed + M.max_bag + 8) * (u64)level;
+  u64 *d_w = nullptr, *d_o = nullptr, *d_m = nullptr;
+  u32* d_ords = nullptr;
+  HIPCHK(hipMalloc((void**)&d_w, maxw * 8));
+  HIPCHK(hipMalloc((void**)&d_o, ((u64)level + 1) * 8));
+  HIPCHK(hipMalloc((void**)&d_m, (u64)std::max(nsteps, 1) * 32));
+  HIPCHK(hipMalloc((void**)&d_ords, (u64)std::max(nsteps, 1) * 4));
+  std::vector<u64> wire, dev(512);
+  init_record_wire(M, wire);
+  int len = wire_to_device(M, wire.data(), dev.data());
+  u64 H[6];
+  hash_full(M, (const u64*)dev.data(), H);
+  for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
+  HIPCHK(hipMemcpy(d_w, dev.data(), len * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d_m, 0, (u64)std::max(nsteps, 1) * 32));
+  if (nsteps > 0) HIPCHK(hipMemcpy(d_ords, ords.data(), (u64)nsteps * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, c->stream, M, d_w, d_o, d_ords, nsteps, d_m);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<u64> hw(maxw), ho(level + 1), hm((size_t)std::max(nsteps, 1) * 4);
+  HIPCHK(hipMemcpy(ho.data(), d_o, ((u64)level + 1) * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hw.data(), d_w, maxw * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hm.data(), d_m, (u64)std::max(nsteps, 1) * 32, hipMemcpyDeviceToHost));
+  (void)hipFree(d_w); (void)hipFree(d_o); (void)hipFree(d_m); (void)hipFree(d_ords);
+  u64 pos = 0;
+  for (int t = 0; t < level; t++) {
+    const u64* r = &hw[ho[t]];
+    u64 wl = (u64)M.h0 + hdr_nmsg(r[0]);
+    if (pos + wl > cap_words) return fail(VSRMC_E_ARG, "word buffer too small");
+    off[t] = pos;
+    device_to_wire(M, r, words + pos);
+    pos += wl;
+    actions[t] = t == 0 ? 0 : (int32_t)hm[4 * (t - 1)];
+    if (t > 0 && hm[4 * (t - 1) + 3]) return fail(VSRMC_E_STATE, "trace replay hit a disabled or failing step");
+  }
+  off[level] = pos;
+  *n_states = (u64)level;
+  return 0;
+}
+
+void vsrmc_checker_destroy(vsrmc_checker* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->opt.device);
+  if (c->table) (void)hipFree(c->table);
+  for (int b = 0; b < 2; b++) {
+    if (c->words[b]) (void)hipFree(c->words[b]);
+    if (c->off[b]) (void)hipFree(c->off[b]);
+  }
+  if (c->lvl_fp) (void)hipFree(c->lvl_fp);
+  if (c->lvl_tr) (void)hipFree(c->lvl_tr);
+  if (c->pending) (void)hipFree(c->pending);
+  if (c->ctl) (void)hipFree(c->ctl);
+  if (c->d_find) (void)hipFree(c->d_find);
+  for (int i = 0; i < 4; i++)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+}  // extern "C"
