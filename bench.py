@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""bench.py — distinct states/s of the GPU BFS model checker on BASELINE.json's 1-GPU configuration.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one complete run of the hot path: level-synchronous BFS of VSR.tla under the shipped VSR.cfg constants
+(BASELINE.json configs[1]: ReplicaCount=3, ClientCount=1, Values={v1,v2}, StartViewOnTimerLimit=2, VIEW + SYMMETRY on,
+INVARIANT AcknowledgedWriteNotLost) from Init until the level that contains the first invariant violation is complete —
+28 levels, 319 228 361 distinct states, 942 M successors generated; the seen-set is cleared at the start of every step,
+HBM allocations are reused.  Inputs are the model itself (deterministic, no data files): "synthetic" in the contract's
+sense.  Timed region: barrier + torch.cuda.synchronize() on both sides, max over ranks, exactly K steps.
+
+N > 1: the seen-set is sharded by the high fingerprint bits, one rank per GPU, successors routed to their owner with
+an all-to-all per level (vsr-tlaplus_amd/sharded.py); total work is fixed as N grows ("strong").
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (k_expand, HIP-event time on the checker's stream)
+and `cpu_baseline` = the CPU oracle (a port, not TLC) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIG = dict(R=3, C=1, n=2, L=2)                     # BASELINE.json configs[1] = /root/reference/.../VSR.cfg:4-8
+EXPECT = dict(distinct=319228361, depth=28, viol_fp=0x22239cb457b78204)   # tests/golden/config2_violation.json
+HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(seconds=15.0):
+    """CPU oracle (oracle/, single thread) on the same config for a bounded time; states/s over the levels it finishes."""
+    exe = os.path.join(ROOT, "oracle", "build", "vsr_oracle")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
+    out = subprocess.run([exe, str(CONFIG["R"]), str(CONFIG["C"]), str(CONFIG["n"]), str(CONFIG["L"]), "--max-seconds",
+                          str(seconds), "--quiet"], capture_output=True, text=True, check=True).stdout
+    s = json.loads(out.strip().splitlines()[-1])
+    return dict(value=round(s["states_per_s"], 1), unit="distinct states/s", cores=1, kind="port",
+                sample="oracle/vsr_oracle (C++ restatement of VSR.tla, not TLC) on the same config for %.0f s: %d distinct "
+                       "states, %d BFS levels" % (s["seconds"], s["distinct"], s["depth"]))
+
+
+def run_single(args):
+    import torch
+    import vsr_tlaplus_amd as vt
+    torch.cuda.set_device(0)
+    m = vt.Model.from_constants(R=CONFIG["R"], C_=CONFIG["C"], n=CONFIG["n"], L=CONFIG["L"])
+    mc = vt.ModelChecker(m, device=0, table_log2=30, frontier_words=1 << 32, frontier_states=1 << 27,
+                         pending_entries=1 << 28, keep_trace=True, trace_entries=1 << 29)
+    S = dict(expand_ms=0.0, mat_ms=0.0, launches=0, alg_bytes=0.0, distinct=0, generated=0, ttfv=[], words=0)
+
+    def one_run(record):
+        mc.reset()
+        t0 = time.perf_counter()
+        cur_words = int(m.layout.fixed_words) + int(m.layout.permutations)      # Init record, device layout
+        while True:
+            d = mc.step()
+            if record and d["frontier"]:
+                S["expand_ms"] += d["expand_ms"]
+                S["mat_ms"] += d["materialize_ms"]
+                S["launches"] += 1
+                # algorithmic bytes of one k_expand launch: every frontier record read once,
+                # one 8-byte key read per generated successor, one 8-byte key write per newly inserted fingerprint
+                S["alg_bytes"] += 8.0 * cur_words + 8.0 * d["generated"] + 8.0 * d["n_new"]
+                S["generated"] += d["generated"]
+                S["words"] += d["words_new"]
+            cur_words = d["words_new"]
+            if d["n_new"] == 0 or mc.violation is not None:
+                break
+        if mc.violation is not None:
+            tr = mc.trace(mc.violation["level"], mc.violation["index"])       # counter-example reconstructed = found
+            assert len(tr) == mc.violation["level"]
+        dt = time.perf_counter() - t0
+        assert mc.distinct == EXPECT["distinct"] and mc.level == EXPECT["depth"], (mc.distinct, mc.level)
+        assert mc.violation and mc.violation["fp"] == EXPECT["viol_fp"]
+        if record:
+            S["distinct"] += mc.distinct
+            S["ttfv"].append(dt)
+
+    for _ in range(args.warmup):
+        one_run(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_run(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return elapsed, S, m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from vsr_tlaplus_amd import sharded_bench
+        return sharded_bench.main(args, CONFIG, EXPECT)
+    elapsed, S, m = run_single(args)
+    value = S["distinct"] / elapsed
+    avg_launch_s = S["expand_ms"] / 1e3 / max(1, S["launches"])
+    achieved = S["alg_bytes"] / max(1, S["launches"]) / avg_launch_s / 1e9
+    g = S["generated"] / S["distinct"]
+    s_bytes = 8.0 * S["words"] / S["distinct"]
+    out = {
+        "metric": "distinct states/sec (whole node), VSR 3-replica", "value": round(value, 1), "unit": "distinct states/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 "
+                               "(BASELINE configs[1] = shipped VSR.cfg), VIEW+SYMMETRY, to first violation: 28 levels, "
+                               "319228361 distinct states", "table_slots_log2": 30, "trace_log": True},
+        "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
+        "generated_per_distinct": round(g, 3), "record_bytes": round(s_bytes, 1),
+        "roofline": {"bound": "hbm", "kernel": "k_expand", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": S["launches"],
+                     "pipeline_alg_GBps": round((2 * s_bytes + 8 * g + 8) * value / 1e9, 2),
+                     "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3),
+                                            "k_materialize": round(S["mat_ms"] / args.steps, 3)}},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

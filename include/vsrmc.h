@@ -95,9 +95,10 @@ typedef struct vsrmc_options {
   uint64_t frontier_words;       /* capacity of each of the two frontier buffers, in 8-byte words */
   uint64_t frontier_states;      /* capacity of each frontier in states */
   uint64_t pending_entries;      /* capacity of the per-level pending list (16 B each) */
-  int32_t keep_trace;            /* 1 = keep (parent, ordinal) per state on the host for counter-examples */
+  int32_t keep_trace;            /* 1 = keep the (parent, ordinal) log in HBM for counter-examples (TLCTrace) */
   int32_t rank, world;           /* shard of the seen-set owned by this process (world = 1: everything) */
-  int32_t reserved[8];
+  uint64_t trace_entries;        /* capacity of that log in states (8 B each); 0 = 8 x frontier_states */
+  int32_t reserved[6];
 } vsrmc_options;
 
 typedef struct vsrmc_level_info {
@@ -125,6 +126,8 @@ typedef struct vsrmc_level_info {
 
 void vsrmc_options_default(vsrmc_options* o);
 int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc_checker** out);
+/* back to the initial state: clears the seen-set and the trace log, keeps every allocation (≙ a fresh TLC run) */
+int32_t vsrmc_checker_reset(vsrmc_checker* c);
 /* expand the newest level by one BFS step; info->n_new == 0 means the search is exhausted */
 int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info);
 /* sorted fingerprints of the newest level */

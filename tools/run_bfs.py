@@ -56,3 +56,4 @@ if mc.violation:
     tr = mc.trace(mc.violation["level"], mc.violation["index"])
     print("trace length", len(tr), [t[0] for t in tr])
     print(m.format_state(tr[-1][1]))
+    print(json.dumps(dict(trace=[dict(action=t[0], words=["%016x" % int(w) for w in t[1]]) for t in tr])))

@@ -18,7 +18,7 @@ class Layout(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("table_log2", C.c_int32), ("frontier_words", C.c_uint64),
                 ("frontier_states", C.c_uint64), ("pending_entries", C.c_uint64), ("keep_trace", C.c_int32),
-                ("rank", C.c_int32), ("world", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("rank", C.c_int32), ("world", C.c_int32), ("trace_entries", C.c_uint64), ("reserved", C.c_int32 * 6)]
 
 
 class LevelInfo(C.Structure):
@@ -60,6 +60,7 @@ SYMBOLS = {
     "vsrmc_fingerprint_batch": (C.c_int32, [V, C.c_int32, V, V, C.c_uint64, V, V]),
     "vsrmc_options_default": (None, [C.POINTER(Options)]),
     "vsrmc_checker_create": (C.c_int32, [V, C.POINTER(Options), C.POINTER(V)]),
+    "vsrmc_checker_reset": (C.c_int32, [V]),
     "vsrmc_checker_step": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_checker_level_fps": (C.c_int32, [V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_frontier": (C.c_int32, [V, V, C.c_uint64, V, C.c_uint64, C.POINTER(C.c_uint64)]),

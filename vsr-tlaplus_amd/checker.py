@@ -162,21 +162,30 @@ class ModelChecker:
     """≙ tlc2.tool.ModelChecker: level-synchronous BFS; `step()` = every Worker draining one level of the StateQueue."""
 
     def __init__(self, model, device=0, table_log2=24, frontier_words=1 << 25, frontier_states=1 << 20,
-                 pending_entries=1 << 21, keep_trace=True):
+                 pending_entries=1 << 21, keep_trace=True, trace_entries=0):
         self.model = model
         o = capi.Options()
         capi.load().vsrmc_options_default(C.byref(o))
         o.device, o.table_log2 = device, table_log2
         o.frontier_words, o.frontier_states, o.pending_entries = frontier_words, frontier_states, pending_entries
         o.keep_trace = int(keep_trace)
+        o.trace_entries = trace_entries
         self.options = o
         self._h = C.c_void_p()
         check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))
+        self._fresh()
+
+    def _fresh(self):
         self.level = 1
         self.n_frontier = 1
         self.distinct = 1
         self.levels = [dict(level=1, n_new=1, generated=0, deadlocks=0)]
         self.violation = None
+
+    def reset(self):
+        """Back to Init with an empty seen-set; keeps the HBM allocations (a fresh TLC run on the same model)."""
+        check(capi.load().vsrmc_checker_reset(self._h))
+        self._fresh()
 
     def step(self):
         info = capi.LevelInfo()

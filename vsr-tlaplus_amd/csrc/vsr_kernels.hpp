@@ -305,7 +305,7 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
       }
       nx_off[idx] = dst;
       lvl_fp[idx] = fp;
-      lvl_tr[idx] = key;
+      if (lvl_tr) lvl_tr[idx] = key;
       if (bad) {
         atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
         atomicOr(&ctl->viol_mask, (u32)bad);
@@ -334,9 +334,21 @@ __global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl
   u32 np = 0;
   table_claim(table, tmask, fp, key, 1, &found_old, &np, &full);
   lvl_fp[0] = fp;
-  lvl_tr[0] = key;
+  if (lvl_tr) lvl_tr[0] = key;
   ctl->n_new = 1;
   ctl->words_new = (u64)(M.fixed + hdr_nmsg(rec[0]));
+}
+
+// TLCTrace.getTrace, backwards half: follow the (parent index, ordinal) log from state `idx` of level `level` to Init.
+// tr_all holds one meta key per state, level l (1-based) starting at level_base[l-1]; ords[l-2] = ordinal of the step
+// into level l.
+__global__ void k_trace_walk(const u64* tr_all, const u64* level_base, int level, u64 idx, u32* ords) {
+  if (threadIdx.x || blockIdx.x) return;
+  for (int l = level; l >= 2; l--) {
+    u64 key = tr_all[level_base[l - 1] + idx];
+    ords[l - 2] = (u32)meta_ord(key);
+    idx = meta_pidx(key);
+  }
 }
 
 // index of the record of the newest level whose fingerprint is `fp`

@@ -583,7 +583,6 @@ struct vsrmc_checker {
   u64* words[2] = {nullptr, nullptr};
   u64* off[2] = {nullptr, nullptr};
   u64* lvl_fp = nullptr;
-  u64* lvl_tr = nullptr;
   u64* pending = nullptr;
   LevelCtl* ctl = nullptr;
   u64* d_find = nullptr;
@@ -594,8 +593,44 @@ struct vsrmc_checker {
   int num_cus = 256;
   int lds_stride = 65;
   int failed = 0;
-  std::vector<std::vector<u64>> trace;   // per level: meta key (parent index, ordinal) of every state
+  u64* tr_all = nullptr;                 // TLCTrace: one meta key (parent index, ordinal) per state, level after level
+  u64 trace_cap = 0;
+  u64* d_level_base = nullptr;           // device copy of level_base (512 entries)
+  std::vector<u64> level_base;           // index of the first state of each level in tr_all
+  std::vector<u64> level_size;
 };
+
+namespace {
+// Put the checker in its initial state (ModelChecker.doInit): empty seen-set, Init in frontier 0 and in the set.
+int checker_seed(vsrmc_checker* c) {
+  const Model& M = c->model.M;
+  HIPCHK(hipSetDevice(c->opt.device));
+  hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
+  HIPCHK(hipGetLastError());
+  std::vector<u64> wire, dev(512);
+  init_record_wire(M, wire);
+  int len = wire_to_device(M, wire.data(), dev.data());
+  u64 H[6];
+  hash_full(M, (const u64*)dev.data(), H);   // pure arithmetic on the constant Init record (same code as the kernels)
+  for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
+  u64 zero = 0;
+  HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->off[0], &zero, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(LevelCtl), c->stream));
+  hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->tr_all, c->ctl);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->cur = 0;
+  c->level = 1;
+  c->n_frontier = 1;
+  c->distinct = 1;
+  c->total_generated = 0;
+  c->failed = 0;
+  c->level_base.assign(1, 0);
+  c->level_size.assign(1, 1);
+  return 0;
+}
+}  // namespace
 
 extern "C" {
 
@@ -608,6 +643,7 @@ void vsrmc_options_default(vsrmc_options* o) {
   o->frontier_states = (uint64_t)1 << 22;
   o->pending_entries = (uint64_t)1 << 23;
   o->keep_trace = 1;
+  o->trace_entries = 0;
   o->rank = 0;
   o->world = 1;
 }
@@ -636,7 +672,11 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     if (e == hipSuccess) e = hipMalloc((void**)&c->off[b], (o->frontier_states + 1) * 8);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&c->lvl_fp, o->frontier_states * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->lvl_tr, o->frontier_states * 8);
+  if (o->keep_trace) {
+    c->trace_cap = o->trace_entries ? o->trace_entries : 8 * o->frontier_states;
+    if (e == hipSuccess) e = hipMalloc((void**)&c->tr_all, c->trace_cap * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_level_base, 512 * 8);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&c->pending, o->pending_entries * 16);
   if (e == hipSuccess) e = hipMalloc((void**)&c->ctl, sizeof(LevelCtl));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_find, 8);
@@ -644,33 +684,15 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     vsrmc_checker_destroy(c);
     return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
-  // empty table: fp = 0, meta = all ones
-  hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, slots);
-  HIPCHK(hipGetLastError());
-  // Init (ModelChecker.doInit)
-  std::vector<u64> wire, dev(512);
-  init_record_wire(M, wire);
-  int len = wire_to_device(M, wire.data(), dev.data());
-  u64 H[6];
-  hash_full(M, (const u64*)dev.data(), H);   // pure arithmetic on the constant Init record (same code as the kernels)
-  for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
-  u64 zero = 0;
-  HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->off[0], &zero, 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(LevelCtl), c->stream));
-  hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->lvl_tr, c->ctl);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
-  c->cur = 0;
-  c->level = 1;
-  c->n_frontier = 1;
-  c->distinct = 1;
-  if (o->keep_trace) {
-    c->trace.emplace_back(1);
-    HIPCHK(hipMemcpy(c->trace[0].data(), c->lvl_tr, 8, hipMemcpyDeviceToHost));
-  }
+  rc = checker_seed(c);
+  if (rc) { vsrmc_checker_destroy(c); return rc; }
   *out = c;
   return 0;
+}
+
+int32_t vsrmc_checker_reset(vsrmc_checker* c) {
+  if (!c) return fail(VSRMC_E_ARG, "NULL argument");
+  return checker_seed(c);
 }
 
 int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
@@ -706,13 +728,16 @@ int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
     info->expand_ms = ms;
   }
   u64 n_pending = h.n_pending;
+  const u64 tr_base = c->level_base.back() + c->level_size.back();
   if (!h.err && n_pending > 0) {
     if (n_pending > c->opt.pending_entries) n_pending = c->opt.pending_entries;
+    u64 nx_cap = c->opt.frontier_states;                       // the trace log bounds the level as well
+    if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > tr_base ? c->trace_cap - tr_base : 0);
     unsigned grid = (unsigned)std::min<u64>((n_pending + VSR_BLOCK - 1) / VSR_BLOCK, (u64)c->num_cus * 16);
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(k_materialize, dim3(grid), dim3(VSR_BLOCK), 0, c->stream, M, c->words[cur], c->off[cur], c->pending,
-                       n_pending, c->table, c->words[nxt], c->opt.frontier_words, c->off[nxt], c->opt.frontier_states, c->lvl_fp,
-                       c->lvl_tr, c->ctl);
+                       n_pending, c->table, c->words[nxt], c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp,
+                       c->tr_all ? c->tr_all + tr_base : nullptr, c->ctl);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     HIPCHK(hipMemcpyAsync(&h, c->ctl, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -749,10 +774,8 @@ int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
   info->n_new = n_new;
   info->words_new = h.words_new;
   if (n_new > 0) {
-    if (c->opt.keep_trace) {
-      c->trace.emplace_back(n_new);
-      HIPCHK(hipMemcpy(c->trace.back().data(), c->lvl_tr, n_new * 8, hipMemcpyDeviceToHost));
-    }
+    c->level_base.push_back(tr_base);
+    c->level_size.push_back(n_new);
     c->cur = nxt;
     c->level = new_level;
     c->distinct += n_new;
@@ -815,19 +838,11 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
 int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words, uint64_t* off,
                             int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
   if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
-  if (!c->opt.keep_trace) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
-  if (level < 1 || level > (int)c->trace.size() || index >= c->trace[level - 1].size())
+  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
+  if (level < 1 || level > (int)c->level_base.size() || index >= c->level_size[level - 1])
     return fail(VSRMC_E_ARG, "no such state");
   const Model& M = c->model.M;
   if (cap_states < (u64)level + 1) return fail(VSRMC_E_ARG, "state buffers too small");
-  // walk the (parent index, ordinal) log back to Init (TLCTrace.getTrace), then re-execute forward on the GPU
-  std::vector<u32> ords(level > 1 ? level - 1 : 1);
-  u64 idx = index;
-  for (int l = level; l >= 2; l--) {
-    u64 key = c->trace[l - 1][idx];
-    ords[l - 2] = (u32)meta_ord(key);
-    idx = meta_pidx(key);
-  }
   int nsteps = level - 1;
   HIPCHK(hipSetDevice(c->opt.device));
   u64 maxw = (u64)(M.fixed + M.max_bag + 8) * (u64)level;
@@ -845,7 +860,11 @@ int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uin
   for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
   HIPCHK(hipMemcpy(d_w, dev.data(), len * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(d_m, 0, (u64)std::max(nsteps, 1) * 32));
-  if (nsteps > 0) HIPCHK(hipMemcpy(d_ords, ords.data(), (u64)nsteps * 4, hipMemcpyHostToDevice));
+  if (nsteps > 0) {   // walk the (parent index, ordinal) log back to Init on the device, then re-execute forward
+    HIPCHK(hipMemcpy(c->d_level_base, c->level_base.data(), c->level_base.size() * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->tr_all, c->d_level_base, level, index, d_ords);
+    HIPCHK(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, c->stream, M, d_w, d_o, d_ords, nsteps, d_m);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -879,7 +898,8 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
     if (c->off[b]) (void)hipFree(c->off[b]);
   }
   if (c->lvl_fp) (void)hipFree(c->lvl_fp);
-  if (c->lvl_tr) (void)hipFree(c->lvl_tr);
+  if (c->tr_all) (void)hipFree(c->tr_all);
+  if (c->d_level_base) (void)hipFree(c->d_level_base);
   if (c->pending) (void)hipFree(c->pending);
   if (c->ctl) (void)hipFree(c->ctl);
   if (c->d_find) (void)hipFree(c->d_find);
