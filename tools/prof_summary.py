@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""rocprofv3 results database (-d DIR -o NAME => DIR/NAME_results.db) -> markdown summary: per-kernel call count, total and
+average duration (`--kernel-trace --stats` view), and, when the run collected PMC counters, their per-kernel sums."""
+import sqlite3
+import sys
+
+
+def main(path, title):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    print("# %s\n" % title)
+    print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+    for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+        short = name.split("(")[0]
+        print("| %s | %d | %.3f | %.1f | %.2f |" % (short, calls, total / 1e3, avg, pct))
+    try:
+        rows = list(cur.execute("select k.name, p.name, sum(e.value), count(*) from pmc_events e join kernels k on "
+                                "e.dispatch_id = k.dispatch_id join pmc_info p on e.pmc_id = p.id group by k.name, p.name"))
+    except sqlite3.Error:
+        rows = []
+    if rows:
+        print("\n| kernel | counter | sum over dispatches | dispatches |\n|---|---|---|---|")
+        for k, c, v, n in rows:
+            print("| %s | %s | %.6g | %d |" % (k.split("(")[0], c, v, n))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else sys.argv[1])
