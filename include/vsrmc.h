@@ -139,7 +139,45 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
  * state (0 = Initial predicate) */
 int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words,
                             uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
+/* forward half of TLCTrace.getTrace on its own: re-execute `nsteps` ordinals from Init */
+int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t* ords, int32_t nsteps, uint64_t* words,
+                           uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
+/* one entry of the trace log: key = level(9) | auxkey(9) | rank(3) | parent index(32) | ordinal(11) */
+int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* key);
+/* index of fingerprint `fp` in the newest level (~0 if absent) */
+int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index);
 void vsrmc_checker_destroy(vsrmc_checker* c);
+
+/* ---- sharded seen-set (≙ tlc2.tool.fp.MultiFPSet across GPUs): the phases of one BFS level -----------------------
+ * world ranks, one per GPU; owner(fp) = ((fp >> 40) & 0xFFFFFF) % world.  The caller (vsr-tlaplus_amd/sharded.py over
+ * torch.distributed / RCCL) owns the exchange buffers and moves them between ranks; every pointer is a device pointer.
+ *   1. vsrmc_shard_expand       expand the local frontier; local-owner candidates are claimed at once, the others are
+ *                               bucketed per owner as (fp, key) pairs in io->cand_send; returns the bucket sizes
+ *   2. [all-to-all of the buckets]
+ *   3. vsrmc_shard_claim        claim the received candidates in the local shard, then answer each with 1 = "won its slot"
+ *   4. [all-to-all of the verdict bytes, back to the generators]
+ *   5. vsrmc_shard_materialize  winners rebuild their successor: local owners straight into the next frontier, the
+ *                               others into io->rec_* per owner; returns record / word counts per owner
+ *   6. [all-to-all of the record streams]
+ *   7. vsrmc_shard_append       per received stream: copy into the next frontier, publish offsets / fps / trace keys
+ *   8. vsrmc_shard_commit       swap the frontiers; local statistics (the caller all-reduces them) */
+typedef struct vsrmc_shard_io {
+  uint64_t* cand_send;           /* [world][cand_cap][2]  (fp, key) */
+  uint64_t cand_cap;             /* entries per owner */
+  uint64_t* rec_words;           /* [world][rec_words_cap] record words per owner (device layout) */
+  uint64_t rec_words_cap;
+  uint64_t* rec_off;             /* [world][rec_cap] word offset of each record inside its owner's region */
+  uint64_t* rec_fp;              /* [world][rec_cap] */
+  uint64_t* rec_key;             /* [world][rec_cap] */
+  uint64_t rec_cap;              /* records per owner */
+} vsrmc_shard_io;
+int32_t vsrmc_shard_expand(vsrmc_checker* c, const vsrmc_shard_io* io, uint64_t* cand_counts);
+int32_t vsrmc_shard_claim(vsrmc_checker* c, const uint64_t* d_cand_recv, uint64_t n, uint8_t* d_verdict);
+int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, const uint8_t* d_verdict_in, uint64_t* rec_counts,
+                                uint64_t* word_counts);
+int32_t vsrmc_shard_append(vsrmc_checker* c, const uint64_t* d_words, uint64_t n_words, const uint64_t* d_off,
+                           const uint64_t* d_fp, const uint64_t* d_key, uint64_t n);
+int32_t vsrmc_shard_commit(vsrmc_checker* c, vsrmc_level_info* info);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,145 @@
+"""TEST INFRASTRUCTURE: a CPU stand-in for one rank's shard engine, built on the CPU oracle, implementing the phase protocol
+of vsr-tlaplus_amd/sharded.py (expand / claim / materialize / append / commit).  It lets the world_size-2 gloo test exercise
+the orchestrator + exchange protocol without a GPU.  Never imported by product code."""
+import numpy as np
+import torch
+
+from oracle import orc
+
+U64_MAX = (1 << 64) - 1
+
+
+def _i64(x):
+    """python ints (possibly >= 2^63) -> int64 tensor with the same bit patterns"""
+    return torch.from_numpy(np.array(x, dtype=np.uint64).astype(np.int64).reshape(-1))
+
+
+def _u64(t):
+    return [int(v) for v in t.cpu().numpy().astype(np.int64).view(np.uint64).reshape(-1)]
+
+
+class FakeShardEngine:
+    def __init__(self, params, rank, world, owner_of):
+        self.P, self.rank, self.world, self.owner_of = params, rank, world, owner_of
+        self.seen = {}            # fp -> best key (level << 55 | auxkey << 46 | rank << 43 | pidx << 11 | ord)
+        self.level = 1
+        init = orc.init_record(params)
+        fp, ak = orc.fingerprint(params, init)
+        self.frontier, self.fps, self.trace = [], [], [[]]
+        if owner_of(fp, world) == rank:
+            self.frontier, self.fps = [init], [fp]
+            self.seen[fp] = self._key(1, ak, 0, 0)
+            self.trace = [[self.seen[fp]]]
+        self.total = len(self.frontier)
+        self._err = ""
+
+    def _key(self, level, ak, pidx, ordinal):
+        return (level << 55) | (ak << 46) | (self.rank << 43) | (pidx << 11) | ordinal
+
+    def error_text(self):
+        return self._err
+
+    def local_distinct(self):
+        return len(self.frontier)
+
+    def _claim(self, fp, key):
+        """-> True if the slot belongs to this level (candidate may still win)"""
+        cur = self.seen.get(fp)
+        if cur is not None and (cur >> 55) < self.level + 1:
+            return False
+        self.seen[fp] = key if cur is None else min(cur, key)
+        return True
+
+    def expand(self):
+        self.generated = self.deadlocks = 0
+        self.local_pending, self.sent = [], [[] for _ in range(self.world)]
+        self.succ_cache = {}
+        for pidx, rec in enumerate(self.frontier):
+            succ = orc.successors(self.P, rec)
+            self.succ_cache[pidx] = succ
+            self.generated += len(succ)
+            self.deadlocks += 0 if succ else 1
+            for k, s in enumerate(succ):
+                key = self._key(self.level + 1, s["auxkey"], pidx, k)
+                o = self.owner_of(s["fp"], self.world)
+                if o == self.rank:
+                    if self._claim(s["fp"], key):
+                        self.local_pending.append((s["fp"], key))
+                else:
+                    self.sent[o].append((s["fp"], key))
+        out = []
+        for o in range(self.world):
+            flat = [x for fk in self.sent[o] for x in fk]
+            out.append(_i64(flat).reshape(-1, 2))
+        return out, 0
+
+    def claim(self, cands):
+        vals = _u64(cands)
+        self.recv = [(vals[2 * i], vals[2 * i + 1]) for i in range(len(vals) // 2)]
+        alive = [self._claim(fp, key) for fp, key in self.recv]
+        verdict = [1 if a and self.seen[fp] == key else 0 for a, (fp, key) in zip(alive, self.recv)]
+        return torch.tensor(verdict, dtype=torch.uint8), 0
+
+    def _record_of(self, key):
+        pidx, k = (key >> 11) & 0xFFFFFFFF, key & 2047
+        return self.succ_cache[pidx][k]
+
+    def materialize(self, verdicts):
+        self.next_frontier, self.next_fps, self.next_keys = [], [], []
+        self.viol_fp, self.viol_mask, self.max_bag = U64_MAX, 0, 0
+        for fp, key in self.local_pending:
+            if self.seen[fp] == key:
+                self._emit_local(self._record_of(key), key)
+        out = []
+        for o in range(self.world):
+            words, off, fps, keys = [], [], [], []
+            if o != self.rank:
+                v = [int(x) for x in verdicts[o].cpu()]
+                assert len(v) == len(self.sent[o])
+                for (fp, key), win in zip(self.sent[o], v):
+                    if win:
+                        s = self._record_of(key)
+                        self._inv(s)
+                        off.append(len(words))
+                        words.extend(int(w) for w in s["words"])
+                        fps.append(s["fp"])
+                        keys.append(key)
+            out.append((_i64(words), _i64(off), _i64(fps), _i64(keys)))
+        return out, 0
+
+    def _inv(self, s):
+        if s["inv"]:
+            self.viol_fp = min(self.viol_fp, s["fp"])
+            self.viol_mask |= s["inv"]
+
+    def _emit_local(self, s, key):
+        self._inv(s)
+        self.next_frontier.append(np.array(s["words"], dtype=np.uint64))
+        self.next_fps.append(s["fp"])
+        self.next_keys.append(key)
+
+    def append(self, words, off, fp, key):
+        w, o, f, k = _u64(words), _u64(off), _u64(fp), _u64(key)
+        bounds = o + [len(w)]
+        for i in range(len(o)):
+            self.next_frontier.append(np.array(w[bounds[i]: bounds[i + 1]], dtype=np.uint64))
+            self.next_fps.append(f[i])
+            self.next_keys.append(k[i])
+        return 0
+
+    def commit(self):
+        self.frontier, self.fps = self.next_frontier, self.next_fps
+        self.trace.append(self.next_keys)
+        self.level += 1
+        self.total += len(self.frontier)
+        return dict(n_new=len(self.frontier), generated=self.generated, deadlocks=self.deadlocks,
+                    pending=len(self.local_pending), viol_fp=self.viol_fp, viol_mask=self.viol_mask, max_bag=0)
+
+    def find_fp(self, fp):
+        return self.fps.index(fp) if fp in self.fps else None
+
+    def trace_entry(self, level, index):
+        return self.trace[level - 1][index]
+
+    def level_fps(self):
+        return np.array(sorted(self.fps), dtype=np.uint64)

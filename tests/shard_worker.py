@@ -1,0 +1,53 @@
+"""TEST INFRASTRUCTURE: one rank of a world_size-N sharded BFS, launched by tests via torch.distributed.run.
+    python -m torch.distributed.run ... tests/shard_worker.py <engine: fake|hip> R C n L max_depth out_prefix
+Writes out_prefix.rank<k>.json with the per-level sorted fingerprints of this rank's shard and the global counters."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    engine_kind, R, C_, n, L, max_depth, out = sys.argv[1], *(int(x) for x in sys.argv[2:7]), sys.argv[7]
+    dist.init_process_group("gloo")           # CPU test: gloo; on the one-GPU box both ranks share device 0 over gloo
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from vsr_tlaplus_amd import sharded
+    if engine_kind == "fake":
+        from fake_shard_engine import FakeShardEngine
+        from oracle import orc
+        eng = FakeShardEngine(orc.Params(R, C_, n, L), rank, world, sharded.owner_of)
+    else:
+        import vsr_tlaplus_amd as vt
+        m = vt.Model.from_constants(R=R, C_=C_, n=n, L=L)
+        eng = sharded.HipShardEngine(m, rank, world, device=0, table_log2=20, frontier_words=1 << 22, frontier_states=1 << 17,
+                                     pending_entries=1 << 19, cand_cap=1 << 18, rec_cap=1 << 17, rec_words_cap=1 << 22)
+    sc = sharded.ShardedChecker(eng, sharded.Exchanger())
+    levels = [dict(level=1, n_new=sc.distinct, generated=0, deadlocks=0, fps=["%016x" % int(f) for f in eng.level_fps()])]
+    while sc.level < max_depth:
+        d = sc.step()
+        if d["n_new"] == 0:
+            break
+        levels.append(dict(level=d["level"], n_new=d["n_new"], generated=d["generated"], deadlocks=d["deadlocks"],
+                           fps=["%016x" % int(f) for f in eng.level_fps()]))
+    # trace of the last state of the deepest non-empty local level (every rank takes part in every walk)
+    walks = []
+    for r in range(world):
+        have = sc.allgather_int(len(eng.level_fps())) if hasattr(sc, "allgather_int") else None
+        nloc = sc.x.allreduce([len(eng.level_fps()) if rank == r else 0], dist.ReduceOp.MAX)[0]
+        if nloc:
+            walks.append(dict(rank=r, level=sc.level, index=nloc - 1, ords=sc.trace_ordinals(sc.level, r, nloc - 1)))
+    with open("%s.rank%d.json" % (out, rank), "w") as f:
+        json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks,
+                       bytes_sent=sc.x.bytes_sent), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

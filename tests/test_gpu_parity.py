@@ -275,3 +275,22 @@ def test_frontier_export_matches_oracle_states(vt, orc):
     assert len(ofp) == len(fps)
     for fp, ak in zip(fps, aks):
         assert ofp[int(fp)] == int(ak)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the CLI (TLC's command-line surface) on BASELINE config 1
+# ---------------------------------------------------------------------------------------------------------------------
+def test_cli_runs_config1_to_completion(vt, tmp_path):
+    import os
+    import subprocess
+    from test_host_cpu import _cfg
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cfg = _cfg(tmp_path, R=2, vals="v1", L=1)
+    r = subprocess.run([cli, "-config", cfg, "VSR.tla", "-noTLA", "-deadlock", "-tableLog2", "16", "-frontierGiB", "0.01"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Model checking completed. No error has been found." in r.stdout
+    assert "76 distinct states found" in r.stdout and "search is 14" in r.stdout
+    r = subprocess.run([cli, "-config", cfg, "VSR.tla", "-noTLA", "-checkDeadlock", "-tableLog2", "16", "-frontierGiB", "0.01"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 11 and "Deadlock reached" in r.stdout          # stock TLC without -deadlock

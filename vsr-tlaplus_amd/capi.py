@@ -35,6 +35,11 @@ class LevelInfo(C.Structure):
         return d
 
 
+class ShardIO(C.Structure):
+    _fields_ = [("cand_send", C.c_void_p), ("cand_cap", C.c_uint64), ("rec_words", C.c_void_p), ("rec_words_cap", C.c_uint64),
+                ("rec_off", C.c_void_p), ("rec_fp", C.c_void_p), ("rec_key", C.c_void_p), ("rec_cap", C.c_uint64)]
+
+
 # every symbol include/vsrmc.h declares: name -> (restype, argtypes)
 V = C.c_void_p
 SYMBOLS = {
@@ -67,6 +72,14 @@ SYMBOLS = {
     "vsrmc_checker_trace": (C.c_int32, [V, C.c_int32, C.c_uint64, V, C.c_uint64, V, V, C.c_uint64,
                                         C.POINTER(C.c_uint64)]),
     "vsrmc_checker_destroy": (None, [V]),
+    "vsrmc_model_replay": (C.c_int32, [V, C.c_int32, V, C.c_int32, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_trace_entry": (C.c_int32, [V, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_find_fp": (C.c_int32, [V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_shard_expand": (C.c_int32, [V, C.POINTER(ShardIO), V]),
+    "vsrmc_shard_claim": (C.c_int32, [V, V, C.c_uint64, V]),
+    "vsrmc_shard_materialize": (C.c_int32, [V, C.POINTER(ShardIO), V, V, V]),
+    "vsrmc_shard_append": (C.c_int32, [V, V, C.c_uint64, V, V, V, C.c_uint64]),
+    "vsrmc_shard_commit": (C.c_int32, [V, C.POINTER(LevelInfo)]),
 }
 
 _lib = None

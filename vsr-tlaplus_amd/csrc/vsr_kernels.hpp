@@ -35,7 +35,13 @@ struct LevelCtl {   // device-resident counters of one BFS level
   u32 err;          // first ERR_* raised
   u64 err_info;     // (parent index << 16) | ordinal of the instance that raised it
   u64 act_generated[16];   // generated successors per action id
+  u64 cand_cnt[8];         // sharded mode: candidates bucketed for each owner rank
+  u64 out_n[8];            // sharded mode: records materialised for each owner rank (self = n_new)
+  u64 out_w[8];            // ... and their words (self = words_new)
 };
+
+// owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
+__host__ __device__ __forceinline__ int owner_of(u64 fp, int world) { return (int)(((fp >> 40) & 0xFFFFFF) % (u64)world); }
 
 #define VSR_TILE 64          // frontier records staged per block iteration
 #define VSR_BLOCK 256
@@ -95,7 +101,8 @@ __device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 ke
 // -----------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(VSR_BLOCK)
 k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
-         Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride) {
+         Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world, u64* cand_send,
+         u64 cand_cap) {
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // VSR_TILE * stride words
   u32* s_cand = (u32*)(smem + VSR_TILE * stride);              // VSR_CAND_CAP entries: parent << 16 | ord
@@ -183,6 +190,22 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
       const u64 key = meta_make(level, ak, rank, p_base + (u64)p, ord);
+      if (world > 1) {                                          // sharded seen-set: route to the owner of fp
+        const int owner = owner_of(fp, world);
+        if (owner != rank) {
+          for (int o = 0; o < world; o++)
+            if (owner == o) {
+              u64 i = wave_alloc(&ctl->cand_cnt[o], 1);
+              if (i < cand_cap) {
+                cand_send[2 * ((u64)o * cand_cap + i)] = fp;
+                cand_send[2 * ((u64)o * cand_cap + i) + 1] = key;
+              } else {
+                raise_error(ctl, ERR_FRONTIER_FULL, i);
+              }
+            }
+          continue;
+        }
+      }
       bool found_old, full;
       u64 slot = table_claim(table, tmask, fp, key, level, &found_old, &my_probes, &full);
       if (full) {
@@ -233,7 +256,7 @@ __device__ __forceinline__ void write_child_serial(const Model& M, const u64* re
 __global__ void __launch_bounds__(VSR_BLOCK)
 k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, const u64* __restrict__ pending,
               u64 n_pending, const Slot* __restrict__ table, u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap,
-              u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl) {
+              u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w) {
   const int lane = threadIdx.x & 63;
   const u64 nthreads = (u64)gridDim.x * blockDim.x;
   const u64 rounds = (n_pending + nthreads - 1) / nthreads;
@@ -247,9 +270,9 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
     D.npatch = 0;
     D.err = 0;
     if (i < n_pending) {
-      u64 slot = pending[2 * i];
       key = pending[2 * i + 1];
-      win = (table[slot].meta == key);
+      // winner test: the owner's verdict (sharded, remote owner) or the slot's final meta word (local owner)
+      win = verdict ? (verdict[i] != 0) : (table[pending[2 * i]].meta == key);
     }
     if (win) {
       src = fr_off[meta_pidx(key)];
@@ -274,8 +297,8 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
     const int total = __shfl(incl, 63);
     u64 idx_base = 0, word_base = 0;
     if (lane == 0) {
-      idx_base = atomicAdd((unsigned long long*)&ctl->n_new, (unsigned long long)nwin);
-      word_base = atomicAdd((unsigned long long*)&ctl->words_new, (unsigned long long)total);
+      idx_base = atomicAdd((unsigned long long*)cnt_n, (unsigned long long)nwin);
+      word_base = atomicAdd((unsigned long long*)cnt_w, (unsigned long long)total);
     }
     idx_base = __shfl(idx_base, 0);
     word_base = __shfl(word_base, 0);
@@ -321,6 +344,39 @@ __global__ void k_table_init(Slot* table, u64 slots) {
     table[i].fp = 0;
     table[i].meta = META_EMPTY;
   }
+}
+
+// ---- sharded seen-set: the owner's side of one level -------------------------------------------------------------
+// k_claim_batch: claim the received (fp, key) candidates in this rank's shard; rslot[i] = slot, or ~0 for a duplicate
+// of an earlier level.
+__global__ void k_claim_batch(Slot* table, u64 tmask, const u64* __restrict__ entries, u64 n, int level, u64* rslot,
+                              LevelCtl* ctl) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool found_old, full;
+  u32 np = 0;
+  u64 slot = table_claim(table, tmask, entries[2 * i], entries[2 * i + 1], level, &found_old, &np, &full);
+  if (full) raise_error(ctl, ERR_TABLE_FULL, entries[2 * i]);
+  rslot[i] = found_old ? ~(u64)0 : slot;
+  atomicAdd((unsigned long long*)&ctl->probes, (unsigned long long)np);
+}
+// k_verdict: after every claim of the level has landed: did candidate i win its slot?
+__global__ void k_verdict(const Slot* __restrict__ table, const u64* __restrict__ entries, const u64* __restrict__ rslot, u64 n,
+                          uint8_t* verdict) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s = rslot[i];
+  verdict[i] = (s != ~(u64)0 && table[s].meta == entries[2 * i + 1]) ? 1 : 0;
+}
+// k_append_fixup: records received from a peer were copied to nx_words[base_words ..); publish their offsets,
+// fingerprints and trace keys at state indices n0 ..
+__global__ void k_append_fixup(u64* nx_off, u64* lvl_fp, u64* lvl_tr, const u64* __restrict__ rel_off,
+                               const u64* __restrict__ fps, const u64* __restrict__ keys, u64 n, u64 base_words) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  nx_off[i] = base_words + rel_off[i];
+  lvl_fp[i] = fps[i];
+  if (lvl_tr) lvl_tr[i] = keys[i];
 }
 
 // Seed the search with the initial state (ModelChecker.doInit): record already in frontier slot 0.

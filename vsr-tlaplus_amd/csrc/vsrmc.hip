@@ -598,6 +598,12 @@ struct vsrmc_checker {
   u64* d_level_base = nullptr;           // device copy of level_base (512 entries)
   std::vector<u64> level_base;           // index of the first state of each level in tr_all
   std::vector<u64> level_size;
+  // state of the level in flight (between the phases)
+  LevelCtl h;
+  double t_level0 = 0, expand_ms = 0, materialize_ms = 0;
+  u64 tr_base = 0, nx_n = 0, nx_w = 0;
+  u64* rslot = nullptr;                  // sharded: slot of every received candidate
+  u64 rslot_cap = 0;
 };
 
 namespace {
@@ -613,21 +619,26 @@ int checker_seed(vsrmc_checker* c) {
   u64 H[6];
   hash_full(M, (const u64*)dev.data(), H);   // pure arithmetic on the constant Init record (same code as the kernels)
   for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
-  u64 zero = 0;
-  HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->off[0], &zero, 8, hipMemcpyHostToDevice, c->stream));
+  u64 zero = 0, init_fp = 0;
+  u32 init_ak = 0;
+  canonical_fp(M, dev[0], &dev[M.h0], &init_fp, &init_ak);
+  const bool mine = c->opt.world <= 1 || owner_of(init_fp, c->opt.world) == c->opt.rank;   // sharded: Init lives on its owner
   HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(LevelCtl), c->stream));
-  hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->tr_all, c->ctl);
-  HIPCHK(hipGetLastError());
+  if (mine) {
+    HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->off[0], &zero, 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->tr_all, c->ctl);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   c->cur = 0;
   c->level = 1;
-  c->n_frontier = 1;
-  c->distinct = 1;
+  c->n_frontier = mine ? 1 : 0;
+  c->distinct = mine ? 1 : 0;
   c->total_generated = 0;
   c->failed = 0;
   c->level_base.assign(1, 0);
-  c->level_size.assign(1, 1);
+  c->level_size.assign(1, c->n_frontier);
   return 0;
 }
 }  // namespace
@@ -652,6 +663,7 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
   if (!m || !o || !out) return fail(VSRMC_E_ARG, "NULL argument");
   if (o->table_log2 < 8 || o->table_log2 > 36 || o->frontier_states < 1 || o->frontier_words < 256 || o->pending_entries < 1)
     return fail(VSRMC_E_ARG, "bad options");
+  if (o->world < 1 || o->world > 8 || o->rank < 0 || o->rank >= o->world) return fail(VSRMC_E_ARG, "bad rank / world (1..8 ranks)");
   int rc = check_device(o->device);
   if (rc) return rc;
   vsrmc_checker* c = new vsrmc_checker();
@@ -695,106 +707,259 @@ int32_t vsrmc_checker_reset(vsrmc_checker* c) {
   return checker_seed(c);
 }
 
-int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
-  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
-  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
-  std::memset(info, 0, sizeof(*info));
+}  // extern "C"
+
+namespace {
+
+// ---- the phases of one BFS level (shared by the single-GPU step and the sharded protocol) --------------------------
+int level_error(vsrmc_checker* c, const LevelCtl& h, int new_level) {
+  c->failed = 1;
+  char buf[256];
+  std::snprintf(buf, sizeof(buf), "device error %u at frontier index %llu ordinal %llu (level %d)", h.err,
+                (unsigned long long)(h.err_info >> 16), (unsigned long long)(h.err_info & 0xFFFF), new_level);
+  std::string msg = buf;
+  if (h.err == ERR_EVAL_421) msg = "VSR.tla:421: record has no field 'commit' (ReceivePrepareMsg, ClientCount >= 2); " + msg;
+  return fail(h.err < ERR_REP_RANGE ? VSRMC_E_EVAL : VSRMC_E_REP, msg);
+}
+
+// phase 1: k_expand over the current frontier.  io == nullptr: unsharded.
+int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
   const Model& M = c->model.M;
   HIPCHK(hipSetDevice(c->opt.device));
-  double t0 = now_s();
-  const int cur = c->cur, nxt = cur ^ 1;
-  const int new_level = c->level + 1;
-  if (new_level >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
-  LevelCtl h;
-  std::memset(&h, 0, sizeof(h));
-  h.viol_fp = ~(u64)0;
-  HIPCHK(hipMemcpyAsync(c->ctl, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-  info->frontier = c->n_frontier;
+  if (c->level + 1 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
+  c->t_level0 = now_s();
+  c->expand_ms = c->materialize_ms = 0;
+  std::memset(&c->h, 0, sizeof(c->h));
+  c->h.viol_fp = ~(u64)0;
+  HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
   if (c->n_frontier > 0) {
     u64 ntiles = (c->n_frontier + VSR_TILE - 1) / VSR_TILE;
     unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 8);
     size_t lds = (size_t)VSR_TILE * c->lds_stride * 8 + VSR_CAND_CAP * 4;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(k_expand, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[cur], c->off[cur], c->n_frontier,
-                       new_level, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, c->lds_stride);
+    hipLaunchKernelGGL(k_expand, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], c->n_frontier,
+                       c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, c->lds_stride,
+                       io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
-  HIPCHK(hipMemcpyAsync(&h, c->ctl, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->n_frontier > 0) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-    info->expand_ms = ms;
+    c->expand_ms = ms;
   }
-  u64 n_pending = h.n_pending;
-  const u64 tr_base = c->level_base.back() + c->level_size.back();
-  if (!h.err && n_pending > 0) {
-    if (n_pending > c->opt.pending_entries) n_pending = c->opt.pending_entries;
-    u64 nx_cap = c->opt.frontier_states;                       // the trace log bounds the level as well
-    if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > tr_base ? c->trace_cap - tr_base : 0);
-    unsigned grid = (unsigned)std::min<u64>((n_pending + VSR_BLOCK - 1) / VSR_BLOCK, (u64)c->num_cus * 16);
-    HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_materialize, dim3(grid), dim3(VSR_BLOCK), 0, c->stream, M, c->words[cur], c->off[cur], c->pending,
-                       n_pending, c->table, c->words[nxt], c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp,
-                       c->tr_all ? c->tr_all + tr_base : nullptr, c->ctl);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(hipMemcpyAsync(&h, c->ctl, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-    info->materialize_ms = ms;
-  }
+  c->tr_base = c->level_base.back() + c->level_size.back();
+  c->nx_n = c->nx_w = 0;
+  if (c->h.err) return level_error(c, c->h, c->level + 1);
+  return 0;
+}
+
+// phase 2: k_materialize over a list of (slot-or-fp, key) entries into one target (next frontier or a peer's bucket)
+int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t* verdict, u64* t_words, u64 t_words_cap,
+                      u64* t_off, u64 t_cap, u64* t_fp, u64* t_key, u64* cnt_n, u64* cnt_w) {
+  if (n == 0) return 0;
+  const Model& M = c->model.M;
+  unsigned grid = (unsigned)std::min<u64>((n + VSR_BLOCK - 1) / VSR_BLOCK, (u64)c->num_cus * 16);
+  HIPCHK(hipEventRecord(c->ev[2], c->stream));
+  hipLaunchKernelGGL(k_materialize, dim3(grid), dim3(VSR_BLOCK), 0, c->stream, M, c->words[c->cur], c->off[c->cur], entries, n,
+                     c->table, t_words, t_words_cap, t_off, t_cap, t_fp, t_key, c->ctl, verdict, cnt_n, cnt_w);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->ev[3], c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+  c->materialize_ms += ms;
+  return 0;
+}
+
+// materialise the local pending list straight into the next frontier (self bucket)
+int phase_materialize_local(vsrmc_checker* c) {
+  u64 n_pending = std::min<u64>(c->h.n_pending, c->opt.pending_entries);
+  u64 nx_cap = c->opt.frontier_states;                         // the trace log bounds the level as well
+  if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base ? c->trace_cap - c->tr_base : 0);
+  const int nxt = c->cur ^ 1;
+  int rc = phase_materialize(c, c->pending, n_pending, nullptr, c->words[nxt], c->opt.frontier_words, c->off[nxt], nx_cap,
+                             c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base : nullptr, &c->ctl->n_new, &c->ctl->words_new);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost));
+  if (c->h.err) return level_error(c, c->h, c->level + 1);
+  c->nx_n = c->h.n_new;
+  c->nx_w = c->h.words_new;
+  return 0;
+}
+
+// phase 3: the level is complete: swap the frontiers, fill in the local statistics
+int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
+  std::memset(info, 0, sizeof(*info));
+  const LevelCtl& h = c->h;
+  info->frontier = c->n_frontier;
   info->generated = h.generated;
   info->deadlocks = h.deadlocks;
   info->pending = h.n_pending;
   info->probes = h.probes;
   info->max_bag = h.max_bag;
   for (int a = 0; a < 16; a++) info->act_generated[a] = h.act_generated[a];
-  info->error_code = (int32_t)h.err;
   info->viol_fp = ~(u64)0;
   info->viol_index = ~(u64)0;
-  if (h.err) {
-    // like a TLC evaluation error: the run aborts, the partial level is not committed
-    c->failed = 1;
-    info->level = c->level;
-    info->distinct = c->distinct;
-    info->total_generated = c->total_generated;
-    info->seconds = now_s() - t0;
-    char buf[256];
-    std::snprintf(buf, sizeof(buf), "device error %u at frontier index %llu ordinal %llu (level %d)", h.err,
-                  (unsigned long long)(h.err_info >> 16), (unsigned long long)(h.err_info & 0xFFFF), new_level);
-    std::string msg = buf;
-    if (h.err == ERR_EVAL_421) msg = "VSR.tla:421: record has no field 'commit' (ReceivePrepareMsg, ClientCount >= 2); " + msg;
-    return fail(h.err < ERR_REP_RANGE ? VSRMC_E_EVAL : VSRMC_E_REP, msg);
-  }
-  u64 n_new = h.n_new;
+  info->expand_ms = c->expand_ms;
+  info->materialize_ms = c->materialize_ms;
+  const u64 n_new = c->nx_n;
   c->total_generated += h.generated;
   info->n_new = n_new;
-  info->words_new = h.words_new;
-  if (n_new > 0) {
-    c->level_base.push_back(tr_base);
+  info->words_new = c->nx_w;
+  if (n_new > 0 || c->opt.world > 1) {   // sharded: levels stay aligned across ranks even when this shard got nothing
+    c->level_base.push_back(c->tr_base);
     c->level_size.push_back(n_new);
-    c->cur = nxt;
-    c->level = new_level;
+    c->cur ^= 1;
+    c->level += 1;
     c->distinct += n_new;
   }
   c->n_frontier = n_new;
   if (h.viol_fp != ~(u64)0) {
     info->viol_fp = h.viol_fp;
     info->viol_mask = (int32_t)h.viol_mask;
-    u64 big = ~(u64)0;
-    HIPCHK(hipMemcpy(c->d_find, &big, 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_find_fp, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, c->stream, c->lvl_fp, n_new, h.viol_fp, c->d_find);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(&info->viol_index, c->d_find, 8, hipMemcpyDeviceToHost));
   }
   info->level = c->level;
   info->distinct = c->distinct;
   info->total_generated = c->total_generated;
-  info->seconds = now_s() - t0;
+  info->seconds = now_s() - c->t_level0;
+  return 0;
+}
+
+int find_fp_newest(vsrmc_checker* c, u64 fp, u64* idx) {
+  *idx = ~(u64)0;
+  if (c->n_frontier == 0) return 0;
+  u64 big = ~(u64)0;
+  HIPCHK(hipMemcpy(c->d_find, &big, 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_find_fp, dim3((unsigned)((c->n_frontier + 255) / 256)), dim3(256), 0, c->stream, c->lvl_fp, c->n_frontier, fp,
+                     c->d_find);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(idx, c->d_find, 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
+  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: drive the level with the vsrmc_shard_* phases");
+  int rc = phase_expand(c, nullptr);
+  if (!rc) rc = phase_materialize_local(c);
+  if (rc) {   // like a TLC evaluation error: the run aborts, the partial level is not committed
+    std::memset(info, 0, sizeof(*info));
+    info->level = c->level;
+    info->distinct = c->distinct;
+    info->error_code = (int32_t)c->h.err;
+    return rc;
+  }
+  rc = phase_commit(c, info);
+  if (rc) return rc;
+  if (info->viol_mask) return find_fp_newest(c, info->viol_fp, &info->viol_index);
+  return 0;
+}
+
+// ---- sharded protocol: one level = expand -> [exchange] -> claim -> [exchange] -> materialize -> [exchange] -> append -> commit
+int32_t vsrmc_shard_expand(vsrmc_checker* c, const vsrmc_shard_io* io, uint64_t* cand_counts) {
+  if (!c || !io || !cand_counts) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  int rc = phase_expand(c, io);
+  for (int o = 0; o < c->opt.world; o++) cand_counts[o] = c->h.cand_cnt[o];
+  return rc;
+}
+
+int32_t vsrmc_shard_claim(vsrmc_checker* c, const uint64_t* d_cand_recv, uint64_t n, uint8_t* d_verdict) {
+  if (!c || (n && (!d_cand_recv || !d_verdict))) return fail(VSRMC_E_ARG, "NULL argument");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(c->opt.device));
+  if (n > c->rslot_cap) {
+    if (c->rslot) (void)hipFree(c->rslot);
+    c->rslot = nullptr;
+    c->rslot_cap = 0;
+    HIPCHK(hipMalloc((void**)&c->rslot, n * 8));
+    c->rslot_cap = n;
+  }
+  unsigned grid = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_claim_batch, dim3(grid), dim3(256), 0, c->stream, c->table, c->tmask, d_cand_recv, n, c->level + 1, c->rslot, c->ctl);
+  hipLaunchKernelGGL(k_verdict, dim3(grid), dim3(256), 0, c->stream, c->table, d_cand_recv, c->rslot, n, d_verdict);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// NOTE: every rank must have finished vsrmc_shard_claim for ALL its received candidates before any verdict is used:
+// the verdict of a slot is final only when every claim of the level has landed (the orchestrator's exchange is the barrier).
+int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, const uint8_t* d_verdict_in, uint64_t* rec_counts,
+                                uint64_t* word_counts) {
+  if (!c || !io || !rec_counts || !word_counts) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  int rc = phase_materialize_local(c);
+  for (int o = 0; o < c->opt.world && !rc; o++) {
+    if (o == c->opt.rank) continue;
+    u64 n = std::min<u64>(c->h.cand_cnt[o], io->cand_cap);
+    rc = phase_materialize(c, io->cand_send + 2 * (u64)o * io->cand_cap, n, d_verdict_in + (u64)o * io->cand_cap,
+                           io->rec_words + (u64)o * io->rec_words_cap, io->rec_words_cap, io->rec_off + (u64)o * io->rec_cap,
+                           io->rec_cap, io->rec_fp + (u64)o * io->rec_cap, io->rec_key + (u64)o * io->rec_cap, &c->ctl->out_n[o],
+                           &c->ctl->out_w[o]);
+  }
+  if (rc) return rc;
+  u64 keep_n = c->nx_n, keep_w = c->nx_w;
+  HIPCHK(hipMemcpy(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost));
+  c->nx_n = keep_n;
+  c->nx_w = keep_w;
+  if (c->h.err) return level_error(c, c->h, c->level + 1);
+  for (int o = 0; o < c->opt.world; o++) {
+    rec_counts[o] = o == c->opt.rank ? 0 : c->h.out_n[o];
+    word_counts[o] = o == c->opt.rank ? 0 : c->h.out_w[o];
+  }
+  return 0;
+}
+
+int32_t vsrmc_shard_append(vsrmc_checker* c, const uint64_t* d_words, uint64_t n_words, const uint64_t* d_off,
+                           const uint64_t* d_fp, const uint64_t* d_key, uint64_t n) {
+  if (!c) return fail(VSRMC_E_ARG, "NULL argument");
+  if (n == 0) return 0;
+  if (!d_words || !d_off || !d_fp || !d_key) return fail(VSRMC_E_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(c->opt.device));
+  u64 nx_cap = c->opt.frontier_states;
+  if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base ? c->trace_cap - c->tr_base : 0);
+  if (c->nx_n + n > nx_cap || c->nx_w + n_words > c->opt.frontier_words) {
+    c->failed = 1;
+    return fail(VSRMC_E_REP, "frontier / trace buffers full while appending received records");
+  }
+  const int nxt = c->cur ^ 1;
+  HIPCHK(hipMemcpyAsync(c->words[nxt] + c->nx_w, d_words, n_words * 8, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_append_fixup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->off[nxt] + c->nx_n,
+                     c->lvl_fp + c->nx_n, c->tr_all ? c->tr_all + c->tr_base + c->nx_n : nullptr, d_off, d_fp, d_key, n, c->nx_w);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->nx_n += n;
+  c->nx_w += n_words;
+  return 0;
+}
+
+int32_t vsrmc_shard_commit(vsrmc_checker* c, vsrmc_level_info* info) {
+  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  return phase_commit(c, info);
+}
+
+int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index) {
+  if (!c || !index) return fail(VSRMC_E_ARG, "NULL argument");
+  return find_fp_newest(c, fp, index);
+}
+
+int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* key) {
+  if (!c || !key) return fail(VSRMC_E_ARG, "NULL argument");
+  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
+  if (level < 1 || level > (int)c->level_base.size() || index >= c->level_size[level - 1]) return fail(VSRMC_E_ARG, "no such state");
+  HIPCHK(hipSetDevice(c->opt.device));
+  HIPCHK(hipMemcpy(key, c->tr_all + c->level_base[level - 1] + index, 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -835,16 +1000,15 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
   return 0;
 }
 
-int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words, uint64_t* off,
-                            int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
-  if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
-  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
-  if (level < 1 || level > (int)c->level_base.size() || index >= c->level_size[level - 1])
-    return fail(VSRMC_E_ARG, "no such state");
-  const Model& M = c->model.M;
+// ≙ the forward half of TLCTrace.getTrace: re-execute `nsteps` ordinals from Init on the GPU (k_replay)
+int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t* ords, int32_t nsteps, uint64_t* words,
+                           uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
+  if (!m || !words || !off || !actions || !n_states || nsteps < 0 || (nsteps && !ords)) return fail(VSRMC_E_ARG, "bad argument");
+  int rc = check_device(device);
+  if (rc) return rc;
+  const Model& M = m->M;
+  const int level = nsteps + 1;
   if (cap_states < (u64)level + 1) return fail(VSRMC_E_ARG, "state buffers too small");
-  int nsteps = level - 1;
-  HIPCHK(hipSetDevice(c->opt.device));
   u64 maxw = (u64)(M.fixed + M.max_bag + 8) * (u64)level;
   u64 *d_w = nullptr, *d_o = nullptr, *d_m = nullptr;
   u32* d_ords = nullptr;
@@ -860,14 +1024,10 @@ int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uin
   for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
   HIPCHK(hipMemcpy(d_w, dev.data(), len * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(d_m, 0, (u64)std::max(nsteps, 1) * 32));
-  if (nsteps > 0) {   // walk the (parent index, ordinal) log back to Init on the device, then re-execute forward
-    HIPCHK(hipMemcpy(c->d_level_base, c->level_base.data(), c->level_base.size() * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->tr_all, c->d_level_base, level, index, d_ords);
-    HIPCHK(hipGetLastError());
-  }
-  hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, c->stream, M, d_w, d_o, d_ords, nsteps, d_m);
+  if (nsteps > 0) HIPCHK(hipMemcpy(d_ords, ords, (u64)nsteps * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, 0, M, d_w, d_o, d_ords, nsteps, d_m);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipDeviceSynchronize());
   std::vector<u64> hw(maxw), ho(level + 1), hm((size_t)std::max(nsteps, 1) * 4);
   HIPCHK(hipMemcpy(ho.data(), d_o, ((u64)level + 1) * 8, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(hw.data(), d_w, maxw * 8, hipMemcpyDeviceToHost));
@@ -889,6 +1049,29 @@ int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uin
   return 0;
 }
 
+int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words, uint64_t* off,
+                            int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
+  if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
+  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
+  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: walk the log with vsrmc_checker_trace_entry on the owning ranks");
+  if (level < 1 || level > (int)c->level_base.size() || index >= c->level_size[level - 1])
+    return fail(VSRMC_E_ARG, "no such state");
+  int nsteps = level - 1;
+  HIPCHK(hipSetDevice(c->opt.device));
+  std::vector<u32> ords(std::max(nsteps, 1));
+  if (nsteps > 0) {   // walk the (parent index, ordinal) log back to Init on the device
+    u32* d_ords = nullptr;
+    HIPCHK(hipMalloc((void**)&d_ords, (u64)nsteps * 4));
+    HIPCHK(hipMemcpy(c->d_level_base, c->level_base.data(), c->level_base.size() * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->tr_all, c->d_level_base, level, index, d_ords);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(ords.data(), d_ords, (u64)nsteps * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_ords);
+  }
+  return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), nsteps, words, cap_words, off, actions, cap_states, n_states);
+}
+
 void vsrmc_checker_destroy(vsrmc_checker* c) {
   if (!c) return;
   (void)hipSetDevice(c->opt.device);
@@ -903,6 +1086,7 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
   if (c->pending) (void)hipFree(c->pending);
   if (c->ctl) (void)hipFree(c->ctl);
   if (c->d_find) (void)hipFree(c->d_find);
+  if (c->rslot) (void)hipFree(c->rslot);
   for (int i = 0; i < 4; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -1,0 +1,140 @@
+// vsrmc — command-line front end over the C ABI (include/vsrmc.h), keeping TLC's surface for this model:
+//     vsrmc -config VSR.cfg VSR.tla [-deadlock] [-maxDepth N] [-device D] [-tableLog2 N] [-frontierGiB G] [-noTLA] [-json]
+// ≙ `java -cp tla2tools.jar tlc2.TLC -config VSR.cfg VSR.tla -deadlock` (README:20 of the reference).  Output follows TLC's
+// wording (progress lines, "Invariant ... is violated", "State k: <Action>" + the state in TLC value syntax, final counts).
+// `-deadlock` (= do NOT check deadlock) is the default here because the spec has terminal states; pass
+// -checkDeadlock to stop at the first state without successors like stock TLC would.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vsrmc.h"
+
+static void usage() {
+  std::printf(
+      "usage: vsrmc -config <file.cfg> <spec.tla> [options]\n"
+      "  -config FILE      TLC configuration (grammar of VSR.cfg: CONSTANTS / INIT / NEXT / VIEW / SYMMETRY / INVARIANT)\n"
+      "  -deadlock         do not check for deadlock (default)      -checkDeadlock   report the first terminal state\n"
+      "  -maxDepth N       stop after N BFS levels (Init = level 1)\n"
+      "  -device D         HIP device ordinal (default 0)\n"
+      "  -tableLog2 N      seen-set slots = 2^N x 16 B (default 28)\n"
+      "  -frontierGiB G    size of each of the two frontier buffers (default 8)\n"
+      "  -noTLA            do not read / hash-check the .tla file (only the cfg)\n"
+      "  -json             one JSON object per level on stdout instead of TLC-style progress lines\n");
+}
+
+int main(int argc, char** argv) {
+  std::string cfg, tla;
+  bool check_deadlock = false, no_tla = false, json = false;
+  int max_depth = 1 << 30, device = 0, table_log2 = 28;
+  double frontier_gib = 8.0;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    if (a == "--help" || a == "-h" || a == "-help") { usage(); return 0; }
+    else if (a == "-config" && i + 1 < argc) cfg = argv[++i];
+    else if (a == "-deadlock") check_deadlock = false;
+    else if (a == "-checkDeadlock") check_deadlock = true;
+    else if (a == "-maxDepth" && i + 1 < argc) max_depth = std::atoi(argv[++i]);
+    else if (a == "-device" && i + 1 < argc) device = std::atoi(argv[++i]);
+    else if (a == "-tableLog2" && i + 1 < argc) table_log2 = std::atoi(argv[++i]);
+    else if (a == "-frontierGiB" && i + 1 < argc) frontier_gib = std::atof(argv[++i]);
+    else if (a == "-noTLA") no_tla = true;
+    else if (a == "-json") json = true;
+    else if (a == "-workers" && i + 1 < argc) ++i;   // accepted for command-line compatibility; the GPU is the worker pool
+    else if (!a.empty() && a[0] != '-') tla = a;
+    else { std::fprintf(stderr, "vsrmc: unknown option %s\n", a.c_str()); usage(); return 2; }
+  }
+  if (cfg.empty()) { usage(); return 2; }
+  vsrmc_model* m = nullptr;
+  if (vsrmc_model_load(no_tla || tla.empty() ? nullptr : tla.c_str(), cfg.c_str(), &m) != 0) {
+    std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());
+    return 1;
+  }
+  vsrmc_layout lay;
+  vsrmc_model_info(m, &lay);
+  if (lay.check_deadlock) check_deadlock = true;
+  vsrmc_options o;
+  vsrmc_options_default(&o);
+  o.device = device;
+  o.table_log2 = table_log2;
+  o.frontier_words = (uint64_t)(frontier_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);
+  o.frontier_states = o.frontier_words / 24;
+  o.pending_entries = o.frontier_states * 3;
+  o.trace_entries = ((uint64_t)1 << table_log2) / 2;
+  vsrmc_checker* c = nullptr;
+  if (vsrmc_checker_create(m, &o, &c) != 0) {
+    std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());
+    return 1;
+  }
+  std::printf("vsrmc: VSR.tla lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), "
+              "invariant mask %d\n", lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
+              lay.permutations, lay.invariant_mask);
+  std::printf("Finished computing initial states: 1 distinct state generated.\n");
+  auto t0 = std::chrono::steady_clock::now();
+  vsrmc_level_info info;
+  std::memset(&info, 0, sizeof(info));
+  info.level = 1;
+  info.distinct = 1;
+  int rc = 0;
+  bool violated = false, deadlocked = false;
+  uint64_t viol_level = 0, viol_index = 0;
+  int depth = 1;
+  while (depth < max_depth) {
+    rc = vsrmc_checker_step(c, &info);
+    if (rc != 0) break;
+    if (info.n_new) depth = info.level;
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (json)
+      std::printf("{\"level\": %d, \"generated\": %llu, \"new\": %llu, \"distinct\": %llu, \"deadlocks\": %llu, \"seconds\": %.4f}\n",
+                  info.level, (unsigned long long)info.generated, (unsigned long long)info.n_new, (unsigned long long)info.distinct,
+                  (unsigned long long)info.deadlocks, dt);
+    else if (info.n_new)
+      std::printf("Progress(%d): %llu states generated, %llu distinct states found, %llu states left on queue. (%.2f s)\n", info.level,
+                  (unsigned long long)info.total_generated, (unsigned long long)info.distinct, (unsigned long long)info.n_new, dt);
+    if (info.viol_mask) { violated = true; viol_level = (uint64_t)info.level; viol_index = info.viol_index; break; }
+    if (check_deadlock && info.deadlocks) { deadlocked = true; break; }
+    if (info.n_new == 0) break;
+  }
+  double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  int exit_code = 0;
+  if (rc != 0) {
+    std::printf("Error: %s\n", vsrmc_last_error());
+    exit_code = rc == VSRMC_E_EVAL ? 12 : 1;
+  } else if (violated) {
+    const char* names[2] = {"AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"};
+    for (int b = 0; b < 2; b++)
+      if (info.viol_mask & (1 << b)) std::printf("Error: Invariant %s is violated.\n", names[b]);
+    std::printf("Error: The behavior up to this point is:\n");
+    uint64_t cap_w = (viol_level + 2) * (uint64_t)lay.max_record_words, n_states = 0;
+    std::vector<uint64_t> words(cap_w), off(viol_level + 2);
+    std::vector<int32_t> acts(viol_level + 2);
+    if (vsrmc_checker_trace(c, (int32_t)viol_level, viol_index, words.data(), cap_w, off.data(), acts.data(), off.size(), &n_states) != 0) {
+      std::printf("Error: %s\n", vsrmc_last_error());
+      exit_code = 1;
+    } else {
+      for (uint64_t t = 0; t < n_states; t++) {
+        int64_t need = 0;
+        vsrmc_model_format_state(m, &words[off[t]], nullptr, 0, &need);
+        std::string buf((size_t)need, '\0');
+        vsrmc_model_format_state(m, &words[off[t]], &buf[0], need, &need);
+        std::printf("State %llu: <%s>\n%s\n\n", (unsigned long long)(t + 1), vsrmc_action_name(acts[t]), buf.c_str());
+      }
+      exit_code = 12;   // TLC's exit code for a safety violation
+    }
+  } else if (deadlocked) {
+    std::printf("Error: Deadlock reached (%llu state(s) of level %d have no successor).\n", (unsigned long long)info.deadlocks, info.level - 1);
+    exit_code = 11;
+  } else if (info.n_new == 0) {
+    std::printf("Model checking completed. No error has been found.\n");
+  }
+  std::printf("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)info.total_generated,
+              (unsigned long long)info.distinct, (unsigned long long)(info.n_new));
+  std::printf("The depth of the complete state graph search is %d.\nFinished in %.3f s (%.3g distinct states/s).\n", depth, dt,
+              dt > 0 ? (double)info.distinct / dt : 0.0);
+  vsrmc_checker_destroy(c);
+  vsrmc_model_destroy(m);
+  return exit_code;
+}

@@ -1,0 +1,322 @@
+"""Multi-GPU level loop: the seen-set sharded by high fingerprint bits, one rank per GPU (≙ TLC's MultiFPSet, across devices).
+
+Per BFS level (phases documented in include/vsrmc.h):
+    expand -> all-to-all (fp, key) candidates to their owners -> owners claim + verdict -> all-to-all verdict bytes back
+           -> generators materialise the winners -> all-to-all record streams to the owners -> append -> commit
+           -> one all-reduce of the level's counters.
+Strict level synchrony: the set of fingerprints per level is independent of the world size.
+
+`Exchanger` moves variable-size buckets with torch.distributed.all_to_all_single (backend "nccl" = RCCL over xGMI on
+device tensors; "gloo": the same call on host tensors, device tensors are staged through the host).  `ShardedChecker`
+drives any engine that implements the phase methods; `HipShardEngine` is the product engine (HIP kernels behind the C ABI).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+from .capi import check
+
+U64_MAX = (1 << 64) - 1
+
+
+def owner_of(fp, world):
+    """Owner rank of a fingerprint — must match owner_of() in csrc/vsr_kernels.hpp."""
+    return ((int(fp) >> 40) & 0xFFFFFF) % world
+
+
+class Exchanger:
+    """Variable-size all-to-all of per-peer buckets, plus the small collectives of the level loop."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.bytes_sent = 0
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        if self.backend == "gloo" and inp.is_cuda:            # gloo moves host memory: stage through the host
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def exchange(self, send_list, err=0):
+        """send_list[p] = tensor of rows for peer p (same dtype / trailing shape).  Returns (recv_list, max err over ranks);
+        recv_list[p] = rows received from peer p (views of one contiguous tensor, peer-major)."""
+        w = self.world
+        dev = send_list[0].device
+        counts = torch.tensor([int(t.shape[0]) for t in send_list] + [int(err)], dtype=torch.int64)
+        # every peer p gets (rows I send to p, my error code)
+        meta_in = torch.stack([torch.stack([counts[p], counts[w]]) for p in range(w)]).reshape(-1)
+        meta_out = torch.empty(2 * w, dtype=torch.int64)
+        if self.backend == "nccl":
+            mi, mo = meta_in.to(dev), meta_out.to(dev)
+            dist.all_to_all_single(mo, mi, group=self.group)
+            meta_out = mo.cpu()
+        else:
+            dist.all_to_all_single(meta_out, meta_in, group=self.group)
+        recv_counts = [int(meta_out[2 * p]) for p in range(w)]
+        max_err = max(int(meta_out[2 * p + 1]) for p in range(w))
+        send_counts = [int(t.shape[0]) for t in send_list]
+        tail = tuple(send_list[0].shape[1:])
+        inp = torch.cat([t.reshape((-1,) + tail) for t in send_list]) if sum(send_counts) else \
+            torch.empty((0,) + tail, dtype=send_list[0].dtype, device=dev)
+        out = torch.empty((sum(recv_counts),) + tail, dtype=send_list[0].dtype, device=dev)
+        self._a2a(out, inp.contiguous(), recv_counts, send_counts)      # every rank calls it, even with nothing to move
+        self.bytes_sent += (sum(send_counts) - send_counts[self.rank]) * inp.element_size() * int(np.prod(tail or (1,)))
+        recv, pos = [], 0
+        for p in range(w):
+            recv.append(out[pos: pos + recv_counts[p]])
+            pos += recv_counts[p]
+        return recv, max_err, out
+
+    def allreduce(self, values, op):
+        """values: list of python ints (< 2^63) -> list of ints reduced over ranks."""
+        t = torch.tensor(values, dtype=torch.int64)
+        if self.backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=op, group=self.group)
+        return [int(x) for x in t.cpu()]
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+
+class ShardError(RuntimeError):
+    pass
+
+
+class ShardedChecker:
+    """The level loop over an engine.  Engine protocol (all tensors int64 unless noted, on the engine's device):
+        expand()                          -> (list of (n_p, 2) candidate tensors per peer, err)
+        claim(cands (n,2))                -> (uint8 verdict tensor (n,), err)
+        materialize(verdicts per peer)    -> (list per peer of (words, off, fp, key) tensors, err)
+        append(words, off, fp, key)       -> err
+        commit()                          -> dict(n_new, generated, deadlocks, viol_fp, viol_mask, max_bag, ...)
+        find_fp(fp) -> index or None ; trace_entry(level, index) -> key ; error_text()
+    """
+
+    def __init__(self, engine, exchanger):
+        self.e = engine
+        self.x = exchanger
+        self.rank, self.world = exchanger.rank, exchanger.world
+        self.level = 1
+        tot = self.x.allreduce([engine.local_distinct()], dist.ReduceOp.SUM)
+        self.distinct = tot[0]
+        self.n_frontier = self.distinct
+        self.violation = None
+        self.levels = []
+
+    def _raise_if(self, err, phase):
+        if err:
+            raise ShardError("level %d, phase %s: error %d on some rank (local: %s)" % (self.level + 1, phase, err,
+                                                                                      self.e.error_text()))
+
+    def step(self):
+        e, x, me = self.e, self.x, self.rank
+        cands, err = e.expand()
+        recv, err, cat = x.exchange(cands, err)
+        self._raise_if(err, "expand")
+        verdict, err = e.claim(cat)
+        back, pos = [], 0
+        for p in range(self.world):
+            back.append(verdict[pos: pos + recv[p].shape[0]])
+            pos += recv[p].shape[0]
+        vrecv, err, _ = x.exchange(back, err)
+        self._raise_if(err, "claim")
+        streams, err = e.materialize(vrecv)
+        got = []
+        for k in range(4):                                  # words, off, fp, key
+            r, err, _ = x.exchange([streams[p][k] for p in range(self.world)], err)
+            got.append(r)
+        self._raise_if(err, "materialize")
+        err = 0
+        for p in range(self.world):
+            if p != me and got[1][p].shape[0]:
+                err = max(err, e.append(got[0][p], got[1][p], got[2][p], got[3][p]))
+        info = e.commit()
+        viol_fp = info["viol_fp"] if info["viol_mask"] else U64_MAX
+        s = x.allreduce([info["n_new"], info["generated"], info["deadlocks"], info["pending"]], dist.ReduceOp.SUM)
+        # a 64-bit fingerprint does not fit a signed int64 min-reduce: reduce the two halves lexicographically;
+        # the error code rides along negated (min of -err = -max err)
+        gmin_hi, neg_err = x.allreduce([viol_fp >> 32, -err], dist.ReduceOp.MIN)
+        lo = (viol_fp & 0xFFFFFFFF) if (viol_fp >> 32) == gmin_hi else 0xFFFFFFFF
+        gmin_lo = x.allreduce([lo], dist.ReduceOp.MIN)[0]
+        self._raise_if(-neg_err, "append")
+        gviol = (gmin_hi << 32) | gmin_lo
+        self.level += 1
+        self.n_frontier = s[0]
+        self.distinct += s[0]
+        out = dict(level=self.level, n_new=s[0], generated=s[1], deadlocks=s[2], pending=s[3], distinct=self.distinct,
+                   local=info, viol_fp=gviol if gviol != U64_MAX else None)
+        if s[0]:
+            self.levels.append(out)
+        if gviol != U64_MAX and self.violation is None:
+            idx = e.find_fp(gviol)
+            where = x.allreduce([me if idx is not None else -1, idx if idx is not None else -1], dist.ReduceOp.MAX)
+            self.violation = dict(level=self.level, rank=where[0], index=where[1], fp=gviol)
+        return out
+
+    def run(self, max_depth=None, stop_on_violation=True):
+        while True:
+            if max_depth is not None and self.level >= max_depth:
+                return "max-depth"
+            d = self.step()
+            if d["n_new"] == 0:
+                return "exhausted"
+            if self.violation is not None and stop_on_violation:
+                return "violation"
+
+    def trace_ordinals(self, level, rank, index):
+        """Walk the distributed (parent rank, parent index, ordinal) log back to Init; every rank must call this."""
+        ords = []
+        for l in range(level, 1, -1):
+            key = self.e.trace_entry(l, index) if rank == self.rank else 0
+            # a 64-bit key crosses ranks as two 32-bit halves (signed int64 all-reduce)
+            parts = self.x.allreduce([key >> 32, key & 0xFFFFFFFF], dist.ReduceOp.MAX)
+            key = (parts[0] << 32) | parts[1]
+            ords.append(key & 2047)
+            rank, index = (key >> 43) & 7, (key >> 11) & 0xFFFFFFFF
+        return ords[::-1]
+
+
+class HipShardEngine:
+    """The product engine: one rank's shard of the checker, HIP kernels behind the C ABI (include/vsrmc.h)."""
+
+    def __init__(self, model, rank, world, device=0, table_log2=26, frontier_words=1 << 27, frontier_states=1 << 22,
+                 pending_entries=1 << 23, cand_cap=1 << 22, rec_cap=1 << 21, rec_words_cap=1 << 26, keep_trace=True,
+                 trace_entries=0):
+        self.model, self.rank, self.world, self.device = model, rank, world, device
+        o = capi.Options()
+        capi.load().vsrmc_options_default(C.byref(o))
+        o.device, o.table_log2 = device, table_log2
+        o.frontier_words, o.frontier_states, o.pending_entries = frontier_words, frontier_states, pending_entries
+        o.keep_trace, o.trace_entries, o.rank, o.world = int(keep_trace), trace_entries, rank, world
+        self._h = C.c_void_p()
+        check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))
+        dev = torch.device("cuda", device)
+        self.dev = dev
+        self.cand_cap, self.rec_cap, self.rec_words_cap = cand_cap, rec_cap, rec_words_cap
+        self.cand_send = torch.zeros((world, cand_cap, 2), dtype=torch.int64, device=dev)
+        self.verdict_in = torch.zeros((world, cand_cap), dtype=torch.uint8, device=dev)
+        self.rec_words = torch.zeros((world, rec_words_cap), dtype=torch.int64, device=dev)
+        self.rec_off = torch.zeros((world, rec_cap), dtype=torch.int64, device=dev)
+        self.rec_fp = torch.zeros((world, rec_cap), dtype=torch.int64, device=dev)
+        self.rec_key = torch.zeros((world, rec_cap), dtype=torch.int64, device=dev)
+        self.io = capi.ShardIO(self.cand_send.data_ptr(), cand_cap, self.rec_words.data_ptr(), rec_words_cap,
+                               self.rec_off.data_ptr(), self.rec_fp.data_ptr(), self.rec_key.data_ptr(), rec_cap)
+        self._cand_counts = [0] * world
+        self._err_text = ""
+        self.kernel_ms = dict(expand=0.0, materialize=0.0)
+
+    def _call(self, rc):
+        if rc != 0:
+            self._err_text = capi.load().vsrmc_last_error().decode()
+            return -rc if rc < 0 else rc
+        return 0
+
+    def error_text(self):
+        return self._err_text
+
+    def local_distinct(self):
+        return self._frontier_counts()[1]
+
+    def _frontier_counts(self):
+        n = C.c_uint64()
+        out = np.zeros(1, dtype=np.uint64)
+        rc = capi.load().vsrmc_checker_level_fps(self._h, C.c_void_p(out.ctypes.data), 1, C.byref(n))
+        return rc, int(n.value)
+
+    def reset(self):
+        check(capi.load().vsrmc_checker_reset(self._h))
+
+    def expand(self):
+        counts = (C.c_uint64 * 8)()
+        err = self._call(capi.load().vsrmc_shard_expand(self._h, C.byref(self.io), counts))
+        self._cand_counts = [min(int(counts[p]), self.cand_cap) if p != self.rank else 0 for p in range(self.world)]
+        if err:
+            self._cand_counts = [0] * self.world
+        return [self.cand_send[p, : self._cand_counts[p]] for p in range(self.world)], err
+
+    def claim(self, cands):
+        n = int(cands.shape[0])
+        verdict = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        cands = cands.contiguous()
+        torch.cuda.synchronize(self.dev)                       # the candidates were produced by a collective on torch's stream
+        err = self._call(capi.load().vsrmc_shard_claim(self._h, C.c_void_p(cands.data_ptr()), n, C.c_void_p(verdict.data_ptr())))
+        return verdict, err
+
+    def materialize(self, verdicts):
+        for p in range(self.world):
+            if p != self.rank and self._cand_counts[p]:
+                assert verdicts[p].shape[0] == self._cand_counts[p]
+                self.verdict_in[p, : self._cand_counts[p]].copy_(verdicts[p])
+        torch.cuda.synchronize(self.dev)
+        rc_n = (C.c_uint64 * 8)()
+        rc_w = (C.c_uint64 * 8)()
+        err = self._call(capi.load().vsrmc_shard_materialize(self._h, C.byref(self.io), C.c_void_p(self.verdict_in.data_ptr()),
+                                                             rc_n, rc_w))
+        out = []
+        for p in range(self.world):
+            n, w = (int(rc_n[p]), int(rc_w[p])) if (p != self.rank and not err) else (0, 0)
+            out.append((self.rec_words[p, :w], self.rec_off[p, :n], self.rec_fp[p, :n], self.rec_key[p, :n]))
+        return out, err
+
+    def append(self, words, off, fp, key):
+        words, off, fp, key = words.contiguous(), off.contiguous(), fp.contiguous(), key.contiguous()
+        torch.cuda.synchronize(self.dev)
+        return self._call(capi.load().vsrmc_shard_append(self._h, C.c_void_p(words.data_ptr()), int(words.shape[0]),
+                                                         C.c_void_p(off.data_ptr()), C.c_void_p(fp.data_ptr()),
+                                                         C.c_void_p(key.data_ptr()), int(off.shape[0])))
+
+    def commit(self):
+        info = capi.LevelInfo()
+        check(capi.load().vsrmc_shard_commit(self._h, C.byref(info)))
+        d = info.as_dict()
+        self.kernel_ms["expand"] += d["expand_ms"]
+        self.kernel_ms["materialize"] += d["materialize_ms"]
+        self.last = d
+        return d
+
+    def find_fp(self, fp):
+        idx = C.c_uint64()
+        check(capi.load().vsrmc_checker_find_fp(self._h, fp, C.byref(idx)))
+        return None if idx.value == U64_MAX else idx.value
+
+    def trace_entry(self, level, index):
+        key = C.c_uint64()
+        check(capi.load().vsrmc_checker_trace_entry(self._h, level, index, C.byref(key)))
+        return key.value
+
+    def level_fps(self):
+        rc, n = self._frontier_counts()
+        out = np.zeros(max(1, n), dtype=np.uint64)
+        nn = C.c_uint64()
+        check(capi.load().vsrmc_checker_level_fps(self._h, C.c_void_p(out.ctypes.data), len(out), C.byref(nn)))
+        return out[: nn.value].copy()
+
+    def close(self):
+        if self._h:
+            capi.load().vsrmc_checker_destroy(self._h)
+            self._h = None
+
+
+def replay(model, ords, device=0):
+    """TLCTrace.getTrace, forward half: [(action name, wire record)] for a path of ordinals from Init."""
+    from .checker import ACTION_NAMES
+    n = len(ords)
+    lay = model.layout
+    cap_w = (n + 2) * int(lay.max_record_words)
+    words = np.zeros(cap_w, dtype=np.uint64)
+    off = np.zeros(n + 3, dtype=np.uint64)
+    acts = np.zeros(n + 3, dtype=np.int32)
+    o = np.array(list(ords) + [0], dtype=np.uint32)
+    ns = C.c_uint64()
+    check(capi.load().vsrmc_model_replay(model._h, device, C.c_void_p(o.ctypes.data), n, C.c_void_p(words.ctypes.data), cap_w,
+                                         C.c_void_p(off.ctypes.data), C.c_void_p(acts.ctypes.data), len(off), C.byref(ns)))
+    return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(ns.value)]

@@ -1,0 +1,99 @@
+"""bench.py's N > 1 leg: the same workload (config 2 to the first violation) with the seen-set sharded over N GPUs.
+One rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run), backend "nccl" (= RCCL over xGMI)."""
+import json
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+# per-level maxima of the workload (tests/golden/config2_violation.json): sizes every buffer
+MAX_NEW, MAX_GENERATED, MAX_WORDS, TOTAL = 80003390, 217755238, 3029987047, 319228361
+HBM_PEAK_GBS = 8000.0
+
+
+def main(args, CONFIG, EXPECT):
+    import vsr_tlaplus_amd as vt
+    from vsr_tlaplus_amd import sharded
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    slack = 1.35                                              # hash imbalance between shards
+    per_rank = lambda x: int(x / world * slack) + (1 << 16)   # noqa: E731
+    per_pair = lambda x: int(x / world / world * slack) + (1 << 16)   # noqa: E731
+    m = vt.Model.from_constants(R=CONFIG["R"], C_=CONFIG["C"], n=CONFIG["n"], L=CONFIG["L"])
+    table_log2 = max(20, int(math.ceil(math.log2(2.2 * TOTAL / world))))
+    eng = sharded.HipShardEngine(
+        m, rank, world, device=local_rank, table_log2=table_log2, frontier_words=per_rank(MAX_WORDS),
+        frontier_states=per_rank(MAX_NEW), pending_entries=per_pair(MAX_GENERATED), cand_cap=per_pair(MAX_GENERATED),
+        rec_cap=per_pair(MAX_NEW), rec_words_cap=per_pair(MAX_WORDS), keep_trace=True, trace_entries=per_rank(TOTAL))
+    x = sharded.Exchanger()
+    S = dict(alg_bytes=0.0, launches=0, distinct=0, ttfv=[])
+
+    def one_run(record):
+        eng.reset()
+        eng.kernel_ms = dict(expand=0.0, materialize=0.0)
+        sc = sharded.ShardedChecker(eng, x)
+        t0 = time.perf_counter()
+        cur_words = (int(m.layout.fixed_words) + int(m.layout.permutations)) if sc.e.local_distinct() else 0
+        while True:
+            d = sc.step()
+            loc = d["local"]
+            if record and loc["frontier"]:
+                S["launches"] += 1
+                S["alg_bytes"] += 8.0 * cur_words + 8.0 * loc["generated"] + 8.0 * loc["n_new"]
+            cur_words = loc["words_new"]
+            if d["n_new"] == 0 or sc.violation is not None:
+                break
+        if sc.violation is not None:                          # counter-example reconstructed = found
+            ords = sc.trace_ordinals(sc.violation["level"], sc.violation["rank"], sc.violation["index"])
+            if rank == 0:
+                tr = sharded.replay(m, ords, device=local_rank)
+                assert len(tr) == sc.violation["level"]
+        dt = time.perf_counter() - t0
+        assert sc.distinct == EXPECT["distinct"] and sc.level == EXPECT["depth"], (sc.distinct, sc.level)
+        assert sc.violation and sc.violation["fp"] == EXPECT["viol_fp"]
+        if record:
+            S["distinct"] += sc.distinct
+            S["ttfv"].append(dt)
+            S["expand_ms"] = S.get("expand_ms", 0.0) + eng.kernel_ms["expand"]
+            S["mat_ms"] = S.get("mat_ms", 0.0) + eng.kernel_ms["materialize"]
+
+    for _ in range(args.warmup):
+        one_run(False)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_run(True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        value = S["distinct"] / elapsed
+        avg_launch_s = S["expand_ms"] / 1e3 / max(1, S["launches"])
+        achieved = S["alg_bytes"] / max(1, S["launches"]) / max(avg_launch_s, 1e-12) / 1e9
+        print(json.dumps({
+            "metric": "distinct states/sec (whole node), VSR 3-replica", "value": round(value, 1), "unit": "distinct states/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 "
+                                   "(BASELINE configs[1] = shipped VSR.cfg), VIEW+SYMMETRY, to first violation: 28 levels, "
+                                   "319228361 distinct states", "parallelism": "seen-set sharded by fingerprint over %d ranks, "
+                                   "all-to-all per level (RCCL)" % world, "table_slots_log2_per_rank": table_log2},
+            "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
+            "xgmi_bytes_sent_rank0_per_step": int(x.bytes_sent / max(1, args.steps + args.warmup)),
+            "roofline": {"bound": "hbm", "kernel": "k_expand (rank 0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": S["launches"],
+                         "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3),
+                                                "k_materialize": round(S["mat_ms"] / args.steps, 3)}},
+        }))
+    dist.barrier()
+    dist.destroy_process_group()
