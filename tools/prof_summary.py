@@ -14,8 +14,8 @@ def main(path, title):
         short = name.split("(")[0]
         print("| %s | %d | %.3f | %.1f | %.2f |" % (short, calls, total / 1e3, avg, pct))
     try:
-        rows = list(cur.execute("select k.name, p.name, sum(e.value), count(*) from pmc_events e join kernels k on "
-                                "e.dispatch_id = k.dispatch_id join pmc_info p on e.pmc_id = p.id group by k.name, p.name"))
+        rows = list(cur.execute("select name, counter_name, sum(counter_value), count(*) from pmc_events group by name, "
+                                "counter_name order by 3 desc"))
     except sqlite3.Error:
         rows = []
     if rows:
