@@ -22,75 +22,124 @@
 
 namespace vsr {
 
-#define VSR_MAXPATCH 5    // 1 discard + (R-1 <= 4) broadcasts
+#define VSR_NSLOT 6        // patch slot 0: the received entry (count - 1); slot 1: a single send, or, for broadcasts,
+                           // slot d = the copy addressed to replica d (1..5).  Slots are compile-time indices everywhere
+                           // (fully unrolled loops), so a Delta lives in registers, never in scratch memory.
 
 struct Delta {
   u64 hdr;                 // new header (nmsg already updated)
-  u64 rep[4];              // new replica block of replica r (wpr <= 4 words)
+  u64 rep[4];              // new replica block of replica r (wpr <= 4 words; rep[3] is 0 when wpr == 3)
   int r;                   // the one replica an action updates
   int action;              // A_* id (for traces)
-  int npatch;
-  int pj[VSR_MAXPATCH];    // bag index patched, or -1 = appended entry
-  u64 pold[VSR_MAXPATCH];  // previous word (0 for appended entries)
-  u64 pnew[VSR_MAXPATCH];
+  int used;                // bit s: patch slot s is in use
+  int pj[VSR_NSLOT];       // bag index patched, or -1 = appended entry
+  u64 pold[VSR_NSLOT];     // previous word (0 for appended entries)
+  u64 pnew[VSR_NSLOT];
   int err;
 };
 
-// ---- x-slot access inside a replica block held in D.rep -------------------------------------------------------
-VSR_HD u32 blk_x(const u64* b, int i) { return (u32)(b[1 + (i >> 1)] >> (32 * (i & 1))); }
-VSR_HD void blk_setx(u64* b, int i, u32 x) {
-  int w = 1 + (i >> 1), sh = 32 * (i & 1);
-  b[w] = (b[w] & ~((u64)0xFFFFFFFFu << sh)) | ((u64)x << sh);
-}
-VSR_HD void blk_clear_dvc(const Model& M, u64* b) {           // rep_dvc_recv[r] = {}  (keeps x0 = own log)
-  b[1] &= 0xFFFFFFFFull;
-  for (int k = 2; k < M.wpr; k++) b[k] = 0;
-}
-VSR_HD int blk_dvc_count(const Model& M, const u64* b) {
+// ---- x-slot access: replica block in memory (parent record) ... ------------------------------------------------------
+template <typename PTR>
+VSR_HD u32 blk_x(PTR b, int i) { return (u32)(b[1 + (i >> 1)] >> (32 * (i & 1))); }
+template <typename PTR>
+VSR_HD int blk_dvc_count(const Model& M, PTR b) {
   int c = 0;
   for (int s = 1; s <= M.R; s++) c += (int)(blk_x(b, s) & 1);
   return c;
 }
-
-// ---- bag algebra (VSR.tla:228-270) on parent bag + patch list ---------------------------------------------------
-// DiscardFunc (VSR.tla:244-245): count - 1, the key stays in the domain.
-VSR_HD void bag_discard(Delta& D, int j, u64 w) {
-  int k = D.npatch++;
-  D.pj[k] = j;
-  D.pold[k] = w;
-  D.pnew[k] = m_set_count(w, m_count(w) - 1);
+// ---- ... and in the Delta's register copy (every index written out so that no dynamic register indexing remains) -----
+VSR_HD void rep_setx(u64* b, int i, u32 x) {
+  // all three words are rewritten under masks: an if-chain over b[1] / b[2] / b[3] gets merged by the optimiser into one
+  // store through a selected pointer, i.e. a dynamically indexed register array, which then lives in scratch memory
+  const int w = 1 + (i >> 1), sh = 32 * (i & 1);
+  const u64 m = (u64)0xFFFFFFFFu << sh, v = (u64)x << sh;
+  const u64 m1 = w == 1 ? m : 0, m2 = w == 2 ? m : 0, m3 = w == 3 ? m : 0;
+  b[1] = (b[1] & ~m1) | (v & m1);
+  b[2] = (b[2] & ~m2) | (v & m2);
+  b[3] = (b[3] & ~m3) | (v & m3);
 }
-// SendFunc (VSR.tla:228-231): existing key -> count + 1 (even from 0), new key -> count 1.
+VSR_HD void rep_clear_dvc(u64* b) {                            // rep_dvc_recv[r] = {}  (keeps x0 = own log)
+  b[1] &= 0xFFFFFFFFull;
+  b[2] = 0;
+  b[3] = 0;
+}
+
+// ---- bag algebra (VSR.tla:228-270) on parent bag + patch slots -----------------------------------------------------
+// DiscardFunc (VSR.tla:244-245): count - 1, the key stays in the domain.  Always slot 0.
+VSR_HD void bag_discard(Delta& D, int j, u64 w) {
+  D.used |= 1;
+  D.pj[0] = j;
+  D.pold[0] = w;
+  D.pnew[0] = m_set_count(w, m_count(w) - 1);
+}
+// SendFunc (VSR.tla:228-231): existing key -> count + 1 (even from 0), new key -> count 1.  SLOT is a compile-time constant
+// at every call site.
 template <typename PTR>
-VSR_HD void bag_send(const Model& M, PTR bag, int nmsg, Delta& D, u64 key) {
-  for (int k = 0; k < D.npatch; k++)
-    if ((D.pnew[k] & KEYMASK) == key) {                        // key touched earlier in this action
+VSR_HD void bag_send_at(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, const int SLOT) {
+#pragma unroll
+  for (int k = 0; k < VSR_NSLOT; k++)
+    if (((D.used >> k) & 1) && (D.pnew[k] & KEYMASK) == key) {   // key touched earlier in this action
       int c = m_count(D.pnew[k]) + 1;
       if (c > 3) { D.err = ERR_REP_COUNT; return; }
       D.pnew[k] = m_set_count(D.pnew[k], c);
       return;
     }
-  int k = D.npatch++;
+  D.used |= 1 << SLOT;
+  D.pj[SLOT] = -1;
+  D.pold[SLOT] = 0;
+  D.pnew[SLOT] = m_set_count(key, 1);
   for (int j = 0; j < nmsg; j++) {
     u64 w = bag[j];
     if ((w & KEYMASK) == key) {
       int c = m_count(w) + 1;
       if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
-      D.pj[k] = j;
-      D.pold[k] = w;
-      D.pnew[k] = m_set_count(w, c);
+      D.pj[SLOT] = j;
+      D.pold[SLOT] = w;
+      D.pnew[SLOT] = m_set_count(w, c);
       return;
     }
   }
-  D.pj[k] = -1;
-  D.pold[k] = 0;
-  D.pnew[k] = m_set_count(key, 1);
 }
-// BroadcastFunc (VSR.tla:233-240): one copy per replica other than the source, dest overwritten.
+template <typename PTR>
+VSR_HD void bag_send(const Model& M, PTR bag, int nmsg, Delta& D, u64 key) { bag_send_at(M, bag, nmsg, D, key, 1); }
+// BroadcastFunc (VSR.tla:233-240): one copy per replica other than the source, dest overwritten.  One scan of the bag
+// serves all copies.
 template <typename PTR>
 VSR_HD void bag_broadcast(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, int source) {
-  for (int d = 1; d <= M.R; d++)
-    if (d != source) bag_send(M, bag, nmsg, D, m_set_dest(key, d));
+#pragma unroll
+  for (int d = 1; d <= 5; d++)
+    if (d <= M.R && d != source) {
+      D.used |= 1 << d;
+      D.pj[d] = -1;
+      D.pold[d] = 0;
+      D.pnew[d] = m_set_count(m_set_dest(key, d), 1);
+    }
+  const u64 nodest = ~((u64)7 << 6);
+  for (int j = 0; j < nmsg; j++) {
+    u64 w = bag[j];
+    if (((w ^ key) & KEYMASK & nodest) != 0) continue;         // same record up to dest
+    const int d = m_dest(w);
+    int c = m_count(w) + 1;
+    if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
+#pragma unroll
+    for (int q = 1; q <= 5; q++)
+      if (q == d && ((D.used >> q) & 1)) {
+        D.pj[q] = j;
+        D.pold[q] = w;
+        D.pnew[q] = m_set_count(w, c);
+      }
+  }
+  // a copy whose key is the entry this action just discarded (slot 0) stacks on that patch instead
+  if (D.used & 1) {
+#pragma unroll
+    for (int q = 1; q <= 5; q++)
+      if (((D.used >> q) & 1) && ((D.pnew[q] ^ D.pnew[0]) & KEYMASK) == 0) {
+        int c = m_count(D.pnew[0]) + 1;
+        if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
+        D.pnew[0] = m_set_count(D.pnew[0], c);
+        D.used &= ~(1 << q);
+      }
+  }
 }
 template <typename PTR>
 VSR_HD bool bag_has_key(PTR bag, int nmsg, u64 key) {          // key \in DOMAIN messages (any count)
@@ -101,8 +150,9 @@ VSR_HD bool bag_has_key(PTR bag, int nmsg, u64 key) {          // key \in DOMAIN
 
 // ResetRecvMsgs + ResetSentVars (VSR.tla:299-305) on a replica block
 VSR_HD void blk_reset_recv(const Model& M, u64* b) {
+  (void)M;
   b[0] = a_set_svcmask(b[0], 0);
-  blk_clear_dvc(M, b);
+  rep_clear_dvc(b);
 }
 VSR_HD void blk_reset_sent(u64* b) { b[0] = a_set_sent_sv(a_set_sent_dvc(b[0], 0), 0); }
 
@@ -152,10 +202,13 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
   if (!GUARD_ONLY) {
     D.hdr = hdr;
     D.r = r;
-    D.npatch = 0;
+    D.used = 0;
     D.err = 0;
     D.action = 0;
-    for (int k = 0; k < M.wpr; k++) D.rep[k] = pb[k];
+    D.rep[0] = pb[0];
+    D.rep[1] = pb[1];
+    D.rep[2] = pb[2];
+    D.rep[3] = M.wpr > 3 ? pb[3] : 0;
   }
   u64* nb = D.rep;
 
@@ -187,7 +240,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
         u32 slot = dvc_make(a_lnv(A), op, commit, lg);
         u32 cur = blk_x(pb, r);
         if ((cur & 1) && cur != slot) { D.err = ERR_REP_I2; return true; }
-        blk_setx(nb, r, slot);
+        rep_setx(nb, r, slot);
       } else {                                                 // :665-667
         bag_send(M, bag, nmsg, D, m_make(T_DVC, view, prim, r, op, commit, a_lnv(A), 0, lg));
       }
@@ -216,7 +269,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
       u32 new_log = dvc_log(blk_x(pb, best_s));                // :740
       int new_on = log_len(new_log);                           // :741  Len(HighestLog(r))
       nb[0] = a_set_status(nb[0], ST_NORMAL);                  // :744
-      blk_setx(nb, 0, new_log);                                // :746
+      rep_setx(nb, 0, new_log);                                // :746
       nb[0] = a_set_op(nb[0], new_on);                         // :747
       for (int p = 1; p <= M.R; p++) nb[0] = a_set_peer(nb[0], p, 0);   // :748
       nb[0] = a_set_commit(nb[0], max_commit);                 // :749
@@ -258,7 +311,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
       int opn = log_len(lg) + 1;                               // :373
       if (req > 3 || opn > 3) { D.err = ERR_REP_RANGE; return true; }
       int e = entry_make(view, o.v, o.c, req);                 // :374-377
-      blk_setx(nb, 0, lg | ((u32)e << (8 * (opn - 1))));       // :379
+      rep_setx(nb, 0, lg | ((u32)e << (8 * (opn - 1))));       // :379
       nb[0] = a_set_op(nb[0], opn);                            // :380
       nb[0] = a_set_ctrow(nb[0], o.c, ct_make(req, opn, 0));   // :381-384
       bag_broadcast(M, bag, nmsg, D, m_make(T_PREPARE, view, 0, r, opn, commit, 0, 0, (u32)e), r);   // :385-391
@@ -280,7 +333,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
         D.action = A_SendGetState;
         // the mask/slot forms of rep_svc_recv / rep_dvc_recv assume records of the replica's own view
         if (a_svcmask(A) || blk_dvc_count(M, pb)) { D.err = ERR_REP_I1; return true; }
-        blk_setx(nb, 0, log_prefix(lg, t));                    // :506
+        rep_setx(nb, 0, log_prefix(lg, t));                    // :506
         nb[0] = a_set_op(nb[0], t);                            // :507
         nb[0] = a_set_view(nb[0], mview);                      // :508
         nb[0] = a_set_lnv(nb[0], mview);                       // :509
@@ -295,7 +348,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
             nb[0] = a_set_view(nb[0], mview);                  // :606
             nb[0] = a_set_status(nb[0], ST_VIEWCHANGE);        // :607
             nb[0] = a_set_svcmask(nb[0], 1 << (msrc - 1));     // :608
-            blk_clear_dvc(M, nb);                              // :609
+            rep_clear_dvc(nb);                              // :609
             blk_reset_sent(nb);                                // :610
             bag_discard(D, o.j, mw);                           // :611
             bag_broadcast(M, bag, nmsg, D, m_make(T_SVC, mview, 0, r, 0, 0, 0, 0, 0), r);
@@ -317,8 +370,8 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
             nb[0] = a_set_view(nb[0], mview);                  // :681
             nb[0] = a_set_status(nb[0], ST_VIEWCHANGE);        // :682
             nb[0] = a_set_svcmask(nb[0], 0);                   // :683
-            blk_clear_dvc(M, nb);                              // :684
-            blk_setx(nb, msrc, slot);
+            rep_clear_dvc(nb);                              // :684
+            rep_setx(nb, msrc, slot);
             blk_reset_sent(nb);                                // :685
             bag_discard(D, o.j, mw);                           // :686
             bag_broadcast(M, bag, nmsg, D, m_make(T_SVC, mview, 0, r, 0, 0, 0, 0, 0), r);
@@ -327,7 +380,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
             D.action = A_ReceiveMatchingDVC;
             u32 cur = blk_x(pb, msrc);
             if ((cur & 1) && cur != slot) { D.err = ERR_REP_I2; return true; }
-            blk_setx(nb, msrc, slot);                          // :700
+            rep_setx(nb, msrc, slot);                          // :700
             bag_discard(D, o.j, mw);                           // :701
           } else {
             return false;
@@ -340,7 +393,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
           D.action = A_ReceiveSV;
           nb[0] = a_set_status(nb[0], ST_NORMAL);              // :777
           nb[0] = a_set_view(nb[0], mview);                    // :778
-          blk_setx(nb, 0, m_lg(mw) & 0xFFFFFF);                // :779
+          rep_setx(nb, 0, m_lg(mw) & 0xFFFFFF);                // :779
           nb[0] = a_set_op(nb[0], mop);                        // :780
           nb[0] = a_set_commit(nb[0], mcommit);                // :781
           nb[0] = a_set_lnv(nb[0], mview);                     // :782
@@ -361,7 +414,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
           u32 lg = blk_x(pb, 0);
           int pos = log_len(lg) + 1;                           // Append :411
           if (pos > 3) { D.err = ERR_REP_RANGE; return true; }
-          blk_setx(nb, 0, lg | ((u32)e << (8 * (pos - 1))));
+          rep_setx(nb, 0, lg | ((u32)e << (8 * (pos - 1))));
           nb[0] = a_set_op(nb[0], mop);                        // :412
           nb[0] = a_set_commit(nb[0], mcommit);                // :413
           for (int c = 1; c <= M.C; c++) {                     // :414-421
@@ -413,7 +466,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
           u32 nl = log_prefix(lg, op) | (log_prefix(ml, mop) & ~log_prefix(0xFFFFFF, op));   // :557-561
           for (int on = 1; on <= mop; on++)
             if (!log_byte(nl, on)) { D.err = ERR_EVAL_DOMAIN; return true; }
-          blk_setx(nb, 0, nl);
+          rep_setx(nb, 0, nl);
           nb[0] = a_set_op(nb[0], mop);                        // :562
           bag_discard(D, o.j, mw);                             // :564 (client table untouched, :563)
           break;
@@ -426,7 +479,8 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
   }
   if (!GUARD_ONLY) {
     int na = 0;
-    for (int k = 0; k < D.npatch; k++) na += D.pj[k] < 0 ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < VSR_NSLOT; k++) na += (((D.used >> k) & 1) && D.pj[k] < 0) ? 1 : 0;
     if (nmsg + na > M.max_bag) D.err = D.err ? D.err : ERR_REP_BAG;
     D.hdr = hdr_set_nmsg(D.hdr, nmsg + na);
   }
@@ -437,21 +491,25 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
 template <typename PTR>
 VSR_HD void hash_child(const Model& M, PTR rec, const Delta& D, u64* Hc) {
   PTR pb = rec + 1 + (D.r - 1) * M.wpr;
-  bool rep_changed = false;
-  for (int k = 0; k < M.wpr; k++) rep_changed |= (pb[k] != D.rep[k]);
+  bool rep_changed = (pb[0] != D.rep[0]) | (pb[1] != D.rep[1]) | (pb[2] != D.rep[2]);
+  if (M.wpr > 3) rep_changed |= (pb[3] != D.rep[3]);
   u64 ha_old = 0, ha_new = 0;
   if (rep_changed) {
-    ha_old = fmix64(pb[0] ^ M.salt_rep[D.r]);
-    ha_new = fmix64(D.rep[0] ^ M.salt_rep[D.r]);
+    ha_old = fmix64(pb[0] ^ salt_rep_of(D.r));
+    ha_new = fmix64(D.rep[0] ^ salt_rep_of(D.r));
   }
-  for (int i = 0; i < M.np; i++) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (i >= M.np) break;
     u32 pt = M.pitab[i];
     u64 h = rec[M.h0 + i];
     if (rep_changed) h += hash_rep_tail(M, ha_new, D.rep, pt) - hash_rep_tail(M, ha_old, pb, pt);
-    for (int k = 0; k < D.npatch; k++) {
-      h += hash_msg(D.pnew[k], pt);
-      if (D.pj[k] >= 0) h -= hash_msg(D.pold[k], pt);
-    }
+#pragma unroll
+    for (int k = 0; k < VSR_NSLOT; k++)
+      if ((D.used >> k) & 1) {
+        h += hash_msg(D.pnew[k], pt);
+        if (D.pj[k] >= 0) h -= hash_msg(D.pold[k], pt);
+      }
     Hc[i] = h;
   }
 }
@@ -461,11 +519,12 @@ template <typename PTR>
 VSR_HD int check_invariants_child(const Model& M, PTR rec, const Delta& D) {
   if (!(M.inv_mask & 3)) return 0;
   int bad = 0;
+  const u32 own_log = (u32)D.rep[1];   // read once: a select between &D.rep[1] and &rec[..] would make the Delta addressable
   for (int v = 0; v < M.n; v++) {
     if (hdr_acked(D.hdr, v) != 2) continue;                    // aux_client_acked[v] = TRUE   :940, :948
     int holders = 0;
     for (int r = 1; r <= M.R; r++) {
-      u32 lg = (r == D.r) ? blk_x(D.rep, 0) : (u32)rec[1 + (r - 1) * M.wpr + 1];
+      u32 lg = (r == D.r) ? own_log : (u32)rec[1 + (r - 1) * M.wpr + 1];
       bool has = false;                                        // ReplicaHasOp :933-935
       for (int i = 1; i <= 3; i++) {
         int e = log_byte(lg, i);

@@ -81,12 +81,12 @@ __device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 ke
     }
     if (cur == fp) {
       u64 m = __hip_atomic_load(&table[i].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (meta_level(m) < level) {                             // inserted at an earlier level: plain duplicate
-        *found_old = true;
-        return i;
+      if (meta_level(m) < level || m < key) {                  // inserted at an earlier level, or a smaller key of this
+        *found_old = true;                                     // level already holds the slot (meta only ever decreases):
+        return i;                                              // this candidate cannot win
       }
-      atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
-      *found_old = false;
+      u64 prev = atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
+      *found_old = prev < key;                                 // lost the race after all
       return i;
     }
     if (step > 4096) break;
@@ -108,6 +108,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
   u32* s_cand = (u32*)(smem + VSR_TILE * stride);              // VSR_CAND_CAP entries: parent << 16 | ord
   __shared__ u32 s_ncand, s_dead;
   __shared__ u32 s_pcount[VSR_TILE];
+  __shared__ u64 s_ref[VSR_TILE];
   __shared__ u32 s_act[16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,13 +121,34 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     if (tid < VSR_TILE) s_pcount[tid] = 0;
     if (tid < 16) s_act[tid] = 0;
 
-    // ---- stage the tile: one wave per record, lane k copies word k (coalesced 8-byte loads)
-    for (int p = wave; p < np_tile; p += VSR_BLOCK / 64) {
-      u64 off = fr_off[p_base + p];
-      u64 hdr = fr_words[off];
-      int len = M.fixed + hdr_nmsg(hdr);
-      if (len > stride) len = stride;                          // cannot happen: max_bag is enforced at creation
-      for (int k = lane; k < len; k += 64) s_rec[p * stride + k] = fr_words[off + k];
+    // ---- stage the tile.  Frontier refs are (word offset << 8 | length): one coalesced load of 64 refs, then 16 lanes per
+    // record / 16 records per pass, all 16 loads of a thread issued before the first LDS store (one HBM latency per tile)
+    if (tid < np_tile) s_ref[tid] = fr_off[p_base + tid];
+    __syncthreads();
+    {
+      u64 v[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int p = (tid >> 4) + 16 * q;
+        const u64 ref = p < np_tile ? s_ref[p] : 0;
+        const u64 off = ref >> 8;
+        const int len = (int)(ref & 255) < stride ? (int)(ref & 255) : stride;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int k = (tid & 15) + 16 * j;
+          v[q][j] = k < len ? fr_words[off + k] : 0;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int p = (tid >> 4) + 16 * q;
+        const int len = p < np_tile ? ((int)(s_ref[p] & 255) < stride ? (int)(s_ref[p] & 255) : stride) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int k = (tid & 15) + 16 * j;
+          if (k < len) s_rec[p * stride + k] = v[q][j];
+        }
+      }
     }
     __syncthreads();
 
@@ -244,97 +266,159 @@ __device__ __forceinline__ void write_child_serial(const Model& M, const u64* re
   for (int k = 0; k < M.wpr; k++) dst[1 + (D.r - 1) * M.wpr + k] = D.rep[k];
   for (int i = 0; i < M.np; i++) dst[M.h0 + i] = Hc[i];
   int a = 0;
-  for (int k = 0; k < D.npatch; k++) {
-    if (D.pj[k] >= 0) dst[M.fixed + D.pj[k]] = D.pnew[k];
-    else dst[M.fixed + nmsg + (a++)] = D.pnew[k];
-  }
+#pragma unroll
+  for (int k = 0; k < VSR_NSLOT; k++)
+    if ((D.used >> k) & 1) {
+      if (D.pj[k] >= 0) dst[M.fixed + D.pj[k]] = D.pnew[k];
+      else dst[M.fixed + nmsg + (a++)] = D.pnew[k];
+    }
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_materialize: one lane per pending entry; winners (slot meta == own key) append their successor.
+// k_materialize: one wave per block, one lane per pending entry.  Winners (slot meta == own key, or the owner's verdict)
+// rebuild their successor: the parent records of the wave's winners are staged in LDS (cooperative, coalesced: lane k
+// moves word k), each winner lane re-runs its action against its LDS slot and patches the slot in place into the child,
+// and the children are written out cooperatively — every HBM word of the next frontier is written exactly once.
 // -----------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(VSR_BLOCK)
+#define VSR_MAT_BLOCK 64
+#define VSR_MAT_GROUP 16     // records moved per batch of independent loads
+
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+  u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+  u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ void lds_wave_sync() {   // orders this wave's LDS writes before its later LDS reads (other lanes)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ void __launch_bounds__(VSR_MAT_BLOCK)
 k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, const u64* __restrict__ pending,
               u64 n_pending, const Slot* __restrict__ table, u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap,
-              u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w) {
-  const int lane = threadIdx.x & 63;
-  const u64 nthreads = (u64)gridDim.x * blockDim.x;
+              u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w, int stride) {
+  extern __shared__ u64 s_slot[];                              // 64 slots of `stride` words
+  const int lane = threadIdx.x;
+  const u64 nthreads = (u64)gridDim.x * VSR_MAT_BLOCK;
   const u64 rounds = (n_pending + nthreads - 1) / nthreads;
   for (u64 it = 0; it < rounds; it++) {
-    const u64 i = it * nthreads + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = it * nthreads + (u64)blockIdx.x * VSR_MAT_BLOCK + lane;
     bool win = false;
-    u64 key = 0, src = 0, fp = 0;
-    int plen = 0, clen = 0, bad = 0;
-    Delta D;
-    u64 Hc[6];
-    D.npatch = 0;
-    D.err = 0;
+    u64 key = 0, src = 0;
+    int plen = 0;
     if (i < n_pending) {
       key = pending[2 * i + 1];
-      // winner test: the owner's verdict (sharded, remote owner) or the slot's final meta word (local owner)
+      // winner test: the owner's verdict (sharded, remote owner) or the slot's final meta word (local owner); the
+      // parent's ref is fetched alongside, not after (one HBM latency, not two)
+      const u64 ref = fr_off[meta_pidx(key)];
       win = verdict ? (verdict[i] != 0) : (table[pending[2 * i]].meta == key);
+      src = ref >> 8;
+      plen = (int)(ref & 255);
+      if (plen > stride) plen = stride;
     }
-    if (win) {
-      src = fr_off[meta_pidx(key)];
-      const u64* rec = fr_words + src;
-      gen<false>(M, rec, meta_ord(key), D);
-      hash_child(M, rec, D, Hc);
-      u32 ak;
-      canonical_fp(M, D.hdr, Hc, &fp, &ak);
-      plen = M.fixed + hdr_nmsg(rec[0]);
-      clen = M.fixed + hdr_nmsg(D.hdr);
-      bad = check_invariants_child(M, rec, D);
-    }
-    // wave-wide allocation: state indices and word ranges
+    if (!win) plen = 0;
     const u64 wmask = __ballot(win);
     if (wmask == 0) continue;
+    // ---- (a) stage the winners' parents: slot w <- record of lane w, VSR_MAT_GROUP independent loads in flight
+    for (int g = 0; g < 64; g += VSR_MAT_GROUP) {
+      if (((wmask >> g) & ((1u << VSR_MAT_GROUP) - 1)) == 0) continue;
+      u64 v[VSR_MAT_GROUP];
+#pragma unroll
+      for (int q = 0; q < VSR_MAT_GROUP; q++) {
+        const u64 s = readlane64(src, g + q);
+        const int n = __builtin_amdgcn_readlane(plen, g + q);
+        v[q] = lane < n ? fr_words[s + lane] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < VSR_MAT_GROUP; q++) {
+        const int n = __builtin_amdgcn_readlane(plen, g + q);
+        if (lane < n) s_slot[(g + q) * stride + lane] = v[q];
+      }
+    }
+    lds_wave_sync();
+    // ---- (b) winners re-run their action on the staged parent and patch the slot into the child
+    u64 fp = 0;
+    int clen = 0, bad = 0, nbag = 0;
+    if (win) {
+      u64* rec = s_slot + lane * stride;
+      Delta D;
+      gen<false>(M, (const u64*)rec, meta_ord(key), D);
+      u64 Hc[6];
+      hash_child(M, (const u64*)rec, D, Hc);
+      u32 ak;
+      canonical_fp(M, D.hdr, Hc, &fp, &ak);
+      bad = check_invariants_child(M, (const u64*)rec, D);
+      nbag = hdr_nmsg(D.hdr);
+      clen = M.fixed + nbag;
+      if (clen > stride) clen = stride;                        // cannot happen: gen() raised ERR_REP_BAG in k_expand
+      rec[0] = D.hdr;
+      u64* pb = rec + 1 + (D.r - 1) * M.wpr;
+      pb[0] = D.rep[0];
+      pb[1] = D.rep[1];
+      pb[2] = D.rep[2];
+      if (M.wpr > 3) pb[3] = D.rep[3];
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+        if (k < M.np) rec[M.h0 + k] = Hc[k];
+      int a = 0;
+#pragma unroll
+      for (int k = 0; k < VSR_NSLOT; k++)
+        if ((D.used >> k) & 1) {
+          if (D.pj[k] >= 0) rec[M.fixed + D.pj[k]] = D.pnew[k];
+          else if (plen + a < stride) rec[plen + (a++)] = D.pnew[k];
+        }
+    }
+    lds_wave_sync();
+    // ---- wave-wide allocation: state indices and word ranges of the next frontier
     const int nwin = __popcll(wmask);
     int incl = clen;                                           // inclusive scan of child lengths over the wave
     for (int o = 1; o < 64; o <<= 1) {
       int t = __shfl_up(incl, o);
       if (lane >= o) incl += t;
     }
-    const int total = __shfl(incl, 63);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
     u64 idx_base = 0, word_base = 0;
     if (lane == 0) {
       idx_base = atomicAdd((unsigned long long*)cnt_n, (unsigned long long)nwin);
       word_base = atomicAdd((unsigned long long*)cnt_w, (unsigned long long)total);
     }
-    idx_base = __shfl(idx_base, 0);
-    word_base = __shfl(word_base, 0);
+    idx_base = readlane64(idx_base, 0);
+    word_base = readlane64(word_base, 0);
     if (idx_base + (u64)nwin > nx_cap || word_base + (u64)total > nx_words_cap) {
       if (lane == 0) raise_error(ctl, ERR_FRONTIER_FULL, idx_base);
       continue;
     }
     const u64 dst = word_base + (u64)(incl - clen);
-    const u64 idx = idx_base + (u64)__popcll(wmask & (((u64)1 << lane) - 1));
-    // cooperative copy parent -> child, one winner at a time, lane k moves word k
-    for (u64 rest = wmask; rest; rest &= rest - 1) {
-      const int w = __ffsll((long long)rest) - 1;
-      const u64 s = __shfl(src, w), d = __shfl(dst, w);
-      const int n = __shfl(plen, w);
-      for (int k = lane; k < n; k += 64) nx_words[d + k] = fr_words[s + k];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the copies land before the patches overwrite them
-    if (win) {
-      u64* out = nx_words + dst;
-      out[0] = D.hdr;
-      for (int k = 0; k < M.wpr; k++) out[1 + (D.r - 1) * M.wpr + k] = D.rep[k];
-      for (int k = 0; k < M.np; k++) out[M.h0 + k] = Hc[k];
-      int a = 0;
-      for (int k = 0; k < D.npatch; k++) {
-        if (D.pj[k] >= 0) out[M.fixed + D.pj[k]] = D.pnew[k];
-        else out[plen + (a++)] = D.pnew[k];
+    // ---- (c) write the children out: lane k moves word k of one record per instruction
+    for (int g = 0; g < 64; g += VSR_MAT_GROUP) {
+      if (((wmask >> g) & ((1u << VSR_MAT_GROUP) - 1)) == 0) continue;
+#pragma unroll
+      for (int q = 0; q < VSR_MAT_GROUP; q++) {
+        const u64 d = readlane64(dst, g + q);
+        const int n = __builtin_amdgcn_readlane(clen, g + q);
+        if (lane < n) nx_words[d + lane] = s_slot[(g + q) * stride + lane];
       }
-      nx_off[idx] = dst;
+    }
+    if (win) {
+      const u64 idx = idx_base + (u64)__popcll(wmask & (((u64)1 << lane) - 1));
+      nx_off[idx] = (dst << 8) | (u64)clen;
       lvl_fp[idx] = fp;
       if (lvl_tr) lvl_tr[idx] = key;
       if (bad) {
         atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
         atomicOr(&ctl->viol_mask, (u32)bad);
       }
-      atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)hdr_nmsg(D.hdr));
     }
+    // one max_bag update per wave
+    int mb = nbag;
+    for (int o = 32; o > 0; o >>= 1) {
+      int t = __shfl_down(mb, o);
+      mb = t > mb ? t : mb;
+    }
+    if (lane == 0 && (u64)mb > __hip_atomic_load(&ctl->max_bag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)mb);
+    lds_wave_sync();                                           // slots are reused by the next round
   }
 }
 
@@ -374,7 +458,7 @@ __global__ void k_append_fixup(u64* nx_off, u64* lvl_fp, u64* lvl_tr, const u64*
                                const u64* __restrict__ fps, const u64* __restrict__ keys, u64 n, u64 base_words) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  nx_off[i] = base_words + rel_off[i];
+  nx_off[i] = rel_off[i] + (base_words << 8);             // refs are (word offset << 8 | length)
   lvl_fp[i] = fps[i];
   if (lvl_tr) lvl_tr[i] = keys[i];
 }

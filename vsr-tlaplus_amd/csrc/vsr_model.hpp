@@ -84,6 +84,9 @@ VSR_HD u64 fmix64(u64 x) {
   return x;
 }
 
+// per-replica hash salt (computed, not tabulated: a per-lane table index would force the table into scratch memory)
+VSR_HD u64 salt_rep_of(int r) { return fmix64(0xA0761D6478BD642FULL + (u64)r); }
+
 // ---- header -------------------------------------------------------------------------------------------------
 VSR_HD int hdr_nmsg(u64 h) { return (int)(h & 0xFF); }
 VSR_HD int hdr_aux_svc(u64 h) { return (int)((h >> 8) & 7); }
@@ -177,7 +180,8 @@ VSR_HD u64 hash_msg(u64 w, u32 pt) { return fmix64(permute_word(w, LOGB_MSG, pt)
 template <typename PTR>
 VSR_HD u64 hash_rep_tail(const Model& M, u64 h_a, PTR b, u32 pt) {
   u64 h = fmix64(h_a ^ permute_word(b[1], LOGB_REP1, pt));
-  for (int k = 2; k < M.wpr; k++) h = fmix64(h ^ permute_word(b[k], LOGB_REPK, pt));
+  if (M.wpr > 2) h = fmix64(h ^ permute_word(b[2], LOGB_REPK, pt));   // written out: b may be a register array
+  if (M.wpr > 3) h = fmix64(h ^ permute_word(b[3], LOGB_REPK, pt));
   return h;
 }
 
@@ -197,7 +201,7 @@ VSR_HD void hash_full(const Model& M, PTR rec, u64* H) {
     u64 sum = 0;
     for (int r = 1; r <= M.R; r++) {
       PTR b = rec + 1 + (r - 1) * M.wpr;
-      sum += hash_rep_tail(M, fmix64(b[0] ^ M.salt_rep[r]), b, pt);
+      sum += hash_rep_tail(M, fmix64(b[0] ^ salt_rep_of(r)), b, pt);
     }
     for (int j = 0; j < nmsg; j++) sum += hash_msg(rec[M.fixed + j], pt);
     H[i] = sum;
@@ -208,7 +212,9 @@ VSR_HD void hash_full(const Model& M, PTR rec, u64* H) {
 VSR_HD void canonical_fp(const Model& M, u64 hdr, const u64* H, u64* fp, u32* auxkey) {
   u64 bf = H[0];
   u32 ba = auxkey_of(M, hdr, M.pitab[0]);
-  for (int i = 1; i < M.np; i++) {
+#pragma unroll
+  for (int i = 1; i < 6; i++) {
+    if (i >= M.np) break;
     u64 h = H[i];
     if (h > bf) continue;
     u32 ak = auxkey_of(M, hdr, M.pitab[i]);

@@ -619,7 +619,7 @@ int checker_seed(vsrmc_checker* c) {
   u64 H[6];
   hash_full(M, (const u64*)dev.data(), H);   // pure arithmetic on the constant Init record (same code as the kernels)
   for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
-  u64 zero = 0, init_fp = 0;
+  u64 zero = (u64)len, init_fp = 0;                            // ref of record 0: offset 0, length len
   u32 init_ak = 0;
   canonical_fp(M, dev[0], &dev[M.h0], &init_fp, &init_ak);
   const bool mine = c->opt.world <= 1 || owner_of(init_fp, c->opt.world) == c->opt.rank;   // sharded: Init lives on its owner
@@ -761,10 +761,11 @@ int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t
                       u64* t_off, u64 t_cap, u64* t_fp, u64* t_key, u64* cnt_n, u64* cnt_w) {
   if (n == 0) return 0;
   const Model& M = c->model.M;
-  unsigned grid = (unsigned)std::min<u64>((n + VSR_BLOCK - 1) / VSR_BLOCK, (u64)c->num_cus * 16);
+  unsigned grid = (unsigned)std::min<u64>((n + VSR_MAT_BLOCK - 1) / VSR_MAT_BLOCK, (u64)c->num_cus * 64);
+  size_t lds = (size_t)VSR_MAT_BLOCK * c->lds_stride * 8;
   HIPCHK(hipEventRecord(c->ev[2], c->stream));
-  hipLaunchKernelGGL(k_materialize, dim3(grid), dim3(VSR_BLOCK), 0, c->stream, M, c->words[c->cur], c->off[c->cur], entries, n,
-                     c->table, t_words, t_words_cap, t_off, t_cap, t_fp, t_key, c->ctl, verdict, cnt_n, cnt_w);
+  hipLaunchKernelGGL(k_materialize, dim3(grid), dim3(VSR_MAT_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], entries, n,
+                     c->table, t_words, t_words_cap, t_off, t_cap, t_fp, t_key, c->ctl, verdict, cnt_n, cnt_w, c->lds_stride);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev[3], c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -983,7 +984,7 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
   std::vector<u64> doff(c->n_frontier);
   HIPCHK(hipMemcpy(doff.data(), c->off[c->cur], c->n_frontier * 8, hipMemcpyDeviceToHost));
   u64 hi = 0;
-  for (u64 o : doff) hi = std::max(hi, o);
+  for (u64& o : doff) { o >>= 8; hi = std::max(hi, o); }       // refs are (word offset << 8 | length)
   std::vector<u64> dev(hi + (u64)M.fixed + 256);
   u64 take = std::min<u64>(dev.size(), c->opt.frontier_words);
   HIPCHK(hipMemcpy(dev.data(), c->words[c->cur], take * 8, hipMemcpyDeviceToHost));
