@@ -122,6 +122,7 @@ typedef struct vsrmc_level_info {
   double expand_ms;              /* HIP-event time of k_expand (on the checker's stream) */
   double materialize_ms;         /* HIP-event time of k_materialize */
   uint64_t act_generated[16];    /* generated successors per action id */
+  uint64_t phase_cycles[8];      /* k_expand shader clocks summed over blocks: stage, enumerate, sort, apply, tail */
 } vsrmc_level_info;
 
 void vsrmc_options_default(vsrmc_options* o);

@@ -39,7 +39,9 @@ try:
             why = "max-seconds"; break
         d = mc.step()
         if d["n_new"]:
-            d.pop("act_generated")
+            acts = d.pop("act_generated"); ph = d.pop("phase_cycles")
+            if d["level"] >= 26:
+                print(json.dumps(dict(level=d["level"], act_generated=acts, phase_cycles=ph)))
             print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()
                               if k in ("level", "frontier", "generated", "n_new", "distinct", "deadlocks", "pending", "probes",
                                        "words_new", "max_bag", "seconds", "expand_ms", "materialize_ms", "viol_mask")}), flush=True)
@@ -52,7 +54,7 @@ except vt.VsrmcError as e:
 dt = time.time() - t0
 print(json.dumps(dict(summary=True, stop=why, depth=mc.level, distinct=mc.distinct, seconds=round(dt, 3),
                       states_per_s=round(mc.distinct / dt, 1), violation=mc.violation)))
-if mc.violation:
+if mc.violation and not a.no_trace:
     tr = mc.trace(mc.violation["level"], mc.violation["index"])
     print("trace length", len(tr), [t[0] for t in tr])
     print(m.format_state(tr[-1][1]))

@@ -27,11 +27,12 @@ class LevelInfo(C.Structure):
                 ("deadlocks", C.c_uint64), ("pending", C.c_uint64), ("probes", C.c_uint64), ("words_new", C.c_uint64),
                 ("max_bag", C.c_uint64), ("viol_fp", C.c_uint64), ("viol_index", C.c_uint64), ("viol_mask", C.c_int32),
                 ("reserved0", C.c_int32), ("seconds", C.c_double), ("expand_ms", C.c_double),
-                ("materialize_ms", C.c_double), ("act_generated", C.c_uint64 * 16)]
+                ("materialize_ms", C.c_double), ("act_generated", C.c_uint64 * 16), ("phase_cycles", C.c_uint64 * 8)]
 
     def as_dict(self):
-        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("act_generated", "reserved0")}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("act_generated", "reserved0", "phase_cycles")}
         d["act_generated"] = list(self.act_generated)
+        d["phase_cycles"] = list(self.phase_cycles)
         return d
 
 

@@ -487,6 +487,87 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
   return true;
 }
 
+// ---- guards only, for frontier enumeration ------------------------------------------------------------------------
+// The same guards as gen<>, restated per *slot* so that a wave can evaluate one slot kind for 64 different records in
+// lock-step: slot < m0 = the replica-bound ordinal itself; slot = m0 + j = "whatever receives bag entry j".
+// Returns a bit mask: bit k set <=> ordinal (slot < m0 ? slot : m0 + j*(R+1) + k) is enabled; *kind0 = action id of bit 0.
+// k_expand re-checks every emitted instance with gen<false> (a disagreement raises ERR_INTERNAL), and the parity tests
+// compare the generated counts with the oracle, so the two statements of the guards cannot drift apart silently.
+template <typename PTR>
+VSR_HD u32 guard_slot(const Model& M, PTR rec, int slot, int* kind0) {
+  const u64 hdr = rec[0];
+  if (slot < M.m0) {
+    int group, r, c = 0, v = 0;
+    if (slot < 4 * M.R) {
+      group = slot / M.R;
+      r = slot % M.R + 1;
+    } else {
+      const int idx = slot - 4 * M.R;
+      group = 4;
+      r = idx / (M.C * M.n) + 1;
+      c = (idx / M.n) % M.C + 1;
+      v = idx % M.n;
+    }
+    PTR pb = rec + 1 + (r - 1) * M.wpr;
+    const u64 A = pb[0];
+    const bool prim = primary_of(M, a_view(A)) == r;
+    const int st = a_status(A);
+    switch (group) {
+      case 0: *kind0 = A_TimerSendSVC; return (hdr_aux_svc(hdr) < M.L && !prim) ? 1u : 0u;                  // VSR.tla:579-581
+      case 1: *kind0 = A_SendDVC;                                                                             // :650-652
+        return (st == ST_VIEWCHANGE && !a_sent_dvc(A) && __builtin_popcount(a_svcmask(A)) >= M.R / 2) ? 1u : 0u;
+      case 2: *kind0 = A_SendSV;                                                                              // :737-739
+        return (st == ST_VIEWCHANGE && !a_sent_sv(A) && blk_dvc_count(M, pb) >= M.R / 2 + 1) ? 1u : 0u;
+      case 3: {                                                                                               // :464-467
+        *kind0 = A_ExecuteOp;
+        if (!(prim && st == ST_NORMAL && a_commit(A) < a_op(A))) return 0;
+        int q = 0;
+        for (int p = 1; p <= M.R; p++) q += a_peer(A, p) >= a_commit(A) + 1 ? 1 : 0;
+        return q >= M.R / 2 ? 1u : 0u;
+      }
+      default: *kind0 = A_ReceiveClientRequest;                                                               // :368-371
+        return (prim && st == ST_NORMAL && hdr_acked(hdr, v) == 0 && ct_exec(a_ctrow(A, c))) ? 1u : 0u;
+    }
+  }
+  const int j = slot - M.m0;
+  if (j >= hdr_nmsg(hdr)) return 0;
+  const u64 mw = rec[M.fixed + j];
+  if (m_count(mw) == 0) return 0;                               // ReceivableMsg VSR.tla:272-275
+  const int r = m_dest(mw);
+  PTR pb = rec + 1 + (r - 1) * M.wpr;
+  const u64 A = pb[0];
+  const int view = a_view(A), st = a_status(A), op = a_op(A);
+  const int mview = m_view(mw), mop = m_op(mw);
+  const bool prim = primary_of(M, view) == r;
+  switch (m_type(mw)) {
+    case T_SVC:
+      if (mview > view) { *kind0 = A_ReceiveHigherSVC; return 1; }                                           // :605
+      *kind0 = A_ReceiveMatchingSVC;
+      return (mview == view && st == ST_VIEWCHANGE) ? 1u : 0u;                                               // :628-630
+    case T_DVC:
+      *kind0 = mview > view ? A_ReceiveHigherDVC : A_ReceiveMatchingDVC;                                     // :680 / :699
+      return mview >= view ? 1u : 0u;
+    case T_SV: *kind0 = A_ReceiveSV; return mview >= view ? 1u : 0u;                                         // :776
+    case T_PREPARE: {
+      *kind0 = A_ReceivePrepareMsg;
+      u32 mask = (st == ST_NORMAL && mview == view && mop == op + 1) ? 1u : 0u;                              // :408-410
+      if (!prim && st == ST_NORMAL && mview > view && mop > op + 1) {                                        // SendGetState :498-503
+        const u32 lg = blk_x(pb, 0);
+        const int t = a_commit(A) < log_len(lg) ? a_commit(A) : log_len(lg);
+        for (int d = 1; d <= M.R; d++)
+          if (d != r && !bag_has_key(rec + M.fixed, hdr_nmsg(hdr), m_make(T_GETSTATE, mview, d, r, t, 0, 0, 0, 0))) mask |= 1u << d;
+      }
+      return mask;
+    }
+    case T_PREPAREOK: *kind0 = A_ReceivePrepareOkMsg;                                                        // :440-443
+      return (prim && st == ST_NORMAL && mview == view && mop > a_peer(A, m_source(mw))) ? 1u : 0u;
+    case T_GETSTATE: *kind0 = A_ReceiveGetState; return (view == mview && st == ST_NORMAL && op > mop) ? 1u : 0u;   // :529-531
+    case T_NEWSTATE: *kind0 = A_ReceiveNewState;                                                             // :554-556
+      return (view == mview && st == ST_NORMAL && op == m_first_op(mw) - 1) ? 1u : 0u;
+  }
+  return 0;
+}
+
 // Incremental view hashes of the child: Hc[i] = Hp[i] - hash(old replica block) + hash(new) + bag patch deltas.
 template <typename PTR>
 VSR_HD void hash_child(const Model& M, PTR rec, const Delta& D, u64* Hc) {

@@ -38,6 +38,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
   u64 cand_cnt[8];         // sharded mode: candidates bucketed for each owner rank
   u64 out_n[8];            // sharded mode: records materialised for each owner rank (self = n_new)
   u64 out_w[8];            // ... and their words (self = words_new)
+  u64 phase_cycles[8];     // k_expand, summed over blocks (wave 0's clock): stage, enumerate, sort, apply, tail; k_materialize: 5..7
 };
 
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
@@ -45,7 +46,7 @@ __host__ __device__ __forceinline__ int owner_of(u64 fp, int world) { return (in
 
 #define VSR_TILE 64          // frontier records staged per block iteration
 #define VSR_BLOCK 256
-#define VSR_CAND_CAP 3072    // enabled instances per tile the LDS work list can hold
+#define VSR_CAND_CAP 2048    // enabled instances per tile the LDS work list can hold
 
 __device__ __forceinline__ void raise_error(LevelCtl* ctl, int code, u64 info) {
   if (atomicCAS(&ctl->err, 0u, (u32)code) == 0u) ctl->err_info = info;
@@ -99,31 +100,46 @@ __device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 ke
 // -----------------------------------------------------------------------------------------------------------------
 // k_expand
 // -----------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(VSR_BLOCK)
+__global__ void __launch_bounds__(VSR_BLOCK, 3)
 k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world, u64* cand_send,
-         u64 cand_cap) {
+         u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= VSR_CAND_CAP */) {
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // VSR_TILE * stride words
-  u32* s_cand = (u32*)(smem + VSR_TILE * stride);              // VSR_CAND_CAP entries: parent << 16 | ord
-  __shared__ u32 s_ncand, s_dead;
-  __shared__ u32 s_pcount[VSR_TILE];
+  u32* s_cand = (u32*)(smem + VSR_TILE * stride);              // VSR_CAND_CAP entries: action << 17 | record << 11 | ordinal
+  u32* s_cand2 = s_cand + VSR_CAND_CAP;                        // the same, sorted by action
+  __shared__ u32 s_ncand, s_dead, s_maxbag;
+  __shared__ u32 s_alive[VSR_TILE];
   __shared__ u64 s_ref[VSR_TILE];
-  __shared__ u32 s_act[16];
+  __shared__ u32 s_kcount[16], s_kbase[16];
+  // per-block accumulators (flushed once at the end: no hot global counters inside the tile loop)
+  __shared__ unsigned long long s_acc[32];                     // 0 generated, 1 deadlocks, 2 probes, 3..7 phase cycles, 16..31 per action
+  // pending list: the block owns a chunk of pchunk entries at a time; unused entries are invalidated (key = ~0)
+  __shared__ u64 s_chunk_base;
+  __shared__ u32 s_chunk_used, s_tile_base, s_tile_cursor;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   const u64 ntiles = (n_parents + VSR_TILE - 1) / VSR_TILE;
+  if (tid < 32) s_acc[tid] = 0;
+  if (tid == 0) { s_chunk_base = 0; s_chunk_used = pchunk; }   // "no chunk yet"
+  __syncthreads();
 
   for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const u64 p_base = tile * VSR_TILE;
     const int np_tile = (int)((n_parents - p_base) < VSR_TILE ? (n_parents - p_base) : VSR_TILE);
-    if (tid == 0) { s_ncand = 0; s_dead = 0; }
-    if (tid < VSR_TILE) s_pcount[tid] = 0;
-    if (tid < 16) s_act[tid] = 0;
+    const u64 t_0 = __builtin_readcyclecounter();
+    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; }
+    if (tid < VSR_TILE) s_alive[tid] = 0;
+    if (tid < 16) s_kcount[tid] = 0;
+    __syncthreads();
 
     // ---- stage the tile.  Frontier refs are (word offset << 8 | length): one coalesced load of 64 refs, then 16 lanes per
     // record / 16 records per pass, all 16 loads of a thread issued before the first LDS store (one HBM latency per tile)
-    if (tid < np_tile) s_ref[tid] = fr_off[p_base + tid];
+    if (tid < np_tile) {
+      const u64 ref = fr_off[p_base + tid];
+      s_ref[tid] = ref;
+      if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
+    }
     __syncthreads();
     {
       u64 v[4][4];
@@ -152,56 +168,88 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     }
     __syncthreads();
 
-    // ---- enumerate enabled instances: 4 threads per record (replica-bound ordinals, and the bag split 3 ways)
+    const u64 t_1 = __builtin_readcyclecounter();
+    // ---- enumerate enabled instances, slot-major: item = slot * 64 + record, so the 64 lanes of a wave evaluate the same
+    // slot kind for 64 different records (LDS columns are conflict-free: odd record stride).  Work list entry =
+    // action id << 17 | record << 11 | ordinal; per-action counters feed the counting sort below.
     {
-      const int p = tid >> 2, part = tid & 3;
-      if (p < np_tile) {
-        const u64* rec = s_rec + p * stride;
-        const int nmsg = hdr_nmsg(rec[0]);
-        Delta dummy;
-        u32 mine = 0;
-        if (part == 0) {
-          for (int ord = 0; ord < M.m0; ord++)
-            if (gen<true>(M, rec, ord, dummy)) {
-              u32 idx = atomicAdd(&s_ncand, 1u);
-              if (idx < VSR_CAND_CAP) s_cand[idx] = ((u32)p << 16) | (u32)ord;
-              mine++;
-            }
-        } else {
-          for (int j = part - 1; j < nmsg; j += 3) {
-            u64 mw = rec[M.fixed + j];
-            if (m_count(mw) == 0) continue;
-            int kmax = (m_type(mw) == T_PREPARE) ? M.R : 0;
-            for (int k = 0; k <= kmax; k++) {
-              int ord = M.m0 + j * (M.R + 1) + k;
-              if (gen<true>(M, rec, ord, dummy)) {
-                u32 idx = atomicAdd(&s_ncand, 1u);
-                if (idx < VSR_CAND_CAP) s_cand[idx] = ((u32)p << 16) | (u32)ord;
-                mine++;
-              }
-            }
+      const int nslots = M.m0 + (int)s_maxbag;
+      const int nitems = nslots * VSR_TILE;
+      for (int item = tid; item < nitems; item += VSR_BLOCK) {
+        const int slot = item >> 6, p = item & 63;
+        u32 mask = 0;
+        int kind0 = 0;
+        if (p < np_tile && s_ref[p] != 0) mask = guard_slot(M, (const u64*)(s_rec + p * stride), slot, &kind0);
+        if (mask) {
+          s_alive[p] = 1;
+          const int ordbase = slot < M.m0 ? slot : M.m0 + (slot - M.m0) * (M.R + 1);
+          while (mask) {
+            const int k = __ffs((int)mask) - 1;
+            mask &= mask - 1;
+            const int kind = k == 0 ? kind0 : A_SendGetState;
+            const u32 idx = atomicAdd(&s_ncand, 1u);
+            atomicAdd(&s_kcount[kind], 1u);
+            if (idx < VSR_CAND_CAP) s_cand[idx] = ((u32)kind << 17) | ((u32)p << 11) | (u32)(ordbase + k);
           }
         }
-        if (mine) atomicAdd(&s_pcount[p], mine);
       }
     }
     __syncthreads();
-    if (tid < np_tile && s_pcount[tid] == 0) atomicAdd(&s_dead, 1u);
+    if (tid < np_tile && s_alive[tid] == 0 && s_ref[tid] != 0) atomicAdd(&s_dead, 1u);   // ref 0 = unused index (see k_materialize)
     u32 ncand = s_ncand;
     if (ncand > VSR_CAND_CAP) {
       if (tid == 0) raise_error(ctl, ERR_FRONTIER_FULL, p_base);
       ncand = VSR_CAND_CAP;
     }
+    const u64 t_2 = __builtin_readcyclecounter();
+    // ---- counting sort of the work list by action id: the lanes of a wave then run the same action (no divergence between
+    // the 15 action bodies, only inside one)
+    if (tid == 0) {
+      u32 acc = 0;
+      for (int a = 0; a < 16; a++) {
+        s_kbase[a] = acc;
+        acc += s_kcount[a];
+      }
+    }
+    __syncthreads();
+    for (u32 c = tid; c < ncand; c += VSR_BLOCK) {
+      const u32 code = s_cand[c];
+      const u32 pos = atomicAdd(&s_kbase[code >> 17], 1u);
+      if (pos < VSR_CAND_CAP) s_cand2[pos] = code;
+    }
+    __syncthreads();
 
+    const u64 t_3 = __builtin_readcyclecounter();
+    // ---- reserve room for this tile's pending entries (at most ncand) in the block's chunk
+    if (s_chunk_used + ncand > pchunk) {                    // block-uniform
+      const u32 used = s_chunk_used;
+      const u64 base = s_chunk_base;
+      for (u32 k = used + tid; k < pchunk && used < pchunk; k += VSR_BLOCK) pending[2 * (base + k) + 1] = ~(u64)0;
+      __syncthreads();
+      if (tid == 0) {
+        u64 nb = atomicAdd((unsigned long long*)&ctl->n_pending, (unsigned long long)pchunk);
+        if (nb + pchunk > pending_cap) {
+          raise_error(ctl, ERR_FRONTIER_FULL, nb);
+          nb = 0;                                               // keep writing inside the buffer; the level is discarded
+        }
+        s_chunk_base = nb;
+        s_chunk_used = 0;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) { s_tile_base = s_chunk_used; s_tile_cursor = 0; }
+    __syncthreads();
     // ---- apply + fingerprint + seen-set claim: one lane per enabled instance
     u32 my_probes = 0;
     for (u32 c = tid; c < ncand; c += VSR_BLOCK) {
-      const u32 code = s_cand[c];
-      const int p = (int)(code >> 16), ord = (int)(code & 0xFFFF);
+      const u32 code = s_cand2[c];
+      const int p = (int)((code >> 11) & 63), ord = (int)(code & 2047);
       const u64* rec = s_rec + p * stride;
       Delta D;
-      gen<false>(M, rec, ord, D);
-      atomicAdd(&s_act[D.action & 15], 1u);
+      if (!gen<false>(M, rec, ord, D) || D.action != (int)(code >> 17)) {
+        raise_error(ctl, ERR_INTERNAL, ((p_base + (u64)p) << 16) | (u64)ord);
+        continue;
+      }
       if (D.err) {
         raise_error(ctl, D.err, ((p_base + (u64)p) << 16) | (u64)ord);
         continue;
@@ -234,26 +282,48 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
         raise_error(ctl, ERR_TABLE_FULL, fp);
         continue;
       }
-      if (!found_old) {
-        u64 i = wave_alloc(&ctl->n_pending, 1);
-        if (i < pending_cap) {
-          pending[2 * i] = slot;
-          pending[2 * i + 1] = key;
-        } else {
-          raise_error(ctl, ERR_FRONTIER_FULL, i);
-        }
+      if (!found_old) {                                         // one LDS atomic per wave, no global counter
+        const u64 active = __ballot(1);
+        const int leader = __ffsll((long long)active) - 1;
+        u32 b = 0;
+        if (lane == leader) b = atomicAdd(&s_tile_cursor, (u32)__popcll(active));
+        b = __shfl(b, leader);
+        const u64 i = s_chunk_base + s_tile_base + b + (u32)__popcll(active & (((u64)1 << lane) - 1));
+        pending[2 * i] = slot;
+        pending[2 * i + 1] = key;
       }
     }
+    const u64 t_4 = __builtin_readcyclecounter();
     // wave-level reduction of the probe statistic
     for (int o = 32; o > 0; o >>= 1) my_probes += __shfl_down(my_probes, o);
-    if (lane == 0 && my_probes) atomicAdd((unsigned long long*)&ctl->probes, (unsigned long long)my_probes);
+    if (lane == 0 && my_probes) atomicAdd(&s_acc[2], (unsigned long long)my_probes);
     __syncthreads();
     if (tid == 0) {
-      atomicAdd((unsigned long long*)&ctl->generated, (unsigned long long)s_ncand);
-      if (s_dead) atomicAdd((unsigned long long*)&ctl->deadlocks, (unsigned long long)s_dead);
+      s_chunk_used += s_tile_cursor;
+      s_acc[0] += s_ncand;
+      s_acc[1] += s_dead;
+      const u64 t_5 = __builtin_readcyclecounter();
+      s_acc[3] += t_1 - t_0;
+      s_acc[4] += t_2 - t_1;
+      s_acc[5] += t_3 - t_2;
+      s_acc[6] += t_4 - t_3;
+      s_acc[7] += t_5 - t_4;
     }
-    if (tid < 16 && s_act[tid]) atomicAdd((unsigned long long*)&ctl->act_generated[tid], (unsigned long long)s_act[tid]);
+    if (tid < 16) s_acc[16 + tid] += s_kcount[tid];
     __syncthreads();
+  }
+  // ---- block epilogue: invalidate the unused tail of the chunk, flush the accumulators
+  {
+    const u32 used = s_chunk_used;
+    const u64 base = s_chunk_base;
+    for (u32 k = used + tid; k < pchunk; k += VSR_BLOCK) pending[2 * (base + k) + 1] = ~(u64)0;
+    if (tid == 0) {
+      if (s_acc[0]) atomicAdd((unsigned long long*)&ctl->generated, s_acc[0]);
+      if (s_acc[1]) atomicAdd((unsigned long long*)&ctl->deadlocks, s_acc[1]);
+      if (s_acc[2]) atomicAdd((unsigned long long*)&ctl->probes, s_acc[2]);
+    }
+    if (tid >= 3 && tid < 8 && s_acc[tid]) atomicAdd((unsigned long long*)&ctl->phase_cycles[tid - 3], s_acc[tid]);
+    if (tid >= 16 && tid < 32 && s_acc[tid]) atomicAdd((unsigned long long*)&ctl->act_generated[tid - 16], s_acc[tid]);
   }
 }
 
@@ -281,7 +351,7 @@ __device__ __forceinline__ void write_child_serial(const Model& M, const u64* re
 // and the children are written out cooperatively — every HBM word of the next frontier is written exactly once.
 // -----------------------------------------------------------------------------------------------------------------
 #define VSR_MAT_BLOCK 64
-#define VSR_MAT_GROUP 16     // records moved per batch of independent loads
+#define VSR_MAT_GROUP 16
 
 __device__ __forceinline__ u64 readlane64(u64 v, int l) {
   u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
@@ -297,9 +367,15 @@ __device__ __forceinline__ void lds_wave_sync() {   // orders this wave's LDS wr
 __global__ void __launch_bounds__(VSR_MAT_BLOCK)
 k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, const u64* __restrict__ pending,
               u64 n_pending, const Slot* __restrict__ table, u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap,
-              u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w, int stride) {
+              u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w, int stride,
+              u32 ichunk /* state indices per reservation, >= 64 */, u32 wchunk /* words per reservation, >= 64 * stride */) {
   extern __shared__ u64 s_slot[];                              // 64 slots of `stride` words
   const int lane = threadIdx.x;
+  // This wave's private chunks of the output (wave-uniform values): state indices [idx_base, idx_base + idx_left) and
+  // words [w_base, w_base + w_left).  One global atomic per chunk instead of two per 64 entries; the unused tail of the
+  // last index chunk is published as invalid refs (0), which every consumer skips.
+  u64 idx_base = 0, w_base = 0;
+  u32 idx_left = 0, w_left = 0;
   const u64 nthreads = (u64)gridDim.x * VSR_MAT_BLOCK;
   const u64 rounds = (n_pending + nthreads - 1) / nthreads;
   for (u64 it = 0; it < rounds; it++) {
@@ -309,13 +385,15 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
     int plen = 0;
     if (i < n_pending) {
       key = pending[2 * i + 1];
-      // winner test: the owner's verdict (sharded, remote owner) or the slot's final meta word (local owner); the
-      // parent's ref is fetched alongside, not after (one HBM latency, not two)
-      const u64 ref = fr_off[meta_pidx(key)];
-      win = verdict ? (verdict[i] != 0) : (table[pending[2 * i]].meta == key);
-      src = ref >> 8;
-      plen = (int)(ref & 255);
-      if (plen > stride) plen = stride;
+      if (key != ~(u64)0) {                                     // ~0 = unused entry of a block's chunk
+        // winner test: the owner's verdict (sharded, remote owner) or the slot's final meta word (local owner); the
+        // parent's ref is fetched alongside, not after (one HBM latency, not two)
+        const u64 ref = fr_off[meta_pidx(key)];
+        win = verdict ? (verdict[i] != 0) : (table[pending[2 * i]].meta == key);
+        src = ref >> 8;
+        plen = (int)(ref & 255);
+        if (plen > stride) plen = stride;
+      }
     }
     if (!win) plen = 0;
     const u64 wmask = __ballot(win);
@@ -370,26 +448,47 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
         }
     }
     lds_wave_sync();
-    // ---- wave-wide allocation: state indices and word ranges of the next frontier
+    // ---- wave-wide allocation out of the wave's chunks
     const int nwin = __popcll(wmask);
     int incl = clen;                                           // inclusive scan of child lengths over the wave
     for (int o = 1; o < 64; o <<= 1) {
       int t = __shfl_up(incl, o);
       if (lane >= o) incl += t;
     }
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    u64 idx_base = 0, word_base = 0;
-    if (lane == 0) {
-      idx_base = atomicAdd((unsigned long long*)cnt_n, (unsigned long long)nwin);
-      word_base = atomicAdd((unsigned long long*)cnt_w, (unsigned long long)total);
+    const u32 total = (u32)__builtin_amdgcn_readlane(incl, 63);
+    const u32 rank = (u32)__popcll(wmask & (((u64)1 << lane) - 1));
+    u64 idx;
+    bool overflow = false;
+    if (idx_left < (u32)nwin) {                                // finish the old index chunk, continue in a new one
+      u64 nb = 0;
+      if (lane == 0) nb = atomicAdd((unsigned long long*)cnt_n, (unsigned long long)ichunk);
+      nb = readlane64(nb, 0);
+      if (nb + ichunk > nx_cap) overflow = true;
+      idx = rank < idx_left ? idx_base + rank : nb + (rank - idx_left);
+      idx_base = nb + ((u32)nwin - idx_left);
+      idx_left = ichunk - ((u32)nwin - idx_left);
+    } else {
+      idx = idx_base + rank;
+      idx_base += (u32)nwin;
+      idx_left -= (u32)nwin;
     }
-    idx_base = readlane64(idx_base, 0);
-    word_base = readlane64(word_base, 0);
-    if (idx_base + (u64)nwin > nx_cap || word_base + (u64)total > nx_words_cap) {
+    if (w_left < total) {                                      // records do not straddle word chunks: the remainder is skipped
+      u64 nb = 0;
+      if (lane == 0) nb = atomicAdd((unsigned long long*)cnt_w, (unsigned long long)wchunk);
+      nb = readlane64(nb, 0);
+      if (nb + wchunk > nx_words_cap) overflow = true;
+      w_base = nb;
+      w_left = wchunk;
+    }
+    const u64 dst = w_base + (u64)(incl - clen);
+    w_base += total;
+    w_left -= total;
+    if (overflow) {
       if (lane == 0) raise_error(ctl, ERR_FRONTIER_FULL, idx_base);
+      idx_left = 0;                                            // nothing of the refused chunks is used
+      w_left = 0;
       continue;
     }
-    const u64 dst = word_base + (u64)(incl - clen);
     // ---- (c) write the children out: lane k moves word k of one record per instruction
     for (int g = 0; g < 64; g += VSR_MAT_GROUP) {
       if (((wmask >> g) & ((1u << VSR_MAT_GROUP) - 1)) == 0) continue;
@@ -401,7 +500,6 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
       }
     }
     if (win) {
-      const u64 idx = idx_base + (u64)__popcll(wmask & (((u64)1 << lane) - 1));
       nx_off[idx] = (dst << 8) | (u64)clen;
       lvl_fp[idx] = fp;
       if (lvl_tr) lvl_tr[idx] = key;
@@ -420,6 +518,22 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
       atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)mb);
     lds_wave_sync();                                           // slots are reused by the next round
   }
+  // the unused tail of the wave's last index chunk: invalid refs
+  for (u32 k = lane; k < idx_left; k += 64) {
+    nx_off[idx_base + k] = 0;
+    lvl_fp[idx_base + k] = 0;
+    if (lvl_tr) lvl_tr[idx_base + k] = ~(u64)0;
+  }
+}
+
+// number of valid (non-zero) refs in a frontier index range
+__global__ void k_count_valid(const u64* __restrict__ refs, u64 n, u64* out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  u32 c = 0;
+  for (; i < n; i += stride) c += refs[i] != 0 ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd((unsigned long long*)out, (unsigned long long)c);
 }
 
 // empty seen-set: fp = 0, meta = all ones
@@ -458,7 +572,7 @@ __global__ void k_append_fixup(u64* nx_off, u64* lvl_fp, u64* lvl_tr, const u64*
                                const u64* __restrict__ fps, const u64* __restrict__ keys, u64 n, u64 base_words) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  nx_off[i] = rel_off[i] + (base_words << 8);             // refs are (word offset << 8 | length)
+  nx_off[i] = rel_off[i] ? rel_off[i] + (base_words << 8) : 0;   // refs are (word offset << 8 | length); 0 stays invalid
   lvl_fp[i] = fps[i];
   if (lvl_tr) lvl_tr[i] = keys[i];
 }

@@ -51,7 +51,8 @@ enum {
   ERR_REP_BAG = 14,        // bag larger than the configured capacity
   ERR_TABLE_FULL = 20,     // seen-set out of slots
   ERR_FRONTIER_FULL = 21,  // frontier / pending buffers out of space
-  ERR_LEVELS = 22          // more BFS levels than the meta word can hold
+  ERR_LEVELS = 22,         // more BFS levels than the meta word can hold
+  ERR_INTERNAL = 30        // the two statements of the guards (guard_slot / gen) disagree
 };
 
 struct Model {

@@ -602,6 +602,7 @@ struct vsrmc_checker {
   LevelCtl h;
   double t_level0 = 0, expand_ms = 0, materialize_ms = 0;
   u64 tr_base = 0, nx_n = 0, nx_w = 0;
+  u64 n_valid = 1;                       // states in the newest level (n_frontier is its index range, holes included)
   u64* rslot = nullptr;                  // sharded: slot of every received candidate
   u64 rslot_cap = 0;
 };
@@ -634,6 +635,7 @@ int checker_seed(vsrmc_checker* c) {
   c->cur = 0;
   c->level = 1;
   c->n_frontier = mine ? 1 : 0;
+  c->n_valid = c->n_frontier;
   c->distinct = mine ? 1 : 0;
   c->total_generated = 0;
   c->failed = 0;
@@ -661,7 +663,8 @@ void vsrmc_options_default(vsrmc_options* o) {
 
 int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc_checker** out) {
   if (!m || !o || !out) return fail(VSRMC_E_ARG, "NULL argument");
-  if (o->table_log2 < 8 || o->table_log2 > 36 || o->frontier_states < 1 || o->frontier_words < 256 || o->pending_entries < 1)
+  if (o->table_log2 < 8 || o->table_log2 > 36 || o->frontier_states < 1 || o->frontier_words < 256 ||
+      o->pending_entries < 4 * (uint64_t)VSR_CAND_CAP)
     return fail(VSRMC_E_ARG, "bad options");
   if (o->world < 1 || o->world > 8 || o->rank < 0 || o->rank >= o->world) return fail(VSRMC_E_ARG, "bad rank / world (1..8 ranks)");
   int rc = check_device(o->device);
@@ -734,12 +737,14 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
   HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
   if (c->n_frontier > 0) {
     u64 ntiles = (c->n_frontier + VSR_TILE - 1) / VSR_TILE;
-    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 8);
-    size_t lds = (size_t)VSR_TILE * c->lds_stride * 8 + VSR_CAND_CAP * 4;
+    // every block reserves pending-list room in chunks: the list must hold one chunk per block beyond the real entries
+    const u32 pchunk = c->opt.pending_entries >= ((u64)1 << 24) ? 8192u : (u32)VSR_CAND_CAP;
+    unsigned grid = (unsigned)std::min<u64>(std::min<u64>(ntiles, (u64)c->num_cus * 8), std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));
+    size_t lds = (size_t)VSR_TILE * c->lds_stride * 8 + 2 * VSR_CAND_CAP * 4;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(k_expand, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], c->n_frontier,
                        c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, c->lds_stride,
-                       io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0);
+                       io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -761,11 +766,17 @@ int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t
                       u64* t_off, u64 t_cap, u64* t_fp, u64* t_key, u64* cnt_n, u64* cnt_w) {
   if (n == 0) return 0;
   const Model& M = c->model.M;
-  unsigned grid = (unsigned)std::min<u64>((n + VSR_MAT_BLOCK - 1) / VSR_MAT_BLOCK, (u64)c->num_cus * 64);
+  // persistent waves: each keeps private output chunks, so the grid is sized to what is resident (LDS: 5 waves / CU)
+  u64 grid64 = std::min<u64>((n + VSR_MAT_BLOCK - 1) / VSR_MAT_BLOCK, (u64)c->num_cus * 5);
+  const u64 min_wchunk = (u64)VSR_MAT_BLOCK * c->lds_stride;
+  grid64 = std::max<u64>(1, std::min<u64>(grid64, std::min<u64>(t_words_cap / (4 * min_wchunk), t_cap / (4 * 64))));
+  const u32 ichunk = (u32)std::min<u64>(1024, std::max<u64>(64, t_cap / (4 * grid64)));
+  const u32 wchunk = (u32)std::min<u64>(65536, std::max<u64>(min_wchunk, t_words_cap / (4 * grid64)));
+  unsigned grid = (unsigned)grid64;
   size_t lds = (size_t)VSR_MAT_BLOCK * c->lds_stride * 8;
   HIPCHK(hipEventRecord(c->ev[2], c->stream));
   hipLaunchKernelGGL(k_materialize, dim3(grid), dim3(VSR_MAT_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], entries, n,
-                     c->table, t_words, t_words_cap, t_off, t_cap, t_fp, t_key, c->ctl, verdict, cnt_n, cnt_w, c->lds_stride);
+                     c->table, t_words, t_words_cap, t_off, t_cap, t_fp, t_key, c->ctl, verdict, cnt_n, cnt_w, c->lds_stride, ichunk, wchunk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev[3], c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -802,22 +813,36 @@ int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
   info->probes = h.probes;
   info->max_bag = h.max_bag;
   for (int a = 0; a < 16; a++) info->act_generated[a] = h.act_generated[a];
+  for (int a = 0; a < 8; a++) info->phase_cycles[a] = h.phase_cycles[a];
   info->viol_fp = ~(u64)0;
   info->viol_index = ~(u64)0;
   info->expand_ms = c->expand_ms;
   info->materialize_ms = c->materialize_ms;
-  const u64 n_new = c->nx_n;
+  // nx_n is an index RANGE: waves allocate indices in chunks and publish unused ones as invalid refs (0)
+  u64 n_new = 0;
+  if (c->nx_n > 0) {
+    u64 zero = 0;
+    HIPCHK(hipMemcpyAsync(c->d_find, &zero, 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_count_valid, dim3(1024), dim3(256), 0, c->stream, c->off[c->cur ^ 1], c->nx_n, c->d_find);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&n_new, c->d_find, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
   c->total_generated += h.generated;
   info->n_new = n_new;
   info->words_new = c->nx_w;
   if (n_new > 0 || c->opt.world > 1) {   // sharded: levels stay aligned across ranks even when this shard got nothing
     c->level_base.push_back(c->tr_base);
-    c->level_size.push_back(n_new);
+    c->level_size.push_back(c->nx_n);
     c->cur ^= 1;
     c->level += 1;
     c->distinct += n_new;
+    c->n_frontier = c->nx_n;
+    c->n_valid = n_new;
+  } else {
+    c->n_frontier = 0;
+    c->n_valid = 0;
   }
-  c->n_frontier = n_new;
   if (h.viol_fp != ~(u64)0) {
     info->viol_fp = h.viol_fp;
     info->viol_mask = (int32_t)h.viol_mask;
@@ -966,11 +991,16 @@ int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t inde
 
 int32_t vsrmc_checker_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, uint64_t* n) {
   if (!c || !n) return fail(VSRMC_E_ARG, "NULL argument");
-  *n = c->n_frontier;
-  if (!out || cap < c->n_frontier) return fail(VSRMC_E_ARG, "buffer too small");
+  *n = c->n_valid;
+  if (!out || cap < c->n_valid) return fail(VSRMC_E_ARG, "buffer too small");
   HIPCHK(hipSetDevice(c->opt.device));
-  HIPCHK(hipMemcpy(out, c->lvl_fp, c->n_frontier * 8, hipMemcpyDeviceToHost));
-  std::sort(out, out + c->n_frontier);
+  std::vector<u64> all(c->n_frontier);
+  HIPCHK(hipMemcpy(all.data(), c->lvl_fp, c->n_frontier * 8, hipMemcpyDeviceToHost));
+  u64 k = 0;
+  for (u64 v : all)
+    if (v != 0 && k < cap) out[k++] = v;        // 0 = unused index of a wave's chunk
+  *n = k;
+  std::sort(out, out + k);
   return 0;
 }
 
@@ -978,26 +1008,33 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
                                uint64_t* n) {
   if (!c || !n || !words || !off) return fail(VSRMC_E_ARG, "NULL argument");
   const Model& M = c->model.M;
-  *n = c->n_frontier;
-  if (cap_states < c->n_frontier + 1) return fail(VSRMC_E_ARG, "offset buffer too small");
+  *n = c->n_valid;
+  if (cap_states < c->n_valid + 1) return fail(VSRMC_E_ARG, "offset buffer too small");
   HIPCHK(hipSetDevice(c->opt.device));
   std::vector<u64> doff(c->n_frontier);
   HIPCHK(hipMemcpy(doff.data(), c->off[c->cur], c->n_frontier * 8, hipMemcpyDeviceToHost));
   u64 hi = 0;
-  for (u64& o : doff) { o >>= 8; hi = std::max(hi, o); }       // refs are (word offset << 8 | length)
+  std::vector<char> valid(c->n_frontier);
+  for (u64 i = 0; i < c->n_frontier; i++) {                    // refs are (word offset << 8 | length); 0 = unused index
+    valid[i] = doff[i] != 0;
+    doff[i] >>= 8;
+    hi = std::max(hi, doff[i]);
+  }
   std::vector<u64> dev(hi + (u64)M.fixed + 256);
   u64 take = std::min<u64>(dev.size(), c->opt.frontier_words);
   HIPCHK(hipMemcpy(dev.data(), c->words[c->cur], take * 8, hipMemcpyDeviceToHost));
-  u64 pos = 0;
+  u64 pos = 0, k = 0;
   for (u64 i = 0; i < c->n_frontier; i++) {
+    if (!valid[i]) continue;
     const u64* r = &dev[doff[i]];
     u64 wl = (u64)M.h0 + hdr_nmsg(r[0]);
-    if (pos + wl > cap_words) return fail(VSRMC_E_ARG, "word buffer too small");
-    off[i] = pos;
+    if (pos + wl > cap_words || k >= cap_states) return fail(VSRMC_E_ARG, "buffers too small");
+    off[k++] = pos;
     device_to_wire(M, r, words + pos);
     pos += wl;
   }
-  off[c->n_frontier] = pos;
+  off[k] = pos;
+  *n = k;
   return 0;
 }
 
