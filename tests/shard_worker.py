@@ -38,10 +38,13 @@ def main():
     # trace of the last state of the deepest non-empty local level (every rank takes part in every walk)
     walks = []
     for r in range(world):
-        have = sc.allgather_int(len(eng.level_fps())) if hasattr(sc, "allgather_int") else None
-        nloc = sc.x.allreduce([len(eng.level_fps()) if rank == r else 0], dist.ReduceOp.MAX)[0]
-        if nloc:
-            walks.append(dict(rank=r, level=sc.level, index=nloc - 1, ords=sc.trace_ordinals(sc.level, r, nloc - 1)))
+        # rank r nominates its state with the largest fingerprint; states are addressed by their index in the level's
+        # index range (which may contain unused slots), found by fingerprint
+        mine = eng.level_fps()
+        idx = eng.find_fp(int(mine[-1])) if (rank == r and len(mine)) else -1
+        idx = sc.x.allreduce([idx if idx is not None else -1], dist.ReduceOp.MAX)[0]
+        if idx >= 0:
+            walks.append(dict(rank=r, level=sc.level, index=idx, ords=sc.trace_ordinals(sc.level, r, idx)))
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks,
                        bytes_sent=sc.x.bytes_sent), f)

@@ -229,6 +229,12 @@ class ModelChecker:
         check(capi.load().vsrmc_checker_frontier(self._h, _p(words), cap_w, _p(off), len(off), C.byref(n)))
         return words[: int(off[n.value])].copy(), off[: n.value + 1].copy()
 
+    def find_fp(self, fp):
+        """Index (in the newest level's index range) of the state with fingerprint `fp`, or None."""
+        idx = C.c_uint64()
+        check(capi.load().vsrmc_checker_find_fp(self._h, int(fp), C.byref(idx)))
+        return None if idx.value == (1 << 64) - 1 else idx.value
+
     def trace(self, level, index):
         """TLCTrace.getTrace -> list of (action name, record words) from Init to the given state."""
         lay = self.model.layout

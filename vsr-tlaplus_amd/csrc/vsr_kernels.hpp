@@ -376,10 +376,12 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
   // last index chunk is published as invalid refs (0), which every consumer skips.
   u64 idx_base = 0, w_base = 0;
   u32 idx_left = 0, w_left = 0;
+  u64 cyc_fetch = 0, cyc_stage = 0, cyc_gen = 0, cyc_write = 0;
   const u64 nthreads = (u64)gridDim.x * VSR_MAT_BLOCK;
   const u64 rounds = (n_pending + nthreads - 1) / nthreads;
   for (u64 it = 0; it < rounds; it++) {
     const u64 i = it * nthreads + (u64)blockIdx.x * VSR_MAT_BLOCK + lane;
+    const u64 c_0 = __builtin_readcyclecounter();
     bool win = false;
     u64 key = 0, src = 0;
     int plen = 0;
@@ -397,24 +399,24 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
     }
     if (!win) plen = 0;
     const u64 wmask = __ballot(win);
+    const u64 c_1 = __builtin_readcyclecounter();
+    cyc_fetch += c_1 - c_0;
     if (wmask == 0) continue;
-    // ---- (a) stage the winners' parents: slot w <- record of lane w, VSR_MAT_GROUP independent loads in flight
-    for (int g = 0; g < 64; g += VSR_MAT_GROUP) {
-      if (((wmask >> g) & ((1u << VSR_MAT_GROUP) - 1)) == 0) continue;
-      u64 v[VSR_MAT_GROUP];
-#pragma unroll
-      for (int q = 0; q < VSR_MAT_GROUP; q++) {
-        const u64 s = readlane64(src, g + q);
-        const int n = __builtin_amdgcn_readlane(plen, g + q);
-        v[q] = lane < n ? fr_words[s + lane] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < VSR_MAT_GROUP; q++) {
-        const int n = __builtin_amdgcn_readlane(plen, g + q);
-        if (lane < n) s_slot[(g + q) * stride + lane] = v[q];
-      }
+    // ---- (a) stage the winners' parents: slot w <- record of lane w, by LDS-DMA (global_load_lds_dword: lane l moves dword l
+    // of the record straight into LDS, no VGPR round trip), so all ~2 x 64 loads of the wave are in flight at once
+    for (int w = 0; w < 64; w++) {
+      const int n2 = 2 * __builtin_amdgcn_readlane(plen, w);    // dwords; 0 for lanes without a winner
+      if (n2 == 0) continue;
+      const u32* g = (const u32*)(fr_words + readlane64(src, w));
+      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(s_slot + w * stride);
+      if (lane < n2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lane), l, 4, 0, 0);
+      // the instruction offset applies to the global address AND the LDS address: same pointers, +256 bytes on both sides
+      if (lane + 64 < n2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lane), l, 4, 256, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_wave_sync();
+    const u64 c_2 = __builtin_readcyclecounter();
+    cyc_stage += c_2 - c_1;
     // ---- (b) winners re-run their action on the staged parent and patch the slot into the child
     u64 fp = 0;
     int clen = 0, bad = 0, nbag = 0;
@@ -448,6 +450,8 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
         }
     }
     lds_wave_sync();
+    const u64 c_3 = __builtin_readcyclecounter();
+    cyc_gen += c_3 - c_2;
     // ---- wave-wide allocation out of the wave's chunks
     const int nwin = __popcll(wmask);
     int incl = clen;                                           // inclusive scan of child lengths over the wave
@@ -517,6 +521,13 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
     if (lane == 0 && (u64)mb > __hip_atomic_load(&ctl->max_bag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)mb);
     lds_wave_sync();                                           // slots are reused by the next round
+    cyc_write += __builtin_readcyclecounter() - c_3;
+  }
+  if (lane == 0) {
+    atomicAdd((unsigned long long*)&ctl->phase_cycles[5], (unsigned long long)(cyc_fetch + cyc_stage));
+    atomicAdd((unsigned long long*)&ctl->phase_cycles[6], (unsigned long long)cyc_gen);
+    atomicAdd((unsigned long long*)&ctl->phase_cycles[7], (unsigned long long)cyc_write);
+    atomicAdd((unsigned long long*)&ctl->act_generated[0], (unsigned long long)cyc_fetch);   // slot 0 of act_generated is unused (Init)
   }
   // the unused tail of the wave's last index chunk: invalid refs
   for (u32 k = lane; k < idx_left; k += 64) {
@@ -600,6 +611,10 @@ __global__ void k_trace_walk(const u64* tr_all, const u64* level_base, int level
   if (threadIdx.x || blockIdx.x) return;
   for (int l = level; l >= 2; l--) {
     u64 key = tr_all[level_base[l - 1] + idx];
+    if (key == ~(u64)0 || meta_level(key) != l) {              // an unused index of a wave's chunk, not a state
+      ords[0] = 0xFFFFFFFFu;
+      return;
+    }
     ords[l - 2] = (u32)meta_ord(key);
     idx = meta_pidx(key);
   }

@@ -1106,6 +1106,7 @@ int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uin
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(ords.data(), d_ords, (u64)nsteps * 4, hipMemcpyDeviceToHost));
     (void)hipFree(d_ords);
+    if (ords[0] == 0xFFFFFFFFu) return fail(VSRMC_E_ARG, "no such state: the index is an unused slot of the level's index range");
   }
   return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), nsteps, words, cap_words, off, actions, cap_states, n_states);
 }
