@@ -98,7 +98,12 @@ typedef struct vsrmc_options {
   int32_t keep_trace;            /* 1 = keep the (parent, ordinal) log in HBM for counter-examples (TLCTrace) */
   int32_t rank, world;           /* shard of the seen-set owned by this process (world = 1: everything) */
   uint64_t trace_entries;        /* capacity of that log in states (8 B each); 0 = 8 x frontier_states */
-  int32_t reserved[6];
+  int32_t exact_ties;            /* 0 (default): single-pass levels — the lane that inserts a fingerprint writes the successor;
+                                    a same-level VIEW collision with different aux variables (never observed) stops the run
+                                    with VSRMC_E_STATE.  1: two-kernel levels (k_expand + k_materialize) that arbitrate
+                                    such ties exactly like the oracle (smallest canonical auxkey wins).  Sharded runs are
+                                    always exact. */
+  int32_t reserved[5];
 } vsrmc_options;
 
 typedef struct vsrmc_level_info {

@@ -133,13 +133,13 @@ def test_successors_of_every_state_of_a_small_space(vt, orc, R, C, n, L, sym, as
 # ---------------------------------------------------------------------------------------------------------------------
 # the BFS: per-level fingerprint sets, generated / new / deadlock counts
 # ---------------------------------------------------------------------------------------------------------------------
-def _compare_levels(vt, orc, params, max_depth, sizes=None, **kw):
+def _compare_levels(vt, orc, params, max_depth, sizes=None, exact_ties=False, **kw):
     R, C, n, L = params
     P = orc.Params(R, C, n, L, **kw)
     m = vt.Model.from_constants(R=R, C_=C, n=n, L=L, symmetry=kw.get("symmetry", True),
                                 assume_commit_number=kw.get("assume_commit_number", False))
-    mc = vt.ModelChecker(m, **(sizes or dict(table_log2=22, frontier_words=1 << 24, frontier_states=1 << 19,
-                                             pending_entries=1 << 21)))
+    mc = vt.ModelChecker(m, exact_ties=exact_ties, **(sizes or dict(table_log2=22, frontier_words=1 << 24,
+                                                                    frontier_states=1 << 19, pending_entries=1 << 21)))
     ob = orc.Bfs(P)
     level = 1
     while level < max_depth:
@@ -161,26 +161,32 @@ def _compare_levels(vt, orc, params, max_depth, sizes=None, **kw):
     return total, level
 
 
-def test_bfs_config1_whole_space(vt, orc):
-    assert _compare_levels(vt, orc, (2, 1, 1, 1), 100) == (76, 14)               # BASELINE config 1
+# exact_ties = False: single-pass levels (k_expand<fused>); True: two-kernel levels (k_expand + k_materialize), the scheme
+# the sharded runs use.  Both must reproduce the oracle bit for bit.
+@pytest.mark.parametrize("exact", [False, True])
+def test_bfs_config1_whole_space(vt, orc, exact):
+    assert _compare_levels(vt, orc, (2, 1, 1, 1), 100, exact_ties=exact) == (76, 14)               # BASELINE config 1
 
 
-def test_bfs_two_replicas_two_values_whole_space(vt, orc):
-    assert _compare_levels(vt, orc, (2, 1, 2, 2), 100) == (2073, 27)
-    assert _compare_levels(vt, orc, (2, 1, 2, 2), 100, symmetry=False) == (4034, 27)
+@pytest.mark.parametrize("exact", [False, True])
+def test_bfs_two_replicas_two_values_whole_space(vt, orc, exact):
+    assert _compare_levels(vt, orc, (2, 1, 2, 2), 100, exact_ties=exact) == (2073, 27)
+    assert _compare_levels(vt, orc, (2, 1, 2, 2), 100, exact_ties=exact, symmetry=False) == (4034, 27)
 
 
 def test_bfs_three_replicas_one_value_whole_space(vt, orc):
     assert _compare_levels(vt, orc, (3, 1, 1, 1), 100) == (43941, 24)
 
 
-def test_bfs_config2_prefix(vt, orc):
-    total, level = _compare_levels(vt, orc, (3, 1, 2, 2), 13)                    # BASELINE config 2 = shipped VSR.cfg
+@pytest.mark.parametrize("exact", [False, True])
+def test_bfs_config2_prefix(vt, orc, exact):
+    total, level = _compare_levels(vt, orc, (3, 1, 2, 2), 13, exact_ties=exact)  # BASELINE config 2 = shipped VSR.cfg
     assert (total, level) == (163346 + 161457, 13)
 
 
-def test_bfs_config3_prefix(vt, orc):
-    total, level = _compare_levels(vt, orc, (3, 1, 3, 3), 11)                    # README defect config, 6 permutations
+@pytest.mark.parametrize("exact", [False, True])
+def test_bfs_config3_prefix(vt, orc, exact):
+    total, level = _compare_levels(vt, orc, (3, 1, 3, 3), 11, exact_ties=exact)  # README defect config, 6 permutations
     assert level == 11 and total == 80646 + 154410
 
 
@@ -218,7 +224,7 @@ def test_golden_level_checksums(vt, golden_counts):
         p = g["params"]
         m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=p["n"], L=p["L"], symmetry=p["symmetry"])
         mc = vt.ModelChecker(m, table_log2=24, frontier_words=1 << 26, frontier_states=1 << 21, pending_entries=1 << 23,
-                             keep_trace=False)
+                             keep_trace=False, exact_ties=(label.startswith("config5")))
         for li, lv in enumerate(g["levels"][:depth]):
             fps = mc.level_fps()
             assert len(fps) == lv["new"], (label, lv["level"])

@@ -18,7 +18,7 @@ class Layout(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("table_log2", C.c_int32), ("frontier_words", C.c_uint64),
                 ("frontier_states", C.c_uint64), ("pending_entries", C.c_uint64), ("keep_trace", C.c_int32),
-                ("rank", C.c_int32), ("world", C.c_int32), ("trace_entries", C.c_uint64), ("reserved", C.c_int32 * 6)]
+                ("rank", C.c_int32), ("world", C.c_int32), ("trace_entries", C.c_uint64), ("exact_ties", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class LevelInfo(C.Structure):

@@ -162,7 +162,7 @@ class ModelChecker:
     """≙ tlc2.tool.ModelChecker: level-synchronous BFS; `step()` = every Worker draining one level of the StateQueue."""
 
     def __init__(self, model, device=0, table_log2=24, frontier_words=1 << 25, frontier_states=1 << 20,
-                 pending_entries=1 << 21, keep_trace=True, trace_entries=0):
+                 pending_entries=1 << 21, keep_trace=True, trace_entries=0, exact_ties=False):
         self.model = model
         o = capi.Options()
         capi.load().vsrmc_options_default(C.byref(o))
@@ -170,6 +170,7 @@ class ModelChecker:
         o.frontier_words, o.frontier_states, o.pending_entries = frontier_words, frontier_states, pending_entries
         o.keep_trace = int(keep_trace)
         o.trace_entries = trace_entries
+        o.exact_ties = int(exact_ties)
         self.options = o
         self._h = C.c_void_p()
         check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))

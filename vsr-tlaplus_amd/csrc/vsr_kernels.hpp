@@ -38,6 +38,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
   u64 cand_cnt[8];         // sharded mode: candidates bucketed for each owner rank
   u64 out_n[8];            // sharded mode: records materialised for each owner rank (self = n_new)
   u64 out_w[8];            // ... and their words (self = words_new)
+  u64 ties;                // fused mode: same-level candidates of one fingerprint with different auxkeys (must stay 0)
   u64 phase_cycles[8];     // k_expand, summed over blocks (wave 0's clock): stage, enumerate, sort, apply, tail; k_materialize: 5..7
 };
 
@@ -97,18 +98,57 @@ __device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 ke
   return 0;
 }
 
+// Fused variant (single-pass BFS level): *claimed = this lane inserted the fingerprint (it writes the successor at once);
+// *tie = another candidate of this level reached the same slot with a different canonical auxkey, i.e. the VIEW collision
+// of SURVEY F2 inside one level, which the single-pass scheme cannot arbitrate — the host then redoes the run with the
+// exact two-kernel scheme (never observed: the oracle's `ties` counter is 0 on every config).
+__device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp, u64 key, int level, bool* claimed, bool* tie,
+                                                  u32* nprobe, bool* full) {
+  u64 i = fp & mask;
+  *full = false;
+  *claimed = false;
+  *tie = false;
+  for (u64 step = 0; step <= mask; step++, i = (i + 1) & mask) {
+    (*nprobe)++;
+    u64 cur = __hip_atomic_load(&table[i].fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) {
+      cur = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
+      if (cur == 0) {
+        cur = fp;
+        *claimed = true;
+      }
+    }
+    if (cur == fp) {
+      u64 m = __hip_atomic_load(&table[i].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (meta_level(m) < level) return;                       // a state of an earlier level
+      if (m != META_EMPTY && m < key) {                        // smaller key of this level already there
+        *tie = meta_auxkey(m) != meta_auxkey(key);
+        return;
+      }
+      u64 prev = atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
+      if (prev != META_EMPTY) *tie = meta_auxkey(prev) != meta_auxkey(key);
+      return;
+    }
+    if (step > 4096) break;
+  }
+  *full = true;
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // k_expand
 // -----------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(VSR_BLOCK, 3)
+template <bool FUSED>
+__global__ void __launch_bounds__(VSR_BLOCK, FUSED ? 2 : 3)
 k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world, u64* cand_send,
-         u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= VSR_CAND_CAP */) {
+         u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= VSR_CAND_CAP */,
+         // fused single-pass mode (nx_words != nullptr): the lane that inserts a fingerprint writes the successor at once
+         u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u64* lvl_tr, u32 ichunk, u32 wchunk) {
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // VSR_TILE * stride words
   u32* s_cand = (u32*)(smem + VSR_TILE * stride);              // VSR_CAND_CAP entries: action << 17 | record << 11 | ordinal
   u32* s_cand2 = s_cand + VSR_CAND_CAP;                        // the same, sorted by action
-  __shared__ u32 s_ncand, s_dead, s_maxbag;
+  __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out;
   __shared__ u32 s_alive[VSR_TILE];
   __shared__ u64 s_ref[VSR_TILE];
   __shared__ u32 s_kcount[16], s_kbase[16];
@@ -117,18 +157,26 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
   // pending list: the block owns a chunk of pchunk entries at a time; unused entries are invalidated (key = ~0)
   __shared__ u64 s_chunk_base;
   __shared__ u32 s_chunk_used, s_tile_base, s_tile_cursor;
+  // fused mode: the block's chunks of next-frontier indices and words
+  __shared__ u64 s_ich_base, s_wch_base;
+  __shared__ u32 s_ich_used, s_wch_used, s_tile_ibase, s_tile_wbase, s_tile_icur, s_tile_wcur, s_wneed;
+  constexpr bool fused = FUSED;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const u64 ntiles = (n_parents + VSR_TILE - 1) / VSR_TILE;
   if (tid < 32) s_acc[tid] = 0;
-  if (tid == 0) { s_chunk_base = 0; s_chunk_used = pchunk; }   // "no chunk yet"
+  if (tid == 0) s_maxbag_out = 0;
+  if (tid == 0) {                                              // "no chunk yet"
+    s_chunk_base = 0; s_chunk_used = pchunk;
+    s_ich_base = 0; s_ich_used = ichunk; s_wch_base = 0; s_wch_used = wchunk;
+  }
   __syncthreads();
 
   for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const u64 p_base = tile * VSR_TILE;
     const int np_tile = (int)((n_parents - p_base) < VSR_TILE ? (n_parents - p_base) : VSR_TILE);
     const u64 t_0 = __builtin_readcyclecounter();
-    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; }
+    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; }
     if (tid < VSR_TILE) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
     __syncthreads();
@@ -189,6 +237,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
             const int kind = k == 0 ? kind0 : A_SendGetState;
             const u32 idx = atomicAdd(&s_ncand, 1u);
             atomicAdd(&s_kcount[kind], 1u);
+            if (fused) atomicAdd(&s_wneed, (u32)(s_ref[p] & 255) + 5u);   // upper bound of the successor's length
             if (idx < VSR_CAND_CAP) s_cand[idx] = ((u32)kind << 17) | ((u32)p << 11) | (u32)(ordbase + k);
           }
         }
@@ -220,6 +269,37 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     __syncthreads();
 
     const u64 t_3 = __builtin_readcyclecounter();
+    if (fused) {
+      // ---- reserve room for this tile's successors (upper bounds: ncand states, s_wneed words) in the block's chunks
+      if (s_ich_used + ncand > ichunk) {                        // block-uniform
+        const u32 used = s_ich_used;
+        const u64 base = s_ich_base;
+        for (u32 k = used + tid; k < ichunk; k += VSR_BLOCK) {  // unused indices of the old chunk: invalid refs
+          nx_off[base + k] = 0;
+          lvl_fp[base + k] = 0;
+          if (lvl_tr) lvl_tr[base + k] = ~(u64)0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          u64 nb = atomicAdd((unsigned long long*)&ctl->n_new, (unsigned long long)ichunk);
+          if (nb + ichunk > nx_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
+          s_ich_base = nb;
+          s_ich_used = 0;
+        }
+        __syncthreads();
+      }
+      if (s_wch_used + s_wneed > wchunk) {                      // records do not straddle chunks: the remainder is skipped
+        __syncthreads();
+        if (tid == 0) {
+          u64 nb = atomicAdd((unsigned long long*)&ctl->words_new, (unsigned long long)wchunk);
+          if (nb + wchunk > nx_words_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
+          s_wch_base = nb;
+          s_wch_used = 0;
+        }
+        __syncthreads();
+      }
+      if (tid == 0) { s_tile_ibase = s_ich_used; s_tile_wbase = s_wch_used; s_tile_icur = 0; s_tile_wcur = 0; }
+    } else
     // ---- reserve room for this tile's pending entries (at most ncand) in the block's chunk
     if (s_chunk_used + ncand > pchunk) {                    // block-uniform
       const u32 used = s_chunk_used;
@@ -276,6 +356,51 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
           continue;
         }
       }
+      if (fused) {
+        bool claimed, tie, full;
+        table_claim_fused(table, tmask, fp, key, level, &claimed, &tie, &my_probes, &full);
+        if (full) {
+          raise_error(ctl, ERR_TABLE_FULL, fp);
+          continue;
+        }
+        if (tie) atomicAdd(&s_acc[8], 1ull);
+        if (claimed) {                                          // new state: this lane writes it out
+          const int plen = (int)(s_ref[p] & 255);
+          const int clen = M.fixed + hdr_nmsg(D.hdr);
+          const u32 io = atomicAdd(&s_tile_icur, 1u);
+          const u32 wo = atomicAdd(&s_tile_wcur, (u32)clen);
+          const u64 idx = s_ich_base + s_tile_ibase + io;
+          const u64 dst = s_wch_base + s_tile_wbase + wo;
+          u64* out = nx_words + dst;
+          for (int k = 0; k < plen; k++) out[k] = rec[k];       // parent from LDS, then the patches on top (same lane: ordered)
+          out[0] = D.hdr;
+          u64* ob = out + 1 + (D.r - 1) * M.wpr;
+          ob[0] = D.rep[0];
+          ob[1] = D.rep[1];
+          ob[2] = D.rep[2];
+          if (M.wpr > 3) ob[3] = D.rep[3];
+#pragma unroll
+          for (int k = 0; k < 6; k++)
+            if (k < M.np) out[M.h0 + k] = Hc[k];
+          int a = 0;
+#pragma unroll
+          for (int k = 0; k < VSR_NSLOT; k++)
+            if ((D.used >> k) & 1) {
+              if (D.pj[k] >= 0) out[M.fixed + D.pj[k]] = D.pnew[k];
+              else out[plen + (a++)] = D.pnew[k];
+            }
+          nx_off[idx] = (dst << 8) | (u64)clen;
+          lvl_fp[idx] = fp;
+          if (lvl_tr) lvl_tr[idx] = key;
+          const int bad = check_invariants_child(M, rec, D);
+          if (bad) {
+            atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
+            atomicOr(&ctl->viol_mask, (u32)bad);
+          }
+          atomicMax(&s_maxbag_out, (u32)hdr_nmsg(D.hdr));
+        }
+        continue;
+      }
       bool found_old, full;
       u64 slot = table_claim(table, tmask, fp, key, level, &found_old, &my_probes, &full);
       if (full) {
@@ -299,7 +424,12 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     if (lane == 0 && my_probes) atomicAdd(&s_acc[2], (unsigned long long)my_probes);
     __syncthreads();
     if (tid == 0) {
-      s_chunk_used += s_tile_cursor;
+      if (fused) {
+        s_ich_used += s_tile_icur;
+        s_wch_used += s_tile_wcur;
+      } else {
+        s_chunk_used += s_tile_cursor;
+      }
       s_acc[0] += s_ncand;
       s_acc[1] += s_dead;
       const u64 t_5 = __builtin_readcyclecounter();
@@ -314,9 +444,23 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
   }
   // ---- block epilogue: invalidate the unused tail of the chunk, flush the accumulators
   {
-    const u32 used = s_chunk_used;
-    const u64 base = s_chunk_base;
-    for (u32 k = used + tid; k < pchunk; k += VSR_BLOCK) pending[2 * (base + k) + 1] = ~(u64)0;
+    if (fused) {
+      const u32 used = s_ich_used;
+      const u64 base = s_ich_base;
+      for (u32 k = used + tid; k < ichunk; k += VSR_BLOCK) {
+        nx_off[base + k] = 0;
+        lvl_fp[base + k] = 0;
+        if (lvl_tr) lvl_tr[base + k] = ~(u64)0;
+      }
+      if (tid == 0) {
+        if (s_acc[8]) atomicAdd((unsigned long long*)&ctl->ties, s_acc[8]);
+        if (s_maxbag_out) atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)s_maxbag_out);
+      }
+    } else {
+      const u32 used = s_chunk_used;
+      const u64 base = s_chunk_base;
+      for (u32 k = used + tid; k < pchunk; k += VSR_BLOCK) pending[2 * (base + k) + 1] = ~(u64)0;
+    }
     if (tid == 0) {
       if (s_acc[0]) atomicAdd((unsigned long long*)&ctl->generated, s_acc[0]);
       if (s_acc[1]) atomicAdd((unsigned long long*)&ctl->deadlocks, s_acc[1]);

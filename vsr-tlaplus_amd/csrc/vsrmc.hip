@@ -602,6 +602,7 @@ struct vsrmc_checker {
   LevelCtl h;
   double t_level0 = 0, expand_ms = 0, materialize_ms = 0;
   u64 tr_base = 0, nx_n = 0, nx_w = 0;
+  u64 tr_base0() const { return level_base.back() + level_size.back(); }
   u64 n_valid = 1;                       // states in the newest level (n_frontier is its index range, holes included)
   u64* rslot = nullptr;                  // sharded: slot of every received candidate
   u64 rslot_cap = 0;
@@ -742,9 +743,27 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
     unsigned grid = (unsigned)std::min<u64>(std::min<u64>(ntiles, (u64)c->num_cus * 8), std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));
     size_t lds = (size_t)VSR_TILE * c->lds_stride * 8 + 2 * VSR_CAND_CAP * 4;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(k_expand, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], c->n_frontier,
-                       c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, c->lds_stride,
-                       io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk);
+    // fused single-pass mode (unsharded, not exact_ties): the lane that inserts a fingerprint writes the successor itself
+    const bool fused = !io && !c->opt.exact_ties;
+    const int nxt = c->cur ^ 1;
+    u64 nx_cap = c->opt.frontier_states;                       // the trace log bounds the level as well
+    if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
+    u32 ichunk = 0, wchunk = 0;
+    if (fused) {
+      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->opt.frontier_words / (4 * 16384))));
+      ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(4096, nx_cap / (4 * (u64)grid)));
+      wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->opt.frontier_words / (4 * (u64)grid)));
+    }
+    if (fused)
+      hipLaunchKernelGGL(k_expand<true>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+                         c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
+                         c->lds_stride, 1, nullptr, 0, pchunk, c->words[nxt], c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp,
+                         c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk, wchunk);
+    else
+      hipLaunchKernelGGL(k_expand<false>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+                         c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
+                         c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
+                         0, nullptr, 0, nullptr, nullptr, 0, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -755,9 +774,19 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->expand_ms = ms;
   }
-  c->tr_base = c->level_base.back() + c->level_size.back();
+  c->tr_base = c->tr_base0();
   c->nx_n = c->nx_w = 0;
   if (c->h.err) return level_error(c, c->h, c->level + 1);
+  if (!io && !c->opt.exact_ties) {                             // fused: the level is already materialised
+    c->nx_n = c->h.n_new;
+    c->nx_w = c->h.words_new;
+    if (c->h.ties) {
+      c->failed = 1;
+      return fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables "
+                                 "(SURVEY F2); the single-pass scheme cannot arbitrate: create the checker with "
+                                 "vsrmc_options.exact_ties = 1");
+    }
+  }
   return 0;
 }
 
@@ -876,7 +905,7 @@ int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: drive the level with the vsrmc_shard_* phases");
   int rc = phase_expand(c, nullptr);
-  if (!rc) rc = phase_materialize_local(c);
+  if (!rc && c->opt.exact_ties) rc = phase_materialize_local(c);
   if (rc) {   // like a TLC evaluation error: the run aborts, the partial level is not committed
     std::memset(info, 0, sizeof(*info));
     info->level = c->level;

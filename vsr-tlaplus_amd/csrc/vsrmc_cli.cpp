@@ -63,7 +63,8 @@ int main(int argc, char** argv) {
   o.frontier_words = (uint64_t)(frontier_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);
   o.frontier_states = o.frontier_words / 24;
   o.pending_entries = o.frontier_states * 3;
-  o.trace_entries = ((uint64_t)1 << table_log2) / 2;
+  // one entry per state plus the unused tails of the per-block index chunks (<= 4096 per block per level, 510 levels at most)
+  o.trace_entries = ((uint64_t)1 << table_log2) / 2 + ((uint64_t)1 << 21);
   vsrmc_checker* c = nullptr;
   if (vsrmc_checker_create(m, &o, &c) != 0) {
     std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());
