@@ -117,7 +117,8 @@ typedef struct vsrmc_level_info {
   uint64_t deadlocks;            /* expanded states without successor */
   uint64_t pending;              /* candidates that raced for a slot claimed in this level */
   uint64_t probes;               /* seen-set slots inspected */
-  uint64_t words_new;            /* words of the next frontier (device layout) */
+  uint64_t words_new;            /* words reserved in the next frontier buffer (device layout, chunk slack included) */
+  uint64_t record_words;         /* words of the records of the next frontier themselves */
   uint64_t max_bag;
   uint64_t viol_fp;              /* smallest fingerprint of a violating new state, ~0 if none */
   uint64_t viol_index;           /* its index in the next frontier */

@@ -24,7 +24,7 @@ class Options(C.Structure):
 class LevelInfo(C.Structure):
     _fields_ = [("level", C.c_int32), ("error_code", C.c_int32), ("frontier", C.c_uint64), ("generated", C.c_uint64),
                 ("n_new", C.c_uint64), ("distinct", C.c_uint64), ("total_generated", C.c_uint64),
-                ("deadlocks", C.c_uint64), ("pending", C.c_uint64), ("probes", C.c_uint64), ("words_new", C.c_uint64),
+                ("deadlocks", C.c_uint64), ("pending", C.c_uint64), ("probes", C.c_uint64), ("words_new", C.c_uint64), ("record_words", C.c_uint64),
                 ("max_bag", C.c_uint64), ("viol_fp", C.c_uint64), ("viol_index", C.c_uint64), ("viol_mask", C.c_int32),
                 ("reserved0", C.c_int32), ("seconds", C.c_double), ("expand_ms", C.c_double),
                 ("materialize_ms", C.c_double), ("act_generated", C.c_uint64 * 16), ("phase_cycles", C.c_uint64 * 8)]

@@ -38,6 +38,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
   u64 cand_cnt[8];         // sharded mode: candidates bucketed for each owner rank
   u64 out_n[8];            // sharded mode: records materialised for each owner rank (self = n_new)
   u64 out_w[8];            // ... and their words (self = words_new)
+  u64 rec_words;           // words of the records actually written to the next frontier (chunk slack excluded)
   u64 ties;                // fused mode: same-level candidates of one fingerprint with different auxkeys (must stay 0)
   u64 phase_cycles[8];     // k_expand, summed over blocks (wave 0's clock): stage, enumerate, sort, apply, tail; k_materialize: 5..7
 };
@@ -45,7 +46,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
 __host__ __device__ __forceinline__ int owner_of(u64 fp, int world) { return (int)(((fp >> 40) & 0xFFFFFF) % (u64)world); }
 
-#define VSR_TILE 64          // frontier records staged per block iteration
+#define VSR_TILE_MAX 128     // frontier records staged per block iteration: 64 or 128 (kernel parameter `tile`)
 #define VSR_BLOCK 256
 #define VSR_CAND_CAP 2048    // enabled instances per tile the LDS work list can hold
 
@@ -141,16 +142,16 @@ template <bool FUSED>
 __global__ void __launch_bounds__(VSR_BLOCK, FUSED ? 2 : 3)
 k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world, u64* cand_send,
-         u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= VSR_CAND_CAP */,
+         u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
          // fused single-pass mode (nx_words != nullptr): the lane that inserts a fingerprint writes the successor at once
-         u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u64* lvl_tr, u32 ichunk, u32 wchunk) {
+         u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u64* lvl_tr, u32 ichunk, u32 wchunk, int tile, u32 ccap /* work-list capacity per tile */) {
   extern __shared__ u64 smem[];
-  u64* s_rec = smem;                                           // VSR_TILE * stride words
-  u32* s_cand = (u32*)(smem + VSR_TILE * stride);              // VSR_CAND_CAP entries: action << 17 | record << 11 | ordinal
-  u32* s_cand2 = s_cand + VSR_CAND_CAP;                        // the same, sorted by action
+  u64* s_rec = smem;                                           // tile * stride words
+  u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
+  u32* s_cand2 = s_cand + ccap;                        // the same, sorted by action
   __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out;
-  __shared__ u32 s_alive[VSR_TILE];
-  __shared__ u64 s_ref[VSR_TILE];
+  __shared__ u32 s_alive[VSR_TILE_MAX];
+  __shared__ u64 s_ref[VSR_TILE_MAX];
   __shared__ u32 s_kcount[16], s_kbase[16];
   // per-block accumulators (flushed once at the end: no hot global counters inside the tile loop)
   __shared__ unsigned long long s_acc[32];                     // 0 generated, 1 deadlocks, 2 probes, 3..7 phase cycles, 16..31 per action
@@ -163,7 +164,8 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
   constexpr bool fused = FUSED;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const u64 ntiles = (n_parents + VSR_TILE - 1) / VSR_TILE;
+  const u64 ntiles = (n_parents + tile - 1) / tile;
+  const int tshift = tile == 128 ? 7 : 6;
   if (tid < 32) s_acc[tid] = 0;
   if (tid == 0) s_maxbag_out = 0;
   if (tid == 0) {                                              // "no chunk yet"
@@ -172,12 +174,12 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
   }
   __syncthreads();
 
-  for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const u64 p_base = tile * VSR_TILE;
-    const int np_tile = (int)((n_parents - p_base) < VSR_TILE ? (n_parents - p_base) : VSR_TILE);
+  for (u64 tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+    const u64 p_base = tile_i * (u64)tile;
+    const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
     const u64 t_0 = __builtin_readcyclecounter();
     if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; }
-    if (tid < VSR_TILE) s_alive[tid] = 0;
+    if (tid < tile) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
     __syncthreads();
 
@@ -189,11 +191,11 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
     }
     __syncthreads();
-    {
+    for (int half = 0; half < tile; half += 64) {
       u64 v[4][4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int p = (tid >> 4) + 16 * q;
+        const int p = half + (tid >> 4) + 16 * q;
         const u64 ref = p < np_tile ? s_ref[p] : 0;
         const u64 off = ref >> 8;
         const int len = (int)(ref & 255) < stride ? (int)(ref & 255) : stride;
@@ -205,7 +207,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int p = (tid >> 4) + 16 * q;
+        const int p = half + (tid >> 4) + 16 * q;
         const int len = p < np_tile ? ((int)(s_ref[p] & 255) < stride ? (int)(s_ref[p] & 255) : stride) : 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -222,9 +224,9 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     // action id << 17 | record << 11 | ordinal; per-action counters feed the counting sort below.
     {
       const int nslots = M.m0 + (int)s_maxbag;
-      const int nitems = nslots * VSR_TILE;
+      const int nitems = nslots << tshift;
       for (int item = tid; item < nitems; item += VSR_BLOCK) {
-        const int slot = item >> 6, p = item & 63;
+        const int slot = item >> tshift, p = item & (tile - 1);
         u32 mask = 0;
         int kind0 = 0;
         if (p < np_tile && s_ref[p] != 0) mask = guard_slot(M, (const u64*)(s_rec + p * stride), slot, &kind0);
@@ -238,7 +240,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
             const u32 idx = atomicAdd(&s_ncand, 1u);
             atomicAdd(&s_kcount[kind], 1u);
             if (fused) atomicAdd(&s_wneed, (u32)(s_ref[p] & 255) + 5u);   // upper bound of the successor's length
-            if (idx < VSR_CAND_CAP) s_cand[idx] = ((u32)kind << 17) | ((u32)p << 11) | (u32)(ordbase + k);
+            if (idx < ccap) s_cand[idx] = ((u32)kind << 18) | ((u32)p << 11) | (u32)(ordbase + k);
           }
         }
       }
@@ -246,9 +248,9 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     __syncthreads();
     if (tid < np_tile && s_alive[tid] == 0 && s_ref[tid] != 0) atomicAdd(&s_dead, 1u);   // ref 0 = unused index (see k_materialize)
     u32 ncand = s_ncand;
-    if (ncand > VSR_CAND_CAP) {
+    if (ncand > ccap) {
       if (tid == 0) raise_error(ctl, ERR_FRONTIER_FULL, p_base);
-      ncand = VSR_CAND_CAP;
+      ncand = ccap;
     }
     const u64 t_2 = __builtin_readcyclecounter();
     // ---- counting sort of the work list by action id: the lanes of a wave then run the same action (no divergence between
@@ -263,8 +265,8 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     __syncthreads();
     for (u32 c = tid; c < ncand; c += VSR_BLOCK) {
       const u32 code = s_cand[c];
-      const u32 pos = atomicAdd(&s_kbase[code >> 17], 1u);
-      if (pos < VSR_CAND_CAP) s_cand2[pos] = code;
+      const u32 pos = atomicAdd(&s_kbase[code >> 18], 1u);
+      if (pos < ccap) s_cand2[pos] = code;
     }
     __syncthreads();
 
@@ -323,10 +325,10 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     u32 my_probes = 0;
     for (u32 c = tid; c < ncand; c += VSR_BLOCK) {
       const u32 code = s_cand2[c];
-      const int p = (int)((code >> 11) & 63), ord = (int)(code & 2047);
+      const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
       const u64* rec = s_rec + p * stride;
       Delta D;
-      if (!gen<false>(M, rec, ord, D) || D.action != (int)(code >> 17)) {
+      if (!gen<false>(M, rec, ord, D) || D.action != (int)(code >> 18)) {
         raise_error(ctl, ERR_INTERNAL, ((p_base + (u64)p) << 16) | (u64)ord);
         continue;
       }
@@ -398,6 +400,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
             atomicOr(&ctl->viol_mask, (u32)bad);
           }
           atomicMax(&s_maxbag_out, (u32)hdr_nmsg(D.hdr));
+          atomicAdd(&s_acc[9], (unsigned long long)clen);
         }
         continue;
       }
@@ -454,6 +457,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       }
       if (tid == 0) {
         if (s_acc[8]) atomicAdd((unsigned long long*)&ctl->ties, s_acc[8]);
+        if (s_acc[9]) atomicAdd((unsigned long long*)&ctl->rec_words, s_acc[9]);
         if (s_maxbag_out) atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)s_maxbag_out);
       }
     } else {
@@ -520,7 +524,7 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
   // last index chunk is published as invalid refs (0), which every consumer skips.
   u64 idx_base = 0, w_base = 0;
   u32 idx_left = 0, w_left = 0;
-  u64 cyc_fetch = 0, cyc_stage = 0, cyc_gen = 0, cyc_write = 0;
+  u64 cyc_fetch = 0, cyc_stage = 0, cyc_gen = 0, cyc_write = 0, rec_words = 0;
   const u64 nthreads = (u64)gridDim.x * VSR_MAT_BLOCK;
   const u64 rounds = (n_pending + nthreads - 1) / nthreads;
   for (u64 it = 0; it < rounds; it++) {
@@ -629,6 +633,7 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
       w_left = wchunk;
     }
     const u64 dst = w_base + (u64)(incl - clen);
+    rec_words += total;
     w_base += total;
     w_left -= total;
     if (overflow) {
@@ -671,7 +676,7 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
     atomicAdd((unsigned long long*)&ctl->phase_cycles[5], (unsigned long long)(cyc_fetch + cyc_stage));
     atomicAdd((unsigned long long*)&ctl->phase_cycles[6], (unsigned long long)cyc_gen);
     atomicAdd((unsigned long long*)&ctl->phase_cycles[7], (unsigned long long)cyc_write);
-    atomicAdd((unsigned long long*)&ctl->act_generated[0], (unsigned long long)cyc_fetch);   // slot 0 of act_generated is unused (Init)
+    atomicAdd((unsigned long long*)&ctl->rec_words, (unsigned long long)rec_words);
   }
   // the unused tail of the wave's last index chunk: invalid refs
   for (u32 k = lane; k < idx_left; k += 64) {

@@ -737,11 +737,14 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
   c->h.viol_fp = ~(u64)0;
   HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
   if (c->n_frontier > 0) {
-    u64 ntiles = (c->n_frontier + VSR_TILE - 1) / VSR_TILE;
+    // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
+    const int tile = M.R <= 3 ? 128 : 64;
+    u64 ntiles = (c->n_frontier + tile - 1) / tile;
     // every block reserves pending-list room in chunks: the list must hold one chunk per block beyond the real entries
     const u32 pchunk = c->opt.pending_entries >= ((u64)1 << 24) ? 8192u : (u32)VSR_CAND_CAP;
-    unsigned grid = (unsigned)std::min<u64>(std::min<u64>(ntiles, (u64)c->num_cus * 8), std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));
-    size_t lds = (size_t)VSR_TILE * c->lds_stride * 8 + 2 * VSR_CAND_CAP * 4;
+    unsigned grid = (unsigned)std::min<u64>(std::min<u64>(ntiles, (u64)c->num_cus * 3), std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));
+    const u32 ccap = tile == 128 ? 1536u : (u32)VSR_CAND_CAP;   // keeps two blocks per CU in LDS at 128 records per tile
+    size_t lds = (size_t)tile * c->lds_stride * 8 + 2 * (size_t)ccap * 4;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     // fused single-pass mode (unsharded, not exact_ties): the lane that inserts a fingerprint writes the successor itself
     const bool fused = !io && !c->opt.exact_ties;
@@ -750,20 +753,23 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
     if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
     u32 ichunk = 0, wchunk = 0;
     if (fused) {
+      // persistent blocks (2 resident per CU: 225 VGPRs, 79 KB LDS): every block leaves one partly used index chunk and
+      // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
+      grid = (unsigned)std::min<u64>(grid, (u64)c->num_cus * 2);
       grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->opt.frontier_words / (4 * 16384))));
-      ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(4096, nx_cap / (4 * (u64)grid)));
+      ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
       wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->opt.frontier_words / (4 * (u64)grid)));
     }
     if (fused)
       hipLaunchKernelGGL(k_expand<true>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, 1, nullptr, 0, pchunk, c->words[nxt], c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp,
-                         c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk, wchunk);
+                         c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk, wchunk, tile, ccap);
     else
       hipLaunchKernelGGL(k_expand<false>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
-                         0, nullptr, 0, nullptr, nullptr, 0, 0);
+                         0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -860,6 +866,7 @@ int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
   c->total_generated += h.generated;
   info->n_new = n_new;
   info->words_new = c->nx_w;
+  info->record_words = h.rec_words;
   if (n_new > 0 || c->opt.world > 1) {   // sharded: levels stay aligned across ranks even when this shard got nothing
     c->level_base.push_back(c->tr_base);
     c->level_size.push_back(c->nx_n);

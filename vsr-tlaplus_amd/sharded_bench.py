@@ -45,7 +45,7 @@ def main(args, CONFIG, EXPECT):
             if record and loc["frontier"]:
                 S["launches"] += 1
                 S["alg_bytes"] += 8.0 * cur_words + 8.0 * loc["generated"] + 8.0 * loc["n_new"]
-            cur_words = loc["words_new"]
+            cur_words = loc["record_words"]
             if d["n_new"] == 0 or sc.violation is not None:
                 break
         if sc.violation is not None:                          # counter-example reconstructed = found
