@@ -127,6 +127,14 @@ def main():
                      "B_alg_per_state": round(2 * s_bytes + 8 * g + 8, 1),
                      "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3)}},
     }
+    # HBM traffic of the same kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
+    tpath = os.path.join(ROOT, "profiles", "r01b_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            t = json.load(f)
+        out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_unit"] = "bytes per launch (PMC, %s)" % t["source"].split(" (")[0]
+        out["roofline"]["alg_bytes_per_launch"] = round(S["alg_bytes"] / max(1, S["launches"]))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     print(json.dumps(out))
