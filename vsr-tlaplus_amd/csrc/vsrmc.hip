@@ -742,12 +742,13 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
     // every block reserves pending-list room in chunks: the list must hold one chunk per block beyond the real entries
     const u32 pchunk = c->opt.pending_entries >= ((u64)1 << 24) ? 8192u : (u32)VSR_CAND_CAP;
-    unsigned grid = (unsigned)std::min<u64>(std::min<u64>(ntiles, (u64)c->num_cus * 3), std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));
+    const bool fused = !io && !c->opt.exact_ties;
+    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 3);
+    if (!fused) grid = (unsigned)std::min<u64>(grid, std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));   // the pending list is only used by the two-kernel scheme
     const u32 ccap = tile == 128 ? 1536u : (u32)VSR_CAND_CAP;   // keeps two blocks per CU in LDS at 128 records per tile
     size_t lds = (size_t)tile * c->lds_stride * 8 + 2 * (size_t)ccap * 4;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     // fused single-pass mode (unsharded, not exact_ties): the lane that inserts a fingerprint writes the successor itself
-    const bool fused = !io && !c->opt.exact_ties;
     const int nxt = c->cur ^ 1;
     u64 nx_cap = c->opt.frontier_states;                       // the trace log bounds the level as well
     if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);

@@ -17,9 +17,15 @@ def main(args, CONFIG, EXPECT):
     import vsr_tlaplus_amd as vt
     from vsr_tlaplus_amd import sharded
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("VSR_BENCH_BACKEND", "nccl")      # "gloo": functional check of this leg on a one-GPU box
+    if backend != "nccl":                                       # (all ranks share device 0, buckets staged through the host)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     slack = 1.35                                              # hash imbalance between shards
     per_rank = lambda x: int(x / world * slack) + (1 << 16)   # noqa: E731
@@ -72,7 +78,7 @@ def main(args, CONFIG, EXPECT):
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     if rank == 0:
