@@ -149,7 +149,7 @@ int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uin
 /* forward half of TLCTrace.getTrace on its own: re-execute `nsteps` ordinals from Init */
 int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t* ords, int32_t nsteps, uint64_t* words,
                            uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
-/* one entry of the trace log: key = level(9) | auxkey(9) | rank(3) | parent index(32) | ordinal(11) */
+/* one entry of the trace log: key = level(9) | auxkey(9) | ordinal(11) | parent index(32) | rank(3) */
 int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* key);
 /* index of fingerprint `fp` in the newest level (~0 if absent) */
 int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index);

@@ -21,7 +21,7 @@ def _u64(t):
 class FakeShardEngine:
     def __init__(self, params, rank, world, owner_of):
         self.P, self.rank, self.world, self.owner_of = params, rank, world, owner_of
-        self.seen = {}            # fp -> best key (level << 55 | auxkey << 46 | rank << 43 | pidx << 11 | ord)
+        self.seen = {}            # fp -> best key (level << 55 | auxkey << 46 | ord << 35 | pidx << 3 | rank)
         self.level = 1
         init = orc.init_record(params)
         fp, ak = orc.fingerprint(params, init)
@@ -34,7 +34,7 @@ class FakeShardEngine:
         self._err = ""
 
     def _key(self, level, ak, pidx, ordinal):
-        return (level << 55) | (ak << 46) | (self.rank << 43) | (pidx << 11) | ordinal
+        return (level << 55) | (ak << 46) | (ordinal << 35) | (pidx << 3) | self.rank
 
     def error_text(self):
         return self._err
@@ -81,7 +81,7 @@ class FakeShardEngine:
         return torch.tensor(verdict, dtype=torch.uint8), 0
 
     def _record_of(self, key):
-        pidx, k = (key >> 11) & 0xFFFFFFFF, key & 2047
+        pidx, k = (key >> 3) & 0xFFFFFFFF, (key >> 35) & 2047
         return self.succ_cache[pidx][k]
 
     def materialize(self, verdicts):

@@ -227,15 +227,16 @@ VSR_HD void canonical_fp(const Model& M, u64 hdr, const u64* H, u64* fp, u32* au
 }
 
 // ---- meta word of a seen-set slot: (level, auxkey, rank, parent index, ordinal); smaller = wins the slot -------
-// level(9) | auxkey(9) | rank(3) | pidx(32) | ord(11)
+// level(9) | auxkey(9) | ord(11) | pidx(32) | rank(3).  The rank sits in the LOWEST bits: with it above the parent index the
+// lowest rank would win every cross-rank duplicate of a level and end up materialising (and shipping) most new states.
 static const u64 META_EMPTY = ~(u64)0;
 VSR_HD u64 meta_make(int level, u32 auxkey, int rank, u64 pidx, int ord) {
-  return ((u64)level << 55) | ((u64)auxkey << 46) | ((u64)rank << 43) | (pidx << 11) | (u64)ord;
+  return ((u64)level << 55) | ((u64)auxkey << 46) | ((u64)ord << 35) | (pidx << 3) | (u64)rank;
 }
 VSR_HD int meta_level(u64 m) { return (int)(m >> 55); }
 VSR_HD int meta_auxkey(u64 m) { return (int)((m >> 46) & 511); }
-VSR_HD int meta_rank(u64 m) { return (int)((m >> 43) & 7); }
-VSR_HD u64 meta_pidx(u64 m) { return (m >> 11) & 0xFFFFFFFFull; }
-VSR_HD int meta_ord(u64 m) { return (int)(m & 2047); }
+VSR_HD int meta_rank(u64 m) { return (int)(m & 7); }
+VSR_HD u64 meta_pidx(u64 m) { return (m >> 3) & 0xFFFFFFFFull; }
+VSR_HD int meta_ord(u64 m) { return (int)((m >> 35) & 2047); }
 
 }  // namespace vsr

@@ -180,8 +180,8 @@ class ShardedChecker:
             # a 64-bit key crosses ranks as two 32-bit halves (signed int64 all-reduce)
             parts = self.x.allreduce([key >> 32, key & 0xFFFFFFFF], dist.ReduceOp.MAX)
             key = (parts[0] << 32) | parts[1]
-            ords.append(key & 2047)
-            rank, index = (key >> 43) & 7, (key >> 11) & 0xFFFFFFFF
+            ords.append((key >> 35) & 2047)                    # key = level(9) | auxkey(9) | ordinal(11) | parent index(32) | rank(3)
+            rank, index = key & 7, (key >> 3) & 0xFFFFFFFF
         return ords[::-1]
 
 

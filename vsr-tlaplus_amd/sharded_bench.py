@@ -27,15 +27,19 @@ def main(args, CONFIG, EXPECT):
         else:
             dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    slack = 1.35                                              # hash imbalance between shards
-    per_rank = lambda x: int(x / world * slack) + (1 << 16)   # noqa: E731
-    per_pair = lambda x: int(x / world / world * slack) + (1 << 16)   # noqa: E731
+    # slack: hash imbalance between shards, plus the unused tails of the per-wave output chunks (k_materialize reserves
+    # indices / words in chunks; up to 1280 waves x (1024 indices, 65536 words) per target and level stay unused)
+    slack = 1.4
+    per_rank = lambda x, extra=0: int(x / world * slack) + extra + (1 << 16)   # noqa: E731
+    per_pair = lambda x, extra=0: int(x / world / world * slack) + extra + (1 << 16)   # noqa: E731
+    tail_idx, tail_words = 1280 * 1024, 1280 * 65536
     m = vt.Model.from_constants(R=CONFIG["R"], C_=CONFIG["C"], n=CONFIG["n"], L=CONFIG["L"])
     table_log2 = max(20, int(math.ceil(math.log2(2.2 * TOTAL / world))))
     eng = sharded.HipShardEngine(
-        m, rank, world, device=local_rank, table_log2=table_log2, frontier_words=per_rank(MAX_WORDS),
-        frontier_states=per_rank(MAX_NEW), pending_entries=per_pair(MAX_GENERATED), cand_cap=per_pair(MAX_GENERATED),
-        rec_cap=per_pair(MAX_NEW), rec_words_cap=per_pair(MAX_WORDS), keep_trace=True, trace_entries=per_rank(TOTAL))
+        m, rank, world, device=local_rank, table_log2=table_log2, frontier_words=per_rank(MAX_WORDS, world * tail_words),
+        frontier_states=per_rank(MAX_NEW, world * tail_idx), pending_entries=per_pair(MAX_GENERATED, 1 << 24),
+        cand_cap=per_pair(MAX_GENERATED), rec_cap=per_pair(MAX_NEW, tail_idx), rec_words_cap=per_pair(MAX_WORDS, tail_words),
+        keep_trace=True, trace_entries=per_rank(TOTAL, 30 * world * tail_idx))
     x = sharded.Exchanger()
     S = dict(alg_bytes=0.0, launches=0, distinct=0, ttfv=[])
 
