@@ -155,6 +155,23 @@ int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t inde
 int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index);
 void vsrmc_checker_destroy(vsrmc_checker* c);
 
+/* ---- simulation mode ≙ `tlc2.TLC -simulate` (the reference README:22 recommends it for the state-transfer defect) -------------
+ * n_walkers random walks run concurrently (one GPU lane each): start at Init, up to max_depth steps chosen uniformly among
+ * the enabled (action, binding) instances, invariants checked after every step, restart at the depth limit or in a terminal
+ * state.  Stops at the first violation or after max_seconds.  The violating walk comes back as ordinals; pass them to
+ * vsrmc_model_replay for the states and action names. */
+typedef struct vsrmc_sim_result {
+  int32_t found;                 /* 1 = invariant violated, 2 = evaluation / representation error on a walk, 0 = time-out */
+  int32_t viol_mask;             /* violated invariants (found = 1) or device error code (found = 2) */
+  int32_t viol_steps;            /* number of steps of the reported walk (trace = viol_steps + 1 states) */
+  int32_t reserved;
+  uint64_t steps, walks;         /* totals over all walkers */
+  double seconds;
+  uint32_t ords[512];
+} vsrmc_sim_result;
+int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t n_walkers, int32_t max_depth, uint64_t seed,
+                       double max_seconds, vsrmc_sim_result* out);
+
 /* ---- sharded seen-set (≙ tlc2.tool.fp.MultiFPSet across GPUs): the phases of one BFS level -----------------------
  * world ranks, one per GPU; owner(fp) = ((fp >> 40) & 0xFFFFFF) % world.  The caller (vsr-tlaplus_amd/sharded.py over
  * torch.distributed / RCCL) owns the exchange buffers and moves them between ranks; every pointer is a device pointer.

@@ -41,6 +41,11 @@ class ShardIO(C.Structure):
                 ("rec_off", C.c_void_p), ("rec_fp", C.c_void_p), ("rec_key", C.c_void_p), ("rec_cap", C.c_uint64)]
 
 
+class SimResult(C.Structure):
+    _fields_ = [("found", C.c_int32), ("viol_mask", C.c_int32), ("viol_steps", C.c_int32), ("reserved", C.c_int32),
+                ("steps", C.c_uint64), ("walks", C.c_uint64), ("seconds", C.c_double), ("ords", C.c_uint32 * 512)]
+
+
 # every symbol include/vsrmc.h declares: name -> (restype, argtypes)
 V = C.c_void_p
 SYMBOLS = {
@@ -76,6 +81,7 @@ SYMBOLS = {
     "vsrmc_model_replay": (C.c_int32, [V, C.c_int32, V, C.c_int32, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_trace_entry": (C.c_int32, [V, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_find_fp": (C.c_int32, [V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_simulate": (C.c_int32, [V, C.c_int32, C.c_uint32, C.c_int32, C.c_uint64, C.c_double, C.POINTER(SimResult)]),
     "vsrmc_shard_expand": (C.c_int32, [V, C.POINTER(ShardIO), V]),
     "vsrmc_shard_claim": (C.c_int32, [V, V, C.c_uint64, V]),
     "vsrmc_shard_materialize": (C.c_int32, [V, C.POINTER(ShardIO), V, V, V]),

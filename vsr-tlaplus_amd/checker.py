@@ -95,6 +95,30 @@ class Model:
         check(capi.load().vsrmc_fingerprint_batch(self._h, device, _p(words), _p(off), n, _p(fps), _p(aks)))
         return fps, aks
 
+    def simulate(self, n_walkers=1 << 16, max_depth=100, seed=1, max_seconds=10.0, device=0):
+        """≙ `tlc2.TLC -simulate -depth max_depth`: random walks on the GPU until an invariant fails or time runs out.
+        -> dict(found, viol_mask, steps, walks, seconds, trace=[(action name, wire record)] or None)."""
+        r = capi.SimResult()
+        check(capi.load().vsrmc_simulate(self._h, device, n_walkers, max_depth, seed, max_seconds, C.byref(r)))
+        out = dict(found=r.found, viol_mask=r.viol_mask, steps=r.steps, walks=r.walks, seconds=r.seconds, trace=None)
+        if r.found == 1:
+            ords = [int(r.ords[k]) for k in range(r.viol_steps)]
+            out["ordinals"] = ords
+            out["trace"] = self.replay(ords, device)
+        return out
+
+    def replay(self, ords, device=0):
+        """Re-execute a path of ordinals from Init on the GPU -> [(action name, wire record)]."""
+        n = len(ords)
+        cap_w = (n + 2) * int(self.layout.max_record_words)
+        words = np.zeros(cap_w, dtype=np.uint64)
+        off = np.zeros(n + 3, dtype=np.uint64)
+        acts = np.zeros(n + 3, dtype=np.int32)
+        o = np.array(list(ords) + [0], dtype=np.uint32)
+        ns = C.c_uint64()
+        check(capi.load().vsrmc_model_replay(self._h, device, _p(o), n, _p(words), cap_w, _p(off), _p(acts), len(off), C.byref(ns)))
+        return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(ns.value)]
+
     def close(self):
         if self._h:
             capi.load().vsrmc_model_destroy(self._h)

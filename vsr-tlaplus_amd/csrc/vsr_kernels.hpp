@@ -191,31 +191,32 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
     }
     __syncthreads();
-    for (int half = 0; half < tile; half += 64) {
-      u64 v[4][4];
+    for (int half = 0; half < tile; half += 64)
+      for (int wbase = 0; wbase < stride; wbase += 64) {      // records longer than 64 words (R >= 4): a second window
+        u64 v[4][4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int p = half + (tid >> 4) + 16 * q;
-        const u64 ref = p < np_tile ? s_ref[p] : 0;
-        const u64 off = ref >> 8;
-        const int len = (int)(ref & 255) < stride ? (int)(ref & 255) : stride;
+        for (int q = 0; q < 4; q++) {
+          const int p = half + (tid >> 4) + 16 * q;
+          const u64 ref = p < np_tile ? s_ref[p] : 0;
+          const u64 off = ref >> 8;
+          const int len = (int)(ref & 255) < stride ? (int)(ref & 255) : stride;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int k = (tid & 15) + 16 * j;
-          v[q][j] = k < len ? fr_words[off + k] : 0;
+          for (int j = 0; j < 4; j++) {
+            const int k = wbase + (tid & 15) + 16 * j;
+            v[q][j] = k < len ? fr_words[off + k] : 0;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int p = half + (tid >> 4) + 16 * q;
+          const int len = p < np_tile ? ((int)(s_ref[p] & 255) < stride ? (int)(s_ref[p] & 255) : stride) : 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int k = wbase + (tid & 15) + 16 * j;
+            if (k < len) s_rec[p * stride + k] = v[q][j];
+          }
         }
       }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int p = half + (tid >> 4) + 16 * q;
-        const int len = p < np_tile ? ((int)(s_ref[p] & 255) < stride ? (int)(s_ref[p] & 255) : stride) : 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int k = (tid & 15) + 16 * j;
-          if (k < len) s_rec[p * stride + k] = v[q][j];
-        }
-      }
-    }
     __syncthreads();
 
     const u64 t_1 = __builtin_readcyclecounter();
@@ -560,6 +561,8 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
       if (lane < n2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lane), l, 4, 0, 0);
       // the instruction offset applies to the global address AND the LDS address: same pointers, +256 bytes on both sides
       if (lane + 64 < n2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lane), l, 4, 256, 0);
+      if (lane + 128 < n2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lane), l, 4, 512, 0);
+      if (lane + 192 < n2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lane), l, 4, 768, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_wave_sync();
@@ -650,6 +653,7 @@ k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__
         const u64 d = readlane64(dst, g + q);
         const int n = __builtin_amdgcn_readlane(clen, g + q);
         if (lane < n) nx_words[d + lane] = s_slot[(g + q) * stride + lane];
+        if (lane + 64 < n) nx_words[d + lane + 64] = s_slot[(g + q) * stride + lane + 64];   // records longer than 64 words (R >= 4)
       }
     }
     if (win) {
@@ -856,6 +860,118 @@ __global__ void k_successors(Model M, const u64* words, const u64* off, u64 n, u
     m[6] = (u64)D.err;
     m[7] = w;
   }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_simulate — TLC's simulation mode (`-simulate`, README:22 of the reference: "has a good chance of hitting it sooner"):
+// every lane is one random walker.  A walk starts at Init, takes up to max_depth steps, each chosen uniformly among the
+// enabled (action, binding) instances of the current state, checks the invariants after every step and restarts at the
+// depth limit or in a terminal state.  No seen-set, no fingerprints.  The first walker that violates an invariant
+// publishes its ordinal sequence (replayed into a TLC-style trace by k_replay).
+// -----------------------------------------------------------------------------------------------------------------
+struct SimCtl {
+  u32 found;          // 0 = searching, 1 = a violating walk was published
+  u32 viol_mask;
+  u32 viol_depth;     // number of steps of the violating walk
+  u32 pad;
+  u64 steps;          // steps taken by all walkers
+  u64 walks;          // walks started
+  u32 ords[512];      // the violating walk
+};
+
+__device__ __forceinline__ u64 sim_rng(u64* s) {   // xorshift64*
+  u64 x = *s;
+  x ^= x >> 12;
+  x ^= x << 25;
+  x ^= x >> 27;
+  *s = x;
+  return x * 0x2545F4914F6CDD1DULL;
+}
+
+__global__ void __launch_bounds__(64)
+k_simulate(Model M, const u64* __restrict__ init_rec, int init_len, u64* walker_words, int stride, u32* walker_depth,
+           u16* walker_ords, u64* walker_rng, u32 n_walkers, int max_depth, int steps_per_launch, SimCtl* ctl) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_walkers) return;
+  u64* w = walker_words + (u64)t * stride;
+  u16* my_ords = walker_ords + (u64)t * max_depth;
+  u64 rng = walker_rng[t];
+  u32 depth = walker_depth[t];
+  u64 steps = 0, walks = 0;
+  for (int it = 0; it < steps_per_launch; it++) {
+    if (__hip_atomic_load(&ctl->found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    if (depth == 0xFFFFFFFFu || depth >= (u32)max_depth) {     // (re)start at Init
+      for (int k = 0; k < init_len; k++) w[k] = init_rec[k];
+      depth = 0;
+      walks++;
+    }
+    // count the enabled instances, then draw one
+    const int nslots = M.m0 + hdr_nmsg(w[0]);
+    int total = 0;
+    for (int slot = 0; slot < nslots; slot++) {
+      int kind0;
+      total += __builtin_popcount(guard_slot(M, (const u64*)w, slot, &kind0));
+    }
+    if (total == 0) {                                           // terminal state: the walk ends (TLC -deadlock)
+      depth = 0xFFFFFFFFu;
+      continue;
+    }
+    int pick = (int)(sim_rng(&rng) % (u64)total), ord = -1;
+    for (int slot = 0; slot < nslots && ord < 0; slot++) {
+      int kind0;
+      u32 mask = guard_slot(M, (const u64*)w, slot, &kind0);
+      const int c = __builtin_popcount(mask);
+      if (pick >= c) { pick -= c; continue; }
+      while (pick--) mask &= mask - 1;
+      const int k = __ffs((int)mask) - 1;
+      ord = slot < M.m0 ? slot : M.m0 + (slot - M.m0) * (M.R + 1) + k;
+    }
+    Delta D;
+    if (ord < 0 || !gen<false>(M, (const u64*)w, ord, D)) {
+      atomicExch(&ctl->viol_mask, 0x80000000u | (u32)ERR_INTERNAL);
+      atomicExch(&ctl->found, 2u);
+      break;
+    }
+    if (D.err) {                                                // evaluation / representation error: report like a violation
+      if (atomicCAS(&ctl->found, 0u, 2u) == 0u) {
+        ctl->viol_mask = 0x80000000u | (u32)D.err;
+        ctl->viol_depth = depth;
+        for (u32 k = 0; k < depth && k < 512; k++) ctl->ords[k] = my_ords[k];
+      }
+      break;
+    }
+    const int bad = check_invariants_child(M, (const u64*)w, D);
+    // apply the step in place
+    const int plen = M.fixed + hdr_nmsg(w[0]);
+    w[0] = D.hdr;
+    u64* pb = w + 1 + (D.r - 1) * M.wpr;
+    pb[0] = D.rep[0];
+    pb[1] = D.rep[1];
+    pb[2] = D.rep[2];
+    if (M.wpr > 3) pb[3] = D.rep[3];
+    int a = 0;
+#pragma unroll
+    for (int k = 0; k < VSR_NSLOT; k++)
+      if ((D.used >> k) & 1) {
+        if (D.pj[k] >= 0) w[M.fixed + D.pj[k]] = D.pnew[k];
+        else w[plen + (a++)] = D.pnew[k];
+      }
+    my_ords[depth] = (u16)ord;
+    depth++;
+    steps++;
+    if (bad) {
+      if (atomicCAS(&ctl->found, 0u, 1u) == 0u) {
+        ctl->viol_mask = (u32)bad;
+        ctl->viol_depth = depth;
+        for (u32 k = 0; k < depth && k < 512; k++) ctl->ords[k] = my_ords[k];
+      }
+      break;
+    }
+  }
+  walker_rng[t] = rng;
+  walker_depth[t] = depth;
+  atomicAdd((unsigned long long*)&ctl->steps, (unsigned long long)steps);
+  atomicAdd((unsigned long long*)&ctl->walks, (unsigned long long)walks);
 }
 
 // k_hash_records: fill in the H words of device-layout records (used when records enter through the C ABI)

@@ -27,6 +27,7 @@ namespace vsr {
 
 typedef uint64_t u64;
 typedef uint32_t u32;
+typedef uint16_t u16;
 
 enum { ST_NORMAL = 0, ST_VIEWCHANGE = 1, ST_RECOVERING = 2 };                                     // VSR.tla:99-101
 enum { T_SVC = 1, T_PREPARE = 2, T_PREPAREOK = 3, T_DVC = 4, T_SV = 5, T_GETSTATE = 6, T_NEWSTATE = 7 };  // :104-115

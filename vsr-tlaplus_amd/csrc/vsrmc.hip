@@ -123,7 +123,9 @@ int build_model(int R, int C, int n, int L, int restart, int symmetry, int inv_m
   M.fixed = M.h0 + M.np;
   M.assume_commit = assume_commit ? 1 : 0;
   M.inv_mask = inv_mask;
-  M.max_bag = 64 - (M.fixed + 1);        // LDS stride of one staged record = 65 words (odd: conflict-free columns)
+  // LDS stride of one staged record: 63 words (R <= 3) or 95 words (R >= 4: more replicas, larger bags); odd, so that the
+  // columns the slot-major enumeration reads are bank-conflict free.  max_bag = stride - fixed.
+  M.max_bag = (R <= 3 ? 63 : 95) - M.fixed;
   M.m0 = 4 * R + R * C * n;
   for (int r = 0; r < 6; r++) M.salt_rep[r] = fmix64(0xA0761D6478BD642FULL + (u64)r);
   out->symmetry = symmetry ? 1 : 0;
@@ -314,7 +316,7 @@ int32_t vsrmc_model_info(const vsrmc_model* m, vsrmc_layout* out) {
   out->symmetry = m->symmetry; out->invariant_mask = M.inv_mask; out->assume_commit_number = M.assume_commit;
   out->check_deadlock = m->check_deadlock;
   out->words_per_replica = M.wpr; out->fixed_words = M.h0; out->permutations = M.np; out->max_bag = M.max_bag;
-  out->max_record_words = M.h0 + M.max_bag;
+  out->max_record_words = 256;   // wire-layout upper bound (8-bit length); BFS records are bounded by max_bag
   return 0;
 }
 
@@ -569,6 +571,67 @@ int32_t vsrmc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// simulation mode
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t n_walkers, int32_t max_depth, uint64_t seed,
+                                  double max_seconds, vsrmc_sim_result* out) {
+  if (!m || !out || n_walkers == 0 || max_depth < 1 || max_depth > 512) return fail(VSRMC_E_ARG, "bad argument (max_depth 1..512)");
+  int rc = check_device(device);
+  if (rc) return rc;
+  Model M = m->M;
+  M.max_bag = 255 - M.fixed;     // walkers live in HBM, not in LDS tiles: the bag may grow to what the 8-bit count can hold
+  std::memset(out, 0, sizeof(*out));
+  const int stride = M.fixed + M.max_bag;
+  std::vector<u64> wire, dev(512);
+  init_record_wire(M, wire);
+  const int len = wire_to_device(M, wire.data(), dev.data());   // the H words stay 0: simulation never fingerprints
+  u64 *d_init = nullptr, *d_words = nullptr, *d_rng = nullptr;
+  u32* d_depth = nullptr;
+  u16* d_ords = nullptr;
+  SimCtl* d_ctl = nullptr;
+  HIPCHK(hipMalloc((void**)&d_init, 512 * 8));
+  HIPCHK(hipMalloc((void**)&d_words, (u64)n_walkers * stride * 8));
+  HIPCHK(hipMalloc((void**)&d_rng, (u64)n_walkers * 8));
+  HIPCHK(hipMalloc((void**)&d_depth, (u64)n_walkers * 4));
+  HIPCHK(hipMalloc((void**)&d_ords, (u64)n_walkers * max_depth * 2));
+  HIPCHK(hipMalloc((void**)&d_ctl, sizeof(SimCtl)));
+  HIPCHK(hipMemcpy(d_init, dev.data(), len * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d_depth, 0xFF, (u64)n_walkers * 4));
+  HIPCHK(hipMemset(d_ctl, 0, sizeof(SimCtl)));
+  std::vector<u64> rng(n_walkers);
+  u64 x = seed;
+  for (u32 i = 0; i < n_walkers; i++) {   // splitmix64 stream: one non-zero xorshift state per walker
+    x += 0x9E3779B97F4A7C15ULL;
+    u64 z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    rng[i] = z ? z : 1;
+  }
+  HIPCHK(hipMemcpy(d_rng, rng.data(), (u64)n_walkers * 8, hipMemcpyHostToDevice));
+  SimCtl h;
+  double t0 = now_s();
+  while (true) {
+    hipLaunchKernelGGL(k_simulate, dim3((n_walkers + 63) / 64), dim3(64), 0, 0, M, d_init, len, d_words, stride, d_depth, d_ords, d_rng,
+                       n_walkers, max_depth, 64, d_ctl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.found || now_s() - t0 > max_seconds) break;
+  }
+  out->seconds = now_s() - t0;
+  out->found = (int32_t)h.found;
+  out->steps = h.steps;
+  out->walks = h.walks;
+  if (h.found) {
+    out->viol_mask = (int32_t)(h.viol_mask & 0x7FFFFFFFu);
+    out->viol_steps = (int32_t)h.viol_depth;
+    for (u32 k = 0; k < h.viol_depth && k < 512; k++) out->ords[k] = h.ords[k];
+  }
+  (void)hipFree(d_init); (void)hipFree(d_words); (void)hipFree(d_rng); (void)hipFree(d_depth); (void)hipFree(d_ords); (void)hipFree(d_ctl);
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // checker
@@ -1081,7 +1144,8 @@ int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t*
   if (!m || !words || !off || !actions || !n_states || nsteps < 0 || (nsteps && !ords)) return fail(VSRMC_E_ARG, "bad argument");
   int rc = check_device(device);
   if (rc) return rc;
-  const Model& M = m->M;
+  Model M = m->M;
+  M.max_bag = 255 - M.fixed;     // replay is not bound by the LDS tile stride (simulation walks carry larger bags)
   const int level = nsteps + 1;
   if (cap_states < (u64)level + 1) return fail(VSRMC_E_ARG, "state buffers too small");
   u64 maxw = (u64)(M.fixed + M.max_bag + 8) * (u64)level;

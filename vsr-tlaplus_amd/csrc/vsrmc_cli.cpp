@@ -22,13 +22,18 @@ static void usage() {
       "  -device D         HIP device ordinal (default 0)\n"
       "  -tableLog2 N      seen-set slots = 2^N x 16 B (default 28)\n"
       "  -frontierGiB G    size of each of the two frontier buffers (default 8)\n"
+      "  -simulate         random walks instead of BFS (TLC -simulate): -depth N (default 100) -walkers N (131072) -seed S -maxSeconds T\n"
       "  -noTLA            do not read / hash-check the .tla file (only the cfg)\n"
       "  -json             one JSON object per level on stdout instead of TLC-style progress lines\n");
 }
 
 int main(int argc, char** argv) {
   std::string cfg, tla;
-  bool check_deadlock = false, no_tla = false, json = false;
+  bool check_deadlock = false, no_tla = false, json = false, simulate = false;
+  int sim_depth = 100;
+  unsigned sim_walkers = 1u << 17;
+  unsigned long long sim_seed = 1;
+  double sim_seconds = 60.0;
   int max_depth = 1 << 30, device = 0, table_log2 = 28;
   double frontier_gib = 8.0;
   for (int i = 1; i < argc; i++) {
@@ -42,6 +47,11 @@ int main(int argc, char** argv) {
     else if (a == "-tableLog2" && i + 1 < argc) table_log2 = std::atoi(argv[++i]);
     else if (a == "-frontierGiB" && i + 1 < argc) frontier_gib = std::atof(argv[++i]);
     else if (a == "-noTLA") no_tla = true;
+    else if (a == "-simulate") simulate = true;
+    else if (a == "-depth" && i + 1 < argc) sim_depth = std::atoi(argv[++i]);
+    else if (a == "-walkers" && i + 1 < argc) sim_walkers = (unsigned)std::strtoul(argv[++i], nullptr, 10);
+    else if (a == "-seed" && i + 1 < argc) sim_seed = std::strtoull(argv[++i], nullptr, 10);
+    else if (a == "-maxSeconds" && i + 1 < argc) sim_seconds = std::atof(argv[++i]);
     else if (a == "-json") json = true;
     else if (a == "-workers" && i + 1 < argc) ++i;   // accepted for command-line compatibility; the GPU is the worker pool
     else if (!a.empty() && a[0] != '-') tla = a;
@@ -56,6 +66,45 @@ int main(int argc, char** argv) {
   vsrmc_layout lay;
   vsrmc_model_info(m, &lay);
   if (lay.check_deadlock) check_deadlock = true;
+  if (simulate) {   // ≙ tlc2.TLC -simulate -depth N
+    vsrmc_sim_result r;
+    if (vsrmc_simulate(m, device, sim_walkers, sim_depth, sim_seed, sim_seconds, &r) != 0) {
+      std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());
+      return 1;
+    }
+    std::printf("Running Random Simulation with seed %llu: %u walkers on the GPU, depth %d.\n", sim_seed, sim_walkers, sim_depth);
+    int code = 0;
+    if (r.found == 1) {
+      const char* names[2] = {"AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"};
+      for (int b = 0; b < 2; b++)
+        if (r.viol_mask & (1 << b)) std::printf("Error: Invariant %s is violated.\n", names[b]);
+      std::printf("Error: The behavior up to this point is:\n");
+      uint64_t cap_w = (uint64_t)(r.viol_steps + 3) * 256, n_states = 0;
+      std::vector<uint64_t> words(cap_w), off(r.viol_steps + 3);
+      std::vector<int32_t> acts(r.viol_steps + 3);
+      if (vsrmc_model_replay(m, device, r.ords, r.viol_steps, words.data(), cap_w, off.data(), acts.data(), off.size(), &n_states) != 0) {
+        std::printf("Error: %s\n", vsrmc_last_error());
+        return 1;
+      }
+      for (uint64_t t = 0; t < n_states; t++) {
+        int64_t need = 0;
+        vsrmc_model_format_state(m, &words[off[t]], nullptr, 0, &need);
+        std::string buf((size_t)need, '\0');
+        vsrmc_model_format_state(m, &words[off[t]], &buf[0], need, &need);
+        std::printf("State %llu: <%s>\n%s\n\n", (unsigned long long)(t + 1), vsrmc_action_name(acts[t]), buf.c_str());
+      }
+      code = 12;
+    } else if (r.found == 2) {
+      std::printf("Error: a walk raised device error %d after %d steps.\n", r.viol_mask, r.viol_steps);
+      code = 1;
+    } else {
+      std::printf("Simulation stopped after %.1f s without a violation.\n", r.seconds);
+    }
+    std::printf("%llu states checked in %llu walks, %.3f s (%.3g steps/s).\n", (unsigned long long)r.steps, (unsigned long long)r.walks,
+                r.seconds, r.seconds > 0 ? (double)r.steps / r.seconds : 0.0);
+    vsrmc_model_destroy(m);
+    return code;
+  }
   vsrmc_options o;
   vsrmc_options_default(&o);
   o.device = device;
