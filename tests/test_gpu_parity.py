@@ -106,6 +106,25 @@ def test_successors_of_every_golden_trace_state(vt, orc, golden_trace):
         assert hits[0]["inv"] == golden_trace["states"][i + 1]["inv_mask"]
 
 
+def test_both_invariants_on_golden_trace_states(vt, orc, golden_trace):
+    """INVARIANT AcknowledgedWriteNotLost + AcknowledgedWritesExistOnMajority (VSR.tla:937-950; the second one is commented
+    out in VSR.cfg:38): verdict masks of every successor of every golden state equal the oracle's."""
+    p = golden_trace["params"]
+    P = orc.Params(p["R"], p["C"], len(p["values"]), p["L"], invariant_mask=3)
+    m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=len(p["values"]), L=p["L"], invariant_mask=3)
+    recs = [np.array([int(w, 16) for w in st["words"]], dtype=np.uint64) for st in golden_trace["states"]]
+    words = np.concatenate(recs)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    succ = m.get_next_states(words, off)
+    seen_masks = set()
+    for i, rec in enumerate(recs):
+        mine = sorted((s["fp"], s["inv"]) for s in succ if s["parent"] == i)
+        want = sorted((s["fp"], s["inv"]) for s in orc.successors(P, rec))
+        assert mine == want, i
+        seen_masks.update(x[1] for x in mine)
+    assert {0, 2, 3} <= seen_masks                    # majority lost first (mask 2), then lost entirely (mask 3)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # every reachable state of a small space: successor multisets agree state by state
 # ---------------------------------------------------------------------------------------------------------------------

@@ -72,16 +72,16 @@ def test_sharded_level_loop_matches_single_process_oracle(tmp_path, world, param
 
 
 @pytest.mark.gpu
-def test_sharded_hip_engine_world2_on_one_gpu(tmp_path):
-    """Both ranks share device 0 and exchange over gloo (staged through the host): every HIP kernel of the sharded
+@pytest.mark.parametrize("world,params,depth", [(2, (3, 1, 2, 2), 11), (3, (3, 1, 3, 3), 9), (2, (5, 1, 2, 2), 6)])
+def test_sharded_hip_engine_on_one_gpu(tmp_path, world, params, depth):
+    """All ranks share device 0 and exchange over gloo (staged through the host): every HIP kernel of the sharded
     protocol runs (k_expand bucketing, k_claim_batch, k_verdict, k_materialize into peer buckets, k_append_fixup)."""
-    params = (3, 1, 2, 2)
-    ranks = run_world("hip", 2, params, 11, tmp_path, 29650)
-    check_against_oracle(ranks, params, 11)
+    ranks = run_world("hip", world, params, depth, tmp_path, 29650 + world)
+    check_against_oracle(ranks, params, depth)
     # trace walks: ordinals of the HIP engine replay on the GPU to a state of the right level
     import vsr_tlaplus_amd as vt
     from vsr_tlaplus_amd import sharded
-    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    m = vt.Model.from_constants(R=params[0], C_=params[1], n=params[2], L=params[3])
     for w in ranks[0]["walks"]:
         tr = sharded.replay(m, w["ords"])
         assert len(tr) == w["level"]
