@@ -180,25 +180,25 @@ int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t n_walkers,
  *   2. [all-to-all of the buckets]
  *   3. vsrmc_shard_claim        claim the received candidates in the local shard, then answer each with 1 = "won its slot"
  *   4. [all-to-all of the verdict bytes, back to the generators]
- *   5. vsrmc_shard_materialize  winners rebuild their successor: local owners straight into the next frontier, the
- *                               others into io->rec_* per owner; returns record / word counts per owner
- *   6. [all-to-all of the record streams]
- *   7. vsrmc_shard_append       per received stream: copy into the next frontier, publish offsets / fps / trace keys
- *   8. vsrmc_shard_commit       swap the frontiers; local statistics (the caller all-reduces them) */
+ *   5. vsrmc_shard_materialize  every winner (local owner or remote verdict) is rebuilt into THIS rank's next frontier:
+ *                               records stay with their generator, only candidates and verdicts cross ranks
+ *   6. vsrmc_shard_count        valid states / index range of the local next frontier; the caller compares the ranks and,
+ *                               when they are out of balance, moves records in bulk:
+ *      vsrmc_shard_export       copy the valid records of an index window into send streams and invalidate them here
+ *      [all-to-all of the streams]
+ *      vsrmc_shard_append       per received stream: copy into the next frontier, publish refs / fps / trace keys
+ *   7. vsrmc_shard_commit       swap the frontiers; local statistics (the caller all-reduces them) */
 typedef struct vsrmc_shard_io {
   uint64_t* cand_send;           /* [world][cand_cap][2]  (fp, key) */
   uint64_t cand_cap;             /* entries per owner */
-  uint64_t* rec_words;           /* [world][rec_words_cap] record words per owner (device layout) */
-  uint64_t rec_words_cap;
-  uint64_t* rec_off;             /* [world][rec_cap] word offset of each record inside its owner's region */
-  uint64_t* rec_fp;              /* [world][rec_cap] */
-  uint64_t* rec_key;             /* [world][rec_cap] */
-  uint64_t rec_cap;              /* records per owner */
 } vsrmc_shard_io;
 int32_t vsrmc_shard_expand(vsrmc_checker* c, const vsrmc_shard_io* io, uint64_t* cand_counts);
 int32_t vsrmc_shard_claim(vsrmc_checker* c, const uint64_t* d_cand_recv, uint64_t n, uint8_t* d_verdict);
-int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, const uint8_t* d_verdict_in, uint64_t* rec_counts,
-                                uint64_t* word_counts);
+int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, const uint8_t* d_verdict_in /* [world][cand_cap] */);
+int32_t vsrmc_shard_count(vsrmc_checker* c, uint64_t* n_valid, uint64_t* n_range);
+/* streams: d_words (device layout records, contiguous), d_off (ref = word offset in d_words << 8 | length), d_fp, d_key */
+int32_t vsrmc_shard_export(vsrmc_checker* c, uint64_t first, uint64_t n, uint64_t* d_words, uint64_t words_cap, uint64_t* d_off,
+                           uint64_t* d_fp, uint64_t* d_key, uint64_t cap, uint64_t* n_out, uint64_t* words_out);
 int32_t vsrmc_shard_append(vsrmc_checker* c, const uint64_t* d_words, uint64_t n_words, const uint64_t* d_off,
                            const uint64_t* d_fp, const uint64_t* d_key, uint64_t n);
 int32_t vsrmc_shard_commit(vsrmc_checker* c, vsrmc_level_info* info);

@@ -90,22 +90,31 @@ class FakeShardEngine:
         for fp, key in self.local_pending:
             if self.seen[fp] == key:
                 self._emit_local(self._record_of(key), key)
-        out = []
         for o in range(self.world):
-            words, off, fps, keys = [], [], [], []
             if o != self.rank:
                 v = [int(x) for x in verdicts[o].cpu()]
                 assert len(v) == len(self.sent[o])
                 for (fp, key), win in zip(self.sent[o], v):
                     if win:
-                        s = self._record_of(key)
-                        self._inv(s)
-                        off.append(len(words))
-                        words.extend(int(w) for w in s["words"])
-                        fps.append(s["fp"])
-                        keys.append(key)
-            out.append((_i64(words), _i64(off), _i64(fps), _i64(keys)))
-        return out, 0
+                        self._emit_local(self._record_of(key), key)     # the record stays with its generator
+        return 0
+
+    def count(self):
+        return len(self.next_frontier), len(self.next_frontier)
+
+    def empty_streams(self):
+        z = torch.zeros(0, dtype=torch.int64)
+        return (z, z, z, z)
+
+    def export(self, first, n):
+        words, off, fps, keys = [], [], [], []
+        for i in range(first, first + n):
+            off.append(len(words))
+            words.extend(int(w) for w in self.next_frontier[i])
+            fps.append(self.next_fps[i])
+            keys.append(self.next_keys[i])
+        del self.next_frontier[first: first + n], self.next_fps[first: first + n], self.next_keys[first: first + n]
+        return (_i64(words), _i64(off), _i64(fps), _i64(keys)), 0
 
     def _inv(self, s):
         if s["inv"]:

@@ -47,7 +47,7 @@ def main():
             walks.append(dict(rank=r, level=sc.level, index=idx, ords=sc.trace_ordinals(sc.level, r, idx)))
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks,
-                       bytes_sent=sc.x.bytes_sent), f)
+                       bytes_sent=sc.x.bytes_sent, moved=sc.moved), f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -37,8 +37,7 @@ class LevelInfo(C.Structure):
 
 
 class ShardIO(C.Structure):
-    _fields_ = [("cand_send", C.c_void_p), ("cand_cap", C.c_uint64), ("rec_words", C.c_void_p), ("rec_words_cap", C.c_uint64),
-                ("rec_off", C.c_void_p), ("rec_fp", C.c_void_p), ("rec_key", C.c_void_p), ("rec_cap", C.c_uint64)]
+    _fields_ = [("cand_send", C.c_void_p), ("cand_cap", C.c_uint64)]
 
 
 class SimResult(C.Structure):
@@ -84,7 +83,10 @@ SYMBOLS = {
     "vsrmc_simulate": (C.c_int32, [V, C.c_int32, C.c_uint32, C.c_int32, C.c_uint64, C.c_double, C.POINTER(SimResult)]),
     "vsrmc_shard_expand": (C.c_int32, [V, C.POINTER(ShardIO), V]),
     "vsrmc_shard_claim": (C.c_int32, [V, V, C.c_uint64, V]),
-    "vsrmc_shard_materialize": (C.c_int32, [V, C.POINTER(ShardIO), V, V, V]),
+    "vsrmc_shard_materialize": (C.c_int32, [V, C.POINTER(ShardIO), V]),
+    "vsrmc_shard_count": (C.c_int32, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vsrmc_shard_export": (C.c_int32, [V, C.c_uint64, C.c_uint64, V, C.c_uint64, V, V, V, C.c_uint64, C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64)]),
     "vsrmc_shard_append": (C.c_int32, [V, V, C.c_uint64, V, V, V, C.c_uint64]),
     "vsrmc_shard_commit": (C.c_int32, [V, C.POINTER(LevelInfo)]),
 }

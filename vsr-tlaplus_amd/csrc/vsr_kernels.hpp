@@ -741,6 +741,55 @@ __global__ void k_append_fixup(u64* nx_off, u64* lvl_fp, u64* lvl_tr, const u64*
   if (lvl_tr) lvl_tr[i] = keys[i];
 }
 
+// k_export: rebalancing between ranks — move the valid records of the index window [first, first + n) of the (new) frontier
+// into contiguous send streams and invalidate them here (ref = 0, fp = 0).  One wave per block, lane per index; records
+// are copied cooperatively (lane k moves word k).  counters[0] = records exported, counters[1] = words exported.
+__global__ void __launch_bounds__(64)
+k_export(const u64* __restrict__ nx_words, u64* nx_off, u64* lvl_fp, const u64* __restrict__ lvl_tr, u64 first, u64 n,
+         u64* out_words, u64 out_words_cap, u64* out_off, u64* out_fp, u64* out_key, u64 out_cap, u64* counters, u32* err) {
+  const int lane = threadIdx.x;
+  const u64 i = (u64)blockIdx.x * 64 + lane;
+  u64 ref = 0;
+  if (i < n) ref = nx_off[first + i];
+  const bool valid = ref != 0;
+  const int len = valid ? (int)(ref & 255) : 0;
+  const u64 wmask = __ballot(valid);
+  if (wmask == 0) return;
+  int incl = len;
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int nval = __popcll(wmask);
+  u64 kb = 0, wb = 0;
+  if (lane == 0) {
+    kb = atomicAdd((unsigned long long*)&counters[0], (unsigned long long)nval);
+    wb = atomicAdd((unsigned long long*)&counters[1], (unsigned long long)total);
+  }
+  kb = readlane64(kb, 0);
+  wb = readlane64(wb, 0);
+  if (kb + (u64)nval > out_cap || wb + (u64)total > out_words_cap) {
+    if (lane == 0) atomicExch(err, (u32)ERR_FRONTIER_FULL);
+    return;
+  }
+  const u64 dst = wb + (u64)(incl - len);
+  for (int w = 0; w < 64; w++) {
+    const int ln = __builtin_amdgcn_readlane(len, w);
+    if (ln == 0) continue;
+    const u64 s = readlane64(ref, w) >> 8, d = readlane64(dst, w);
+    for (int k = lane; k < ln; k += 64) out_words[d + k] = nx_words[s + k];
+  }
+  if (valid) {
+    const u64 k = kb + (u64)__popcll(wmask & (((u64)1 << lane) - 1));
+    out_off[k] = (dst << 8) | (u64)len;
+    out_fp[k] = lvl_fp[first + i];
+    out_key[k] = lvl_tr ? lvl_tr[first + i] : 0;
+    nx_off[first + i] = 0;
+    lvl_fp[first + i] = 0;
+  }
+}
+
 // Seed the search with the initial state (ModelChecker.doInit): record already in frontier slot 0.
 __global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl) {
   if (threadIdx.x || blockIdx.x) return;

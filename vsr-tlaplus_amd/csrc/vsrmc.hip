@@ -1020,29 +1020,68 @@ int32_t vsrmc_shard_claim(vsrmc_checker* c, const uint64_t* d_cand_recv, uint64_
 
 // NOTE: every rank must have finished vsrmc_shard_claim for ALL its received candidates before any verdict is used:
 // the verdict of a slot is final only when every claim of the level has landed (the orchestrator's exchange is the barrier).
-int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, const uint8_t* d_verdict_in, uint64_t* rec_counts,
-                                uint64_t* word_counts) {
-  if (!c || !io || !rec_counts || !word_counts) return fail(VSRMC_E_ARG, "NULL argument");
+int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, const uint8_t* d_verdict_in) {
+  if (!c || !io) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  // every winner — local owner or remote verdict — is written into THIS rank's next frontier: records stay with their
+  // generator, only 16-byte candidates and verdict bytes cross ranks (rebalancing moves records in bulk when needed)
   int rc = phase_materialize_local(c);
+  const int nxt = c->cur ^ 1;
+  u64 nx_cap = c->opt.frontier_states;
+  if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base ? c->trace_cap - c->tr_base : 0);
   for (int o = 0; o < c->opt.world && !rc; o++) {
     if (o == c->opt.rank) continue;
     u64 n = std::min<u64>(c->h.cand_cnt[o], io->cand_cap);
-    rc = phase_materialize(c, io->cand_send + 2 * (u64)o * io->cand_cap, n, d_verdict_in + (u64)o * io->cand_cap,
-                           io->rec_words + (u64)o * io->rec_words_cap, io->rec_words_cap, io->rec_off + (u64)o * io->rec_cap,
-                           io->rec_cap, io->rec_fp + (u64)o * io->rec_cap, io->rec_key + (u64)o * io->rec_cap, &c->ctl->out_n[o],
-                           &c->ctl->out_w[o]);
+    if (n && !d_verdict_in) return fail(VSRMC_E_ARG, "verdicts missing");
+    rc = phase_materialize(c, io->cand_send + 2 * (u64)o * io->cand_cap, n, d_verdict_in + (u64)o * io->cand_cap, c->words[nxt],
+                           c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base : nullptr,
+                           &c->ctl->n_new, &c->ctl->words_new);
   }
   if (rc) return rc;
-  u64 keep_n = c->nx_n, keep_w = c->nx_w;
   HIPCHK(hipMemcpy(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost));
-  c->nx_n = keep_n;
-  c->nx_w = keep_w;
   if (c->h.err) return level_error(c, c->h, c->level + 1);
-  for (int o = 0; o < c->opt.world; o++) {
-    rec_counts[o] = o == c->opt.rank ? 0 : c->h.out_n[o];
-    word_counts[o] = o == c->opt.rank ? 0 : c->h.out_w[o];
-  }
+  c->nx_n = c->h.n_new;
+  c->nx_w = c->h.words_new;
+  return 0;
+}
+
+int32_t vsrmc_shard_count(vsrmc_checker* c, uint64_t* n_valid, uint64_t* n_range) {
+  if (!c || !n_valid || !n_range) return fail(VSRMC_E_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(c->opt.device));
+  *n_range = c->nx_n;
+  *n_valid = 0;
+  if (c->nx_n == 0) return 0;
+  u64 zero = 0;
+  HIPCHK(hipMemcpyAsync(c->d_find, &zero, 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_count_valid, dim3(1024), dim3(256), 0, c->stream, c->off[c->cur ^ 1], c->nx_n, c->d_find);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(n_valid, c->d_find, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int32_t vsrmc_shard_export(vsrmc_checker* c, uint64_t first, uint64_t n, uint64_t* d_words, uint64_t words_cap, uint64_t* d_off,
+                           uint64_t* d_fp, uint64_t* d_key, uint64_t cap, uint64_t* n_out, uint64_t* words_out) {
+  if (!c || !n_out || !words_out) return fail(VSRMC_E_ARG, "NULL argument");
+  *n_out = *words_out = 0;
+  if (n == 0) return 0;
+  if (!d_words || !d_off || !d_fp || !d_key || first + n > c->nx_n) return fail(VSRMC_E_ARG, "bad export window");
+  HIPCHK(hipSetDevice(c->opt.device));
+  const int nxt = c->cur ^ 1;
+  u64* d_cnt = nullptr;
+  HIPCHK(hipMalloc((void**)&d_cnt, 32));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, 32, c->stream));
+  hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->words[nxt], c->off[nxt] + 0, c->lvl_fp,
+                     c->tr_all ? c->tr_all + c->tr_base : nullptr, first, n, d_words, words_cap, d_off, d_fp, d_key, cap, d_cnt,
+                     (u32*)(d_cnt + 2));
+  HIPCHK(hipGetLastError());
+  u64 h[4];
+  HIPCHK(hipMemcpyAsync(h, d_cnt, 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(d_cnt);
+  if ((u32)h[2]) return fail(VSRMC_E_REP, "export buffers too small");
+  *n_out = h[0];
+  *words_out = h[1];
   return 0;
 }
 

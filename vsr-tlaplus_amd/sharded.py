@@ -2,8 +2,9 @@
 
 Per BFS level (phases documented in include/vsrmc.h):
     expand -> all-to-all (fp, key) candidates to their owners -> owners claim + verdict -> all-to-all verdict bytes back
-           -> generators materialise the winners -> all-to-all record streams to the owners -> append -> commit
-           -> one all-reduce of the level's counters.
+           -> generators materialise the winners INTO THEIR OWN next frontier (records stay with their generator; only
+              16-byte candidates and verdict bytes cross ranks) -> if the ranks' frontiers are out of balance, the surplus
+              is moved in bulk (export / all-to-all / append) -> commit -> small all-reduces of the level's counters.
 Strict level synchrony: the set of fingerprints per level is independent of the world size.
 
 `Exchanger` moves variable-size buckets with torch.distributed.all_to_all_single (backend "nccl" = RCCL over xGMI on
@@ -83,6 +84,15 @@ class Exchanger:
         dist.all_reduce(t, op=op, group=self.group)
         return [int(x) for x in t.cpu()]
 
+    def allgather(self, values):
+        """values: list of ints -> list (per rank) of lists."""
+        t = torch.tensor(values, dtype=torch.int64)
+        if self.backend == "nccl":
+            t = t.cuda()
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return [[int(v) for v in o.cpu()] for o in out]
+
     def barrier(self):
         dist.barrier(group=self.group)
 
@@ -91,17 +101,45 @@ class ShardError(RuntimeError):
     pass
 
 
+def balance_plan(counts, tol=1.25, min_per_rank=64):
+    """Deterministic (same on every rank) list of (src, dst, k): move k states from src to dst so that every rank ends
+    within `tol` of the mean.  Empty when the frontier is tiny or already balanced."""
+    w = len(counts)
+    total = sum(counts)
+    if w < 2 or total < w * min_per_rank:
+        return []
+    mean = total / float(w)
+    if max(counts) <= tol * mean and min(counts) >= mean / tol:
+        return []
+    target = [total // w + (1 if r < total % w else 0) for r in range(w)]
+    surplus = [[r, counts[r] - target[r]] for r in range(w) if counts[r] > target[r]]
+    deficit = [[r, target[r] - counts[r]] for r in range(w) if counts[r] < target[r]]
+    plan = []
+    for src in surplus:
+        for dst in deficit:
+            if src[1] == 0:
+                break
+            k = min(src[1], dst[1])
+            if k > 0:
+                plan.append((src[0], dst[0], k))
+                src[1] -= k
+                dst[1] -= k
+    return plan
+
+
 class ShardedChecker:
     """The level loop over an engine.  Engine protocol (all tensors int64 unless noted, on the engine's device):
         expand()                          -> (list of (n_p, 2) candidate tensors per peer, err)
         claim(cands (n,2))                -> (uint8 verdict tensor (n,), err)
-        materialize(verdicts per peer)    -> (list per peer of (words, off, fp, key) tensors, err)
+        materialize(verdicts per peer)    -> err                       (winners go to the local next frontier)
+        count()                           -> (valid states, index range) of the local next frontier
+        export(first, n)                  -> ((words, off, fp, key) tensors, err): records of an index window, removed locally
         append(words, off, fp, key)       -> err
         commit()                          -> dict(n_new, generated, deadlocks, viol_fp, viol_mask, max_bag, ...)
         find_fp(fp) -> index or None ; trace_entry(level, index) -> key ; error_text()
     """
 
-    def __init__(self, engine, exchanger):
+    def __init__(self, engine, exchanger, balance_tol=1.25):
         self.e = engine
         self.x = exchanger
         self.rank, self.world = exchanger.rank, exchanger.world
@@ -111,11 +149,47 @@ class ShardedChecker:
         self.n_frontier = self.distinct
         self.violation = None
         self.levels = []
+        self.balance_tol = balance_tol
+        self.moved = 0
 
     def _raise_if(self, err, phase):
         if err:
             raise ShardError("level %d, phase %s: error %d on some rank (local: %s)" % (self.level + 1, phase, err,
                                                                                       self.e.error_text()))
+
+    def _rebalance(self, err):
+        """All ranks: compare the sizes of the new frontiers; move the surplus (tail of the index range) where it is missing."""
+        e, x, me, w = self.e, self.x, self.rank, self.world
+        valid, rng = e.count()
+        both = x.allgather([valid, err])
+        counts = [b[0] for b in both]
+        self._raise_if(max(b[1] for b in both), "materialize")
+        plan = balance_plan(counts, self.balance_tol)
+        if not plan:
+            return 0
+        empty = e.empty_streams()
+        send = [empty] * w
+        err = 0
+        hi = rng
+        for src, dst, k in plan:
+            if src != me:
+                continue
+            width = min(hi, -(-k * rng // max(1, valid)))       # index window holding about k valid records (holes are skipped)
+            streams, er = e.export(hi - width, width)
+            err = max(err, er)
+            hi -= width
+            send[dst] = streams
+        got = []
+        for s in range(4):                                      # words, off, fp, key
+            r, err, _ = x.exchange([send[p][s] for p in range(w)], err)
+            got.append(r)
+        self._raise_if(err, "rebalance")
+        err = 0
+        for p in range(w):
+            if p != me and got[1][p].shape[0]:
+                err = max(err, e.append(got[0][p], got[1][p], got[2][p], got[3][p]))
+                self.moved += int(got[1][p].shape[0])
+        return err
 
     def step(self):
         e, x, me = self.e, self.x, self.rank
@@ -129,16 +203,8 @@ class ShardedChecker:
             pos += recv[p].shape[0]
         vrecv, err, _ = x.exchange(back, err)
         self._raise_if(err, "claim")
-        streams, err = e.materialize(vrecv)
-        got = []
-        for k in range(4):                                  # words, off, fp, key
-            r, err, _ = x.exchange([streams[p][k] for p in range(self.world)], err)
-            got.append(r)
-        self._raise_if(err, "materialize")
-        err = 0
-        for p in range(self.world):
-            if p != me and got[1][p].shape[0]:
-                err = max(err, e.append(got[0][p], got[1][p], got[2][p], got[3][p]))
+        err = e.materialize(vrecv)
+        err = self._rebalance(err)
         info = e.commit()
         viol_fp = info["viol_fp"] if info["viol_mask"] else U64_MAX
         s = x.allreduce([info["n_new"], info["generated"], info["deadlocks"], info["pending"]], dist.ReduceOp.SUM)
@@ -191,6 +257,8 @@ class HipShardEngine:
     def __init__(self, model, rank, world, device=0, table_log2=26, frontier_words=1 << 27, frontier_states=1 << 22,
                  pending_entries=1 << 23, cand_cap=1 << 22, rec_cap=1 << 21, rec_words_cap=1 << 26, keep_trace=True,
                  trace_entries=0):
+        """cand_cap: (fp, key) candidates per peer and level; rec_cap / rec_words_cap: records / words one rebalancing move
+        to one peer may carry."""
         self.model, self.rank, self.world, self.device = model, rank, world, device
         o = capi.Options()
         capi.load().vsrmc_options_default(C.byref(o))
@@ -204,12 +272,8 @@ class HipShardEngine:
         self.cand_cap, self.rec_cap, self.rec_words_cap = cand_cap, rec_cap, rec_words_cap
         self.cand_send = torch.zeros((world, cand_cap, 2), dtype=torch.int64, device=dev)
         self.verdict_in = torch.zeros((world, cand_cap), dtype=torch.uint8, device=dev)
-        self.rec_words = torch.zeros((world, rec_words_cap), dtype=torch.int64, device=dev)
-        self.rec_off = torch.zeros((world, rec_cap), dtype=torch.int64, device=dev)
-        self.rec_fp = torch.zeros((world, rec_cap), dtype=torch.int64, device=dev)
-        self.rec_key = torch.zeros((world, rec_cap), dtype=torch.int64, device=dev)
-        self.io = capi.ShardIO(self.cand_send.data_ptr(), cand_cap, self.rec_words.data_ptr(), rec_words_cap,
-                               self.rec_off.data_ptr(), self.rec_fp.data_ptr(), self.rec_key.data_ptr(), rec_cap)
+        self.io = capi.ShardIO(self.cand_send.data_ptr(), cand_cap)
+        self._export_bufs = []                                  # allocated on first use: rebalancing is rare
         self._cand_counts = [0] * world
         self._err_text = ""
         self.kernel_ms = dict(expand=0.0, materialize=0.0)
@@ -257,15 +321,30 @@ class HipShardEngine:
                 assert verdicts[p].shape[0] == self._cand_counts[p]
                 self.verdict_in[p, : self._cand_counts[p]].copy_(verdicts[p])
         torch.cuda.synchronize(self.dev)
-        rc_n = (C.c_uint64 * 8)()
-        rc_w = (C.c_uint64 * 8)()
-        err = self._call(capi.load().vsrmc_shard_materialize(self._h, C.byref(self.io), C.c_void_p(self.verdict_in.data_ptr()),
-                                                             rc_n, rc_w))
-        out = []
-        for p in range(self.world):
-            n, w = (int(rc_n[p]), int(rc_w[p])) if (p != self.rank and not err) else (0, 0)
-            out.append((self.rec_words[p, :w], self.rec_off[p, :n], self.rec_fp[p, :n], self.rec_key[p, :n]))
-        return out, err
+        return self._call(capi.load().vsrmc_shard_materialize(self._h, C.byref(self.io), C.c_void_p(self.verdict_in.data_ptr())))
+
+    def count(self):
+        nv, nr = C.c_uint64(), C.c_uint64()
+        check(capi.load().vsrmc_shard_count(self._h, C.byref(nv), C.byref(nr)))
+        return nv.value, nr.value
+
+    def empty_streams(self):
+        z = torch.zeros(0, dtype=torch.int64, device=self.dev)
+        return (z, z, z, z)
+
+    def export(self, first, n):
+        words = torch.empty(self.rec_words_cap, dtype=torch.int64, device=self.dev)
+        off = torch.empty(self.rec_cap, dtype=torch.int64, device=self.dev)
+        fp = torch.empty(self.rec_cap, dtype=torch.int64, device=self.dev)
+        key = torch.empty(self.rec_cap, dtype=torch.int64, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        no, nw = C.c_uint64(), C.c_uint64()
+        err = self._call(capi.load().vsrmc_shard_export(self._h, first, n, C.c_void_p(words.data_ptr()), self.rec_words_cap,
+                                                        C.c_void_p(off.data_ptr()), C.c_void_p(fp.data_ptr()),
+                                                        C.c_void_p(key.data_ptr()), self.rec_cap, C.byref(no), C.byref(nw)))
+        if err:
+            return self.empty_streams(), err
+        return (words[: nw.value], off[: no.value], fp[: no.value], key[: no.value]), 0
 
     def append(self, words, off, fp, key):
         words, off, fp, key = words.contiguous(), off.contiguous(), fp.contiguous(), key.contiguous()

@@ -38,10 +38,13 @@ def main(args, CONFIG, EXPECT):
     eng = sharded.HipShardEngine(
         m, rank, world, device=local_rank, table_log2=table_log2, frontier_words=per_rank(MAX_WORDS, world * tail_words),
         frontier_states=per_rank(MAX_NEW, world * tail_idx), pending_entries=per_pair(MAX_GENERATED, 1 << 24),
-        cand_cap=per_pair(MAX_GENERATED), rec_cap=per_pair(MAX_NEW, tail_idx), rec_words_cap=per_pair(MAX_WORDS, tail_words),
+        cand_cap=per_pair(MAX_GENERATED),
+        # records stay with their generator; these two only bound one rebalancing move to one peer (early, small levels)
+        rec_cap=1 << 22, rec_words_cap=1 << 28,
         keep_trace=True, trace_entries=per_rank(TOTAL, 30 * world * tail_idx))
     x = sharded.Exchanger()
     S = dict(alg_bytes=0.0, launches=0, distinct=0, ttfv=[])
+    moved = [0]
 
     def one_run(record):
         eng.reset()
@@ -66,6 +69,7 @@ def main(args, CONFIG, EXPECT):
         dt = time.perf_counter() - t0
         assert sc.distinct == EXPECT["distinct"] and sc.level == EXPECT["depth"], (sc.distinct, sc.level)
         assert sc.violation and sc.violation["fp"] == EXPECT["viol_fp"]
+        moved[0] = sc.moved
         if record:
             S["distinct"] += sc.distinct
             S["ttfv"].append(dt)
@@ -99,6 +103,7 @@ def main(args, CONFIG, EXPECT):
                                    "all-to-all per level (RCCL)" % world, "table_slots_log2_per_rank": table_log2},
             "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
             "xgmi_bytes_sent_rank0_per_step": int(x.bytes_sent / max(1, args.steps + args.warmup)),
+            "records_moved_by_rebalancing_rank0": moved[0],
             "roofline": {"bound": "hbm", "kernel": "k_expand (rank 0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": S["launches"],
