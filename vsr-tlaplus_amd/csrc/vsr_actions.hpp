@@ -536,36 +536,39 @@ VSR_HD u32 guard_slot(const Model& M, PTR rec, int slot, int* kind0) {
   const int r = m_dest(mw);
   PTR pb = rec + 1 + (r - 1) * M.wpr;
   const u64 A = pb[0];
-  const int view = a_view(A), st = a_status(A), op = a_op(A);
+  // Branch-free: the lanes of a wave look at 64 different messages of 64 different types; every type's guard is evaluated
+  // with predicated arithmetic and selected by type, instead of seven divergent branches.
+  const int t = m_type(mw);
+  const int view = a_view(A), op = a_op(A);
   const int mview = m_view(mw), mop = m_op(mw);
+  const bool normal = a_status(A) == ST_NORMAL, vc = a_status(A) == ST_VIEWCHANGE;
   const bool prim = primary_of(M, view) == r;
-  switch (m_type(mw)) {
-    case T_SVC:
-      if (mview > view) { *kind0 = A_ReceiveHigherSVC; return 1; }                                           // :605
-      *kind0 = A_ReceiveMatchingSVC;
-      return (mview == view && st == ST_VIEWCHANGE) ? 1u : 0u;                                               // :628-630
-    case T_DVC:
-      *kind0 = mview > view ? A_ReceiveHigherDVC : A_ReceiveMatchingDVC;                                     // :680 / :699
-      return mview >= view ? 1u : 0u;
-    case T_SV: *kind0 = A_ReceiveSV; return mview >= view ? 1u : 0u;                                         // :776
-    case T_PREPARE: {
-      *kind0 = A_ReceivePrepareMsg;
-      u32 mask = (st == ST_NORMAL && mview == view && mop == op + 1) ? 1u : 0u;                              // :408-410
-      if (!prim && st == ST_NORMAL && mview > view && mop > op + 1) {                                        // SendGetState :498-503
-        const u32 lg = blk_x(pb, 0);
-        const int t = a_commit(A) < log_len(lg) ? a_commit(A) : log_len(lg);
-        for (int d = 1; d <= M.R; d++)
-          if (d != r && !bag_has_key(rec + M.fixed, hdr_nmsg(hdr), m_make(T_GETSTATE, mview, d, r, t, 0, 0, 0, 0))) mask |= 1u << d;
-      }
-      return mask;
-    }
-    case T_PREPAREOK: *kind0 = A_ReceivePrepareOkMsg;                                                        // :440-443
-      return (prim && st == ST_NORMAL && mview == view && mop > a_peer(A, m_source(mw))) ? 1u : 0u;
-    case T_GETSTATE: *kind0 = A_ReceiveGetState; return (view == mview && st == ST_NORMAL && op > mop) ? 1u : 0u;   // :529-531
-    case T_NEWSTATE: *kind0 = A_ReceiveNewState;                                                             // :554-556
-      return (view == mview && st == ST_NORMAL && op == m_first_op(mw) - 1) ? 1u : 0u;
+  const bool higher = mview > view, same = mview == view;
+  const bool en_svc = higher | (same & vc);                                                                   // :605 / :628-630
+  const bool en_dvc = higher | same;                                                                          // :680 / :699 ; SV :776
+  const bool en_prep = normal & same & (mop == op + 1);                                                       // :408-410
+  const bool en_pok = prim & normal & same & (mop > a_peer(A, m_source(mw)));                                 // :440-443
+  const bool en_gs = same & normal & (op > mop);                                                              // :529-531
+  const bool en_ns = same & normal & (op == m_first_op(mw) - 1);                                              // :554-556
+  const bool en = t == T_SVC ? en_svc : (t == T_DVC || t == T_SV) ? en_dvc : t == T_PREPARE ? en_prep : t == T_PREPAREOK ? en_pok
+                  : t == T_GETSTATE ? en_gs : t == T_NEWSTATE ? en_ns : false;
+  // action id by (type, higher): one 64-bit table lookup, 4 bits per entry, index = type * 2 + higher
+  const u64 KIND = ((u64)A_ReceiveMatchingSVC << (4 * (2 * T_SVC))) | ((u64)A_ReceiveHigherSVC << (4 * (2 * T_SVC + 1))) |
+                   ((u64)A_ReceivePrepareMsg << (4 * (2 * T_PREPARE))) | ((u64)A_ReceivePrepareMsg << (4 * (2 * T_PREPARE + 1))) |
+                   ((u64)A_ReceivePrepareOkMsg << (4 * (2 * T_PREPAREOK))) | ((u64)A_ReceivePrepareOkMsg << (4 * (2 * T_PREPAREOK + 1))) |
+                   ((u64)A_ReceiveMatchingDVC << (4 * (2 * T_DVC))) | ((u64)A_ReceiveHigherDVC << (4 * (2 * T_DVC + 1))) |
+                   ((u64)A_ReceiveSV << (4 * (2 * T_SV))) | ((u64)A_ReceiveSV << (4 * (2 * T_SV + 1))) |
+                   ((u64)A_ReceiveGetState << (4 * (2 * T_GETSTATE))) | ((u64)A_ReceiveGetState << (4 * (2 * T_GETSTATE + 1))) |
+                   ((u64)A_ReceiveNewState << (4 * (2 * T_NEWSTATE))) | ((u64)A_ReceiveNewState << (4 * (2 * T_NEWSTATE + 1)));
+  *kind0 = (int)((KIND >> (4 * (2 * t + (higher ? 1 : 0)))) & 15);
+  u32 mask = en ? 1u : 0u;
+  if (t == T_PREPARE && !prim && normal && higher && mop > op + 1) {                                          // SendGetState :498-503 (rare)
+    const u32 lg = blk_x(pb, 0);
+    const int tr = a_commit(A) < log_len(lg) ? a_commit(A) : log_len(lg);
+    for (int d = 1; d <= M.R; d++)
+      if (d != r && !bag_has_key(rec + M.fixed, hdr_nmsg(hdr), m_make(T_GETSTATE, mview, d, r, tr, 0, 0, 0, 0))) mask |= 1u << d;
   }
-  return 0;
+  return mask;
 }
 
 // Incremental view hashes of the child: Hc[i] = Hp[i] - hash(old replica block) + hash(new) + bag patch deltas.

@@ -103,31 +103,42 @@ __device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 ke
 // *tie = another candidate of this level reached the same slot with a different canonical auxkey, i.e. the VIEW collision
 // of SURVEY F2 inside one level, which the single-pass scheme cannot arbitrate — the host then redoes the run with the
 // exact two-kernel scheme (never observed: the oracle's `ties` counter is 0 on every config).
-__device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp, u64 key, int level, bool* claimed, bool* tie,
+__device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp, u64 key, int level, bool* claimed, u64* prev_meta,
                                                   u32* nprobe, bool* full) {
+  // *prev_meta: the meta word this candidate displaced / found (META_EMPTY if none): the caller compares auxkeys AFTER it has
+  // done its other work, so that the returning atomic's latency overlaps with the successor write
   u64 i = fp & mask;
   *full = false;
   *claimed = false;
-  *tie = false;
+  *prev_meta = META_EMPTY;
   for (u64 step = 0; step <= mask; step++, i = (i + 1) & mask) {
     (*nprobe)++;
-    u64 cur = __hip_atomic_load(&table[i].fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one 16-byte load brings fingerprint and meta of the slot (a stale copy is harmless: slots only move
+    // empty -> fp, and meta only decreases; a stale "empty" just sends us to the atomic)
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 sm = *(const u64x2*)&table[i];
+    u64 cur = sm.x;
+    bool mine = false;
     if (cur == 0) {
       cur = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
       if (cur == 0) {
         cur = fp;
-        *claimed = true;
+        mine = true;
       }
     }
     if (cur == fp) {
-      u64 m = __hip_atomic_load(&table[i].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (meta_level(m) < level) return;                       // a state of an earlier level
-      if (m != META_EMPTY && m < key) {                        // smaller key of this level already there
-        *tie = meta_auxkey(m) != meta_auxkey(key);
+      if (mine) {                                               // just claimed: meta is still empty, publish our key
+        *claimed = true;
+        *prev_meta = atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
         return;
       }
-      u64 prev = atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
-      if (prev != META_EMPTY) *tie = meta_auxkey(prev) != meta_auxkey(key);
+      const u64 m = sm.x == fp ? sm.y : __hip_atomic_load(&table[i].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (meta_level(m) < level) return;                       // a state of an earlier level
+      if (m != META_EMPTY && m < key) {                        // smaller key of this level already there
+        *prev_meta = m;
+        return;
+      }
+      *prev_meta = atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
       return;
     }
     if (step > 4096) break;
@@ -226,23 +237,58 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     {
       const int nslots = M.m0 + (int)s_maxbag;
       const int nitems = nslots << tshift;
-      for (int item = tid; item < nitems; item += VSR_BLOCK) {
+      // four independent guard evaluations per trip (their LDS load chains overlap), then the appends one after the other
+      for (int item0 = tid; item0 < nitems; item0 += 4 * VSR_BLOCK) {
+        u32 masks[4];
+        int kinds[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int item = item0 + u * VSR_BLOCK;
+          const int slot = item >> tshift, p = item & (tile - 1);
+          masks[u] = 0;
+          kinds[u] = 0;
+          if (item < nitems && p < np_tile && s_ref[p] != 0) masks[u] = guard_slot(M, (const u64*)(s_rec + p * stride), slot, &kinds[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+        const int item = item0 + u * VSR_BLOCK;
+        if (item >= nitems) break;                              // wave-uniform: nitems is a multiple of 64
         const int slot = item >> tshift, p = item & (tile - 1);
-        u32 mask = 0;
-        int kind0 = 0;
-        if (p < np_tile && s_ref[p] != 0) mask = guard_slot(M, (const u64*)(s_rec + p * stride), slot, &kind0);
-        if (mask) {
+        u32 mask = masks[u];
+        const int kind0 = kinds[u];
+        // wave-aggregated append.  Bit 0 (the instance that receives / fires the slot) is at most one entry per lane: its
+        // position is a popcount of the ballot below the lane — no cross-lane shuffles (a 6-step shuffle scan per slot
+        // cost more than the guards themselves).  The rare extra bits (SendGetState, one per destination) take the
+        // per-lane atomic path.
+        const u64 b0 = __ballot((mask & 1u) != 0);
+        if (b0) {
+          u32 base = 0;
+          if (lane == 0) {
+            base = atomicAdd(&s_ncand, (u32)__popcll(b0));
+            if (fused) atomicAdd(&s_wneed, (u32)__popcll(b0) * (u32)(M.fixed + (int)s_maxbag + 5));   // bound of the successors' lengths
+          }
+          base = (u32)__builtin_amdgcn_readlane((int)base, 0);
+          if (mask & 1u) {
+            s_alive[p] = 1;
+            const int ordbase = slot < M.m0 ? slot : M.m0 + (slot - M.m0) * (M.R + 1);
+            const u32 idx = base + (u32)__popcll(b0 & (((u64)1 << lane) - 1));
+            atomicAdd(&s_kcount[kind0], 1u);
+            if (idx < ccap) s_cand[idx] = ((u32)kind0 << 18) | ((u32)p << 11) | (u32)ordbase;
+          }
+        }
+        mask &= ~1u;
+        if (mask) {                                             // SendGetState instances of a Prepare entry
           s_alive[p] = 1;
-          const int ordbase = slot < M.m0 ? slot : M.m0 + (slot - M.m0) * (M.R + 1);
+          const int ordbase = M.m0 + (slot - M.m0) * (M.R + 1);
           while (mask) {
             const int k = __ffs((int)mask) - 1;
             mask &= mask - 1;
-            const int kind = k == 0 ? kind0 : A_SendGetState;
             const u32 idx = atomicAdd(&s_ncand, 1u);
-            atomicAdd(&s_kcount[kind], 1u);
-            if (fused) atomicAdd(&s_wneed, (u32)(s_ref[p] & 255) + 5u);   // upper bound of the successor's length
-            if (idx < ccap) s_cand[idx] = ((u32)kind << 18) | ((u32)p << 11) | (u32)(ordbase + k);
+            if (fused) atomicAdd(&s_wneed, (u32)(M.fixed + (int)s_maxbag + 5));
+            atomicAdd(&s_kcount[A_SendGetState], 1u);
+            if (idx < ccap) s_cand[idx] = ((u32)A_SendGetState << 18) | ((u32)p << 11) | (u32)(ordbase + k);
           }
+        }
         }
       }
     }
@@ -329,6 +375,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
       const u64* rec = s_rec + p * stride;
       Delta D;
+      const u64 a_0 = __builtin_readcyclecounter();
       if (!gen<false>(M, rec, ord, D) || D.action != (int)(code >> 18)) {
         raise_error(ctl, ERR_INTERNAL, ((p_base + (u64)p) << 16) | (u64)ord);
         continue;
@@ -337,12 +384,15 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
         raise_error(ctl, D.err, ((p_base + (u64)p) << 16) | (u64)ord);
         continue;
       }
+      const u64 a_1 = __builtin_readcyclecounter();
       u64 Hc[6];
       hash_child(M, rec, D, Hc);
       u64 fp;
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
       const u64 key = meta_make(level, ak, rank, p_base + (u64)p, ord);
+      const u64 a_2 = __builtin_readcyclecounter();
+      if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
       if (world > 1) {                                          // sharded seen-set: route to the owner of fp
         const int owner = owner_of(fp, world);
         if (owner != rank) {
@@ -360,13 +410,15 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
         }
       }
       if (fused) {
-        bool claimed, tie, full;
-        table_claim_fused(table, tmask, fp, key, level, &claimed, &tie, &my_probes, &full);
+        bool claimed, full;
+        u64 prev_meta;
+        table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, &my_probes, &full);
+        const u64 a_3 = __builtin_readcyclecounter();
+        if (tid == 0) s_acc[12] += a_3 - a_2;
         if (full) {
           raise_error(ctl, ERR_TABLE_FULL, fp);
           continue;
         }
-        if (tie) atomicAdd(&s_acc[8], 1ull);
         if (claimed) {                                          // new state: this lane writes it out
           const int plen = (int)(s_ref[p] & 255);
           const int clen = M.fixed + hdr_nmsg(D.hdr);
@@ -375,7 +427,16 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
           const u64 idx = s_ich_base + s_tile_ibase + io;
           const u64 dst = s_wch_base + s_tile_wbase + wo;
           u64* out = nx_words + dst;
-          for (int k = 0; k < plen; k++) out[k] = rec[k];       // parent from LDS, then the patches on top (same lane: ordered)
+          // parent from LDS, 16 bytes per store (records are 8-byte aligned), then the patches on top (same lane: ordered)
+          typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+          int k = 0;
+          for (; k + 1 < plen; k += 2) {
+            u64x2_a8 v2;
+            v2.x = rec[k];
+            v2.y = rec[k + 1];
+            *(u64x2_a8*)(out + k) = v2;
+          }
+          if (k < plen) out[k] = rec[k];
           out[0] = D.hdr;
           u64* ob = out + 1 + (D.r - 1) * M.wpr;
           ob[0] = D.rep[0];
@@ -403,6 +464,9 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
           atomicMax(&s_maxbag_out, (u32)hdr_nmsg(D.hdr));
           atomicAdd(&s_acc[9], (unsigned long long)clen);
         }
+        // same-level duplicate with a different canonical auxkey = the tie the single-pass scheme cannot arbitrate
+        if (prev_meta != META_EMPTY && meta_level(prev_meta) == level && meta_auxkey(prev_meta) != meta_auxkey(key)) atomicAdd(&s_acc[8], 1ull);
+        if (tid == 0) s_acc[13] += __builtin_readcyclecounter() - a_3;
         continue;
       }
       bool found_old, full;
@@ -472,6 +536,9 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       if (s_acc[2]) atomicAdd((unsigned long long*)&ctl->probes, s_acc[2]);
     }
     if (tid >= 3 && tid < 8 && s_acc[tid]) atomicAdd((unsigned long long*)&ctl->phase_cycles[tid - 3], s_acc[tid]);
+    // wave 0's clock inside the apply loop: gen, hash, probe (into phase_cycles[5..7]), successor write (act_generated[0])
+    if (tid >= 10 && tid < 13 && s_acc[tid]) atomicAdd((unsigned long long*)&ctl->phase_cycles[tid - 5], s_acc[tid]);
+    if (tid == 13 && s_acc[13]) atomicAdd((unsigned long long*)&ctl->act_generated[0], s_acc[13]);
     if (tid >= 16 && tid < 32 && s_acc[tid]) atomicAdd((unsigned long long*)&ctl->act_generated[tid - 16], s_acc[tid]);
   }
 }

@@ -66,6 +66,7 @@ struct Model {
   int inv_mask;          // bit0 AcknowledgedWriteNotLost, bit1 AcknowledgedWritesExistOnMajority
   int max_bag;           // bag capacity enforced by the kernels
   int m0;                // first message-bound ordinal = 4R + R*C*n
+  u32 primtab;           // Primary(v) for v = 0..7, 3 bits each (a table: `%` by a run-time R costs ~20 instructions)
   u32 pitab[6];          // permutation i: pi[v] in bits 2v..2v+1
   u64 salt_rep[6];       // per-replica hash salt, index r (1..R)
 };
@@ -160,11 +161,12 @@ VSR_HD u64 m_make(int type, int view, int dest, int source, int op, int commit, 
 VSR_HD u64 m_set_dest(u64 w, int d) { return (w & ~((u64)7 << 6)) | ((u64)d << 6); }
 VSR_HD u64 m_set_count(u64 w, int c) { return (w & KEYMASK) | ((u64)c << 21); }
 
-VSR_HD int primary_of(const Model& M, int view) { return 1 + ((view - 1) % M.R); }                // VSR.tla:287-288
+VSR_HD int primary_of(const Model& M, int view) { return (int)((M.primtab >> (3 * view)) & 7); }   // VSR.tla:287-288, tabulated
 
 // ---- value permutation (VSR.tla:151) of the log-entry bytes of one word ----------------------------------------
 // m01 has 0x01 in every byte that is a log entry; an entry byte is in use iff its view field (bits 0-2) != 0.
 VSR_HD u64 permute_word(u64 w, u64 m01, u32 pt) {
+  if (pt == 0x24u) return w;                                    // identity (pi[v] = v): permutation 0 of every model
   u64 nz = (w | (w >> 1) | (w >> 2)) & m01;
   if (!nz) return w;
   u64 a = (w >> 3) & nz, b = (w >> 4) & nz;

@@ -127,6 +127,8 @@ int build_model(int R, int C, int n, int L, int restart, int symmetry, int inv_m
   // columns the slot-major enumeration reads are bank-conflict free.  max_bag = stride - fixed.
   M.max_bag = (R <= 3 ? 63 : 95) - M.fixed;
   M.m0 = 4 * R + R * C * n;
+  M.primtab = 0;
+  for (int v = 1; v <= 7; v++) M.primtab |= (u32)(1 + ((v - 1) % R)) << (3 * v);   // Primary(v) == 1 + ((v - 1) % ReplicaCount), VSR.tla:287-288
   for (int r = 0; r < 6; r++) M.salt_rep[r] = fmix64(0xA0761D6478BD642FULL + (u64)r);
   out->symmetry = symmetry ? 1 : 0;
   out->value_names.clear();

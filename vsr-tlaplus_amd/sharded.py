@@ -47,13 +47,15 @@ class Exchanger:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     def exchange(self, send_list, err=0):
-        """send_list[p] = tensor of rows for peer p (same dtype / trailing shape).  Returns (recv_list, max err over ranks);
-        recv_list[p] = rows received from peer p (views of one contiguous tensor, peer-major)."""
+        """send_list[p] = tensor of rows for peer p (same dtype / trailing shape).  Returns (recv_list, max err over ranks,
+        the contiguous peer-major tensor the recv_list entries are views of).
+        Every bucket travels with one padding row, so that no rank ever passes an empty tensor to the collective
+        (early BFS levels move nothing between most pairs of ranks)."""
         w = self.world
         dev = send_list[0].device
-        counts = torch.tensor([int(t.shape[0]) for t in send_list] + [int(err)], dtype=torch.int64)
+        send_counts = [int(t.shape[0]) for t in send_list]
         # every peer p gets (rows I send to p, my error code)
-        meta_in = torch.stack([torch.stack([counts[p], counts[w]]) for p in range(w)]).reshape(-1)
+        meta_in = torch.tensor([v for p in range(w) for v in (send_counts[p], int(err))], dtype=torch.int64)
         meta_out = torch.empty(2 * w, dtype=torch.int64)
         if self.backend == "nccl":
             mi, mo = meta_in.to(dev), meta_out.to(dev)
@@ -63,18 +65,22 @@ class Exchanger:
             dist.all_to_all_single(meta_out, meta_in, group=self.group)
         recv_counts = [int(meta_out[2 * p]) for p in range(w)]
         max_err = max(int(meta_out[2 * p + 1]) for p in range(w))
-        send_counts = [int(t.shape[0]) for t in send_list]
         tail = tuple(send_list[0].shape[1:])
-        inp = torch.cat([t.reshape((-1,) + tail) for t in send_list]) if sum(send_counts) else \
-            torch.empty((0,) + tail, dtype=send_list[0].dtype, device=dev)
-        out = torch.empty((sum(recv_counts),) + tail, dtype=send_list[0].dtype, device=dev)
-        self._a2a(out, inp.contiguous(), recv_counts, send_counts)      # every rank calls it, even with nothing to move
+        pad = torch.zeros((1,) + tail, dtype=send_list[0].dtype, device=dev)
+        inp = torch.cat([x for t in send_list for x in (t.reshape((-1,) + tail), pad)])
+        out = torch.empty((sum(recv_counts) + w,) + tail, dtype=send_list[0].dtype, device=dev)
+        self._a2a(out, inp.contiguous(), [c + 1 for c in recv_counts], [c + 1 for c in send_counts])
         self.bytes_sent += (sum(send_counts) - send_counts[self.rank]) * inp.element_size() * int(np.prod(tail or (1,)))
         recv, pos = [], 0
         for p in range(w):
             recv.append(out[pos: pos + recv_counts[p]])
+            pos += recv_counts[p] + 1
+        cat = torch.cat(recv) if w > 1 else recv[0]
+        recv2, pos = [], 0
+        for p in range(w):                                      # views of the padding-free contiguous tensor
+            recv2.append(cat[pos: pos + recv_counts[p]])
             pos += recv_counts[p]
-        return recv, max_err, out
+        return recv2, max_err, cat
 
     def allreduce(self, values, op):
         """values: list of python ints (< 2^63) -> list of ints reduced over ranks."""
