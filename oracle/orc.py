@@ -12,12 +12,14 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "build", "liborc.so")
 BIN = os.path.join(HERE, "build", "vsr_oracle")
+BIN_MT = os.path.join(HERE, "build", "vsr_oracle_mt")
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, f) for f in ("vsr_oracle.cpp", "vsr_oracle_bfs.cpp", "vsr_oracle.hpp", "Makefile")]
-    stale = force or not (os.path.exists(LIB) and os.path.exists(BIN)) or any(
-        os.path.getmtime(s) > min(os.path.getmtime(LIB), os.path.getmtime(BIN)) for s in srcs)
+    srcs = [os.path.join(HERE, f) for f in ("vsr_oracle.cpp", "vsr_oracle_bfs.cpp", "vsr_oracle_mt.cpp", "vsr_oracle.hpp", "Makefile")]
+    outs = (LIB, BIN, BIN_MT)
+    stale = force or not all(os.path.exists(o) for o in outs) or any(
+        os.path.getmtime(s) > min(os.path.getmtime(o) for o in outs) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", HERE, "-s"], check=True)
     return LIB
