@@ -155,6 +155,22 @@ int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t inde
 int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index);
 void vsrmc_checker_destroy(vsrmc_checker* c);
 
+/* ≙ tlc2.tool.ModelChecker.runTLC / Worker.run until the queue is empty, an invariant fails, a bound is hit or the spec raises an
+ * evaluation error: vsrmc_checker_step in a loop.  stop_reason: 0 exhausted, 1 invariant violated (last->viol_*), 2 max_depth,
+ * 3 max_seconds; errors come back as the return code, with `last` describing the last completed level. */
+int32_t vsrmc_check(vsrmc_checker* c, int32_t max_depth, double max_seconds, int32_t* stop_reason, vsrmc_level_info* last);
+
+/* ---- StateQueue ≙ tlc2.tool.queue.StateQueue (sEnqueue(TLCState[]) / sDequeue(int) / size): a FIFO of state records kept in
+ * HBM; batches cross the boundary in wire layout (words + n+1 offsets).  The checker keeps its own two frontier buffers; this
+ * handle is the stand-alone queue for callers that drive the loop themselves (e.g. with vsrmc_expand_batch). */
+typedef struct vsrmc_queue vsrmc_queue;
+int32_t vsrmc_queue_create(int32_t device, uint64_t capacity_words, uint64_t capacity_states, vsrmc_queue** out);
+int32_t vsrmc_queue_enqueue_batch(vsrmc_queue* q, const uint64_t* words, const uint64_t* off, uint64_t n);
+int32_t vsrmc_queue_dequeue_batch(vsrmc_queue* q, uint64_t max_states, uint64_t* words, uint64_t cap_words, uint64_t* off,
+                                  uint64_t* n);
+int32_t vsrmc_queue_size(vsrmc_queue* q, uint64_t* n_states);
+void vsrmc_queue_destroy(vsrmc_queue* q);
+
 /* ---- simulation mode ≙ `tlc2.TLC -simulate` (the reference README:22 recommends it for the state-transfer defect) -------------
  * n_walkers random walks run concurrently (one GPU lane each): start at Init, up to max_depth steps chosen uniformly among
  * the enabled (action, binding) instances, invariants checked after every step, restart at the depth limit or in a terminal

@@ -351,3 +351,50 @@ def test_simulation_without_violation_times_out_cleanly(vt):
     m = vt.Model.from_constants(R=2, C_=1, n=1, L=1)        # config 1 has no violation at all (76 states)
     r = m.simulate(n_walkers=4096, max_depth=30, seed=1, max_seconds=1.0)
     assert r["found"] == 0 and r["steps"] > 0 and r["walks"] > 0 and r["trace"] is None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# StateQueue (tlc2.tool.queue.StateQueue) and the one-call Worker.run (vsrmc_check)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_state_queue_is_a_fifo_of_records(vt, orc):
+    P = orc.Params(3, 1, 2, 2)
+    b = orc.Bfs(P)
+    for _ in range(6):
+        b.step()
+    words, off = b.frontier()
+    n = len(off) - 1
+    q = vt.StateQueue(capacity_words=int(off[-1]) + 64, capacity_states=n)       # tight ring: exercises the wrap-around
+    q.s_enqueue(words, off)
+    assert q.size() == n
+    w1, o1 = q.s_dequeue(n // 2)
+    assert len(o1) - 1 == n // 2 and np.array_equal(w1, words[: int(off[n // 2])])
+    q.s_enqueue(words[: int(off[n // 4])], off[: n // 4 + 1])                     # wraps to the front of the ring
+    with pytest.raises(vt.VsrmcError):
+        q.s_enqueue(words, off)                                                     # does not fit: the queue refuses
+    w2, o2 = q.s_dequeue(n)
+    assert len(o2) - 1 == n - n // 2 + n // 4
+    want = np.concatenate([words[int(off[n // 2]):], words[: int(off[n // 4])]])
+    assert np.array_equal(w2, want) and q.size() == 0
+    q.close()
+
+
+def test_check_runs_the_whole_loop_natively(vt):
+    m = vt.Model.from_constants(R=2, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=16, frontier_words=1 << 20, frontier_states=1 << 15, pending_entries=1 << 16)
+    assert mc.check() == "exhausted" and (mc.distinct, mc.level) == (2073, 27)
+    mc.reset()
+    assert mc.check(max_depth=10) == "max-depth" and mc.level == 10
+    mc.close()
+
+
+def test_cli_simulate_finds_the_readme_defect(vt, tmp_path):
+    import os
+    import subprocess
+    from test_host_cpu import _cfg
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cfg = _cfg(tmp_path, R=3, vals="v1, v2, v3", L=3)                              # README:13-18
+    r = subprocess.run([cli, "-config", cfg, "VSR.tla", "-noTLA", "-simulate", "-depth", "60", "-seed", "2", "-maxSeconds", "40"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 12, r.stdout[-2000:] + r.stderr
+    assert "Invariant AcknowledgedWriteNotLost is violated" in r.stdout and "State 1: <Initial predicate>" in r.stdout
+    assert "rep_log |-> <<<<>>, <<>>, <<>>>>" in r.stdout or "aux_client_acked" in r.stdout

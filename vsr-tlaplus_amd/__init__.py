@@ -5,4 +5,4 @@ mirror of the TLC interfaces the path replaces), sharded.py (multi-GPU level loo
 Importable as `vsr_tlaplus_amd` through the shim at the repo root.
 """
 from .capi import VsrmcError, load  # noqa: F401
-from .checker import ACTION_NAMES, FPSet, Model, ModelChecker  # noqa: F401
+from .checker import ACTION_NAMES, FPSet, Model, ModelChecker, StateQueue  # noqa: F401

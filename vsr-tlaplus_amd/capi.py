@@ -80,6 +80,12 @@ SYMBOLS = {
     "vsrmc_model_replay": (C.c_int32, [V, C.c_int32, V, C.c_int32, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_trace_entry": (C.c_int32, [V, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_find_fp": (C.c_int32, [V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_check": (C.c_int32, [V, C.c_int32, C.c_double, C.POINTER(C.c_int32), C.POINTER(LevelInfo)]),
+    "vsrmc_queue_create": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(V)]),
+    "vsrmc_queue_enqueue_batch": (C.c_int32, [V, V, V, C.c_uint64]),
+    "vsrmc_queue_dequeue_batch": (C.c_int32, [V, C.c_uint64, V, C.c_uint64, V, C.POINTER(C.c_uint64)]),
+    "vsrmc_queue_size": (C.c_int32, [V, C.POINTER(C.c_uint64)]),
+    "vsrmc_queue_destroy": (None, [V]),
     "vsrmc_simulate": (C.c_int32, [V, C.c_int32, C.c_uint32, C.c_int32, C.c_uint64, C.c_double, C.POINTER(SimResult)]),
     "vsrmc_shard_expand": (C.c_int32, [V, C.POINTER(ShardIO), V]),
     "vsrmc_shard_claim": (C.c_int32, [V, V, C.c_uint64, V]),

@@ -182,6 +182,43 @@ class FPSet:
             pass
 
 
+class StateQueue:
+    """≙ tlc2.tool.queue.StateQueue: a FIFO of state records in HBM (sEnqueue(TLCState[]) / sDequeue(int) / size)."""
+
+    def __init__(self, capacity_words=1 << 24, capacity_states=1 << 20, device=0):
+        self._h = C.c_void_p()
+        check(capi.load().vsrmc_queue_create(device, capacity_words, capacity_states, C.byref(self._h)))
+
+    def s_enqueue(self, words, off):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        check(capi.load().vsrmc_queue_enqueue_batch(self._h, _p(words), _p(off), len(off) - 1))
+
+    def s_dequeue(self, max_states, cap_words=None):
+        cap_words = cap_words or 256 * max_states
+        words = np.zeros(cap_words, dtype=np.uint64)
+        off = np.zeros(max_states + 1, dtype=np.uint64)
+        n = C.c_uint64()
+        check(capi.load().vsrmc_queue_dequeue_batch(self._h, max_states, _p(words), cap_words, _p(off), C.byref(n)))
+        return words[: int(off[n.value])].copy(), off[: n.value + 1].copy()
+
+    def size(self):
+        n = C.c_uint64()
+        check(capi.load().vsrmc_queue_size(self._h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            capi.load().vsrmc_queue_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ModelChecker:
     """≙ tlc2.tool.ModelChecker: level-synchronous BFS; `step()` = every Worker draining one level of the StateQueue."""
 
@@ -222,6 +259,17 @@ class ModelChecker:
         if d["viol_mask"] and self.violation is None:
             self.violation = dict(level=d["level"], index=d["viol_index"], fp=d["viol_fp"], mask=d["viol_mask"])
         return d
+
+    def check(self, max_depth=0, max_seconds=0.0):
+        """≙ ModelChecker.runTLC in one native call (vsrmc_check) -> "exhausted" | "violation" | "max-depth" | "max-seconds"."""
+        reason = C.c_int32()
+        info = capi.LevelInfo()
+        check(capi.load().vsrmc_check(self._h, max_depth, max_seconds, C.byref(reason), C.byref(info)))
+        d = info.as_dict()
+        self.level, self.n_frontier, self.distinct = d["level"], d["n_new"], d["distinct"]
+        if reason.value == 1:
+            self.violation = dict(level=d["level"], index=d["viol_index"], fp=d["viol_fp"], mask=d["viol_mask"])
+        return ["exhausted", "violation", "max-depth", "max-seconds"][reason.value]
 
     def run(self, max_depth=None, max_seconds=None, stop_on_violation=True):
         """Worker.run until the queue is empty, an invariant is violated, or a bound is hit."""

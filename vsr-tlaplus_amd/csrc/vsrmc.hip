@@ -575,6 +575,97 @@ int32_t vsrmc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------------
+// StateQueue: a ring of record words + a ring of (offset, length) refs, both in HBM
+// ---------------------------------------------------------------------------------------------------------------
+struct vsrmc_queue {
+  int device = 0;
+  u64 cap_words = 0, cap_states = 0;
+  u64* words = nullptr;
+  std::vector<std::pair<u64, u32>> refs;   // (word position in the ring, length) of every queued record, oldest at `head`
+  u64 head = 0;
+  u64 wpos = 0;                            // next write position in the word ring
+  u64 wtail() const { return head < refs.size() ? refs[head].first : wpos; }   // position of the oldest record
+};
+
+extern "C" {
+
+int32_t vsrmc_queue_create(int32_t device, uint64_t capacity_words, uint64_t capacity_states, vsrmc_queue** out) {
+  if (!out || capacity_words < 256 || capacity_states < 1) return fail(VSRMC_E_ARG, "bad argument");
+  int rc = check_device(device);
+  if (rc) return rc;
+  vsrmc_queue* q = new vsrmc_queue();
+  q->device = device;
+  q->cap_words = capacity_words;
+  q->cap_states = capacity_states;
+  hipError_t e = hipMalloc((void**)&q->words, capacity_words * 8);
+  if (e != hipSuccess) { delete q; return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  *out = q;
+  return 0;
+}
+
+int32_t vsrmc_queue_enqueue_batch(vsrmc_queue* q, const uint64_t* words, const uint64_t* off, uint64_t n) {
+  if (!q || (n && (!words || !off))) return fail(VSRMC_E_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(q->device));
+  if (q->refs.size() - q->head + n > q->cap_states) return fail(VSRMC_E_REP, "state queue full (states)");
+  for (u64 i = 0; i < n; i++) {
+    const u64 len = off[i + 1] - off[i];
+    if (len == 0 || len > 255) return fail(VSRMC_E_ARG, "bad record length");
+    if (q->head == q->refs.size()) { q->refs.clear(); q->head = 0; q->wpos = 0; }   // empty: start over at the front of the ring
+    const u64 tail = q->wtail();
+    u64 at;
+    if (q->wpos >= tail) {                                    // data in [tail, wpos): append, or wrap to the front
+      if (q->wpos + len <= q->cap_words) at = q->wpos;
+      else if (len < tail) at = 0;                            // records never straddle the end of the ring
+      else return fail(VSRMC_E_REP, "state queue full (words)");
+    } else {                                                  // wrapped: data in [tail, cap) and [0, wpos)
+      if (q->wpos + len < tail) at = q->wpos;
+      else return fail(VSRMC_E_REP, "state queue full (words)");
+    }
+    HIPCHK(hipMemcpy(q->words + at, words + off[i], len * 8, hipMemcpyHostToDevice));
+    q->refs.emplace_back(at, (u32)len);
+    q->wpos = at + len;
+  }
+  return 0;
+}
+
+int32_t vsrmc_queue_dequeue_batch(vsrmc_queue* q, uint64_t max_states, uint64_t* words, uint64_t cap_words, uint64_t* off, uint64_t* n) {
+  if (!q || !words || !off || !n) return fail(VSRMC_E_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(q->device));
+  u64 k = 0, pos = 0;
+  off[0] = 0;
+  while (k < max_states && q->head < q->refs.size()) {
+    const u64 wp = q->refs[q->head].first;
+    const u32 len = q->refs[q->head].second;
+    if (pos + len > cap_words) break;
+    HIPCHK(hipMemcpy(words + pos, q->words + wp, (u64)len * 8, hipMemcpyDeviceToHost));
+    pos += len;
+    off[++k] = pos;
+    q->head++;
+  }
+  if (q->head > 4096 && q->head * 2 > q->refs.size()) {       // drop the consumed prefix of the ref list now and then
+    q->refs.erase(q->refs.begin(), q->refs.begin() + (long)q->head);
+    q->head = 0;
+  }
+  *n = k;
+  return 0;
+}
+
+int32_t vsrmc_queue_size(vsrmc_queue* q, uint64_t* n_states) {
+  if (!q || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
+  *n_states = q->refs.size() - q->head;
+  return 0;
+}
+
+void vsrmc_queue_destroy(vsrmc_queue* q) {
+  if (!q) return;
+  (void)hipSetDevice(q->device);
+  if (q->words) (void)hipFree(q->words);
+  delete q;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
 // simulation mode
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t n_walkers, int32_t max_depth, uint64_t seed,
@@ -990,6 +1081,22 @@ int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
   if (rc) return rc;
   if (info->viol_mask) return find_fp_newest(c, info->viol_fp, &info->viol_index);
   return 0;
+}
+
+int32_t vsrmc_check(vsrmc_checker* c, int32_t max_depth, double max_seconds, int32_t* stop_reason, vsrmc_level_info* last) {
+  if (!c || !stop_reason || !last) return fail(VSRMC_E_ARG, "NULL argument");
+  const double t0 = now_s();
+  std::memset(last, 0, sizeof(*last));
+  last->level = c->level;
+  last->distinct = c->distinct;
+  while (true) {
+    if (max_depth > 0 && c->level >= max_depth) { *stop_reason = 2; return 0; }
+    if (max_seconds > 0 && now_s() - t0 > max_seconds) { *stop_reason = 3; return 0; }
+    int rc = vsrmc_checker_step(c, last);
+    if (rc) return rc;
+    if (last->viol_mask) { *stop_reason = 1; return 0; }
+    if (last->n_new == 0) { *stop_reason = 0; return 0; }
+  }
 }
 
 // ---- sharded protocol: one level = expand -> [exchange] -> claim -> [exchange] -> materialize -> [exchange] -> append -> commit
