@@ -36,11 +36,12 @@ struct LevelCtl {   // device-resident counters of one BFS level
   u64 err_info;     // (parent index << 16) | ordinal of the instance that raised it
   u64 act_generated[16];   // generated successors per action id
   u64 cand_cnt[8];         // sharded mode: candidates bucketed for each owner rank
-  u64 out_n[8];            // sharded mode: records materialised for each owner rank (self = n_new)
-  u64 out_w[8];            // ... and their words (self = words_new)
   u64 rec_words;           // words of the records actually written to the next frontier (chunk slack excluded)
   u64 ties;                // fused mode: same-level candidates of one fingerprint with different auxkeys (must stay 0)
-  u64 phase_cycles[8];     // k_expand, summed over blocks (wave 0's clock): stage, enumerate, sort, apply, tail; k_materialize: 5..7
+  // shader-clock breakdown (cheap, always on; printed by tools/run_bfs.py).  k_expand, wave 0 of every block: [0..4] stage,
+  // enumerate, sort, apply, tail; fused apply loop of thread 0: [5..7] gen, hash, probe (+ act_generated[0] = successor write);
+  // k_materialize (two-kernel levels) adds its lane-0 clocks to [5..7]: fetch + stage, gen + patch, allocate + write
+  u64 phase_cycles[8];
 };
 
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
@@ -58,8 +59,7 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 
 // One atomic per wave: returns base + rank of this lane among the lanes that call it (all callers must pass the
 // same counter).  Lanes call this from inside a divergent branch; the ballot only sees the active ones.
-__device__ __forceinline__ u64 wave_alloc(u64* counter, u64 amount_per_lane_one) {
-  (void)amount_per_lane_one;
+__device__ __forceinline__ u64 wave_alloc(u64* counter) {
   u64 active = __ballot(1);
   int lane = lane_id();
   int leader = __ffsll((long long)active) - 1;
@@ -398,7 +398,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
         if (owner != rank) {
           for (int o = 0; o < world; o++)
             if (owner == o) {
-              u64 i = wave_alloc(&ctl->cand_cnt[o], 1);
+              u64 i = wave_alloc(&ctl->cand_cnt[o]);
               if (i < cand_cap) {
                 cand_send[2 * ((u64)o * cand_cap + i)] = fp;
                 cand_send[2 * ((u64)o * cand_cap + i) + 1] = key;

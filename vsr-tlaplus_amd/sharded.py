@@ -46,25 +46,29 @@ class Exchanger:
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
-    def exchange(self, send_list, err=0):
+    def exchange(self, send_list, err=0, recv_counts=None):
         """send_list[p] = tensor of rows for peer p (same dtype / trailing shape).  Returns (recv_list, max err over ranks,
         the contiguous peer-major tensor the recv_list entries are views of).
+        recv_counts: rows expected from every peer, when the caller already knows them (answers to an earlier exchange);
+        otherwise a small all-to-all of (count, error code) pairs precedes the payload.
         Every bucket travels with one padding row, so that no rank ever passes an empty tensor to the collective
         (early BFS levels move nothing between most pairs of ranks)."""
         w = self.world
         dev = send_list[0].device
         send_counts = [int(t.shape[0]) for t in send_list]
-        # every peer p gets (rows I send to p, my error code)
-        meta_in = torch.tensor([v for p in range(w) for v in (send_counts[p], int(err))], dtype=torch.int64)
-        meta_out = torch.empty(2 * w, dtype=torch.int64)
-        if self.backend == "nccl":
-            mi, mo = meta_in.to(dev), meta_out.to(dev)
-            dist.all_to_all_single(mo, mi, group=self.group)
-            meta_out = mo.cpu()
-        else:
-            dist.all_to_all_single(meta_out, meta_in, group=self.group)
-        recv_counts = [int(meta_out[2 * p]) for p in range(w)]
-        max_err = max(int(meta_out[2 * p + 1]) for p in range(w))
+        max_err = int(err)
+        if recv_counts is None:
+            # every peer p gets (rows I send to p, my error code)
+            meta_in = torch.tensor([v for p in range(w) for v in (send_counts[p], int(err))], dtype=torch.int64)
+            meta_out = torch.empty(2 * w, dtype=torch.int64)
+            if self.backend == "nccl":
+                mi, mo = meta_in.to(dev), meta_out.to(dev)
+                dist.all_to_all_single(mo, mi, group=self.group)
+                meta_out = mo.cpu()
+            else:
+                dist.all_to_all_single(meta_out, meta_in, group=self.group)
+            recv_counts = [int(meta_out[2 * p]) for p in range(w)]
+            max_err = max(int(meta_out[2 * p + 1]) for p in range(w))
         tail = tuple(send_list[0].shape[1:])
         pad = torch.zeros((1,) + tail, dtype=send_list[0].dtype, device=dev)
         inp = torch.cat([x for t in send_list for x in (t.reshape((-1,) + tail), pad)])
@@ -200,32 +204,30 @@ class ShardedChecker:
     def step(self):
         e, x, me = self.e, self.x, self.rank
         cands, err = e.expand()
-        recv, err, cat = x.exchange(cands, err)
-        self._raise_if(err, "expand")
+        recv, gerr, cat = x.exchange(cands, err)                # 2 collectives: (count, err) pairs, then the buckets
+        self._raise_if(gerr, "expand")
         verdict, err = e.claim(cat)
         back, pos = [], 0
         for p in range(self.world):
             back.append(verdict[pos: pos + recv[p].shape[0]])
             pos += recv[p].shape[0]
-        vrecv, err, _ = x.exchange(back, err)
-        self._raise_if(err, "claim")
-        err = e.materialize(vrecv)
-        err = self._rebalance(err)
+        # the answers: as many rows come back from p as candidates went to p — no count exchange needed
+        vrecv, _, _ = x.exchange(back, recv_counts=[int(c.shape[0]) for c in cands])
+        err = max(err, e.materialize(vrecv))
+        err = self._rebalance(err)                              # 1 all-gather (+ the moves, when the ranks drifted apart)
         info = e.commit()
         viol_fp = info["viol_fp"] if info["viol_mask"] else U64_MAX
-        s = x.allreduce([info["n_new"], info["generated"], info["deadlocks"], info["pending"]], dist.ReduceOp.SUM)
-        # a 64-bit fingerprint does not fit a signed int64 min-reduce: reduce the two halves lexicographically;
-        # the error code rides along negated (min of -err = -max err)
-        gmin_hi, neg_err = x.allreduce([viol_fp >> 32, -err], dist.ReduceOp.MIN)
-        lo = (viol_fp & 0xFFFFFFFF) if (viol_fp >> 32) == gmin_hi else 0xFFFFFFFF
-        gmin_lo = x.allreduce([lo], dist.ReduceOp.MIN)[0]
-        self._raise_if(-neg_err, "append")
-        gviol = (gmin_hi << 32) | gmin_lo
+        # one all-gather carries every per-level figure (a 64-bit fingerprint travels as two 32-bit halves: int64 tensors)
+        rows = x.allgather([info["n_new"], info["generated"], info["deadlocks"], info["pending"], viol_fp >> 32,
+                            viol_fp & 0xFFFFFFFF, err])
+        self._raise_if(max(r[6] for r in rows), "append")
+        s = [sum(r[k] for r in rows) for k in range(4)]
+        gviol = min((r[4] << 32) | r[5] for r in rows)
         self.level += 1
         self.n_frontier = s[0]
         self.distinct += s[0]
         out = dict(level=self.level, n_new=s[0], generated=s[1], deadlocks=s[2], pending=s[3], distinct=self.distinct,
-                   local=info, viol_fp=gviol if gviol != U64_MAX else None)
+                   local=info, viol_fp=gviol if gviol != U64_MAX else None, per_rank_new=[r[0] for r in rows])
         if s[0]:
             self.levels.append(out)
         if gviol != U64_MAX and self.violation is None:
