@@ -398,3 +398,78 @@ def test_cli_simulate_finds_the_readme_defect(vt, tmp_path):
     assert r.returncode == 12, r.stdout[-2000:] + r.stderr
     assert "Invariant AcknowledgedWriteNotLost is violated" in r.stdout and "State 1: <Initial predicate>" in r.stdout
     assert "rep_log |-> <<<<>>, <<>>, <<>>>>" in r.stdout or "aux_client_acked" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# edge cases: empty batches, capacity traps, saturation — the device path fails loudly, never wraps
+# ---------------------------------------------------------------------------------------------------------------------
+def test_empty_batches(vt):
+    m = vt.Model.from_constants()
+    assert m.get_next_states(np.zeros(0, dtype=np.uint64), np.zeros(1, dtype=np.uint64)) == []
+    fps, aks = m.fingerprints(np.zeros(0, dtype=np.uint64), np.zeros(1, dtype=np.uint64))
+    assert len(fps) == 0 and len(aks) == 0
+
+
+def test_delivery_count_saturation_is_an_error_like_in_the_oracle(vt, orc):
+    """A bag entry already at count 3 that the action would re-send: the packed count cannot hold 4 — the oracle raises a
+    representation error, the device path reports ERR_REP_COUNT (13) for exactly that successor."""
+    P = orc.Params(3, 1, 2, 2)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    rec = orc.init_record(P)
+    succ = {s["action"]: s for s in orc.successors(P, rec)}
+    rec = succ[1]["words"].copy() if 1 in succ else None            # after one TimerSendSVC: two SVC entries with count 1
+    assert rec is not None
+    fixed = m.layout.fixed_words
+    svc = [j for j in range(fixed, len(rec)) if int(rec[j]) & 7 == 1]
+    assert len(svc) == 2
+    # the other non-primary replica would broadcast the same keys?  No: keys carry the source.  Saturate differently: set the
+    # count of both entries to 3, then let replica 2 receive one (count 2) — fine — and check that nothing saturates there,
+    # while a hand-made duplicate broadcast does: replica r broadcasts SVC(view+1) whose keys already sit at count 3.
+    view_r3 = (int(rec[1 + 2 * 3]) >> 2) & 7                         # replica 3's view in its A word
+    bumped = rec.copy()
+    for j in svc:
+        bumped[j] = np.uint64((int(bumped[j]) & ~(3 << 21)) | (3 << 21))
+    out = m.get_next_states(bumped, np.array([0, len(bumped)], dtype=np.uint64))
+    assert all(s["err"] == 0 for s in out)                           # receiving only decrements
+    assert view_r3 in (1, 2)
+    # now a record where the key the action creates already exists at count 3: take a successor of `rec` by ReceiveHigherSVC
+    # (it broadcasts SVC(view, src = receiver)) and plant those keys at count 3 in the parent
+    higher = [s for s in orc.successors(P, rec) if s["action"] == 2][0]
+    new_keys = [int(w) for w in higher["words"][fixed:] if int(w) not in set(int(x) for x in rec[fixed:]) and (int(w) >> 21) & 3 == 1]
+    assert new_keys
+    planted = np.concatenate([rec, np.array([(k & ~(3 << 21)) | (3 << 21) for k in new_keys], dtype=np.uint64)])
+    planted[0] = np.uint64(int(planted[0]) + len(new_keys))          # nmsg
+    errs = [s["err"] for s in m.get_next_states(planted, np.array([0, len(planted)], dtype=np.uint64))]
+    assert 13 in errs
+    with pytest.raises(orc.OracleError):
+        orc.successors(P, planted)
+
+
+def test_bag_capacity_trap(vt):
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    lay = m.layout
+    rec = m.init_state()
+    # fill the bag to capacity with distinct, never-receivable entries (count 0), then fire a timer: the broadcast cannot fit
+    filler = [np.uint64(1 | (7 << 3) | (1 << 6) | (2 << 9) | (k << 32)) for k in range(lay.max_bag)]   # SVC view 7, log bits as tag
+    full = np.concatenate([rec, np.array(filler, dtype=np.uint64)])
+    full[0] = np.uint64(int(full[0]) + lay.max_bag)
+    out = m.get_next_states(full, np.array([0, len(full)], dtype=np.uint64))
+    assert out and all(s["err"] == 14 for s in out if s["action"] == 1)          # ERR_REP_BAG on every TimerSendSVC
+
+
+def test_seen_set_and_frontier_overflow_are_errors(vt):
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=8, frontier_words=1 << 20, frontier_states=1 << 15, pending_entries=1 << 16)
+    with pytest.raises(vt.VsrmcError) as ei:
+        for _ in range(12):
+            mc.step()
+    assert ei.value.code == -5 and "error 20" in ei.value.message               # ERR_TABLE_FULL
+    mc.close()
+    mc = vt.ModelChecker(m, table_log2=20, frontier_words=1 << 14, frontier_states=1 << 15, pending_entries=1 << 16)
+    with pytest.raises(vt.VsrmcError) as ei:
+        for _ in range(14):
+            mc.step()
+    assert ei.value.code == -5 and "error 21" in ei.value.message               # ERR_FRONTIER_FULL
+    with pytest.raises(vt.VsrmcError):
+        mc.step()                                                                   # the handle stays failed
+    mc.close()
