@@ -493,23 +493,25 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
 // Returns a bit mask: bit k set <=> ordinal (slot < m0 ? slot : m0 + j*(R+1) + k) is enabled; *kind0 = action id of bit 0.
 // k_expand re-checks every emitted instance with gen<false> (a disagreement raises ERR_INTERNAL), and the parity tests
 // compare the generated counts with the oracle, so the two statements of the guards cannot drift apart silently.
+// `Areg[r]` = A word of replica r (1..5), already in registers: the frontier enumeration evaluates ~50 slots per record and
+// must not re-read them from LDS every time.  Selected by value (never through a pointer into the array).
+VSR_HD u64 areg_of(const u64* Areg, int r) {
+  return r == 1 ? Areg[1] : r == 2 ? Areg[2] : r == 3 ? Areg[3] : r == 4 ? Areg[4] : Areg[5];
+}
+// decode of a replica-bound slot: group | r << 3 | c << 6 | v << 8 (integer divisions by run-time constants: k_expand
+// tabulates this once per block and passes the entry as `info`; info < 0 = decode here)
+VSR_HD int slot_info(const Model& M, int slot) {
+  if (slot < 4 * M.R) return (slot / M.R) | ((slot % M.R + 1) << 3);
+  const int idx = slot - 4 * M.R;
+  return 4 | ((idx / (M.C * M.n) + 1) << 3) | (((idx / M.n) % M.C + 1) << 6) | ((idx % M.n) << 8);
+}
 template <typename PTR>
-VSR_HD u32 guard_slot(const Model& M, PTR rec, int slot, int* kind0) {
-  const u64 hdr = rec[0];
+VSR_HD u32 guard_slot_pre(const Model& M, PTR rec, u64 hdr, const u64* Areg, int slot, int* kind0, int info = -1) {
   if (slot < M.m0) {
-    int group, r, c = 0, v = 0;
-    if (slot < 4 * M.R) {
-      group = slot / M.R;
-      r = slot % M.R + 1;
-    } else {
-      const int idx = slot - 4 * M.R;
-      group = 4;
-      r = idx / (M.C * M.n) + 1;
-      c = (idx / M.n) % M.C + 1;
-      v = idx % M.n;
-    }
+    if (info < 0) info = slot_info(M, slot);
+    const int group = info & 7, r = (info >> 3) & 7, c = (info >> 6) & 3, v = (info >> 8) & 3;
     PTR pb = rec + 1 + (r - 1) * M.wpr;
-    const u64 A = pb[0];
+    const u64 A = areg_of(Areg, r);
     const bool prim = primary_of(M, a_view(A)) == r;
     const int st = a_status(A);
     switch (group) {
@@ -535,7 +537,7 @@ VSR_HD u32 guard_slot(const Model& M, PTR rec, int slot, int* kind0) {
   if (m_count(mw) == 0) return 0;                               // ReceivableMsg VSR.tla:272-275
   const int r = m_dest(mw);
   PTR pb = rec + 1 + (r - 1) * M.wpr;
-  const u64 A = pb[0];
+  const u64 A = areg_of(Areg, r);
   // Branch-free: the lanes of a wave look at 64 different messages of 64 different types; every type's guard is evaluated
   // with predicated arithmetic and selected by type, instead of seven divergent branches.
   const int t = m_type(mw);
@@ -569,6 +571,15 @@ VSR_HD u32 guard_slot(const Model& M, PTR rec, int slot, int* kind0) {
       if (d != r && !bag_has_key(rec + M.fixed, hdr_nmsg(hdr), m_make(T_GETSTATE, mview, d, r, tr, 0, 0, 0, 0))) mask |= 1u << d;
   }
   return mask;
+}
+
+template <typename PTR>
+VSR_HD u32 guard_slot(const Model& M, PTR rec, int slot, int* kind0) {
+  u64 Areg[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 1; r <= 5; r++)
+    if (r <= M.R) Areg[r] = rec[1 + (r - 1) * M.wpr];
+  return guard_slot_pre(M, rec, rec[0], Areg, slot, kind0);
 }
 
 // Incremental view hashes of the child: Hc[i] = Hp[i] - hash(old replica block) + hash(new) + bag patch deltas.

@@ -164,6 +164,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
   __shared__ u32 s_alive[VSR_TILE_MAX];
   __shared__ u64 s_ref[VSR_TILE_MAX];
   __shared__ u32 s_kcount[16], s_kbase[16];
+  __shared__ int s_slotinfo[64];                               // decode of the replica-bound slots (m0 <= 50), see slot_info()
   // per-block accumulators (flushed once at the end: no hot global counters inside the tile loop)
   __shared__ unsigned long long s_acc[32];                     // 0 generated, 1 deadlocks, 2 probes, 3..7 phase cycles, 16..31 per action
   // pending list: the block owns a chunk of pchunk entries at a time; unused entries are invalidated (key = ~0)
@@ -179,6 +180,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
   const int tshift = tile == 128 ? 7 : 6;
   if (tid < 32) s_acc[tid] = 0;
   if (tid == 0) s_maxbag_out = 0;
+  if (tid < 64) s_slotinfo[tid] = tid < M.m0 ? slot_info(M, tid) : 0;
   if (tid == 0) {                                              // "no chunk yet"
     s_chunk_base = 0; s_chunk_used = pchunk;
     s_ich_base = 0; s_ich_used = ichunk; s_wch_base = 0; s_wch_used = wchunk;
@@ -237,81 +239,84 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     {
       const int nslots = M.m0 + (int)s_maxbag;
       const int nitems = nslots << tshift;
-      // four independent guard evaluations per trip (their LDS load chains overlap), then the appends one after the other
+      // A thread always looks at the same record (p = tid mod tile; the block size is a multiple of the tile size): its
+      // header and replica A words are read from LDS once, every slot's guard then costs one LDS read (the bag word).
+      const int p_mine = tid & (tile - 1);
+      const bool mine_valid = p_mine < np_tile && s_ref[p_mine] != 0;
+      const u64* rec_mine = s_rec + p_mine * stride;
+      u64 Areg[6] = {0, 0, 0, 0, 0, 0};
+      u64 hdr_mine = 0;
+      if (mine_valid) {
+        hdr_mine = rec_mine[0];
+#pragma unroll
+        for (int r = 1; r <= 5; r++)
+          if (r <= M.R) Areg[r] = rec_mine[1 + (r - 1) * M.wpr];
+      }
+      // Work-list layout during enumeration: thread t owns entries [t*PRIV, t*PRIV + PRIV) — it appends there with a cursor
+      // in a register, no atomics, no cross-lane traffic inside the slot loop; the entries beyond 256*PRIV are a shared
+      // overflow area (atomic cursor) for the rare thread that finds more.  Unused entries hold ~0; the counting sort below
+      // skips them.
+      const u32 PRIV = (ccap - 256u) / VSR_BLOCK;               // 5 at ccap 1536, 7 at 2048
+      const u32 shared0 = PRIV * VSR_BLOCK;
+      for (u32 k = tid; k < ccap; k += VSR_BLOCK) s_cand[k] = ~0u;
+      __syncthreads();
+      u32 nmine = 0;
+      bool alive = false;
+      // four independent guard evaluations per trip
       for (int item0 = tid; item0 < nitems; item0 += 4 * VSR_BLOCK) {
         u32 masks[4];
         int kinds[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int item = item0 + u * VSR_BLOCK;
-          const int slot = item >> tshift, p = item & (tile - 1);
+          const int slot = item >> tshift;
           masks[u] = 0;
           kinds[u] = 0;
-          if (item < nitems && p < np_tile && s_ref[p] != 0) masks[u] = guard_slot(M, (const u64*)(s_rec + p * stride), slot, &kinds[u]);
+          if (item < nitems && mine_valid) masks[u] = guard_slot_pre(M, rec_mine, hdr_mine, Areg, slot, &kinds[u], s_slotinfo[slot & 63]);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-        const int item = item0 + u * VSR_BLOCK;
-        if (item >= nitems) break;                              // wave-uniform: nitems is a multiple of 64
-        const int slot = item >> tshift, p = item & (tile - 1);
-        u32 mask = masks[u];
-        const int kind0 = kinds[u];
-        // wave-aggregated append.  Bit 0 (the instance that receives / fires the slot) is at most one entry per lane: its
-        // position is a popcount of the ballot below the lane — no cross-lane shuffles (a 6-step shuffle scan per slot
-        // cost more than the guards themselves).  The rare extra bits (SendGetState, one per destination) take the
-        // per-lane atomic path.
-        const u64 b0 = __ballot((mask & 1u) != 0);
-        if (b0) {
-          u32 base = 0;
-          if (lane == 0) {
-            base = atomicAdd(&s_ncand, (u32)__popcll(b0));
-            if (fused) atomicAdd(&s_wneed, (u32)__popcll(b0) * (u32)(M.fixed + (int)s_maxbag + 5));   // bound of the successors' lengths
-          }
-          base = (u32)__builtin_amdgcn_readlane((int)base, 0);
-          if (mask & 1u) {
-            s_alive[p] = 1;
-            const int ordbase = slot < M.m0 ? slot : M.m0 + (slot - M.m0) * (M.R + 1);
-            const u32 idx = base + (u32)__popcll(b0 & (((u64)1 << lane) - 1));
-            atomicAdd(&s_kcount[kind0], 1u);
-            if (idx < ccap) s_cand[idx] = ((u32)kind0 << 18) | ((u32)p << 11) | (u32)ordbase;
-          }
-        }
-        mask &= ~1u;
-        if (mask) {                                             // SendGetState instances of a Prepare entry
-          s_alive[p] = 1;
-          const int ordbase = M.m0 + (slot - M.m0) * (M.R + 1);
+          u32 mask = masks[u];
+          if (!mask) continue;
+          const int slot = (item0 + u * VSR_BLOCK) >> tshift;
+          const int ordbase = slot < M.m0 ? slot : M.m0 + (slot - M.m0) * (M.R + 1);
+          alive = true;
           while (mask) {
             const int k = __ffs((int)mask) - 1;
             mask &= mask - 1;
-            const u32 idx = atomicAdd(&s_ncand, 1u);
-            if (fused) atomicAdd(&s_wneed, (u32)(M.fixed + (int)s_maxbag + 5));
-            atomicAdd(&s_kcount[A_SendGetState], 1u);
-            if (idx < ccap) s_cand[idx] = ((u32)A_SendGetState << 18) | ((u32)p << 11) | (u32)(ordbase + k);
+            const int kind = k == 0 ? kinds[u] : A_SendGetState;   // bits 1.. = SendGetState, one per destination
+            atomicAdd(&s_kcount[kind], 1u);
+            u32 idx;
+            if (nmine < PRIV) idx = (u32)tid * PRIV + nmine;
+            else idx = shared0 + atomicAdd(&s_ncand, 1u);
+            nmine++;
+            if (idx < ccap) s_cand[idx] = ((u32)kind << 18) | ((u32)p_mine << 11) | (u32)(ordbase + k);
+            else s_ncand = 0x40000000u;                           // overflow marker (work list too small)
           }
         }
-        }
       }
+      if (alive) s_alive[p_mine] = 1;
     }
     __syncthreads();
     if (tid < np_tile && s_alive[tid] == 0 && s_ref[tid] != 0) atomicAdd(&s_dead, 1u);   // ref 0 = unused index (see k_materialize)
-    u32 ncand = s_ncand;
-    if (ncand > ccap) {
-      if (tid == 0) raise_error(ctl, ERR_FRONTIER_FULL, p_base);
-      ncand = ccap;
-    }
-    const u64 t_2 = __builtin_readcyclecounter();
     // ---- counting sort of the work list by action id: the lanes of a wave then run the same action (no divergence between
     // the 15 action bodies, only inside one)
     if (tid == 0) {
+      if (s_ncand >= 0x40000000u) raise_error(ctl, ERR_FRONTIER_FULL, p_base);
       u32 acc = 0;
       for (int a = 0; a < 16; a++) {
         s_kbase[a] = acc;
         acc += s_kcount[a];
       }
+      s_ncand = acc > ccap ? ccap : acc;
+      if (fused) s_wneed = s_ncand * (u32)(M.fixed + (int)s_maxbag + 5);   // upper bound of the successors' total length
     }
+    const u64 t_2 = __builtin_readcyclecounter();
     __syncthreads();
-    for (u32 c = tid; c < ncand; c += VSR_BLOCK) {
+    const u32 ncand = s_ncand;
+    for (u32 c = tid; c < ccap; c += VSR_BLOCK) {
       const u32 code = s_cand[c];
+      if (code == ~0u) continue;
       const u32 pos = atomicAdd(&s_kbase[code >> 18], 1u);
       if (pos < ccap) s_cand2[pos] = code;
     }
