@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("VSR_BENCH_SHARDED"):   # VSR_BENCH_SHARDED=1: the N > 1 leg on one rank
         from vsr_tlaplus_amd import sharded_bench
         return sharded_bench.main(args, CONFIG, EXPECT)
     elapsed, S, m = run_single(args)

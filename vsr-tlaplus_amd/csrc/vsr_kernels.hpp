@@ -69,81 +69,96 @@ __device__ __forceinline__ u64 wave_alloc(u64* counter) {
   return base + (u64)__popcll(active & (((u64)1 << lane) - 1));
 }
 
-// Seen-set probe.  Returns the slot index; *found_old = true when the fingerprint was inserted at an earlier level
-// (nothing else to do), otherwise the caller's key has been min-merged into the slot's meta word.
+// Find-or-insert of a fingerprint: linear probing from fp & mask, one 64-byte line (4 slots) per memory round trip.
+// A loaded line may be stale with respect to concurrent inserts, which is harmless: a slot only ever goes empty -> fp and
+// never changes afterwards, so "other key" and "this key" are final, and "empty" is re-checked by the atomicCAS.
+struct Probe {
+  u64 slot;         // index of the slot that holds fp
+  u64 meta;         // its meta word as loaded with the line (valid unless `claimed` or `reload`)
+  bool claimed;     // this lane inserted fp
+  bool reload;      // fp was inserted by someone else between the load and our CAS: meta must be re-read
+  bool full;
+};
+__device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32* nprobe) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  Probe r;
+  r.slot = 0; r.meta = META_EMPTY; r.claimed = false; r.reload = false; r.full = false;
+  u64 i = fp & mask;
+  for (u32 lines = 0; lines < 2048; lines++) {
+    const u64 lb = i & ~(u64)3;
+    const u64x2* lp = (const u64x2*)&table[lb];
+    const u64x2 s0 = lp[0], s1 = lp[1], s2 = lp[2], s3 = lp[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (lb + k < i) continue;                                 // slots of the line before the probe start
+      const u64x2 sk = k == 0 ? s0 : k == 1 ? s1 : k == 2 ? s2 : s3;
+      (*nprobe)++;
+      u64 cur = sk.x;
+      if (cur == 0) {
+        cur = atomicCAS((unsigned long long*)&table[lb + k].fp, 0ull, (unsigned long long)fp);
+        if (cur == 0) {
+          r.slot = lb + k;
+          r.claimed = true;
+          return r;
+        }
+        if (cur == fp) {
+          r.slot = lb + k;
+          r.reload = true;
+          return r;
+        }
+        continue;                                               // another fingerprint took the slot meanwhile
+      }
+      if (cur == fp) {
+        r.slot = lb + k;
+        r.meta = sk.y;
+        return r;
+      }
+    }
+    i = (lb + 4) & mask;
+  }
+  r.full = true;
+  return r;
+}
+
+// Seen-set claim of the two-kernel scheme.  Returns the slot index; *found_old = true when the candidate cannot win (the
+// fingerprint belongs to an earlier level, or a smaller key of this level already holds the slot), otherwise the caller's key
+// has been min-merged into the slot's meta word and the candidate goes to the pending list.
 __device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 key, int level, bool* found_old,
                                            u32* nprobe, bool* full) {
-  u64 i = fp & mask;
-  *full = false;
-  for (u64 step = 0; step <= mask; step++, i = (i + 1) & mask) {
-    (*nprobe)++;
-    u64 cur = __hip_atomic_load(&table[i].fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == 0) {
-      cur = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
-      if (cur == 0) cur = fp;                                  // claimed by this lane
-    }
-    if (cur == fp) {
-      u64 m = __hip_atomic_load(&table[i].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (meta_level(m) < level || m < key) {                  // inserted at an earlier level, or a smaller key of this
-        *found_old = true;                                     // level already holds the slot (meta only ever decreases):
-        return i;                                              // this candidate cannot win
-      }
-      u64 prev = atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
-      *found_old = prev < key;                                 // lost the race after all
-      return i;
-    }
-    if (step > 4096) break;
-  }
-  *full = true;
+  const Probe p = probe_insert(table, mask, fp, nprobe);
+  *full = p.full;
   *found_old = true;
-  return 0;
+  if (p.full) return 0;
+  if (!p.claimed) {
+    const u64 m = p.reload ? __hip_atomic_load(&table[p.slot].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.meta;
+    if (meta_level(m) < level || m < key) return p.slot;       // earlier level, or beaten already (meta only ever decreases)
+  }
+  const u64 prev = atomicMin((unsigned long long*)&table[p.slot].meta, (unsigned long long)key);
+  *found_old = prev < key;                                     // lost the race after all
+  return p.slot;
 }
 
 // Fused variant (single-pass BFS level): *claimed = this lane inserted the fingerprint (it writes the successor at once);
-// *tie = another candidate of this level reached the same slot with a different canonical auxkey, i.e. the VIEW collision
-// of SURVEY F2 inside one level, which the single-pass scheme cannot arbitrate — the host then redoes the run with the
-// exact two-kernel scheme (never observed: the oracle's `ties` counter is 0 on every config).
+// *prev_meta = the meta word this candidate displaced / found (META_EMPTY if none): the caller compares auxkeys AFTER it
+// has done its other work, so that the returning atomic's latency overlaps with the successor write.  A same-level
+// duplicate with a different canonical auxkey is the VIEW collision of SURVEY F2 inside one level, which the single-pass
+// scheme cannot arbitrate — the host then asks for the exact two-kernel scheme (never observed: `ties` is 0 everywhere).
 __device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp, u64 key, int level, bool* claimed, u64* prev_meta,
                                                   u32* nprobe, bool* full) {
-  // *prev_meta: the meta word this candidate displaced / found (META_EMPTY if none): the caller compares auxkeys AFTER it has
-  // done its other work, so that the returning atomic's latency overlaps with the successor write
-  u64 i = fp & mask;
-  *full = false;
-  *claimed = false;
+  const Probe p = probe_insert(table, mask, fp, nprobe);
+  *full = p.full;
+  *claimed = p.claimed;
   *prev_meta = META_EMPTY;
-  for (u64 step = 0; step <= mask; step++, i = (i + 1) & mask) {
-    (*nprobe)++;
-    // one 16-byte load brings fingerprint and meta of the slot (a stale copy is harmless: slots only move
-    // empty -> fp, and meta only decreases; a stale "empty" just sends us to the atomic)
-    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-    const u64x2 sm = *(const u64x2*)&table[i];
-    u64 cur = sm.x;
-    bool mine = false;
-    if (cur == 0) {
-      cur = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
-      if (cur == 0) {
-        cur = fp;
-        mine = true;
-      }
-    }
-    if (cur == fp) {
-      if (mine) {                                               // just claimed: meta is still empty, publish our key
-        *claimed = true;
-        *prev_meta = atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
-        return;
-      }
-      const u64 m = sm.x == fp ? sm.y : __hip_atomic_load(&table[i].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (meta_level(m) < level) return;                       // a state of an earlier level
-      if (m != META_EMPTY && m < key) {                        // smaller key of this level already there
-        *prev_meta = m;
-        return;
-      }
-      *prev_meta = atomicMin((unsigned long long*)&table[i].meta, (unsigned long long)key);
+  if (p.full) return;
+  if (!p.claimed) {
+    const u64 m = p.reload ? __hip_atomic_load(&table[p.slot].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.meta;
+    if (meta_level(m) < level) return;                         // a state of an earlier level
+    if (m != META_EMPTY && m < key) {                          // smaller key of this level already there
+      *prev_meta = m;
       return;
     }
-    if (step > 4096) break;
   }
-  *full = true;
+  *prev_meta = atomicMin((unsigned long long*)&table[p.slot].meta, (unsigned long long)key);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
