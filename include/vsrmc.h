@@ -101,9 +101,11 @@ typedef struct vsrmc_options {
   int32_t exact_ties;            /* 0 (default): single-pass levels — the lane that inserts a fingerprint writes the successor;
                                     a same-level VIEW collision with different aux variables (never observed) stops the run
                                     with VSRMC_E_STATE.  1: two-kernel levels (k_expand + k_materialize) that arbitrate
-                                    such ties exactly like the oracle (smallest canonical auxkey wins).  Sharded runs are
-                                    always exact. */
-  int32_t reserved[5];
+                                    such ties exactly like the oracle (smallest canonical auxkey wins).  Sharded runs
+                                    follow the same switch. */
+  int32_t filter_log2;           /* sharded single-pass runs: entries (8 B) of this rank's sent-filter = 2^filter_log2;
+                                    0 = table_log2 */
+  int32_t reserved[4];
 } vsrmc_options;
 
 typedef struct vsrmc_level_info {
@@ -203,7 +205,19 @@ int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t n_walkers,
  *      vsrmc_shard_export       copy the valid records of an index window into send streams and invalidate them here
  *      [all-to-all of the streams]
  *      vsrmc_shard_append       per received stream: copy into the next frontier, publish refs / fps / trace keys
- *   7. vsrmc_shard_commit       swap the frontiers; local statistics (the caller all-reduces them) */
+ *   7. vsrmc_shard_commit       swap the frontiers; local statistics (the caller all-reduces them)
+ * With exact_ties = 0 (default) the levels are single-pass: in step 1 a successor owned by another rank that passes this
+ * rank's sent-filter (exact repeats are dropped there) is written to the local next frontier SPECULATIVELY and announced;
+ * in step 3 the candidate that inserts the fingerprint wins; step 5 only withdraws the announced successors that lost.
+ * With exact_ties = 1 step 5 rebuilds the winners (k_materialize) and same-level ties follow the oracle's rule.
+ *
+ * Replicated phase: a sharded checker starts with Init on EVERY rank.  While the frontier is small the ranks explore whole
+ * levels on their own, without any exchange (vsrmc_shard_local_step = vsrmc_checker_step on this rank's private copy;
+ * every rank sees the same state sets, trace keys carry the local rank).  vsrmc_shard_partition ends that phase: each
+ * rank keeps the states of the current frontier it owns and the sharded protocol above takes over.  (The early
+ * fingerprints then sit in every rank's table, owners included, which is all the protocol needs.) */
+int32_t vsrmc_shard_local_step(vsrmc_checker* c, vsrmc_level_info* info);
+int32_t vsrmc_shard_partition(vsrmc_checker* c, uint64_t* n_kept);
 typedef struct vsrmc_shard_io {
   uint64_t* cand_send;           /* [world][cand_cap][2]  (fp, key) */
   uint64_t cand_cap;             /* entries per owner */

@@ -25,13 +25,29 @@ class FakeShardEngine:
         self.level = 1
         init = orc.init_record(params)
         fp, ak = orc.fingerprint(params, init)
-        self.frontier, self.fps, self.trace = [], [], [[]]
-        if owner_of(fp, world) == rank:
-            self.frontier, self.fps = [init], [fp]
-            self.seen[fp] = self._key(1, ak, 0, 0)
-            self.trace = [[self.seen[fp]]]
+        # replicated start: Init on every rank (sharded.ShardedChecker partitions when its replicated phase ends)
+        self.frontier, self.fps = [init], [fp]
+        self.seen[fp] = self._key(1, ak, 0, 0)
+        self.trace = [[self.seen[fp]]]
         self.total = len(self.frontier)
         self._err = ""
+
+    def local_step(self):
+        """one whole level on this rank alone: every successor is claimed locally, whoever owns it"""
+        owner_of, self.owner_of = self.owner_of, (lambda fp, world: self.rank)
+        try:
+            self.expand()
+            self.materialize([None] * self.world)
+        finally:
+            self.owner_of = owner_of
+        return self.commit()
+
+    def partition(self):
+        keep = set(i for i, f in enumerate(self.fps) if f is not None and self.owner_of(f, self.world) == self.rank)
+        # indices stay what they were (the trace log is addressed by index): withdrawn states become holes
+        self.frontier = [self.frontier[i] if i in keep else None for i in range(len(self.frontier))]
+        self.fps = [self.fps[i] if self.frontier[i] is not None else None for i in range(len(self.fps))]
+        return len(keep)
 
     def _key(self, level, ak, pidx, ordinal):
         return (level << 55) | (ak << 46) | (ordinal << 35) | (pidx << 3) | self.rank
@@ -40,7 +56,7 @@ class FakeShardEngine:
         return self._err
 
     def local_distinct(self):
-        return len(self.frontier)
+        return sum(1 for r in self.frontier if r is not None)
 
     def _claim(self, fp, key):
         """-> True if the slot belongs to this level (candidate may still win)"""
@@ -55,6 +71,8 @@ class FakeShardEngine:
         self.local_pending, self.sent = [], [[] for _ in range(self.world)]
         self.succ_cache = {}
         for pidx, rec in enumerate(self.frontier):
+            if rec is None:                                     # withdrawn by partition()
+                continue
             succ = orc.successors(self.P, rec)
             self.succ_cache[pidx] = succ
             self.generated += len(succ)
@@ -91,7 +109,7 @@ class FakeShardEngine:
             if self.seen[fp] == key:
                 self._emit_local(self._record_of(key), key)
         for o in range(self.world):
-            if o != self.rank:
+            if o != self.rank and self.sent[o]:
                 v = [int(x) for x in verdicts[o].cpu()]
                 assert len(v) == len(self.sent[o])
                 for (fp, key), win in zip(self.sent[o], v):
@@ -141,7 +159,7 @@ class FakeShardEngine:
         self.trace.append(self.next_keys)
         self.level += 1
         self.total += len(self.frontier)
-        return dict(n_new=len(self.frontier), generated=self.generated, deadlocks=self.deadlocks,
+        return dict(n_new=len(self.frontier), expand_ms=0.0, materialize_ms=0.0, generated=self.generated, deadlocks=self.deadlocks,
                     pending=len(self.local_pending), viol_fp=self.viol_fp, viol_mask=self.viol_mask, max_bag=0)
 
     def find_fp(self, fp):
@@ -151,4 +169,4 @@ class FakeShardEngine:
         return self.trace[level - 1][index]
 
     def level_fps(self):
-        return np.array(sorted(self.fps), dtype=np.uint64)
+        return np.array(sorted(f for f in self.fps if f is not None), dtype=np.uint64)

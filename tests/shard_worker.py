@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: one rank of a world_size-N sharded BFS, launched by tests via torch.distributed.run.
-    python -m torch.distributed.run ... tests/shard_worker.py <engine: fake|hip> R C n L max_depth out_prefix
+    python -m torch.distributed.run ... tests/shard_worker.py <engine: fake|hip|hip-exact> R C n L max_depth out_prefix [replicate_below]
 Writes out_prefix.rank<k>.json with the per-level sorted fingerprints of this rank's shard and the global counters."""
 import json
 import os
@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     engine_kind, R, C_, n, L, max_depth, out = sys.argv[1], *(int(x) for x in sys.argv[2:7]), sys.argv[7]
+    replicate_below = int(sys.argv[8]) if len(sys.argv) > 8 else 0
     dist.init_process_group("gloo")           # CPU test: gloo; on the one-GPU box both ranks share device 0 over gloo
     rank, world = dist.get_rank(), dist.get_world_size()
     from vsr_tlaplus_amd import sharded
@@ -26,15 +27,18 @@ def main():
         import vsr_tlaplus_amd as vt
         m = vt.Model.from_constants(R=R, C_=C_, n=n, L=L)
         eng = sharded.HipShardEngine(m, rank, world, device=0, table_log2=20, frontier_words=1 << 22, frontier_states=1 << 17,
-                                     pending_entries=1 << 19, cand_cap=1 << 18, rec_cap=1 << 17, rec_words_cap=1 << 22)
-    sc = sharded.ShardedChecker(eng, sharded.Exchanger())
-    levels = [dict(level=1, n_new=sc.distinct, generated=0, deadlocks=0, fps=["%016x" % int(f) for f in eng.level_fps()])]
+                                     pending_entries=1 << 19, cand_cap=1 << 18, rec_cap=1 << 17, rec_words_cap=1 << 22,
+                                     exact_ties=engine_kind == "hip-exact", filter_log2=16)
+    sc = sharded.ShardedChecker(eng, sharded.Exchanger(), replicate_below=replicate_below)
+    # "replicated": the level's states are on every rank (the ranks explored it on their own), else each state is on one rank
+    levels = [dict(level=1, n_new=sc.distinct, generated=0, deadlocks=0, replicated=sc.replicated,
+                   fps=["%016x" % int(f) for f in eng.level_fps()])]
     while sc.level < max_depth:
         d = sc.step()
         if d["n_new"] == 0:
             break
         levels.append(dict(level=d["level"], n_new=d["n_new"], generated=d["generated"], deadlocks=d["deadlocks"],
-                           fps=["%016x" % int(f) for f in eng.level_fps()]))
+                           replicated=sc.replicated, fps=["%016x" % int(f) for f in eng.level_fps()]))
     # trace of the last state of the deepest non-empty local level (every rank takes part in every walk)
     walks = []
     for r in range(world):

@@ -12,11 +12,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(engine, world, params, max_depth, tmp_path, port):
+def run_world(engine, world, params, max_depth, tmp_path, port, replicate_below=0):
     out = str(tmp_path / ("shard_%s_w%d" % (engine, world)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "shard_worker.py"), engine] + \
-          [str(x) for x in params] + [str(max_depth), out]
+          [str(x) for x in params] + [str(max_depth), out, str(replicate_below)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -35,15 +35,22 @@ def check_against_oracle(ranks, params, max_depth):
     for li in range(nlev):
         want = [int(x) for x in ob.level_fps(li + 1)]
         got = []
+        assert all(r["levels"][li]["replicated"] == ranks[0]["levels"][li]["replicated"] for r in ranks)
+        if ranks[0]["levels"][li]["replicated"]:                    # replicated phase: every rank holds the whole level
+            for r in ranks:
+                assert sorted(int(x, 16) for x in r["levels"][li]["fps"]) == want, "level %d rank %d" % (li + 1, r["rank"])
+            got = want
         for r in ranks:
-            got += [int(x, 16) for x in r["levels"][li]["fps"]]     # records live with their generator, not their owner
+            if not r["levels"][li]["replicated"]:
+                got += [int(x, 16) for x in r["levels"][li]["fps"]]     # records live with their generator, not their owner
         assert sorted(got) == want, "level %d" % (li + 1)
+        assert ranks[0]["levels"][li]["n_new"] == len(want)
         if li > 0:
             assert ranks[0]["levels"][li]["generated"] == ob.info["generated"]
             assert ranks[0]["levels"][li]["deadlocks"] == ob.info["deadlocks"]
         if li + 1 < nlev or ranks[0]["depth"] < max_depth:
             ob.step()
-    assert ranks[0]["distinct"] == sum(len(r["levels"][li]["fps"]) for r in ranks for li in range(nlev))
+    assert all(r["distinct"] == ob.info["distinct"] for r in ranks)
     return ob
 
 
@@ -59,13 +66,21 @@ def replay_walks_with_oracle(ranks, params):
         assert "%016x" % fp in ranks[w["rank"]]["levels"][-1]["fps"]
 
 
-@pytest.mark.parametrize("world,params,max_depth", [(2, (2, 1, 2, 2), 40), (3, (2, 1, 1, 1), 40), (2, (3, 1, 2, 2), 7)])
-def test_sharded_level_loop_matches_single_process_oracle(tmp_path, world, params, max_depth):
-    ranks = run_world("fake", world, params, max_depth, tmp_path, 29640 + world)
+@pytest.mark.parametrize("world,params,max_depth,rb", [(2, (2, 1, 2, 2), 40, 0), (3, (2, 1, 1, 1), 40, 0), (2, (3, 1, 2, 2), 7, 0),
+                                                       (2, (2, 1, 2, 2), 40, 30), (3, (2, 1, 2, 2), 40, 10 ** 9)])
+def test_sharded_level_loop_matches_single_process_oracle(tmp_path, world, params, max_depth, rb):
+    """rb = replicate_below: 0 = sharded from Init on, 30 = the ranks explore the first levels on their own and partition the
+    first level with >= 30 new states, 10^9 = never sharded (every rank explores everything)"""
+    ranks = run_world("fake", world, params, max_depth, tmp_path, 29640 + world, rb)
     check_against_oracle(ranks, params, max_depth)
     replay_walks_with_oracle(ranks, params)
     assert all(r["walks"] == ranks[0]["walks"] for r in ranks)
-    if world > 1:
+    if rb >= 10 ** 9:
+        assert all(lv["replicated"] for r in ranks for lv in r["levels"])
+    elif rb:
+        flags = [lv["replicated"] for lv in ranks[0]["levels"]]
+        assert flags[0] and not flags[-1] and flags == sorted(flags, reverse=True)     # one switch, early
+    if world > 1 and rb == 0:
         assert sum(r["bytes_sent"] for r in ranks) > 0
         biggest = max(sum(len(r["levels"][li]["fps"]) for r in ranks) for li in range(len(ranks[0]["levels"])))
         if biggest >= 64 * world:                                       # Init lives on one rank: rebalancing must have spread it
@@ -94,11 +109,16 @@ def test_balance_plan_is_deterministic_and_conservative():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,params,depth", [(2, (3, 1, 2, 2), 11), (3, (3, 1, 3, 3), 9), (2, (5, 1, 2, 2), 6)])
-def test_sharded_hip_engine_on_one_gpu(tmp_path, world, params, depth):
-    """All ranks share device 0 and exchange over gloo (staged through the host): every HIP kernel of the sharded
-    protocol runs (k_expand bucketing, k_claim_batch, k_verdict, k_materialize into peer buckets, k_append_fixup)."""
-    ranks = run_world("hip", world, params, depth, tmp_path, 29650 + world)
+@pytest.mark.parametrize("engine,world,params,depth,rb", [
+    ("hip", 2, (3, 1, 2, 2), 11, 0), ("hip", 3, (3, 1, 3, 3), 9, 0), ("hip", 2, (5, 1, 2, 2), 6, 0),
+    ("hip", 2, (3, 1, 2, 2), 12, 200), ("hip", 3, (3, 1, 2, 2), 9, 10 ** 9),
+    ("hip-exact", 2, (3, 1, 2, 2), 11, 0), ("hip-exact", 3, (3, 1, 3, 3), 8, 50)])
+def test_sharded_hip_engine_on_one_gpu(tmp_path, engine, world, params, depth, rb):
+    """All ranks share device 0 and exchange over gloo (staged through the host): every HIP kernel of the sharded protocol
+    runs.  "hip" = single-pass levels (k_expand<true> with the sent-filter and speculative writes, k_claim_batch_fused,
+    k_apply_verdict), "hip-exact" = two-kernel levels (k_expand<false> bucketing, k_claim_batch, k_verdict, k_materialize);
+    rb > 0 adds the replicated phase (vsrmc_shard_local_step, k_partition); k_export / k_append_fixup when ranks drift."""
+    ranks = run_world(engine, world, params, depth, tmp_path, 29650 + world, rb)
     check_against_oracle(ranks, params, depth)
     # trace walks: ordinals of the HIP engine replay on the GPU to a state of the right level
     import vsr_tlaplus_amd as vt

@@ -21,13 +21,14 @@ ap.add_argument("--inv-mask", type=int, default=1)
 ap.add_argument("--no-symmetry", action="store_true")
 ap.add_argument("--assume-commit-number", action="store_true")
 ap.add_argument("--no-trace", action="store_true")
+ap.add_argument("--exact-ties", action="store_true")
 a = ap.parse_args()
 m = vt.Model.from_constants(R=a.R, C_=a.C, n=a.n, L=a.L, symmetry=not a.no_symmetry, invariant_mask=a.inv_mask,
                             assume_commit_number=a.assume_commit_number)
 t0 = time.time()
 mc = vt.ModelChecker(m, table_log2=a.table_log2, frontier_words=1 << a.frontier_words_log2,
                      frontier_states=1 << a.frontier_states_log2, pending_entries=1 << a.pending_log2,
-                     keep_trace=not a.no_trace)
+                     keep_trace=not a.no_trace, exact_ties=a.exact_ties)
 print(json.dumps(dict(setup_seconds=round(time.time() - t0, 3))))
 t0 = time.time()
 why = "exhausted"

@@ -18,7 +18,7 @@ class Layout(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("table_log2", C.c_int32), ("frontier_words", C.c_uint64),
                 ("frontier_states", C.c_uint64), ("pending_entries", C.c_uint64), ("keep_trace", C.c_int32),
-                ("rank", C.c_int32), ("world", C.c_int32), ("trace_entries", C.c_uint64), ("exact_ties", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("rank", C.c_int32), ("world", C.c_int32), ("trace_entries", C.c_uint64), ("exact_ties", C.c_int32), ("filter_log2", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class LevelInfo(C.Structure):
@@ -95,6 +95,8 @@ SYMBOLS = {
                                       C.POINTER(C.c_uint64)]),
     "vsrmc_shard_append": (C.c_int32, [V, V, C.c_uint64, V, V, V, C.c_uint64]),
     "vsrmc_shard_commit": (C.c_int32, [V, C.POINTER(LevelInfo)]),
+    "vsrmc_shard_local_step": (C.c_int32, [V, C.POINTER(LevelInfo)]),
+    "vsrmc_shard_partition": (C.c_int32, [V, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

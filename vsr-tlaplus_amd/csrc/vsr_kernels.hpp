@@ -170,7 +170,10 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
          // fused single-pass mode (nx_words != nullptr): the lane that inserts a fingerprint writes the successor at once
-         u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u64* lvl_tr, u32 ichunk, u32 wchunk, int tile, u32 ccap /* work-list capacity per tile */) {
+         u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u64* lvl_tr, u32 ichunk, u32 wchunk, int tile, u32 ccap /* work-list capacity per tile */,
+         // fused + sharded (world > 1): successors owned by another rank pass the rank's sent-filter, are written to the local
+         // next frontier SPECULATIVELY and announced to their owner; cand_idx remembers where, for k_apply_verdict
+         u64* filter, u64 fmask, u64* cand_idx, u32 cchunk /* candidate entries a block reserves per owner and global atomic */) {
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
@@ -188,7 +191,11 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
   // fused mode: the block's chunks of next-frontier indices and words
   __shared__ u64 s_ich_base, s_wch_base;
   __shared__ u32 s_ich_used, s_wch_used, s_tile_ibase, s_tile_wbase, s_tile_icur, s_tile_wcur, s_wneed;
+  // fused + sharded: the block's chunk of each owner's candidate bucket, (chunk base << 24 | entries used) in ONE word so
+  // that a lane's atomicAdd sees a consistent pair; "used == cchunk" = no room, the lane that draws it fetches a new chunk
+  __shared__ unsigned long long s_cstate[8];
   constexpr bool fused = FUSED;
+  constexpr u64 CS_NONE = ((u64)1 << 40) - 1;                   // chunk base of "no chunk yet"
 
   const int tid = threadIdx.x, lane = tid & 63;
   const u64 ntiles = (n_parents + tile - 1) / tile;
@@ -200,6 +207,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     s_chunk_base = 0; s_chunk_used = pchunk;
     s_ich_base = 0; s_ich_used = ichunk; s_wch_base = 0; s_wch_used = wchunk;
   }
+  if (tid < 8) s_cstate[tid] = (CS_NONE << 24) | cchunk;
   __syncthreads();
 
   for (u64 tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
@@ -413,7 +421,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       const u64 key = meta_make(level, ak, rank, p_base + (u64)p, ord);
       const u64 a_2 = __builtin_readcyclecounter();
       if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
-      if (world > 1) {                                          // sharded seen-set: route to the owner of fp
+      if (!fused && world > 1) {                                // sharded seen-set, exact scheme: route to the owner of fp
         const int owner = owner_of(fp, world);
         if (owner != rank) {
           for (int o = 0; o < world; o++)
@@ -430,16 +438,33 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
         }
       }
       if (fused) {
-        bool claimed, full;
-        u64 prev_meta;
-        table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, &my_probes, &full);
+        bool do_write, remote = false;
+        u64 prev_meta = META_EMPTY;
+        const int owner = world > 1 ? owner_of(fp, world) : rank;
+        if (owner != rank) {
+          // sent-filter: a direct-mapped, lossy set of (fingerprint, auxkey) tags this rank has announced before (any level).
+          // A hit = an exact repeat, dropped; a miss (or an evicted tag) only costs a redundant announcement.  Plain 8-byte
+          // loads / stores: a lost update has the same effect as an eviction.
+          u64 tag = fp ^ ((u64)(ak + 1) * 0x9E3779B97F4A7C15ull);
+          if (tag == 0) tag = 1;
+          u64* fs = filter + ((fp >> 6) & fmask);
+          my_probes++;
+          if (__hip_atomic_load(fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) continue;
+          __hip_atomic_store(fs, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          remote = true;
+          do_write = true;
+        } else {
+          bool claimed, full;
+          table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, &my_probes, &full);
+          if (full) {
+            raise_error(ctl, ERR_TABLE_FULL, fp);
+            continue;
+          }
+          do_write = claimed;
+        }
         const u64 a_3 = __builtin_readcyclecounter();
         if (tid == 0) s_acc[12] += a_3 - a_2;
-        if (full) {
-          raise_error(ctl, ERR_TABLE_FULL, fp);
-          continue;
-        }
-        if (claimed) {                                          // new state: this lane writes it out
+        if (do_write) {                                         // new state (or: possibly new, the owner decides): write it out
           const int plen = (int)(s_ref[p] & 255);
           const int clen = M.fixed + hdr_nmsg(D.hdr);
           const u32 io = atomicAdd(&s_tile_icur, 1u);
@@ -477,12 +502,37 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
           lvl_fp[idx] = fp;
           if (lvl_tr) lvl_tr[idx] = key;
           const int bad = check_invariants_child(M, rec, D);
-          if (bad) {
+          if (bad && !remote) {
             atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
             atomicOr(&ctl->viol_mask, (u32)bad);
           }
           atomicMax(&s_maxbag_out, (u32)hdr_nmsg(D.hdr));
           atomicAdd(&s_acc[9], (unsigned long long)clen);
+          if (remote) {
+            // announce (fp, key) to the owner: entry i of the block's chunk of that owner's bucket
+            u64 i = 0;
+            for (;;) {
+              const unsigned long long old = atomicAdd(&s_cstate[owner], 1ull);
+              const u32 pos = (u32)(old & 0xFFFFFFull);
+              if (pos == cchunk) {                              // drew the "chunk is full" ticket: fetch the next chunk
+                u64 nb = atomicAdd((unsigned long long*)&ctl->cand_cnt[owner], (unsigned long long)cchunk);
+                if (nb + cchunk > cand_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
+                const u64 ob_ = (u64)(old >> 24);
+                (void)ob_;                                      // the old chunk was used up completely: nothing to invalidate
+                i = nb;
+                atomicExch(&s_cstate[owner], ((unsigned long long)nb << 24) | 1ull);
+                break;
+              }
+              if (pos < cchunk) {
+                i = (u64)(old >> 24) + pos;
+                break;
+              }
+            }                                                   // pos > cchunk: another lane is fetching the chunk; draw again
+            const u64 e = (u64)owner * cand_cap + i;
+            cand_send[2 * e] = fp;
+            cand_send[2 * e + 1] = key;
+            cand_idx[e] = idx | ((u64)bad << 62);
+          }
         }
         // same-level duplicate with a different canonical auxkey = the tie the single-pass scheme cannot arbitrate
         if (prev_meta != META_EMPTY && meta_level(prev_meta) == level && meta_auxkey(prev_meta) != meta_auxkey(key)) atomicAdd(&s_acc[8], 1ull);
@@ -539,6 +589,19 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
         nx_off[base + k] = 0;
         lvl_fp[base + k] = 0;
         if (lvl_tr) lvl_tr[base + k] = ~(u64)0;
+      }
+      if (world > 1) {
+        __syncthreads();
+        for (int o = 0; o < world; o++) {
+          const u64 st = s_cstate[o];
+          const u64 base = st >> 24;
+          const u32 used = (u32)(st & 0xFFFFFFull) < cchunk ? (u32)(st & 0xFFFFFFull) : cchunk;
+          if (base == CS_NONE) continue;
+          for (u32 k = used + tid; k < cchunk; k += VSR_BLOCK) {
+            cand_send[2 * ((u64)o * cand_cap + base + k)] = 0;  // fingerprint 0 = no candidate
+            cand_send[2 * ((u64)o * cand_cap + base + k) + 1] = ~(u64)0;
+          }
+        }
       }
       if (tid == 0) {
         if (s_acc[8]) atomicAdd((unsigned long long*)&ctl->ties, s_acc[8]);
@@ -816,6 +879,68 @@ __global__ void k_verdict(const Slot* __restrict__ table, const u64* __restrict_
   if (i >= n) return;
   u64 s = rslot[i];
   verdict[i] = (s != ~(u64)0 && table[s].meta == entries[2 * i + 1]) ? 1 : 0;
+}
+// Single-pass (fused) flavour of the owner's side: the candidate that INSERTS the fingerprint wins, every other candidate
+// of the same fingerprint loses — the same rule k_expand<true> applies to the successors this rank owns itself, which are
+// already in the table when the received candidates are claimed.  verdict[i] = 1 for winners; entries with fp == 0 are the
+// unused tails of the senders' chunks.
+__global__ void k_claim_batch_fused(Slot* table, u64 tmask, const u64* __restrict__ entries, u64 n, int level, uint8_t* verdict,
+                                    LevelCtl* ctl) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 fp = entries[2 * i], key = entries[2 * i + 1];
+  if (fp == 0) {
+    verdict[i] = 0;
+    return;
+  }
+  bool claimed, full;
+  u64 prev_meta;
+  u32 np = 0;
+  table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, &np, &full);
+  if (full) raise_error(ctl, ERR_TABLE_FULL, fp);
+  verdict[i] = claimed ? 1 : 0;
+  if (prev_meta != META_EMPTY && meta_level(prev_meta) == level && meta_auxkey(prev_meta) != meta_auxkey(key))
+    atomicAdd((unsigned long long*)&ctl->ties, 1ull);
+  for (int o = 32; o > 0; o >>= 1) np += __shfl_down(np, o);
+  if ((threadIdx.x & 63) == 0 && np) atomicAdd((unsigned long long*)&ctl->probes, (unsigned long long)np);
+}
+// k_apply_verdict: the generator's side of the single-pass sharded level — candidate i of the bucket sent to one owner was
+// written speculatively at state index cand_idx[i] (bits 62..63: violated-invariant mask); losers are withdrawn (invalid
+// ref, exactly like an unused index), winners that violate an invariant are reported now.
+__global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __restrict__ cand_idx, const uint8_t* __restrict__ verdict,
+                                u64 n, u64* nx_off, u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 fp = entries[2 * i];
+  if (fp == 0) return;
+  const u64 e = cand_idx[i];
+  const u64 idx = e & (((u64)1 << 62) - 1);
+  if (verdict[i]) {
+    const u32 bad = (u32)(e >> 62);
+    if (bad) {
+      atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
+      atomicOr(&ctl->viol_mask, bad);
+    }
+  } else {
+    nx_off[idx] = 0;
+    lvl_fp[idx] = 0;
+    if (lvl_tr) lvl_tr[idx] = ~(u64)0;
+  }
+}
+// k_partition: end of the replicated phase of a sharded run (every rank explored the small early levels by itself): keep
+// the states of the current frontier this rank owns, withdraw the others.  counter[0] = states kept.
+__global__ void k_partition(u64* off, u64* lvl_fp, u64 n, int rank, int world, u64* counter) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u32 keep = 0;
+  if (i < n && off[i] != 0) {
+    if (owner_of(lvl_fp[i], world) == rank) keep = 1;
+    else {
+      off[i] = 0;
+      lvl_fp[i] = 0;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) keep += __shfl_down(keep, o);
+  if ((threadIdx.x & 63) == 0 && keep) atomicAdd((unsigned long long*)counter, (unsigned long long)keep);
 }
 // k_append_fixup: records received from a peer were copied to nx_words[base_words ..); publish their offsets,
 // fingerprints and trace keys at state indices n0 ..

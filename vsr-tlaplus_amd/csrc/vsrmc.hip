@@ -762,6 +762,11 @@ struct vsrmc_checker {
   u64 n_valid = 1;                       // states in the newest level (n_frontier is its index range, holes included)
   u64* rslot = nullptr;                  // sharded: slot of every received candidate
   u64 rslot_cap = 0;
+  u64* filter = nullptr;                 // sharded single-pass levels: this rank's sent-filter (vsr_kernels.hpp, k_expand)
+  u64 fmask = 0;
+  u64* cand_idx = nullptr;               // ... and where each announced candidate was written (world x cand_cap)
+  u64 cand_idx_cap = 0;
+  bool level_fused = false;              // the level in flight is a single-pass level
 };
 
 namespace {
@@ -780,7 +785,10 @@ int checker_seed(vsrmc_checker* c) {
   u64 zero = (u64)len, init_fp = 0;                            // ref of record 0: offset 0, length len
   u32 init_ak = 0;
   canonical_fp(M, dev[0], &dev[M.h0], &init_fp, &init_ak);
-  const bool mine = c->opt.world <= 1 || owner_of(init_fp, c->opt.world) == c->opt.rank;   // sharded: Init lives on its owner
+  // sharded: every rank starts with Init (replicated phase: the small early levels are explored by every rank on its own,
+  // vsrmc_shard_local_step); vsrmc_shard_partition then leaves each state with its owner
+  const bool mine = true;
+  if (c->filter) HIPCHK(hipMemsetAsync(c->filter, 0, (c->fmask + 1) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(LevelCtl), c->stream));
   if (mine) {
     HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyHostToDevice, c->stream));
@@ -849,6 +857,11 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     if (e == hipSuccess) e = hipMalloc((void**)&c->tr_all, c->trace_cap * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_level_base, 512 * 8);
   }
+  if (e == hipSuccess && o->world > 1 && !o->exact_ties) {
+    const int fl = o->filter_log2 > 0 ? o->filter_log2 : o->table_log2;
+    c->fmask = ((u64)1 << fl) - 1;
+    e = hipMalloc((void**)&c->filter, (c->fmask + 1) * 8);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&c->pending, o->pending_entries * 16);
   if (e == hipSuccess) e = hipMalloc((void**)&c->ctl, sizeof(LevelCtl));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_find, 8);
@@ -892,13 +905,21 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
   std::memset(&c->h, 0, sizeof(c->h));
   c->h.viol_fp = ~(u64)0;
   HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
+  c->level_fused = !c->opt.exact_ties;
   if (c->n_frontier > 0) {
     // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
     const int tile = M.R <= 3 ? 128 : 64;
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
     // every block reserves pending-list room in chunks: the list must hold one chunk per block beyond the real entries
     const u32 pchunk = c->opt.pending_entries >= ((u64)1 << 24) ? 8192u : (u32)VSR_CAND_CAP;
-    const bool fused = !io && !c->opt.exact_ties;
+    const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
+    if (fused && io && c->cand_idx_cap < (u64)c->opt.world * io->cand_cap) {
+      if (c->cand_idx) (void)hipFree(c->cand_idx);
+      c->cand_idx = nullptr;
+      c->cand_idx_cap = 0;
+      HIPCHK(hipMalloc((void**)&c->cand_idx, (u64)c->opt.world * io->cand_cap * 8));
+      c->cand_idx_cap = (u64)c->opt.world * io->cand_cap;
+    }
     unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 3);
     if (!fused) grid = (unsigned)std::min<u64>(grid, std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));   // the pending list is only used by the two-kernel scheme
     const u32 ccap = tile == 128 ? 1536u : (u32)VSR_CAND_CAP;   // keeps two blocks per CU in LDS at 128 records per tile
@@ -908,7 +929,9 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
     const int nxt = c->cur ^ 1;
     u64 nx_cap = c->opt.frontier_states;                       // the trace log bounds the level as well
     if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
-    u32 ichunk = 0, wchunk = 0;
+    u32 ichunk = 0, wchunk = 0, cchunk = 0;
+    if (fused && io)   // candidate entries a block reserves per owner at a time: <= 1/4 of a bucket in total over all blocks
+      cchunk = (u32)std::max<u64>(16, std::min<u64>(512, io->cand_cap / (4 * (u64)c->num_cus * 2)));
     if (fused) {
       // persistent blocks (2 resident per CU: 225 VGPRs, 79 KB LDS): every block leaves one partly used index chunk and
       // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
@@ -920,13 +943,14 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
     if (fused)
       hipLaunchKernelGGL(k_expand<true>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
-                         c->lds_stride, 1, nullptr, 0, pchunk, c->words[nxt], c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp,
-                         c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk, wchunk, tile, ccap);
+                         c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
+                         c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
+                         wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk);
     else
       hipLaunchKernelGGL(k_expand<false>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
-                         0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap);
+                         0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap, nullptr, 0, nullptr, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -940,7 +964,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
   c->tr_base = c->tr_base0();
   c->nx_n = c->nx_w = 0;
   if (c->h.err) return level_error(c, c->h, c->level + 1);
-  if (!io && !c->opt.exact_ties) {                             // fused: the level is already materialised
+  if (!c->opt.exact_ties) {                                    // fused: the level is already materialised (sharded: speculatively)
     c->nx_n = c->h.n_new;
     c->nx_w = c->h.words_new;
     if (c->h.ties) {
@@ -1064,10 +1088,7 @@ int find_fp_newest(vsrmc_checker* c, u64 fp, u64* idx) {
 
 extern "C" {
 
-int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
-  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
-  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
-  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: drive the level with the vsrmc_shard_* phases");
+static int32_t step_local(vsrmc_checker* c, vsrmc_level_info* info) {
   int rc = phase_expand(c, nullptr);
   if (!rc && c->opt.exact_ties) rc = phase_materialize_local(c);
   if (rc) {   // like a TLC evaluation error: the run aborts, the partial level is not committed
@@ -1080,6 +1101,35 @@ int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
   rc = phase_commit(c, info);
   if (rc) return rc;
   if (info->viol_mask) return find_fp_newest(c, info->viol_fp, &info->viol_index);
+  return 0;
+}
+
+int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
+  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: drive the level with the vsrmc_shard_* phases");
+  return step_local(c, info);
+}
+
+int32_t vsrmc_shard_local_step(vsrmc_checker* c, vsrmc_level_info* info) {
+  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  return step_local(c, info);
+}
+
+int32_t vsrmc_shard_partition(vsrmc_checker* c, uint64_t* n_kept) {
+  if (!c || !n_kept) return fail(VSRMC_E_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(c->opt.device));
+  *n_kept = c->n_valid;
+  if (c->opt.world <= 1 || c->n_frontier == 0) return 0;
+  u64 zero = 0;
+  HIPCHK(hipMemcpyAsync(c->d_find, &zero, 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_partition, dim3((unsigned)((c->n_frontier + 255) / 256)), dim3(256), 0, c->stream, c->off[c->cur], c->lvl_fp,
+                     c->n_frontier, c->opt.rank, c->opt.world, c->d_find);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(n_kept, c->d_find, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->n_valid = *n_kept;
   return 0;
 }
 
@@ -1112,7 +1162,7 @@ int32_t vsrmc_shard_claim(vsrmc_checker* c, const uint64_t* d_cand_recv, uint64_
   if (!c || (n && (!d_cand_recv || !d_verdict))) return fail(VSRMC_E_ARG, "NULL argument");
   if (n == 0) return 0;
   HIPCHK(hipSetDevice(c->opt.device));
-  if (n > c->rslot_cap) {
+  if (c->opt.exact_ties && n > c->rslot_cap) {
     if (c->rslot) (void)hipFree(c->rslot);
     c->rslot = nullptr;
     c->rslot_cap = 0;
@@ -1120,6 +1170,13 @@ int32_t vsrmc_shard_claim(vsrmc_checker* c, const uint64_t* d_cand_recv, uint64_
     c->rslot_cap = n;
   }
   unsigned grid = (unsigned)((n + 255) / 256);
+  if (!c->opt.exact_ties) {   // single-pass level: the inserting candidate wins, the verdict is known at once
+    hipLaunchKernelGGL(k_claim_batch_fused, dim3(grid), dim3(256), 0, c->stream, c->table, c->tmask, d_cand_recv, n, c->level + 1, d_verdict,
+                       c->ctl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+  }
   hipLaunchKernelGGL(k_claim_batch, dim3(grid), dim3(256), 0, c->stream, c->table, c->tmask, d_cand_recv, n, c->level + 1, c->rslot, c->ctl);
   hipLaunchKernelGGL(k_verdict, dim3(grid), dim3(256), 0, c->stream, c->table, d_cand_recv, c->rslot, n, d_verdict);
   HIPCHK(hipGetLastError());
@@ -1134,6 +1191,37 @@ int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, cons
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   // every winner — local owner or remote verdict — is written into THIS rank's next frontier: records stay with their
   // generator, only 16-byte candidates and verdict bytes cross ranks (rebalancing moves records in bulk when needed)
+  if (c->level_fused) {
+    // single-pass level: k_expand wrote the announced successors speculatively; withdraw the ones whose owner said no
+    HIPCHK(hipSetDevice(c->opt.device));
+    const int nxt = c->cur ^ 1;
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    for (int o = 0; o < c->opt.world; o++) {
+      if (o == c->opt.rank) continue;
+      const u64 n = std::min<u64>(c->h.cand_cnt[o], io->cand_cap);
+      if (n == 0) continue;
+      if (!d_verdict_in) return fail(VSRMC_E_ARG, "verdicts missing");
+      hipLaunchKernelGGL(k_apply_verdict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, io->cand_send + 2 * (u64)o * io->cand_cap,
+                         c->cand_idx + (u64)o * io->cand_cap, d_verdict_in + (u64)o * io->cand_cap, n, c->off[nxt], c->lvl_fp,
+                         c->tr_all ? c->tr_all + c->tr_base : nullptr, c->ctl);
+      HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    c->materialize_ms += ms;
+    if (c->h.err) return level_error(c, c->h, c->level + 1);
+    if (c->h.ties) {
+      c->failed = 1;
+      return fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables (SURVEY F2): "
+                                 "create the checker with vsrmc_options.exact_ties = 1");
+    }
+    c->nx_n = c->h.n_new;
+    c->nx_w = c->h.words_new;
+    return 0;
+  }
   int rc = phase_materialize_local(c);
   const int nxt = c->cur ^ 1;
   u64 nx_cap = c->opt.frontier_states;
@@ -1375,6 +1463,8 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
   if (c->ctl) (void)hipFree(c->ctl);
   if (c->d_find) (void)hipFree(c->d_find);
   if (c->rslot) (void)hipFree(c->rslot);
+  if (c->filter) (void)hipFree(c->filter);
+  if (c->cand_idx) (void)hipFree(c->cand_idx);
   for (int i = 0; i < 4; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -147,20 +147,53 @@ class ShardedChecker:
         append(words, off, fp, key)       -> err
         commit()                          -> dict(n_new, generated, deadlocks, viol_fp, viol_mask, max_bag, ...)
         find_fp(fp) -> index or None ; trace_entry(level, index) -> key ; error_text()
+        local_step()                      -> dict like commit(): one whole level on this rank alone (replicated phase)
+        partition()                       -> states of the current frontier this rank keeps (its own)
+
+    Replicated phase: an engine starts with Init on every rank.  While a level has fewer than `replicate_below` new states
+    every rank explores it on its own — no collective at all, the ranks compute identical state sets — because a level of
+    a few thousand states costs less than the five collectives of a sharded level.  The first level that reaches
+    `replicate_below` new states is partitioned by owner and the sharded protocol takes over.  0 = sharded from Init on.
     """
 
-    def __init__(self, engine, exchanger, balance_tol=1.25):
+    def __init__(self, engine, exchanger, balance_tol=1.25, replicate_below=0):
         self.e = engine
         self.x = exchanger
         self.rank, self.world = exchanger.rank, exchanger.world
         self.level = 1
-        tot = self.x.allreduce([engine.local_distinct()], dist.ReduceOp.SUM)
-        self.distinct = tot[0]
-        self.n_frontier = self.distinct
+        self.distinct = 1
+        self.n_frontier = 1
         self.violation = None
         self.levels = []
         self.balance_tol = balance_tol
         self.moved = 0
+        self.replicated = True
+        self.replicate_below = replicate_below
+        if replicate_below <= 1:
+            self._end_replicated()
+
+    def _end_replicated(self):
+        self.e.partition()
+        self.replicated = False
+
+    def _step_replicated(self):
+        info = self.e.local_step()
+        self.level += 1
+        self.n_frontier = info["n_new"]
+        self.distinct += info["n_new"]
+        viol = info["viol_fp"] if info["viol_mask"] else None
+        out = dict(level=self.level, n_new=info["n_new"], generated=info["generated"], deadlocks=info["deadlocks"],
+                   pending=info["pending"], distinct=self.distinct, local=info, viol_fp=viol, replicated=True,
+                   per_rank_new=[info["n_new"]] * self.world)
+        if info["n_new"]:
+            self.levels.append(out)
+        if viol is not None and self.violation is None:
+            # every rank holds the state; rank 0's copy (and its private trace log) is the one that gets walked
+            self.violation = dict(level=self.level, rank=0, index=self.e.find_fp(viol) if self.rank == 0 else -1, fp=viol)
+            self.violation["index"] = self.x.allreduce([self.violation["index"]], dist.ReduceOp.MAX)[0]
+        elif info["n_new"] >= self.replicate_below:
+            self._end_replicated()
+        return out
 
     def _raise_if(self, err, phase):
         if err:
@@ -202,6 +235,8 @@ class ShardedChecker:
         return err
 
     def step(self):
+        if self.replicated:
+            return self._step_replicated()
         e, x, me = self.e, self.x, self.rank
         cands, err = e.expand()
         recv, gerr, cat = x.exchange(cands, err)                # 2 collectives: (count, err) pairs, then the buckets
@@ -264,7 +299,7 @@ class HipShardEngine:
 
     def __init__(self, model, rank, world, device=0, table_log2=26, frontier_words=1 << 27, frontier_states=1 << 22,
                  pending_entries=1 << 23, cand_cap=1 << 22, rec_cap=1 << 21, rec_words_cap=1 << 26, keep_trace=True,
-                 trace_entries=0):
+                 trace_entries=0, exact_ties=False, filter_log2=0):
         """cand_cap: (fp, key) candidates per peer and level; rec_cap / rec_words_cap: records / words one rebalancing move
         to one peer may carry."""
         self.model, self.rank, self.world, self.device = model, rank, world, device
@@ -273,6 +308,7 @@ class HipShardEngine:
         o.device, o.table_log2 = device, table_log2
         o.frontier_words, o.frontier_states, o.pending_entries = frontier_words, frontier_states, pending_entries
         o.keep_trace, o.trace_entries, o.rank, o.world = int(keep_trace), trace_entries, rank, world
+        o.exact_ties, o.filter_log2 = int(exact_ties), filter_log2
         self._h = C.c_void_p()
         check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))
         dev = torch.device("cuda", device)
@@ -369,6 +405,23 @@ class HipShardEngine:
         self.kernel_ms["materialize"] += d["materialize_ms"]
         self.last = d
         return d
+
+    def local_step(self):
+        info = capi.LevelInfo()
+        rc = capi.load().vsrmc_shard_local_step(self._h, C.byref(info))
+        if rc != 0:
+            self._err_text = capi.load().vsrmc_last_error().decode()
+            raise ShardError("replicated level: %s" % self._err_text)
+        d = info.as_dict()
+        self.kernel_ms["expand"] += d["expand_ms"]
+        self.kernel_ms["materialize"] += d["materialize_ms"]
+        self.last = d
+        return d
+
+    def partition(self):
+        n = C.c_uint64()
+        check(capi.load().vsrmc_shard_partition(self._h, C.byref(n)))
+        return n.value
 
     def find_fp(self, fp):
         idx = C.c_uint64()
