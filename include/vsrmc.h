@@ -84,6 +84,20 @@ void vsrmc_fpset_destroy(vsrmc_fpset* s);
 int32_t vsrmc_expand_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off, uint64_t n,
                            uint64_t* out_words, uint64_t out_words_cap, uint64_t* out_meta, uint64_t out_cap,
                            uint64_t* n_out, uint64_t* words_out);
+/* ---- TLC state / trace import (≙ reading a TLC trace file or -dump output) ------------------------------
+ * `text` holds states in TLC's value syntax: a trace expression  << [ _TEAction |-> [...], var |-> value, ... ], ... >>
+ * (the format of the reference's state_transfer_violation_trace.txt), one state record  [ var |-> value, ... ]  (what
+ * vsrmc_model_format_state prints), or TLC's console form ("State k: <Action ...>" + "/\ var = value" conjuncts).
+ * out: wire records (bag words sorted), n+1 offsets, per state the action id named in the text (-1 if none).
+ * words == NULL: only *n_states is set.  Variables the text leaves out keep their Init value. */
+int32_t vsrmc_model_parse_states(const vsrmc_model* m, const char* text, uint64_t* words, uint64_t cap_words, uint64_t* off,
+                                 int32_t* actions, uint64_t cap_states, uint64_t* n_states);
+/* Is this sequence of states a behaviour of the model?  State 0 must be Init and every later state one of the successors the
+ * GPU generates for its predecessor.  ords[i] / actions[i+1]: ordinal and action id of the step into state i+1 (ords can be fed
+ * to vsrmc_model_replay); *first_bad: index of the first state that does not follow, -1 if none; *inv_mask_last: invariants
+ * the last state violates. */
+int32_t vsrmc_model_check_trace(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off, uint64_t n_states,
+                                uint32_t* ords, int32_t* actions, int64_t* first_bad, int32_t* inv_mask_last);
 /* canonical VIEW fingerprints (TLCState.fingerPrint with VIEW + SYMMETRY) of n records */
 int32_t vsrmc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off,
                                 uint64_t n, uint64_t* fps, uint32_t* auxkeys);

@@ -1,0 +1,157 @@
+"""TLC state / trace import (vsr-tlaplus_amd/csrc/vsr_parse.hpp behind vsrmc_model_parse_states).
+
+CPU part: the reader is the inverse of the printer, and the printer is pinned line by line to the reference's
+state_transfer_violation_trace.txt (test_host_cpu.py), so reading back the printed golden states must give the golden
+records; when /root/reference is present (this container, not the GPU box) the real file is read as well.
+GPU part (-m gpu): the 24 states of that trace are a behaviour of the lowered model — every step is a successor generated
+by the HIP kernels, under the action TLC names, and the last state violates AcknowledgedWriteNotLost."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+REF_TRACE = "/root/reference/state_transfer_violation_trace.txt"
+
+
+@pytest.fixture(scope="module")
+def vt():
+    import __graft_entry__
+    __graft_entry__.build()
+    import vsr_tlaplus_amd as vt
+    return vt
+
+
+def _model(vt, p):
+    return vt.Model.from_constants(R=p["R"], C_=p["C"], n=len(p["values"]), L=p["L"])
+
+
+def _rec(st):
+    return np.array([int(w, 16) for w in st["words"]], dtype=np.uint64)
+
+
+def _normal(m, rec):
+    h0 = int(m.layout.fixed_words)                                      # wire layout: header + replica blocks, then the bag
+    r = np.array(rec, dtype=np.uint64)
+    r[h0:] = np.sort(r[h0:])
+    return r
+
+
+def _trace_expression(m, states):
+    """the golden states printed in the layout of the reference's file (trace:1-30)"""
+    blocks = []
+    for st in states:
+        body = m.format_state(_rec(st)).splitlines()[1:-1]
+        head = ' _TEAction |-> [\n   position |-> %d,\n   name |-> "%s",\n   location |-> "Unknown location"\n ],' % (
+            int(st["position"]), st["action"])
+        blocks.append("[\n" + head + "\n" + "\n".join(body) + "\n]")
+    return "<<\n" + ",\n".join(blocks) + "\n>>\n"
+
+
+def test_reader_inverts_the_printer_on_the_golden_trace(vt, golden_trace):
+    m = _model(vt, golden_trace["params"])
+    for st in golden_trace["states"]:
+        got = m.parse_states(m.format_state(_rec(st)))
+        assert len(got) == 1 and got[0][0] is None
+        assert np.array_equal(got[0][1], _normal(m, _rec(st))), st["position"]
+
+
+def test_reader_takes_a_trace_expression_and_the_console_form(vt, golden_trace):
+    m = _model(vt, golden_trace["params"])
+    states = golden_trace["states"]
+    got = m.parse_states(_trace_expression(m, states))
+    assert [a for a, _ in got] == [st["action"] for st in states]
+    for (_, rec), st in zip(got, states):
+        assert np.array_equal(rec, _normal(m, _rec(st)))
+    # TLC's console form: "State k: <Action line ...>" + /\ var = value
+    text = ""
+    for st in states[:6]:
+        body = [l.rstrip(",") for l in m.format_state(_rec(st)).splitlines()[1:-1]]
+        name = st["action"] if st["action"] != "Initial predicate" else "Initial predicate"
+        text += "State %d: <%s line 1, col 1 to line 2, col 2 of module VSR>\n" % (int(st["position"]), name)
+        text += "\n".join("/\\ " + l.replace(" |-> ", " = ", 1) for l in body) + "\n\n"
+    got = m.parse_states(text)
+    assert [a for a, _ in got] == [st["action"] for st in states[:6]]
+    for (_, rec), st in zip(got, states):
+        assert np.array_equal(rec, _normal(m, _rec(st)))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TRACE), reason="the reference checkout is not on this machine")
+def test_reader_on_the_reference_file_itself(vt, golden_trace):
+    m = _model(vt, golden_trace["params"])
+    with open(REF_TRACE) as f:
+        got = m.parse_states(f.read())
+    assert len(got) == 24
+    for (action, rec), st in zip(got, golden_trace["states"]):
+        assert action == st["action"]
+        assert np.array_equal(rec, _normal(m, _rec(st))), st["position"]
+
+
+def test_reader_refuses_what_the_packed_record_cannot_hold(vt, golden_trace):
+    m = _model(vt, golden_trace["params"])
+    good = m.format_state(_rec(golden_trace["states"][7]))
+    for bad, what in [(good.replace("rep_view_number |-> <<", "rep_view_number |-> <<9, "), "ReplicaCount"),
+                      (good.replace("aux_svc |-> ", "aux_svc |-> 9"), "outside the range"),
+                      (good.replace("rep_status |-> <<Normal", "rep_status |-> <<Recovering"), "Recovering"),
+                      (good.replace("aux_svc", "aux_bogus"), "unknown variable"),
+                      (good.replace("operation |-> v1", "operation |-> v9"), "Values"),
+                      (good[: len(good) // 2], "expected"),
+                      ("", "empty")]:
+        with pytest.raises(vt.VsrmcError) as ei:
+            m.parse_states(bad)
+        assert what in str(ei.value), (what, str(ei.value))
+    # variables the text leaves out keep their Init value
+    only = m.parse_states("[ rep_view_number |-> <<1, 1, 1>> ]")
+    assert np.array_equal(only[0][1], m.init_state())
+
+
+def test_reader_round_trips_deep_config2_states(vt):
+    """NewState messages with first_op > 1 (function-valued logs), DVC slots, acked values: the 28-state counter-example"""
+    with open(os.path.join(GOLDEN, "config2_violation.json")) as f:
+        fx = json.load(f)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    for st in fx["trace"]:
+        rec = np.array([int(w, 16) for w in st["words"]], dtype=np.uint64)
+        got = m.parse_states(m.format_state(rec))
+        assert np.array_equal(got[0][1], _normal(m, rec))
+
+
+@pytest.mark.gpu
+def test_reference_trace_is_a_behaviour_of_the_hip_successor_function(vt, golden_trace):
+    m = _model(vt, golden_trace["params"])
+    states = golden_trace["states"]
+    parsed = m.parse_states(_trace_expression(m, states))
+    res = m.check_trace([rec for _, rec in parsed])
+    assert res["ok"] and res["first_bad"] == -1
+    assert res["actions"] == [st["action"] for st in states]
+    assert res["inv_mask_last"] == 1                                     # AcknowledgedWriteNotLost
+    # the ordinals replay to the same states
+    tr = m.replay(res["ords"])
+    assert [a for a, _ in tr] == res["actions"]
+    for (_, rec), (_, want) in zip(tr, parsed):
+        assert np.array_equal(_normal(m, rec), want)
+    # a corrupted behaviour is caught at the right place
+    broken = [rec.copy() for _, rec in parsed]
+    broken[10] = broken[9]
+    res = m.check_trace(broken)
+    assert not res["ok"] and res["first_bad"] == 10
+    res = m.check_trace(broken[1:])
+    assert not res["ok"] and res["first_bad"] == 0
+
+
+@pytest.mark.gpu
+def test_cli_validate_trace(vt, golden_trace, tmp_path):
+    m = _model(vt, golden_trace["params"])
+    from test_host_cpu import _cfg
+    cfg = _cfg(tmp_path, R=3, vals="v1, v2, v3", L=3)                              # README:13-18
+    tf = tmp_path / "trace.txt"
+    tf.write_text(_trace_expression(m, golden_trace["states"]))
+    r = subprocess.run([os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc"), "-config", str(cfg), "-noTLA", "-validateTrace", str(tf)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 12, r.stdout + r.stderr
+    assert "24 states read" in r.stdout and "The trace is a behaviour of the model." in r.stdout
+    assert "Its last state violates invariant AcknowledgedWriteNotLost." in r.stdout
+    assert "State 24: <%s>" % golden_trace["states"][-1]["action"] in r.stdout

@@ -119,6 +119,36 @@ class Model:
         check(capi.load().vsrmc_model_replay(self._h, device, _p(o), n, _p(words), cap_w, _p(off), _p(acts), len(off), C.byref(ns)))
         return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(ns.value)]
 
+    def parse_states(self, text):
+        """TLC's value syntax (trace expression, one state record, or console form) -> [(action name or None, wire record)];
+        the inverse of format_state (≙ reading a TLC trace file)."""
+        raw = text.encode() if isinstance(text, str) else text
+        ns = C.c_uint64()
+        check(capi.load().vsrmc_model_parse_states(self._h, raw, None, 0, None, None, 0, C.byref(ns)))
+        n = ns.value
+        cap_w = max(1, n) * int(self.layout.fixed_words + 255)
+        words = np.zeros(cap_w, dtype=np.uint64)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        acts = np.zeros(max(1, n), dtype=np.int32)
+        check(capi.load().vsrmc_model_parse_states(self._h, raw, _p(words), cap_w, _p(off), _p(acts), n + 1, C.byref(ns)))
+        return [(ACTION_NAMES[acts[t]] if acts[t] >= 0 else None, words[int(off[t]): int(off[t + 1])].copy()) for t in range(n)]
+
+    def check_trace(self, records, device=0):
+        """Is this list of wire records a behaviour of the model (Init, then successor after successor, as generated on the
+        GPU)?  -> dict(ok, first_bad, ords, actions, inv_mask_last)."""
+        n = len(records)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        for t, r in enumerate(records):
+            off[t + 1] = off[t] + np.uint64(len(r))
+        words = np.concatenate([np.asarray(r, dtype=np.uint64) for r in records]) if n else np.zeros(1, dtype=np.uint64)
+        ords = np.zeros(max(1, n), dtype=np.uint32)
+        acts = np.full(max(1, n), -1, dtype=np.int32)
+        bad, inv = C.c_int64(), C.c_int32()
+        check(capi.load().vsrmc_model_check_trace(self._h, device, _p(words), _p(off), n, _p(ords), _p(acts), C.byref(bad), C.byref(inv)))
+        good = n if bad.value < 0 else bad.value
+        return dict(ok=bad.value < 0, first_bad=bad.value, ords=[int(x) for x in ords[: max(0, good - 1)]],
+                    actions=[ACTION_NAMES[a] for a in acts[:good]], inv_mask_last=inv.value)
+
     def close(self):
         if self._h:
             capi.load().vsrmc_model_destroy(self._h)

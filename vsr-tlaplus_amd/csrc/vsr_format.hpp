@@ -71,6 +71,8 @@ inline std::string fmt_msg(const std::vector<std::string>& vals, u64 w) {
       u32 lg = m_lg(w) & 0xFFFFFF;
       if (fo == 1) {
         s += ", log |-> " + fmt_seq_log(vals, lg);
+      } else if (!(lg >> (8 * (fo - 1)))) {  // first_op > op_number: the empty function
+        s += ", log |-> <<>>";
       } else {                             // a function on first_op..op_number that is not a sequence
         s += ", log |-> (";
         bool first = true;

@@ -16,6 +16,7 @@
 
 #include "../../include/vsrmc.h"
 #include "vsr_format.hpp"
+#include "vsr_parse.hpp"
 #include "vsr_kernels.hpp"
 
 using namespace vsr;
@@ -546,6 +547,87 @@ int32_t vsrmc_expand_batch(const vsrmc_model* m, int32_t device, const uint64_t*
   }
   (void)hipFree(d_words); (void)hipFree(d_off); (void)hipFree(d_ow); (void)hipFree(d_om); (void)hipFree(d_cnt);
   return ret;
+}
+
+// ---- TLC trace / state import: text in TLC's value syntax -> wire records ---------------------------------
+int32_t vsrmc_model_parse_states(const vsrmc_model* m, const char* text, uint64_t* words, uint64_t cap_words, uint64_t* off,
+                                 int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
+  if (!m || !text || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
+  std::vector<ParsedState> st;
+  std::string err;
+  if (!parse_states_tlc(m->M, m->value_names, text, &st, &err)) return fail(VSRMC_E_CFG, "TLC state text: " + err);
+  *n_states = st.size();
+  u64 total = 0;
+  for (const ParsedState& s : st) total += s.rec.size();
+  if (!words || !off) return 0;                                 // size query
+  if (cap_states < st.size() + 1 || cap_words < total) return fail(VSRMC_E_ARG, "buffer too small");
+  u64 pos = 0;
+  for (size_t i = 0; i < st.size(); i++) {
+    off[i] = pos;
+    std::copy(st[i].rec.begin(), st[i].rec.end(), words + pos);
+    pos += st[i].rec.size();
+    if (actions) {
+      actions[i] = -1;
+      for (int a = 0; a < 16; a++)
+        if (st[i].action == vsrmc_action_name(a)) actions[i] = a;
+    }
+  }
+  off[st.size()] = pos;
+  return 0;
+}
+
+// Is the sequence of states a behaviour of the model?  State 0 must be Init; every later state must be among the successors
+// the GPU generates for its predecessor (k_successors, the same gen() the BFS kernels run).  ords[i] / actions[i + 1] = the
+// (action, binding) ordinal and action id of the step into state i + 1; *first_bad = index of the first state that does not
+// follow (or -1); *inv_mask_last = invariants violated by the last state (when the whole sequence is legal).
+int32_t vsrmc_model_check_trace(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off, uint64_t n_states,
+                                uint32_t* ords, int32_t* actions, int64_t* first_bad, int32_t* inv_mask_last) {
+  if (!m || !words || !off || !first_bad) return fail(VSRMC_E_ARG, "NULL argument");
+  const Model& M = m->M;
+  *first_bad = -1;
+  if (inv_mask_last) *inv_mask_last = 0;
+  if (n_states == 0) return 0;
+  auto normal = [&](const u64* rec, u64 len) {
+    std::vector<u64> v(rec, rec + len);
+    if (len > (u64)M.h0) std::sort(v.begin() + M.h0, v.end());
+    return v;
+  };
+  std::vector<u64> init;
+  init_record_wire(M, init);
+  if (normal(words + off[0], off[1] - off[0]) != init) {
+    *first_bad = 0;
+    return 0;
+  }
+  if (actions) actions[0] = 0;
+  if (n_states == 1) return 0;
+  // Walk like vsrmc_model_replay does: the state that is expanded next is the successor as the GPU produced it (its bag order
+  // defines the ordinals of the message-bound actions), the text's states are only compared against.
+  const u64 cap = 2048, capw = cap * 64;
+  std::vector<u64> ow(capw), om(cap * 8), cur = init;
+  for (u64 i = 0; i + 1 < n_states; i++) {
+    const std::vector<u64> want = normal(words + off[i + 1], off[i + 2] - off[i + 1]);
+    const u64 coff[2] = {0, cur.size()};
+    u64 n_out = 0, w_out = 0;
+    int rc = vsrmc_expand_batch(m, device, cur.data(), coff, 1, ow.data(), capw, om.data(), cap, &n_out, &w_out);
+    if (rc) return rc;
+    bool found = false;
+    for (u64 k = 0; k < n_out && !found; k++) {
+      if (om[8 * k + 6]) continue;                             // an instance that raises an evaluation error has no successor
+      const u64 wo = om[8 * k + 7];
+      const u64 len = (u64)M.h0 + (u64)hdr_nmsg(ow[wo]);
+      if (normal(&ow[wo], len) != want) continue;
+      found = true;
+      if (ords) ords[i] = (uint32_t)om[8 * k + 1];
+      if (actions) actions[i + 1] = (int32_t)om[8 * k + 2];
+      if (i + 2 == n_states && inv_mask_last) *inv_mask_last = (int32_t)om[8 * k + 5];
+      cur.assign(&ow[wo], &ow[wo] + len);
+    }
+    if (!found) {
+      *first_bad = (int64_t)(i + 1);
+      return 0;
+    }
+  }
+  return 0;
 }
 
 int32_t vsrmc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off, uint64_t n,

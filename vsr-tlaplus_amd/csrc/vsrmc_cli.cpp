@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -23,12 +25,15 @@ static void usage() {
       "  -tableLog2 N      seen-set slots = 2^N x 16 B (default 28)\n"
       "  -frontierGiB G    size of each of the two frontier buffers (default 8)\n"
       "  -simulate         random walks instead of BFS (TLC -simulate): -depth N (default 100) -walkers N (131072) -seed S -maxSeconds T\n"
+      "  -validateTrace F  read a TLC trace (trace expression, or console \"State k:\" form) and check on the GPU that it is a\n"
+      "                    behaviour of the model: Init, then one generated successor after the other; reports the invariants\n"
+      "                    its last state violates\n"
       "  -noTLA            do not read / hash-check the .tla file (only the cfg)\n"
       "  -json             one JSON object per level on stdout instead of TLC-style progress lines\n");
 }
 
 int main(int argc, char** argv) {
-  std::string cfg, tla;
+  std::string cfg, tla, trace_file;
   bool check_deadlock = false, no_tla = false, json = false, simulate = false;
   int sim_depth = 100;
   unsigned sim_walkers = 1u << 17;
@@ -47,6 +52,7 @@ int main(int argc, char** argv) {
     else if (a == "-tableLog2" && i + 1 < argc) table_log2 = std::atoi(argv[++i]);
     else if (a == "-frontierGiB" && i + 1 < argc) frontier_gib = std::atof(argv[++i]);
     else if (a == "-noTLA") no_tla = true;
+    else if (a == "-validateTrace" && i + 1 < argc) trace_file = argv[++i];
     else if (a == "-simulate") simulate = true;
     else if (a == "-depth" && i + 1 < argc) sim_depth = std::atoi(argv[++i]);
     else if (a == "-walkers" && i + 1 < argc) sim_walkers = (unsigned)std::strtoul(argv[++i], nullptr, 10);
@@ -66,6 +72,47 @@ int main(int argc, char** argv) {
   vsrmc_layout lay;
   vsrmc_model_info(m, &lay);
   if (lay.check_deadlock) check_deadlock = true;
+  if (!trace_file.empty()) {   // import of a TLC trace: is it a behaviour of the lowered model?
+    std::ifstream f(trace_file, std::ios::binary);
+    if (!f) { std::fprintf(stderr, "Error: cannot read %s\n", trace_file.c_str()); return 1; }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string text = ss.str();
+    uint64_t n = 0;
+    if (vsrmc_model_parse_states(m, text.c_str(), nullptr, 0, nullptr, nullptr, 0, &n) != 0) {
+      std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());
+      return 1;
+    }
+    std::vector<uint64_t> words((n + 1) * 320), off(n + 1);
+    std::vector<int32_t> named(n + 1), acts(n + 1, -1);
+    std::vector<uint32_t> ords(n + 1);
+    int64_t bad = -1;
+    int32_t inv = 0;
+    if (vsrmc_model_parse_states(m, text.c_str(), words.data(), words.size(), off.data(), named.data(), n + 1, &n) != 0 ||
+        vsrmc_model_check_trace(m, device, words.data(), off.data(), n, ords.data(), acts.data(), &bad, &inv) != 0) {
+      std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());
+      return 1;
+    }
+    std::printf("%llu states read from %s.\n", (unsigned long long)n, trace_file.c_str());
+    const uint64_t good = bad < 0 ? n : (uint64_t)bad;
+    for (uint64_t t = 0; t < good; t++) {
+      const char* mark = (named[t] >= 0 && named[t] != acts[t]) ? "   (the file names a different action for the same step)" : "";
+      if (t == 0) std::printf("State 1: <Initial predicate>%s\n", mark);
+      else std::printf("State %llu: <%s> ordinal %u%s\n", (unsigned long long)(t + 1), vsrmc_action_name(acts[t]), ords[t - 1], mark);
+    }
+    int code = 0;
+    if (bad >= 0) {
+      std::printf("Error: state %lld is not %s.\n", (long long)(bad + 1), bad == 0 ? "the initial state" : "a successor of its predecessor");
+      code = 1;
+    } else {
+      std::printf("The trace is a behaviour of the model.\n");
+      const char* names[2] = {"AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"};
+      for (int b = 0; b < 2; b++)
+        if (inv & (1 << b)) { std::printf("Its last state violates invariant %s.\n", names[b]); code = 12; }
+    }
+    vsrmc_model_destroy(m);
+    return code;
+  }
   if (simulate) {   // ≙ tlc2.TLC -simulate -depth N
     vsrmc_sim_result r;
     if (vsrmc_simulate(m, device, sim_walkers, sim_depth, sim_seed, sim_seconds, &r) != 0) {
