@@ -171,6 +171,15 @@ int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t inde
 int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index);
 void vsrmc_checker_destroy(vsrmc_checker* c);
 
+/* ≙ TLC's checkpoints (ModelChecker.checkpoint → FPSet.beginChkpt/commitChkpt, StateQueue and TLCTrace checkpoints; `-recover`):
+ * one file holds the search between two levels — the occupied seen-set slots, the newest frontier, the trace log.  It is written
+ * to <path>.tmp and renamed.  vsrmc_checker_load creates a checker with `o` (capacities and table size may differ from the
+ * run that saved; the model constants may not) and continues where the checkpoint stopped.  Unsharded checkers only. */
+int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path);
+/* where the search stands (after create / reset / load / step): level, n_new = states of the newest level, distinct, total_generated */
+int32_t vsrmc_checker_status(vsrmc_checker* c, vsrmc_level_info* info);
+int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const char* path, vsrmc_checker** out);
+
 /* ≙ tlc2.tool.ModelChecker.runTLC / Worker.run until the queue is empty, an invariant fails, a bound is hit or the spec raises an
  * evaluation error: vsrmc_checker_step in a loop.  stop_reason: 0 exhausted, 1 invariant violated (last->viol_*), 2 max_depth,
  * 3 max_seconds; errors come back as the return code, with `last` describing the last completed level. */

@@ -473,3 +473,65 @@ def test_seen_set_and_frontier_overflow_are_errors(vt):
     with pytest.raises(vt.VsrmcError):
         mc.step()                                                                   # the handle stays failed
     mc.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# checkpoint / recover (TLC: FPSet.beginChkpt/commitChkpt + StateQueue + TLCTrace checkpoints, `-recover`)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_checkpoint_and_recover_continue_to_the_same_result(vt, orc, tmp_path):
+    P = orc.Params(3, 1, 2, 2)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    ref = vt.ModelChecker(m, table_log2=20, frontier_words=1 << 25, frontier_states=1 << 20)
+    for _ in range(11):
+        ref.step()
+    a = vt.ModelChecker(m, table_log2=20, frontier_words=1 << 25, frontier_states=1 << 20)
+    for _ in range(6):
+        a.step()
+    path = str(tmp_path / "run.chk")
+    a.save(path)
+    fps7 = a.level_fps()
+    a.close()
+    # recover into a checker with a different table size and different capacities
+    b = vt.ModelChecker(m, table_log2=21, frontier_words=1 << 24, frontier_states=1 << 19, recover=path)
+    assert (b.level, b.distinct) == (7, sum(l["n_new"] for l in ref.levels[:7]))
+    assert np.array_equal(b.level_fps(), fps7)
+    for _ in range(5):
+        b.step()
+    assert (b.level, b.distinct) == (ref.level, ref.distinct)
+    assert np.array_equal(b.level_fps(), ref.level_fps())
+    ob = orc.Bfs(P)
+    for _ in range(11):
+        ob.step()
+    assert np.array_equal(b.level_fps(), ob.level_fps(12))
+    # the trace log came along: a state of the last level walks back to Init through the recovered levels
+    fp = int(b.level_fps()[-1])
+    tr = b.trace(b.level, b.find_fp(fp))
+    assert len(tr) == 12 and tr[0][0] == "Initial predicate"
+    fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
+    assert int(fps[0]) == fp
+    # refusals: other constants, options too small, not a checkpoint
+    with pytest.raises(vt.VsrmcError):
+        vt.ModelChecker(vt.Model.from_constants(R=3, C_=1, n=3, L=3), recover=path)
+    with pytest.raises(vt.VsrmcError):
+        vt.ModelChecker(m, table_log2=10, recover=path)
+    junk = tmp_path / "junk.chk"
+    junk.write_bytes(b"not a checkpoint at all" * 10)
+    with pytest.raises(vt.VsrmcError):
+        vt.ModelChecker(m, recover=str(junk))
+
+
+def test_cli_checkpoint_and_recover(vt, tmp_path):
+    import os
+    import subprocess
+    from test_host_cpu import _cfg
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cfg = _cfg(tmp_path, R=2, vals="v1", L=1)
+    chk = str(tmp_path / "c1.chk")
+    r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01", "-maxDepth", "8", "-checkpoint", chk,
+                        "-checkpointMinutes", "0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "Checkpointing of run" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01", "-recover", chk],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Recovered from" in r.stdout and "Model checking completed. No error has been found." in r.stdout
+    assert "76 distinct states found" in r.stdout and "search is 14" in r.stdout

@@ -87,6 +87,9 @@ SYMBOLS = {
     "vsrmc_queue_size": (C.c_int32, [V, C.POINTER(C.c_uint64)]),
     "vsrmc_queue_destroy": (None, [V]),
     "vsrmc_simulate": (C.c_int32, [V, C.c_int32, C.c_uint32, C.c_int32, C.c_uint64, C.c_double, C.POINTER(SimResult)]),
+    "vsrmc_checker_save": (C.c_int32, [V, C.c_char_p]),
+    "vsrmc_checker_status": (C.c_int32, [V, C.POINTER(LevelInfo)]),
+    "vsrmc_checker_load": (C.c_int32, [V, C.POINTER(Options), C.c_char_p, C.POINTER(V)]),
     "vsrmc_model_parse_states": (C.c_int32, [V, C.c_char_p, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_model_check_trace": (C.c_int32, [V, C.c_int32, V, V, C.c_uint64, V, V, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "vsrmc_shard_expand": (C.c_int32, [V, C.POINTER(ShardIO), V]),

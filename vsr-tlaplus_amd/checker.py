@@ -7,6 +7,7 @@
 Everything below is plumbing: all model semantics, hashing and set operations run in the HIP kernels.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -253,7 +254,8 @@ class ModelChecker:
     """≙ tlc2.tool.ModelChecker: level-synchronous BFS; `step()` = every Worker draining one level of the StateQueue."""
 
     def __init__(self, model, device=0, table_log2=24, frontier_words=1 << 25, frontier_states=1 << 20,
-                 pending_entries=1 << 21, keep_trace=True, trace_entries=0, exact_ties=False):
+                 pending_entries=1 << 21, keep_trace=True, trace_entries=0, exact_ties=False, recover=None):
+        """recover: path of a checkpoint written by save() — continue that search (≙ `tlc2.TLC -recover`)."""
         self.model = model
         o = capi.Options()
         capi.load().vsrmc_options_default(C.byref(o))
@@ -264,8 +266,20 @@ class ModelChecker:
         o.exact_ties = int(exact_ties)
         self.options = o
         self._h = C.c_void_p()
-        check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))
-        self._fresh()
+        if recover is None:
+            check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))
+            self._fresh()
+        else:
+            check(capi.load().vsrmc_checker_load(model._h, C.byref(o), os.fsencode(recover), C.byref(self._h)))
+            info = capi.LevelInfo()
+            check(capi.load().vsrmc_checker_status(self._h, C.byref(info)))
+            self.level, self.n_frontier, self.distinct = info.level, info.n_new, info.distinct
+            self.levels = [dict(level=info.level, n_new=info.n_new, generated=0, deadlocks=0, recovered=True)]
+            self.violation = None
+
+    def save(self, path):
+        """Checkpoint between two levels (≙ TLC's checkpoint of FPSet + StateQueue + TLCTrace): one file."""
+        check(capi.load().vsrmc_checker_save(self._h, os.fsencode(path)))
 
     def _fresh(self):
         self.level = 1

@@ -1002,6 +1002,32 @@ k_export(const u64* __restrict__ nx_words, u64* nx_off, u64* lvl_fp, const u64* 
   }
 }
 
+// ---- checkpoint / recover (TLC's FPSet.beginChkpt / recover): the seen-set travels as its occupied slots only -----------
+// k_table_export: copy the occupied slots of [first, first + n) to out (any order), counter[0] = how many.
+__global__ void k_table_export(const Slot* __restrict__ table, u64 first, u64 n, Slot* out, u64 out_cap, u64* counter) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  Slot s;
+  s.fp = 0;
+  s.meta = 0;
+  if (i < n) s = table[first + i];
+  if (s.fp != 0) {
+    const u64 k = wave_alloc(counter);
+    if (k < out_cap) out[k] = s;
+  }
+}
+// k_table_import: insert (fp, meta) pairs into a table of any size (the probe sequence depends on the size, the content does not)
+__global__ void k_table_import(Slot* table, u64 tmask, const Slot* __restrict__ in, u64 n, u32* err) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 np = 0;
+  const Probe p = probe_insert(table, tmask, in[i].fp, &np);
+  if (p.full) {
+    atomicExch(err, (u32)ERR_TABLE_FULL);
+    return;
+  }
+  table[p.slot].meta = in[i].meta;
+}
+
 // Seed the search with the initial state (ModelChecker.doInit): record already in frontier slot 0.
 __global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl) {
   if (threadIdx.x || blockIdx.x) return;

@@ -842,6 +842,7 @@ struct vsrmc_checker {
   u64 tr_base = 0, nx_n = 0, nx_w = 0;
   u64 tr_base0() const { return level_base.back() + level_size.back(); }
   u64 n_valid = 1;                       // states in the newest level (n_frontier is its index range, holes included)
+  u64 cur_w = 0;                         // words of the current frontier buffer in use (chunk slack included)
   u64* rslot = nullptr;                  // sharded: slot of every received candidate
   u64 rslot_cap = 0;
   u64* filter = nullptr;                 // sharded single-pass levels: this rank's sent-filter (vsr_kernels.hpp, k_expand)
@@ -883,6 +884,7 @@ int checker_seed(vsrmc_checker* c) {
   c->level = 1;
   c->n_frontier = mine ? 1 : 0;
   c->n_valid = c->n_frontier;
+  c->cur_w = (u64)len;
   c->distinct = mine ? 1 : 0;
   c->total_generated = 0;
   c->failed = 0;
@@ -1138,6 +1140,7 @@ int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
     c->distinct += n_new;
     c->n_frontier = c->nx_n;
     c->n_valid = n_new;
+    c->cur_w = c->nx_w;
   } else {
     c->n_frontier = 0;
     c->n_valid = 0;
@@ -1391,6 +1394,185 @@ int32_t vsrmc_shard_commit(vsrmc_checker* c, vsrmc_level_info* info) {
   if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   return phase_commit(c, info);
+}
+
+// ---- checkpoint / recover ≙ TLC's checkpoints (ModelChecker.checkpoint: FPSet.beginChkpt/commitChkpt, StateQueue, TLCTrace) ----
+namespace {
+struct ChkHeader {
+  char magic[8];                 // "VSRMCCK1"
+  int32_t consts[8];             // R, C, n, L, symmetry, inv_mask, assume_commit, np
+  int32_t level, cur_unused;
+  u64 n_frontier, n_valid, cur_w, distinct, total_generated, n_levels, table_entries, trace_entries;
+};
+bool dev_to_file(FILE* f, const void* d_ptr, u64 bytes, std::vector<char>& buf) {
+  for (u64 pos = 0; pos < bytes; pos += buf.size()) {
+    const u64 k = std::min<u64>(buf.size(), bytes - pos);
+    if (hipMemcpy(buf.data(), (const char*)d_ptr + pos, k, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (std::fwrite(buf.data(), 1, k, f) != k) return false;
+  }
+  return true;
+}
+bool file_to_dev(FILE* f, void* d_ptr, u64 bytes, std::vector<char>& buf) {
+  for (u64 pos = 0; pos < bytes; pos += buf.size()) {
+    const u64 k = std::min<u64>(buf.size(), bytes - pos);
+    if (std::fread(buf.data(), 1, k, f) != k) return false;
+    if (hipMemcpy((char*)d_ptr + pos, buf.data(), k, hipMemcpyHostToDevice) != hipSuccess) return false;
+  }
+  return true;
+}
+}  // namespace
+
+int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
+  if (!c || !path) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "checkpoints of sharded checkers are not supported");
+  HIPCHK(hipSetDevice(c->opt.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const Model& M = c->model.M;
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return fail(VSRMC_E_CFG, "cannot write " + tmp);
+  ChkHeader h;
+  std::memset(&h, 0, sizeof(h));
+  std::memcpy(h.magic, "VSRMCCK1", 8);
+  const int32_t consts[8] = {M.R, M.C, M.n, M.L, c->model.symmetry, M.inv_mask, M.assume_commit, M.np};
+  std::memcpy(h.consts, consts, sizeof(consts));
+  h.level = c->level;
+  h.n_frontier = c->n_frontier;
+  h.n_valid = c->n_valid;
+  h.cur_w = c->cur_w;
+  h.distinct = c->distinct;
+  h.total_generated = c->total_generated;
+  h.n_levels = c->level_base.size();
+  h.trace_entries = c->tr_all ? c->tr_base0() : 0;
+  std::vector<char> buf((size_t)64 << 20);
+  bool ok = true;
+  // the seen-set: occupied slots only, window by window (the export buffer holds one window)
+  const u64 slots = c->tmask + 1, win = std::min<u64>(slots, (u64)1 << 26);
+  Slot* d_out = nullptr;
+  u64* d_cnt = nullptr;
+  HIPCHK(hipMalloc((void**)&d_out, win * sizeof(Slot)));
+  HIPCHK(hipMalloc((void**)&d_cnt, 8));
+  ok = std::fwrite(&h, sizeof(h), 1, f) == 1;                   // rewritten at the end with table_entries
+  ok = ok && std::fwrite(c->level_base.data(), 8, c->level_base.size(), f) == c->level_base.size();
+  ok = ok && std::fwrite(c->level_size.data(), 8, c->level_size.size(), f) == c->level_size.size();
+  u64 total = 0;
+  for (u64 first = 0; first < slots && ok; first += win) {
+    u64 cnt = 0;
+    ok = hipMemset(d_cnt, 0, 8) == hipSuccess;
+    hipLaunchKernelGGL(k_table_export, dim3((unsigned)((win + 255) / 256)), dim3(256), 0, c->stream, c->table, first, win, d_out, win, d_cnt);
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(&cnt, d_cnt, 8, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && dev_to_file(f, d_out, cnt * sizeof(Slot), buf);
+    total += cnt;
+  }
+  (void)hipFree(d_out);
+  (void)hipFree(d_cnt);
+  ok = ok && dev_to_file(f, c->words[c->cur], c->cur_w * 8, buf);
+  ok = ok && dev_to_file(f, c->off[c->cur], c->n_frontier * 8, buf);
+  ok = ok && dev_to_file(f, c->lvl_fp, c->n_frontier * 8, buf);
+  if (c->tr_all) ok = ok && dev_to_file(f, c->tr_all, h.trace_entries * 8, buf);
+  h.table_entries = total;
+  ok = ok && std::fseek(f, 0, SEEK_SET) == 0 && std::fwrite(&h, sizeof(h), 1, f) == 1;
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok || std::rename(tmp.c_str(), path) != 0) {
+    std::remove(tmp.c_str());
+    return fail(VSRMC_E_CFG, std::string("writing the checkpoint ") + path + " failed");
+  }
+  return 0;
+}
+
+int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const char* path, vsrmc_checker** out) {
+  if (!m || !o || !path || !out) return fail(VSRMC_E_ARG, "NULL argument");
+  if (o->world > 1) return fail(VSRMC_E_STATE, "checkpoints of sharded checkers are not supported");
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + path);
+  ChkHeader h;
+  std::vector<u64> level_base, level_size;
+  bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VSRMCCK1", 8) == 0 && h.n_levels >= 1 && h.n_levels < 512;
+  if (ok) {
+    level_base.resize(h.n_levels);
+    level_size.resize(h.n_levels);
+    ok = std::fread(level_base.data(), 8, h.n_levels, f) == h.n_levels && std::fread(level_size.data(), 8, h.n_levels, f) == h.n_levels;
+  }
+  if (!ok) {
+    std::fclose(f);
+    return fail(VSRMC_E_CFG, std::string(path) + " is not a vsrmc checkpoint");
+  }
+  const Model& M = m->M;
+  const int32_t consts[8] = {M.R, M.C, M.n, M.L, m->symmetry, M.inv_mask, M.assume_commit, M.np};
+  if (std::memcmp(h.consts, consts, sizeof(consts)) != 0) {
+    std::fclose(f);
+    return fail(VSRMC_E_CFG, "the checkpoint was written for different model constants");
+  }
+  if (h.n_frontier > o->frontier_states || h.cur_w > o->frontier_words || 2 * h.table_entries > ((u64)1 << o->table_log2) ||
+      (o->keep_trace && h.trace_entries == 0 && h.level > 1)) {
+    std::fclose(f);
+    return fail(VSRMC_E_ARG, "the options are too small for this checkpoint (frontier, table) or ask for a trace log it does not have");
+  }
+  vsrmc_checker* c = nullptr;
+  int rc = vsrmc_checker_create(m, o, &c);
+  if (rc) {
+    std::fclose(f);
+    return rc;
+  }
+  if (c->tr_all && h.trace_entries > c->trace_cap) {
+    std::fclose(f);
+    vsrmc_checker_destroy(c);
+    return fail(VSRMC_E_ARG, "trace_entries too small for this checkpoint");
+  }
+  std::vector<char> buf((size_t)64 << 20);
+  // the seen-set: empty it (create seeded Init), re-insert the saved slots
+  hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
+  const u64 win = (u64)1 << 24;
+  Slot* d_in = nullptr;
+  u32* d_err = nullptr;
+  ok = hipMalloc((void**)&d_in, win * sizeof(Slot)) == hipSuccess && hipMalloc((void**)&d_err, 4) == hipSuccess &&
+       hipMemset(d_err, 0, 4) == hipSuccess;
+  for (u64 done = 0; done < h.table_entries && ok; done += win) {
+    const u64 k = std::min<u64>(win, h.table_entries - done);
+    ok = file_to_dev(f, d_in, k * sizeof(Slot), buf);
+    hipLaunchKernelGGL(k_table_import, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, c->table, c->tmask, d_in, k, d_err);
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+  }
+  u32 terr = 0;
+  if (ok) ok = hipMemcpy(&terr, d_err, 4, hipMemcpyDeviceToHost) == hipSuccess && terr == 0;
+  if (d_in) (void)hipFree(d_in);
+  if (d_err) (void)hipFree(d_err);
+  c->cur = 0;
+  ok = ok && file_to_dev(f, c->words[0], h.cur_w * 8, buf);
+  ok = ok && file_to_dev(f, c->off[0], h.n_frontier * 8, buf);
+  ok = ok && file_to_dev(f, c->lvl_fp, h.n_frontier * 8, buf);
+  if (h.trace_entries) {
+    if (c->tr_all) ok = ok && file_to_dev(f, c->tr_all, h.trace_entries * 8, buf);
+  }
+  std::fclose(f);
+  if (!ok) {
+    vsrmc_checker_destroy(c);
+    return fail(VSRMC_E_CFG, std::string("reading the checkpoint ") + path + " failed");
+  }
+  c->level = h.level;
+  c->n_frontier = h.n_frontier;
+  c->n_valid = h.n_valid;
+  c->cur_w = h.cur_w;
+  c->distinct = h.distinct;
+  c->total_generated = h.total_generated;
+  c->level_base = level_base;
+  c->level_size = level_size;
+  *out = c;
+  return 0;
+}
+
+int32_t vsrmc_checker_status(vsrmc_checker* c, vsrmc_level_info* info) {
+  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
+  std::memset(info, 0, sizeof(*info));
+  info->level = c->level;
+  info->n_new = c->n_valid;
+  info->distinct = c->distinct;
+  info->total_generated = c->total_generated;
+  info->words_new = c->cur_w;
+  info->viol_fp = ~(u64)0;
+  info->viol_index = ~(u64)0;
+  return 0;
 }
 
 int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index) {

@@ -28,12 +28,15 @@ static void usage() {
       "  -validateTrace F  read a TLC trace (trace expression, or console \"State k:\" form) and check on the GPU that it is a\n"
       "                    behaviour of the model: Init, then one generated successor after the other; reports the invariants\n"
       "                    its last state violates\n"
+      "  -checkpoint FILE  write a checkpoint between levels, at most every -checkpointMinutes M (default 30; 0 = after every level)\n"
+      "  -recover FILE     continue the search a checkpoint stopped at (same constants; buffer sizes may differ)\n"
       "  -noTLA            do not read / hash-check the .tla file (only the cfg)\n"
       "  -json             one JSON object per level on stdout instead of TLC-style progress lines\n");
 }
 
 int main(int argc, char** argv) {
-  std::string cfg, tla, trace_file;
+  std::string cfg, tla, trace_file, chk_file, recover_file;
+  double chk_minutes = 30.0;
   bool check_deadlock = false, no_tla = false, json = false, simulate = false;
   int sim_depth = 100;
   unsigned sim_walkers = 1u << 17;
@@ -53,6 +56,9 @@ int main(int argc, char** argv) {
     else if (a == "-frontierGiB" && i + 1 < argc) frontier_gib = std::atof(argv[++i]);
     else if (a == "-noTLA") no_tla = true;
     else if (a == "-validateTrace" && i + 1 < argc) trace_file = argv[++i];
+    else if (a == "-checkpoint" && i + 1 < argc) chk_file = argv[++i];
+    else if (a == "-checkpointMinutes" && i + 1 < argc) chk_minutes = std::atof(argv[++i]);
+    else if (a == "-recover" && i + 1 < argc) recover_file = argv[++i];
     else if (a == "-simulate") simulate = true;
     else if (a == "-depth" && i + 1 < argc) sim_depth = std::atoi(argv[++i]);
     else if (a == "-walkers" && i + 1 < argc) sim_walkers = (unsigned)std::strtoul(argv[++i], nullptr, 10);
@@ -162,23 +168,24 @@ int main(int argc, char** argv) {
   // one entry per state plus the unused tails of the per-block index chunks (<= 4096 per block per level, 510 levels at most)
   o.trace_entries = ((uint64_t)1 << table_log2) / 2 + ((uint64_t)1 << 21);
   vsrmc_checker* c = nullptr;
-  if (vsrmc_checker_create(m, &o, &c) != 0) {
+  if ((recover_file.empty() ? vsrmc_checker_create(m, &o, &c) : vsrmc_checker_load(m, &o, recover_file.c_str(), &c)) != 0) {
     std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());
     return 1;
   }
   std::printf("vsrmc: VSR.tla lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), "
               "invariant mask %d\n", lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
               lay.permutations, lay.invariant_mask);
-  std::printf("Finished computing initial states: 1 distinct state generated.\n");
   auto t0 = std::chrono::steady_clock::now();
+  auto t_chk = t0;
   vsrmc_level_info info;
-  std::memset(&info, 0, sizeof(info));
-  info.level = 1;
-  info.distinct = 1;
+  vsrmc_checker_status(c, &info);
+  if (recover_file.empty()) std::printf("Finished computing initial states: 1 distinct state generated.\n");
+  else std::printf("Recovered from %s: level %d, %llu distinct states found, %llu states left on queue.\n", recover_file.c_str(), info.level,
+                   (unsigned long long)info.distinct, (unsigned long long)info.n_new);
   int rc = 0;
   bool violated = false, deadlocked = false;
   uint64_t viol_level = 0, viol_index = 0;
-  int depth = 1;
+  int depth = info.level;
   while (depth < max_depth) {
     rc = vsrmc_checker_step(c, &info);
     if (rc != 0) break;
@@ -194,6 +201,12 @@ int main(int argc, char** argv) {
     if (info.viol_mask) { violated = true; viol_level = (uint64_t)info.level; viol_index = info.viol_index; break; }
     if (check_deadlock && info.deadlocks) { deadlocked = true; break; }
     if (info.n_new == 0) break;
+    if (!chk_file.empty() &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_chk).count() >= 60.0 * chk_minutes) {
+      if (vsrmc_checker_save(c, chk_file.c_str()) != 0) std::printf("Warning: %s\n", vsrmc_last_error());
+      else std::printf("Checkpointing of run %s completed (level %d).\n", chk_file.c_str(), info.level);
+      t_chk = std::chrono::steady_clock::now();
+    }
   }
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   int exit_code = 0;
