@@ -130,3 +130,27 @@ def test_sharded_hip_engine_on_one_gpu(tmp_path, engine, world, params, depth, r
         words = tr[-1][1]
         fps, _ = m.fingerprints(words, np.array([0, len(words)], dtype=np.uint64))
         assert "%016x" % int(fps[0]) in ranks[w["rank"]]["levels"][-1]["fps"]
+
+
+@pytest.mark.gpu
+def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
+    """`vsrmc` on N ranks (vsr-tlaplus_amd/sharded_cli.py): config 1 to completion, and the shipped cfg to its violation
+    with the counter-example printed in TLC's syntax."""
+    from test_host_cpu import _cfg
+
+    def run(cfg, *extra):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29671", "-m", "vsr_tlaplus_amd.sharded_cli", "-config", cfg, "-noTLA", "-backend", "gloo",
+               "-tableLog2", "20", "-frontierGiB", "0.05"] + list(extra)
+        return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"))
+
+    r = run(_cfg(tmp_path, R=2, vals="v1", L=1), "-replicateBelow", "8")
+    assert "Model checking completed. No error has been found." in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "76 distinct states found" in r.stdout and "search is 14" in r.stdout and "[sharded]" in r.stdout
+    # the shipped VSR.cfg constants: the run ends in the depth-28 violation of AcknowledgedWriteNotLost (319 M states)
+    d2 = tmp_path / "c2"
+    d2.mkdir()
+    r = run(_cfg(d2), "-tableLog2", "29", "-frontierGiB", "18")
+    assert "Error: Invariant AcknowledgedWriteNotLost is violated." in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "State 1: <Initial predicate>" in r.stdout and "State 28: <" in r.stdout and "State 29: <" not in r.stdout
+    assert "319228361 distinct states found" in r.stdout

@@ -12,7 +12,7 @@ import vsr_tlaplus_amd as vt  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("R", type=int); ap.add_argument("C", type=int); ap.add_argument("n", type=int); ap.add_argument("L", type=int)
 ap.add_argument("--table-log2", type=int, default=30)
-ap.add_argument("--frontier-words-log2", type=int, default=31)
+ap.add_argument("--frontier-words-log2", type=float, default=31)
 ap.add_argument("--frontier-states-log2", type=int, default=27)
 ap.add_argument("--pending-log2", type=int, default=28)
 ap.add_argument("--max-seconds", type=float, default=120)
@@ -26,7 +26,7 @@ a = ap.parse_args()
 m = vt.Model.from_constants(R=a.R, C_=a.C, n=a.n, L=a.L, symmetry=not a.no_symmetry, invariant_mask=a.inv_mask,
                             assume_commit_number=a.assume_commit_number)
 t0 = time.time()
-mc = vt.ModelChecker(m, table_log2=a.table_log2, frontier_words=1 << a.frontier_words_log2,
+mc = vt.ModelChecker(m, table_log2=a.table_log2, frontier_words=int(2 ** a.frontier_words_log2),
                      frontier_states=1 << a.frontier_states_log2, pending_entries=1 << a.pending_log2,
                      keep_trace=not a.no_trace, exact_ties=a.exact_ties)
 print(json.dumps(dict(setup_seconds=round(time.time() - t0, 3))))

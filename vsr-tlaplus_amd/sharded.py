@@ -189,7 +189,8 @@ class ShardedChecker:
             self.levels.append(out)
         if viol is not None and self.violation is None:
             # every rank holds the state; rank 0's copy (and its private trace log) is the one that gets walked
-            self.violation = dict(level=self.level, rank=0, index=self.e.find_fp(viol) if self.rank == 0 else -1, fp=viol)
+            self.violation = dict(level=self.level, rank=0, index=self.e.find_fp(viol) if self.rank == 0 else -1, fp=viol,
+                                  mask=info["viol_mask"])
             self.violation["index"] = self.x.allreduce([self.violation["index"]], dist.ReduceOp.MAX)[0]
         elif info["n_new"] >= self.replicate_below:
             self._end_replicated()
@@ -254,7 +255,7 @@ class ShardedChecker:
         viol_fp = info["viol_fp"] if info["viol_mask"] else U64_MAX
         # one all-gather carries every per-level figure (a 64-bit fingerprint travels as two 32-bit halves: int64 tensors)
         rows = x.allgather([info["n_new"], info["generated"], info["deadlocks"], info["pending"], viol_fp >> 32,
-                            viol_fp & 0xFFFFFFFF, err])
+                            viol_fp & 0xFFFFFFFF, err, info["viol_mask"]])
         self._raise_if(max(r[6] for r in rows), "append")
         s = [sum(r[k] for r in rows) for k in range(4)]
         gviol = min((r[4] << 32) | r[5] for r in rows)
@@ -268,7 +269,11 @@ class ShardedChecker:
         if gviol != U64_MAX and self.violation is None:
             idx = e.find_fp(gviol)
             where = x.allreduce([me if idx is not None else -1, idx if idx is not None else -1], dist.ReduceOp.MAX)
-            self.violation = dict(level=self.level, rank=where[0], index=where[1], fp=gviol)
+            mask = 0
+            for r in rows:
+                if ((r[4] << 32) | r[5]) == gviol:
+                    mask |= r[7]
+            self.violation = dict(level=self.level, rank=where[0], index=where[1], fp=gviol, mask=mask)
         return out
 
     def run(self, max_depth=None, stop_on_violation=True):

@@ -1,0 +1,155 @@
+"""vsrmc on N GPUs — the TLC-style command line of the sharded checker (`vsrmc ... --gpus N`).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        -m vsr_tlaplus_amd.sharded_cli -config VSR.cfg [VSR.tla] [options]
+
+One rank per GPU (backend "nccl" = RCCL over xGMI; "gloo" stages through the host and lets several ranks share one GPU).
+Rank 0 prints TLC's progress lines, the violated invariant and the counter-example in TLC's value syntax; every rank returns
+TLC's exit code (0 = no error, 12 = safety violation, 11 = deadlock, 1 = failure).
+
+  -config FILE        TLC configuration (VSR.cfg grammar)              -noTLA   do not read / hash-check the .tla file
+  -maxDepth N         stop after N BFS levels (Init = level 1)         -checkDeadlock   stop at the first terminal state
+  -tableLog2 N        seen-set slots PER RANK = 2^N x 16 B (default 26)
+  -frontierGiB G      size of each of the two frontier buffers PER RANK (default 2)
+  -replicateBelow K   levels with fewer than K new states are explored by every rank on its own (default 2^20; 0 = never)
+  -exactTies          two-kernel levels that arbitrate same-level VIEW ties like the oracle (default: single-pass levels)
+  -backend nccl|gloo  (default nccl)                                   -json    one JSON object per level
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+INVARIANTS = ["AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"]
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    opt = dict(cfg=None, tla=None, max_depth=1 << 30, table_log2=26, frontier_gib=2.0, replicate_below=1 << 20, exact=False,
+               backend="nccl", json=False, no_tla=False, check_deadlock=False)
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        val = argv[i + 1] if i + 1 < len(argv) else None
+        if a == "-config" and val:
+            opt["cfg"] = val; i += 1
+        elif a == "-maxDepth" and val:
+            opt["max_depth"] = int(val); i += 1
+        elif a == "-tableLog2" and val:
+            opt["table_log2"] = int(val); i += 1
+        elif a == "-frontierGiB" and val:
+            opt["frontier_gib"] = float(val); i += 1
+        elif a == "-replicateBelow" and val:
+            opt["replicate_below"] = int(val); i += 1
+        elif a == "-backend" and val:
+            opt["backend"] = val; i += 1
+        elif a == "-exactTies":
+            opt["exact"] = True
+        elif a == "-json":
+            opt["json"] = True
+        elif a == "-noTLA":
+            opt["no_tla"] = True
+        elif a == "-deadlock":
+            opt["check_deadlock"] = False
+        elif a == "-checkDeadlock":
+            opt["check_deadlock"] = True
+        elif a == "-workers" and val:
+            i += 1                                              # accepted for command-line compatibility
+        elif not a.startswith("-"):
+            opt["tla"] = a
+        else:
+            print(__doc__)
+            return 2
+        i += 1
+    if not opt["cfg"]:
+        print(__doc__)
+        return 2
+
+    import vsr_tlaplus_amd as vt
+    from vsr_tlaplus_amd import sharded
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if opt["backend"] == "nccl" else 0
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        if opt["backend"] == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(opt["backend"])
+    rank, world = dist.get_rank(), dist.get_world_size()
+    say = print if rank == 0 else (lambda *a, **k: None)
+    try:
+        m = vt.Model.load(opt["cfg"], None if (opt["no_tla"] or not opt["tla"]) else opt["tla"])
+    except vt.VsrmcError as e:
+        say("Error: %s" % e)
+        return 1
+    lay = m.layout
+    words = int(opt["frontier_gib"] * (1 << 30) / 8)
+    states = max(1 << 12, words // 24)
+    eng = sharded.HipShardEngine(
+        m, rank, world, device=local_rank, table_log2=opt["table_log2"], frontier_words=words, frontier_states=states,
+        pending_entries=max(1 << 16, 3 * states if opt["exact"] else 0), cand_cap=int(1.5 * states / world) + (1 << 16),
+        rec_cap=max(1 << 12, states // 8), rec_words_cap=max(1 << 16, words // 8), keep_trace=True,
+        trace_entries=(1 << opt["table_log2"]) // 2 + (1 << 21), exact_ties=opt["exact"])
+    sc = sharded.ShardedChecker(eng, sharded.Exchanger(), replicate_below=opt["replicate_below"])
+    say("vsrmc: VSR.tla lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), invariant "
+        "mask %d; %d rank(s), backend %s" % (lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
+                                             lay.permutations, lay.invariant_mask, world, opt["backend"]))
+    say("Finished computing initial states: 1 distinct state generated.")
+    t0 = time.time()
+    total_generated, code, last, deadlocked = 0, 0, dict(n_new=1), False
+    try:
+        while sc.level < opt["max_depth"]:
+            d = sc.step()
+            last = d
+            total_generated += d["generated"]
+            dt = time.time() - t0
+            if opt["json"]:
+                say(json.dumps(dict(level=d["level"], generated=d["generated"], new=d["n_new"], distinct=d["distinct"],
+                                    deadlocks=d["deadlocks"], replicated=bool(d.get("replicated")), seconds=round(dt, 4))))
+            elif d["n_new"]:
+                say("Progress(%d): %d states generated, %d distinct states found, %d states left on queue. (%.2f s)%s"
+                    % (d["level"], total_generated, d["distinct"], d["n_new"], dt, "" if d.get("replicated") else "  [sharded]"))
+            if sc.violation is not None:
+                break
+            if opt["check_deadlock"] and d["deadlocks"]:
+                deadlocked = True
+                break
+            if d["n_new"] == 0:
+                break
+    except (sharded.ShardError, vt.VsrmcError) as e:
+        say("Error: %s" % e)
+        code = 1
+    dt = time.time() - t0
+    if code == 0 and sc.violation is not None:
+        v = sc.violation
+        ords = sc.trace_ordinals(v["level"], v["rank"], v["index"])       # every rank takes part in the walk
+        if rank == 0:
+            tr = sharded.replay(m, ords, device=local_rank)
+            fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64), device=local_rank)
+            assert int(fps[0]) == v["fp"], "trace replay does not end in the violating state"
+            for b, name in enumerate(INVARIANTS):
+                if (int(v["mask"]) >> b) & 1:
+                    print("Error: Invariant %s is violated." % name)
+            print("Error: The behavior up to this point is:")
+            for t, (action, rec) in enumerate(tr):
+                print("State %d: <%s>\n%s\n" % (t + 1, action, m.format_state(rec)))
+        code = 12
+    elif code == 0 and deadlocked:
+        say("Error: Deadlock reached (%d state(s) of level %d have no successor)." % (last["deadlocks"], sc.level - 1))
+        code = 11
+    elif code == 0 and last["n_new"] == 0:
+        say("Model checking completed. No error has been found.")
+    say("%d states generated, %d distinct states found, %d states left on queue." % (total_generated, sc.distinct, last["n_new"]))
+    depth = sc.level if last["n_new"] else sc.level - 1
+    say("The depth of the complete state graph search is %d.\nFinished in %.3f s (%.3g distinct states/s) on %d rank(s)."
+        % (depth, dt, sc.distinct / dt if dt > 0 else 0.0, world))
+    dist.barrier()
+    dist.destroy_process_group()
+    return code
+
+
+if __name__ == "__main__":
+    sys.exit(main())
