@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 CONFIG = dict(R=3, C=1, n=2, L=2)                     # BASELINE.json configs[1] = /root/reference/.../VSR.cfg:4-8
 EXPECT = dict(distinct=319228361, depth=28, viol_fp=0x22239cb457b78204)   # tests/golden/config2_violation.json
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TABLE_LOG2 = 31                                       # seen-set: 2^31 slots x 16 B = 32 GiB of the 288 GB (load 0.15 at the end)
 
 
 def cpu_baseline(seconds=15.0):
@@ -52,7 +53,7 @@ def run_single(args):
     import vsr_tlaplus_amd as vt
     torch.cuda.set_device(0)
     m = vt.Model.from_constants(R=CONFIG["R"], C_=CONFIG["C"], n=CONFIG["n"], L=CONFIG["L"])
-    mc = vt.ModelChecker(m, device=0, table_log2=30, frontier_words=1 << 32, frontier_states=1 << 27,
+    mc = vt.ModelChecker(m, device=0, table_log2=TABLE_LOG2, frontier_words=1 << 32, frontier_states=1 << 27,
                          pending_entries=1 << 28, keep_trace=True, trace_entries=1 << 29)
     S = dict(expand_ms=0.0, mat_ms=0.0, launches=0, alg_bytes=0.0, distinct=0, generated=0, ttfv=[], words=0)
 
@@ -120,7 +121,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 "
                                "(BASELINE configs[1] = shipped VSR.cfg), VIEW+SYMMETRY, to first violation: 28 levels, "
-                               "319228361 distinct states", "table_slots_log2": 30, "trace_log": True},
+                               "319228361 distinct states", "table_slots_log2": TABLE_LOG2, "trace_log": True},
         "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
         "generated_per_distinct": round(g, 3), "record_bytes": round(s_bytes, 1),
         "roofline": {"bound": "hbm", "kernel": "k_expand", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -130,7 +131,7 @@ def main():
                      "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3)}},
     }
     # HBM traffic of the same kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
-    tpath = os.path.join(ROOT, "profiles", "r01c_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01d_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             t = json.load(f)

@@ -37,7 +37,7 @@ def main(args, CONFIG, EXPECT):
     per_pair = lambda x, extra=0: int(x / world / world * slack) + extra + (1 << 16)   # noqa: E731
     tail_idx, tail_words = 1280 * 1024, 1280 * 65536
     m = vt.Model.from_constants(R=CONFIG["R"], C_=CONFIG["C"], n=CONFIG["n"], L=CONFIG["L"])
-    table_log2 = max(20, int(math.ceil(math.log2(2.2 * TOTAL / world))))
+    table_log2 = max(20, int(math.ceil(math.log2(4.4 * TOTAL / world))))
     eng = sharded.HipShardEngine(
         m, rank, world, device=local_rank, table_log2=table_log2, frontier_words=per_rank(MAX_WORDS, world * tail_words),
         frontier_states=per_rank(MAX_NEW, world * tail_idx), pending_entries=1 << 16,   # single-pass levels: no pending list
