@@ -397,7 +397,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     if (tid == 0) { s_tile_base = s_chunk_used; s_tile_cursor = 0; }
     __syncthreads();
     // ---- apply + fingerprint + seen-set claim: one lane per enabled instance
-    u32 my_probes = 0;
+    u32 my_probes = 0, my_maxbag = 0, my_words = 0;
     for (u32 c = tid; c < ncand; c += VSR_BLOCK) {
       const u32 code = s_cand2[c];
       const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
@@ -506,8 +506,8 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
             atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
             atomicOr(&ctl->viol_mask, (u32)bad);
           }
-          atomicMax(&s_maxbag_out, (u32)hdr_nmsg(D.hdr));
-          atomicAdd(&s_acc[9], (unsigned long long)clen);
+          my_maxbag = my_maxbag > (u32)hdr_nmsg(D.hdr) ? my_maxbag : (u32)hdr_nmsg(D.hdr);
+          my_words += (u32)clen;
           if (remote) {
             // announce (fp, key) to the owner: entry i of the block's chunk of that owner's bucket
             u64 i = 0;
@@ -557,9 +557,20 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       }
     }
     const u64 t_4 = __builtin_readcyclecounter();
-    // wave-level reduction of the probe statistic
-    for (int o = 32; o > 0; o >>= 1) my_probes += __shfl_down(my_probes, o);
+    // wave-level reduction of the per-lane statistics (probes; fused: words written, largest bag)
+    for (int o = 32; o > 0; o >>= 1) {
+      my_probes += __shfl_down(my_probes, o);
+      if (fused) {
+        my_words += __shfl_down(my_words, o);
+        const u32 t = __shfl_down(my_maxbag, o);
+        my_maxbag = t > my_maxbag ? t : my_maxbag;
+      }
+    }
     if (lane == 0 && my_probes) atomicAdd(&s_acc[2], (unsigned long long)my_probes);
+    if (fused && lane == 0 && my_words) {
+      atomicAdd(&s_acc[9], (unsigned long long)my_words);
+      atomicMax(&s_maxbag_out, my_maxbag);
+    }
     __syncthreads();
     if (tid == 0) {
       if (fused) {
