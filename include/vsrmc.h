@@ -119,7 +119,12 @@ typedef struct vsrmc_options {
                                     follow the same switch. */
   int32_t filter_log2;           /* sharded single-pass runs: entries (8 B) of this rank's sent-filter = 2^filter_log2;
                                     0 = table_log2 */
-  int32_t reserved[4];
+  int32_t host_frontier;         /* 1: the two record buffers (frontier_words each) are pinned HOST memory that the kernels
+                                    read and write over PCIe; refs, fingerprints, trace log and seen-set stay in HBM.  For
+                                    frontiers beyond 288 GB (≙ TLC's DiskStateQueue) */
+  int32_t reserved0;
+  uint64_t frontier_words_b;     /* capacity of the SECOND record buffer (levels 2, 4, 6, ...); 0 = frontier_words.  Level sizes
+                                    grow geometrically, so the last two levels differ by that factor: size the buffers apart */
 } vsrmc_options;
 
 typedef struct vsrmc_level_info {
@@ -170,6 +175,15 @@ int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t inde
 /* index of fingerprint `fp` in the newest level (~0 if absent) */
 int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index);
 void vsrmc_checker_destroy(vsrmc_checker* c);
+
+/* Probe level: expand the newest level without storing its successors — invariants are evaluated on every successor that is
+ * not a state of an earlier level, nothing is inserted or written, so the level costs no frontier memory; the search cannot
+ * continue afterwards.  Finds a violation one level beyond what memory can hold.  Also valid right after a step that failed
+ * with "frontier full".  info: level (the probed one), generated, viol_fp / viol_mask, viol_index = index of the violator's
+ * PARENT in the newest level, pending = violating successors seen.  vsrmc_checker_probe_trace: Init .. violator. */
+int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info);
+int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
+                                  uint64_t cap_states, uint64_t* n_states);
 
 /* ≙ TLC's checkpoints (ModelChecker.checkpoint → FPSet.beginChkpt/commitChkpt, StateQueue and TLCTrace checkpoints; `-recover`):
  * one file holds the search between two levels — the occupied seen-set slots, the newest frontier, the trace log.  It is written

@@ -4,6 +4,9 @@ committed golden fixtures.  Integer / byte work throughout: the bar is bit-exact
 Nothing here reads /root/reference (it does not exist on the GPU box); the reference's golden vector travels as
 tests/golden/state_transfer_trace.json.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -535,3 +538,65 @@ def test_cli_checkpoint_and_recover(vt, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Recovered from" in r.stdout and "Model checking completed. No error has been found." in r.stdout
     assert "76 distinct states found" in r.stdout and "search is 14" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# beyond HBM: the probe level (invariants of a level that is never stored) and the host-resident frontier
+# ---------------------------------------------------------------------------------------------------------------------
+def test_probe_level_finds_the_violation_one_level_early(vt, orc):
+    """Config 2 violates AcknowledgedWriteNotLost in level 28.  Stop after level 27 and PROBE level 28: no insert, no frontier
+    written — the same violating fingerprint comes back, with a 28-state counter-example the oracle accepts."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_violation.json")) as f:
+        fx = json.load(f)
+    P = orc.Params(3, 1, 2, 2)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=30, frontier_words=int(3.2e9), frontier_states=1 << 27, pending_entries=1 << 20,
+                         trace_entries=1 << 29)
+    while mc.level < 27:
+        d = mc.step()
+        assert d["viol_mask"] == 0
+    before = (mc.level, mc.distinct)
+    p = mc.probe()
+    assert p["level"] == 28 and p["viol_mask"] == 1 and p["viol_fp"] == int(fx["viol_fp"], 16)
+    assert p["generated"] == fx["levels"][27]["generated"]
+    assert (mc.level, mc.distinct) == before                      # nothing was committed
+    tr = mc.probe_trace()
+    assert len(tr) == 28 and tr[0][0] == "Initial predicate"
+    _check_walk_with_oracle(orc, P, tr, 1)
+    fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
+    assert int(fps[0]) == p["viol_fp"]
+    # a probe of a level without violation reports none (fresh checker, level 5)
+    mc.reset()
+    for _ in range(3):
+        mc.step()
+    q = mc.probe()
+    assert q["viol_mask"] == 0 and q["level"] == 5 and q["generated"] > 0
+    mc.close()
+
+
+def test_probe_after_frontier_full_and_host_frontier(vt, orc):
+    """(a) a step that fails with "frontier full" can be followed by probe() — the fingerprints the failed attempt inserted carry
+    the new level and do not hide anything; (b) host_frontier=1 (records in pinned host memory, zero-copy) gives the same levels."""
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    ref = vt.ModelChecker(m, table_log2=22, frontier_words=1 << 26, frontier_states=1 << 21)
+    gen = []
+    for _ in range(13):
+        gen.append(ref.step()["generated"])
+    small = vt.ModelChecker(m, table_log2=22, frontier_words=1 << 22, frontier_states=1 << 17)   # level 13 (161 457 states) cannot fit
+    with pytest.raises(vt.VsrmcError) as ei:
+        while True:
+            small.step()
+    assert "device error 21" in str(ei.value)
+    lvl = small.level
+    p = small.probe()
+    assert p["level"] == lvl + 1 and p["viol_mask"] == 0 and p["generated"] == gen[lvl - 1]
+    small.close()
+    host = vt.ModelChecker(m, table_log2=22, frontier_words=1 << 26, frontier_states=1 << 21, host_frontier=True)
+    for _ in range(13):
+        host.step()
+    assert (host.level, host.distinct) == (ref.level, ref.distinct)
+    assert np.array_equal(host.level_fps(), ref.level_fps())
+    fp = int(host.level_fps()[0])
+    assert len(host.trace(host.level, host.find_fp(fp))) == host.level
+    host.close()
+    ref.close()

@@ -22,13 +22,19 @@ ap.add_argument("--no-symmetry", action="store_true")
 ap.add_argument("--assume-commit-number", action="store_true")
 ap.add_argument("--no-trace", action="store_true")
 ap.add_argument("--exact-ties", action="store_true")
+ap.add_argument("--host-frontier", action="store_true")
+ap.add_argument("--frontier-b-words-log2", type=float, default=0)
+ap.add_argument("--trace-log2", type=float, default=0)
+ap.add_argument("--probe-at", type=int, default=0)
 a = ap.parse_args()
 m = vt.Model.from_constants(R=a.R, C_=a.C, n=a.n, L=a.L, symmetry=not a.no_symmetry, invariant_mask=a.inv_mask,
                             assume_commit_number=a.assume_commit_number)
 t0 = time.time()
 mc = vt.ModelChecker(m, table_log2=a.table_log2, frontier_words=int(2 ** a.frontier_words_log2),
                      frontier_states=1 << a.frontier_states_log2, pending_entries=1 << a.pending_log2,
-                     keep_trace=not a.no_trace, exact_ties=a.exact_ties)
+                     keep_trace=not a.no_trace, exact_ties=a.exact_ties, host_frontier=a.host_frontier,
+                     frontier_words_b=int(2 ** a.frontier_b_words_log2) if a.frontier_b_words_log2 else 0,
+                     trace_entries=int(2 ** a.trace_log2) if a.trace_log2 else 0)
 print(json.dumps(dict(setup_seconds=round(time.time() - t0, 3))))
 t0 = time.time()
 why = "exhausted"
@@ -38,6 +44,16 @@ try:
             why = "max-depth"; break
         if time.time() - t0 > a.max_seconds:
             why = "max-seconds"; break
+        if a.probe_at and mc.level + 1 == a.probe_at:
+            p = mc.probe()
+            print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items() if k not in ("act_generated", "phase_cycles")}))
+            why = "probe"
+            if p["viol_mask"]:
+                tr = mc.probe_trace()
+                print("probe trace length", len(tr), [t[0] for t in tr])
+                print(m.format_state(tr[-1][1]))
+                print(json.dumps(dict(trace=[dict(action=t[0], words=["%016x" % int(w) for w in t[1]]) for t in tr])))
+            break
         d = mc.step()
         if d["n_new"]:
             acts = d.pop("act_generated"); ph = d.pop("phase_cycles")

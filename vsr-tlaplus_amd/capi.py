@@ -18,7 +18,7 @@ class Layout(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("table_log2", C.c_int32), ("frontier_words", C.c_uint64),
                 ("frontier_states", C.c_uint64), ("pending_entries", C.c_uint64), ("keep_trace", C.c_int32),
-                ("rank", C.c_int32), ("world", C.c_int32), ("trace_entries", C.c_uint64), ("exact_ties", C.c_int32), ("filter_log2", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("rank", C.c_int32), ("world", C.c_int32), ("trace_entries", C.c_uint64), ("exact_ties", C.c_int32), ("filter_log2", C.c_int32), ("host_frontier", C.c_int32), ("reserved0", C.c_int32), ("frontier_words_b", C.c_uint64)]
 
 
 class LevelInfo(C.Structure):
@@ -87,6 +87,8 @@ SYMBOLS = {
     "vsrmc_queue_size": (C.c_int32, [V, C.POINTER(C.c_uint64)]),
     "vsrmc_queue_destroy": (None, [V]),
     "vsrmc_simulate": (C.c_int32, [V, C.c_int32, C.c_uint32, C.c_int32, C.c_uint64, C.c_double, C.POINTER(SimResult)]),
+    "vsrmc_checker_probe": (C.c_int32, [V, C.POINTER(LevelInfo)]),
+    "vsrmc_checker_probe_trace": (C.c_int32, [V, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_save": (C.c_int32, [V, C.c_char_p]),
     "vsrmc_checker_status": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_checker_load": (C.c_int32, [V, C.POINTER(Options), C.c_char_p, C.POINTER(V)]),

@@ -254,7 +254,7 @@ class ModelChecker:
     """≙ tlc2.tool.ModelChecker: level-synchronous BFS; `step()` = every Worker draining one level of the StateQueue."""
 
     def __init__(self, model, device=0, table_log2=24, frontier_words=1 << 25, frontier_states=1 << 20,
-                 pending_entries=1 << 21, keep_trace=True, trace_entries=0, exact_ties=False, recover=None):
+                 pending_entries=1 << 21, keep_trace=True, trace_entries=0, exact_ties=False, recover=None, host_frontier=False, frontier_words_b=0):
         """recover: path of a checkpoint written by save() — continue that search (≙ `tlc2.TLC -recover`)."""
         self.model = model
         o = capi.Options()
@@ -264,6 +264,8 @@ class ModelChecker:
         o.keep_trace = int(keep_trace)
         o.trace_entries = trace_entries
         o.exact_ties = int(exact_ties)
+        o.frontier_words_b = frontier_words_b         # second record buffer (levels 2, 4, ...); 0 = frontier_words
+        o.host_frontier = int(host_frontier)     # records in pinned host memory, read / written over PCIe (≙ DiskStateQueue)
         self.options = o
         self._h = C.c_void_p()
         if recover is None:
@@ -362,6 +364,30 @@ class ModelChecker:
         n = C.c_uint64()
         check(capi.load().vsrmc_checker_trace(self._h, level, index, _p(words), cap_w, _p(off), _p(acts), len(off),
                                               C.byref(n)))
+        return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(n.value)]
+
+    def probe(self):
+        """Expand the newest level without storing it: invariants of every successor that is not an earlier-level state are
+        checked, nothing is inserted or written (no frontier memory needed; the search cannot continue afterwards).  Also valid
+        right after a step() that failed with "frontier full".  -> dict(level, generated, viol_fp, viol_mask, parent_index, ...)"""
+        info = capi.LevelInfo()
+        check(capi.load().vsrmc_checker_probe(self._h, C.byref(info)))
+        d = info.as_dict()
+        d["parent_index"] = d.pop("viol_index")
+        if d["viol_mask"] and self.violation is None:
+            self.violation = dict(level=d["level"], index=None, fp=d["viol_fp"], mask=d["viol_mask"], probed=True)
+        return d
+
+    def probe_trace(self):
+        """The counter-example of the violation probe() reported: [(action name, record)] from Init to the violator."""
+        lay = self.model.layout
+        n_max = self.level + 2
+        cap_w = (n_max + 1) * int(lay.max_record_words)
+        words = np.zeros(cap_w, dtype=np.uint64)
+        off = np.zeros(n_max + 2, dtype=np.uint64)
+        acts = np.zeros(n_max + 2, dtype=np.int32)
+        n = C.c_uint64()
+        check(capi.load().vsrmc_checker_probe_trace(self._h, _p(words), cap_w, _p(off), _p(acts), len(off), C.byref(n)))
         return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(n.value)]
 
     def close(self):

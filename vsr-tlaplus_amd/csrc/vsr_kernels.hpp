@@ -120,6 +120,30 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32
   return r;
 }
 
+// Lookup without insertion (probe level, vsrmc_checker_probe): is fp in the table, and with which meta word?
+__device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp, u64* meta, u32* nprobe) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  u64 i = fp & mask;
+  for (u32 lines = 0; lines < 2048; lines++) {
+    const u64 lb = i & ~(u64)3;
+    const u64x2* lp = (const u64x2*)&table[lb];
+    const u64x2 s0 = lp[0], s1 = lp[1], s2 = lp[2], s3 = lp[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (lb + k < i) continue;
+      const u64x2 sk = k == 0 ? s0 : k == 1 ? s1 : k == 2 ? s2 : s3;
+      (*nprobe)++;
+      if (sk.x == fp) {
+        *meta = sk.y;
+        return true;
+      }
+      if (sk.x == 0) return false;
+    }
+    i = (lb + 4) & mask;
+  }
+  return false;
+}
+
 // Seen-set claim of the two-kernel scheme.  Returns the slot index; *found_old = true when the candidate cannot win (the
 // fingerprint belongs to an earlier level, or a smaller key of this level already holds the slot), otherwise the caller's key
 // has been min-merged into the slot's meta word and the candidate goes to the pending list.
@@ -173,7 +197,10 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
          u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u64* lvl_tr, u32 ichunk, u32 wchunk, int tile, u32 ccap /* work-list capacity per tile */,
          // fused + sharded (world > 1): successors owned by another rank pass the rank's sent-filter, are written to the local
          // next frontier SPECULATIVELY and announced to their owner; cand_idx remembers where, for k_apply_verdict
-         u64* filter, u64 fmask, u64* cand_idx, u32 cchunk /* candidate entries a block reserves per owner and global atomic */) {
+         u64* filter, u64 fmask, u64* cand_idx, u32 cchunk /* candidate entries a block reserves per owner and global atomic */,
+         // probe level (fused, unsharded): nothing is inserted or written; every successor that is not a state of an EARLIER level
+         // gets its invariants checked, violators go to the `pending` list as (fp, key) pairs (n_pending counts them)
+         int probe) {
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
@@ -346,7 +373,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     __syncthreads();
 
     const u64 t_3 = __builtin_readcyclecounter();
-    if (fused) {
+    if (fused && !probe) {
       // ---- reserve room for this tile's successors (upper bounds: ncand states, s_wneed words) in the block's chunks
       if (s_ich_used + ncand > ichunk) {                        // block-uniform
         const u32 used = s_ich_used;
@@ -378,7 +405,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       if (tid == 0) { s_tile_ibase = s_ich_used; s_tile_wbase = s_wch_used; s_tile_icur = 0; s_tile_wcur = 0; }
     } else
     // ---- reserve room for this tile's pending entries (at most ncand) in the block's chunk
-    if (s_chunk_used + ncand > pchunk) {                    // block-uniform
+    if (!fused && s_chunk_used + ncand > pchunk) {          // block-uniform
       const u32 used = s_chunk_used;
       const u64 base = s_chunk_base;
       for (u32 k = used + tid; k < pchunk && used < pchunk; k += VSR_BLOCK) pending[2 * (base + k) + 1] = ~(u64)0;
@@ -436,6 +463,23 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
             }
           continue;
         }
+      }
+      if (fused && probe) {
+        u64 m = META_EMPTY;
+        const bool seen = probe_lookup(table, tmask, fp, &m, &my_probes) && meta_level(m) < level;
+        if (!seen) {
+          const int bad = check_invariants_child(M, rec, D);
+          if (bad) {
+            const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
+            if (i < pending_cap) {
+              pending[2 * i] = fp;
+              pending[2 * i + 1] = key;
+            }
+            atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
+            atomicOr(&ctl->viol_mask, (u32)bad);
+          }
+        }
+        continue;
       }
       if (fused) {
         bool do_write, remote = false;

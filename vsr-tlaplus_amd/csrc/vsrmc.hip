@@ -850,6 +850,10 @@ struct vsrmc_checker {
   u64* cand_idx = nullptr;               // ... and where each announced candidate was written (world x cand_cap)
   u64 cand_idx_cap = 0;
   bool level_fused = false;              // the level in flight is a single-pass level
+  int failed_code = 0;                   // device ERR_* that stopped the search (failed == 1)
+  u64 probe_key = ~(u64)0;               // vsrmc_checker_probe: trace key (parent index, ordinal) of the reported violator
+  bool host_frontier = false;            // the two record buffers live in pinned host memory (zero-copy over PCIe)
+  u64 words_cap(int b) const { return (b == 1 && opt.frontier_words_b) ? opt.frontier_words_b : opt.frontier_words; }
 };
 
 namespace {
@@ -888,6 +892,8 @@ int checker_seed(vsrmc_checker* c) {
   c->distinct = mine ? 1 : 0;
   c->total_generated = 0;
   c->failed = 0;
+  c->failed_code = 0;
+  c->probe_key = ~(u64)0;
   c->level_base.assign(1, 0);
   c->level_size.assign(1, c->n_frontier);
   return 0;
@@ -931,8 +937,12 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
   u64 slots = (u64)1 << o->table_log2;
   c->tmask = slots - 1;
   hipError_t e = hipMalloc((void**)&c->table, slots * sizeof(Slot));
+  c->host_frontier = o->host_frontier != 0;
   for (int b = 0; b < 2 && e == hipSuccess; b++) {
-    e = hipMalloc((void**)&c->words[b], o->frontier_words * 8);
+    // host_frontier: the records stay in pinned host memory and the kernels read / write them over PCIe (zero-copy); the
+    // refs, fingerprints, trace log and the seen-set stay in HBM.  For state spaces whose frontier outgrows the 288 GB.
+    if (c->host_frontier) e = hipHostMalloc((void**)&c->words[b], c->words_cap(b) * 8, hipHostMallocMapped | hipHostMallocPortable);
+    else e = hipMalloc((void**)&c->words[b], c->words_cap(b) * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&c->off[b], (o->frontier_states + 1) * 8);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&c->lvl_fp, o->frontier_states * 8);
@@ -971,6 +981,7 @@ namespace {
 // ---- the phases of one BFS level (shared by the single-GPU step and the sharded protocol) --------------------------
 int level_error(vsrmc_checker* c, const LevelCtl& h, int new_level) {
   c->failed = 1;
+  c->failed_code = (int)h.err;
   char buf[256];
   std::snprintf(buf, sizeof(buf), "device error %u at frontier index %llu ordinal %llu (level %d)", h.err,
                 (unsigned long long)(h.err_info >> 16), (unsigned long long)(h.err_info & 0xFFFF), new_level);
@@ -980,7 +991,7 @@ int level_error(vsrmc_checker* c, const LevelCtl& h, int new_level) {
 }
 
 // phase 1: k_expand over the current frontier.  io == nullptr: unsharded.
-int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
+int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, bool probe = false) {
   const Model& M = c->model.M;
   HIPCHK(hipSetDevice(c->opt.device));
   if (c->level + 1 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
@@ -1020,21 +1031,21 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io) {
       // persistent blocks (2 resident per CU: 225 VGPRs, 79 KB LDS): every block leaves one partly used index chunk and
       // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
       grid = (unsigned)std::min<u64>(grid, (u64)c->num_cus * 2);
-      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->opt.frontier_words / (4 * 16384))));
+      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
       ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
-      wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->opt.frontier_words / (4 * (u64)grid)));
+      wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     }
     if (fused)
       hipLaunchKernelGGL(k_expand<true>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
-                         c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
-                         wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk);
+                         c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
+                         wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk, probe ? 1 : 0);
     else
       hipLaunchKernelGGL(k_expand<false>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
-                         0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap, nullptr, 0, nullptr, 0);
+                         0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap, nullptr, 0, nullptr, 0, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -1092,7 +1103,7 @@ int phase_materialize_local(vsrmc_checker* c) {
   u64 nx_cap = c->opt.frontier_states;                         // the trace log bounds the level as well
   if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base ? c->trace_cap - c->tr_base : 0);
   const int nxt = c->cur ^ 1;
-  int rc = phase_materialize(c, c->pending, n_pending, nullptr, c->words[nxt], c->opt.frontier_words, c->off[nxt], nx_cap,
+  int rc = phase_materialize(c, c->pending, n_pending, nullptr, c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap,
                              c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base : nullptr, &c->ctl->n_new, &c->ctl->words_new);
   if (rc) return rc;
   HIPCHK(hipMemcpy(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost));
@@ -1187,6 +1198,70 @@ static int32_t step_local(vsrmc_checker* c, vsrmc_level_info* info) {
   if (rc) return rc;
   if (info->viol_mask) return find_fp_newest(c, info->viol_fp, &info->viol_index);
   return 0;
+}
+
+// Probe level: expand the newest level WITHOUT storing its successors — every successor that is not a state of an earlier
+// level gets its invariants checked, nothing is inserted into the seen-set, no frontier is written.  The search cannot
+// continue afterwards (the level does not exist), but a violation one level beyond what memory can hold is found and its
+// counter-example reconstructed (vsrmc_checker_probe_trace).  Also valid right after a step that failed with "frontier full".
+int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
+  if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
+  if (c->failed && c->failed_code != ERR_FRONTIER_FULL) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  c->failed = 0;
+  c->probe_key = ~(u64)0;
+  int rc = phase_expand(c, nullptr, true);
+  if (rc) return rc;
+  std::memset(info, 0, sizeof(*info));
+  info->level = c->level + 1;
+  info->frontier = c->n_frontier;
+  info->generated = c->h.generated;
+  info->deadlocks = c->h.deadlocks;
+  info->probes = c->h.probes;
+  info->pending = c->h.n_pending;                               // violating successors seen (duplicates included)
+  info->distinct = c->distinct;
+  info->total_generated = c->total_generated + c->h.generated;
+  info->expand_ms = c->expand_ms;
+  info->seconds = now_s() - c->t_level0;
+  info->viol_fp = ~(u64)0;
+  info->viol_index = ~(u64)0;
+  for (int a = 0; a < 16; a++) info->act_generated[a] = c->h.act_generated[a];
+  for (int a = 0; a < 8; a++) info->phase_cycles[a] = c->h.phase_cycles[a];
+  if (c->h.viol_fp != ~(u64)0) {
+    info->viol_fp = c->h.viol_fp;
+    info->viol_mask = (int32_t)c->h.viol_mask;
+    // the violator that is reported: smallest fingerprint; among its (fp, key) entries the smallest key
+    const u64 n = std::min<u64>(c->h.n_pending, std::min<u64>(c->opt.pending_entries, (u64)1 << 20));
+    std::vector<u64> list(2 * n);
+    HIPCHK(hipMemcpy(list.data(), c->pending, 16 * n, hipMemcpyDeviceToHost));
+    for (u64 i = 0; i < n; i++)
+      if (list[2 * i] == c->h.viol_fp && list[2 * i + 1] < c->probe_key) c->probe_key = list[2 * i + 1];
+    if (c->probe_key != ~(u64)0) info->viol_index = meta_pidx(c->probe_key);   // index of its PARENT in the newest level
+  }
+  return 0;
+}
+
+int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
+                                  uint64_t cap_states, uint64_t* n_states) {
+  if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->probe_key == ~(u64)0) return fail(VSRMC_E_STATE, "no violation recorded by vsrmc_checker_probe");
+  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
+  const int level = c->level, nsteps = level;                   // level - 1 logged steps + the probed one
+  HIPCHK(hipSetDevice(c->opt.device));
+  std::vector<u32> ords((size_t)nsteps);
+  if (level > 1) {
+    u32* d_ords = nullptr;
+    HIPCHK(hipMalloc((void**)&d_ords, (u64)(level - 1) * 4));
+    HIPCHK(hipMemcpy(c->d_level_base, c->level_base.data(), c->level_base.size() * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->tr_all, c->d_level_base, level, meta_pidx(c->probe_key), d_ords);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(ords.data(), d_ords, (u64)(level - 1) * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_ords);
+    if (ords[0] == 0xFFFFFFFFu) return fail(VSRMC_E_STATE, "the trace log does not hold the violator's parent");
+  }
+  ords[(size_t)nsteps - 1] = (u32)meta_ord(c->probe_key);
+  return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), nsteps, words, cap_words, off, actions, cap_states, n_states);
 }
 
 int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
@@ -1316,7 +1391,7 @@ int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, cons
     u64 n = std::min<u64>(c->h.cand_cnt[o], io->cand_cap);
     if (n && !d_verdict_in) return fail(VSRMC_E_ARG, "verdicts missing");
     rc = phase_materialize(c, io->cand_send + 2 * (u64)o * io->cand_cap, n, d_verdict_in + (u64)o * io->cand_cap, c->words[nxt],
-                           c->opt.frontier_words, c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base : nullptr,
+                           c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base : nullptr,
                            &c->ctl->n_new, &c->ctl->words_new);
   }
   if (rc) return rc;
@@ -1375,7 +1450,7 @@ int32_t vsrmc_shard_append(vsrmc_checker* c, const uint64_t* d_words, uint64_t n
   HIPCHK(hipSetDevice(c->opt.device));
   u64 nx_cap = c->opt.frontier_states;
   if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base ? c->trace_cap - c->tr_base : 0);
-  if (c->nx_n + n > nx_cap || c->nx_w + n_words > c->opt.frontier_words) {
+  if (c->nx_n + n > nx_cap || c->nx_w + n_words > c->words_cap(c->cur ^ 1)) {
     c->failed = 1;
     return fail(VSRMC_E_REP, "frontier / trace buffers full while appending received records");
   }
@@ -1621,7 +1696,7 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
     hi = std::max(hi, doff[i]);
   }
   std::vector<u64> dev(hi + (u64)M.fixed + 256);
-  u64 take = std::min<u64>(dev.size(), c->opt.frontier_words);
+  u64 take = std::min<u64>(dev.size(), c->words_cap(c->cur));
   HIPCHK(hipMemcpy(dev.data(), c->words[c->cur], take * 8, hipMemcpyDeviceToHost));
   u64 pos = 0, k = 0;
   for (u64 i = 0; i < c->n_frontier; i++) {
@@ -1717,7 +1792,7 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
   (void)hipSetDevice(c->opt.device);
   if (c->table) (void)hipFree(c->table);
   for (int b = 0; b < 2; b++) {
-    if (c->words[b]) (void)hipFree(c->words[b]);
+    if (c->words[b]) (void)(c->host_frontier ? hipHostFree(c->words[b]) : hipFree(c->words[b]));
     if (c->off[b]) (void)hipFree(c->off[b]);
   }
   if (c->lvl_fp) (void)hipFree(c->lvl_fp);

@@ -23,11 +23,15 @@ static void usage() {
       "  -maxDepth N       stop after N BFS levels (Init = level 1)\n"
       "  -device D         HIP device ordinal (default 0)\n"
       "  -tableLog2 N      seen-set slots = 2^N x 16 B (default 28)\n"
-      "  -frontierGiB G    size of each of the two frontier buffers (default 8)\n"
+      "  -frontierGiB G    size of each of the two frontier buffers (default 8); -frontierBGiB G: the second one (levels 2, 4, ..)\n"
       "  -simulate         random walks instead of BFS (TLC -simulate): -depth N (default 100) -walkers N (131072) -seed S -maxSeconds T\n"
       "  -validateTrace F  read a TLC trace (trace expression, or console \"State k:\" form) and check on the GPU that it is a\n"
       "                    behaviour of the model: Init, then one generated successor after the other; reports the invariants\n"
       "                    its last state violates\n"
+      "  -hostFrontier     keep the two record buffers (-frontierGiB each) in pinned host memory, read / written over PCIe\n"
+      "                    (state spaces whose frontier outgrows HBM; TLC's DiskStateQueue)\n"
+      "  -probeLast        when the next level does not fit the frontier buffers, still check its states' invariants without\n"
+      "                    storing them (finds a violation one level beyond memory; the search ends there)\n"
       "  -checkpoint FILE  write a checkpoint between levels, at most every -checkpointMinutes M (default 30; 0 = after every level)\n"
       "  -recover FILE     continue the search a checkpoint stopped at (same constants; buffer sizes may differ)\n"
       "  -noTLA            do not read / hash-check the .tla file (only the cfg)\n"
@@ -37,13 +41,13 @@ static void usage() {
 int main(int argc, char** argv) {
   std::string cfg, tla, trace_file, chk_file, recover_file;
   double chk_minutes = 30.0;
-  bool check_deadlock = false, no_tla = false, json = false, simulate = false;
+  bool check_deadlock = false, no_tla = false, json = false, simulate = false, host_frontier = false, probe_last = false;
   int sim_depth = 100;
   unsigned sim_walkers = 1u << 17;
   unsigned long long sim_seed = 1;
   double sim_seconds = 60.0;
   int max_depth = 1 << 30, device = 0, table_log2 = 28;
-  double frontier_gib = 8.0;
+  double frontier_gib = 8.0, frontier_b_gib = 0.0;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--help" || a == "-h" || a == "-help") { usage(); return 0; }
@@ -54,7 +58,10 @@ int main(int argc, char** argv) {
     else if (a == "-device" && i + 1 < argc) device = std::atoi(argv[++i]);
     else if (a == "-tableLog2" && i + 1 < argc) table_log2 = std::atoi(argv[++i]);
     else if (a == "-frontierGiB" && i + 1 < argc) frontier_gib = std::atof(argv[++i]);
+    else if (a == "-frontierBGiB" && i + 1 < argc) frontier_b_gib = std::atof(argv[++i]);
     else if (a == "-noTLA") no_tla = true;
+    else if (a == "-hostFrontier") host_frontier = true;
+    else if (a == "-probeLast") probe_last = true;
     else if (a == "-validateTrace" && i + 1 < argc) trace_file = argv[++i];
     else if (a == "-checkpoint" && i + 1 < argc) chk_file = argv[++i];
     else if (a == "-checkpointMinutes" && i + 1 < argc) chk_minutes = std::atof(argv[++i]);
@@ -162,7 +169,9 @@ int main(int argc, char** argv) {
   vsrmc_options_default(&o);
   o.device = device;
   o.table_log2 = table_log2;
+  o.host_frontier = host_frontier ? 1 : 0;
   o.frontier_words = (uint64_t)(frontier_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);
+  o.frontier_words_b = (uint64_t)(frontier_b_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);   // 0 = like the first
   o.frontier_states = o.frontier_words / 24;
   o.pending_entries = o.frontier_states * 3;
   // one entry per state plus the unused tails of the per-block index chunks (<= 4096 per block per level, 510 levels at most)
@@ -183,11 +192,30 @@ int main(int argc, char** argv) {
   else std::printf("Recovered from %s: level %d, %llu distinct states found, %llu states left on queue.\n", recover_file.c_str(), info.level,
                    (unsigned long long)info.distinct, (unsigned long long)info.n_new);
   int rc = 0;
-  bool violated = false, deadlocked = false;
+  bool violated = false, deadlocked = false, probed_violation = false;
   uint64_t viol_level = 0, viol_index = 0;
   int depth = info.level;
   while (depth < max_depth) {
     rc = vsrmc_checker_step(c, &info);
+    if (rc == VSRMC_E_REP && probe_last && std::strstr(vsrmc_last_error(), "device error 21") != nullptr) {
+      // the level does not fit: probe it (invariants only, nothing stored)
+      std::printf("Level %d does not fit the frontier buffers (%s); probing it without storing its states.\n", depth + 1, vsrmc_last_error());
+      vsrmc_level_info pi;
+      rc = vsrmc_checker_probe(c, &pi);
+      if (rc != 0) break;
+      double dtp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      std::printf("Probe(%d): %llu states generated from %llu states, %llu violating successors seen. (%.2f s)\n", pi.level,
+                  (unsigned long long)pi.generated, (unsigned long long)pi.frontier, (unsigned long long)pi.pending, dtp);
+      info.total_generated = pi.total_generated;
+      if (pi.viol_mask) {
+        probed_violation = true;
+        info.viol_mask = pi.viol_mask;
+        viol_level = (uint64_t)pi.level;
+      } else {
+        std::printf("No violation in level %d; the search is incomplete beyond it.\n", pi.level);
+      }
+      break;
+    }
     if (rc != 0) break;
     if (info.n_new) depth = info.level;
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -213,7 +241,7 @@ int main(int argc, char** argv) {
   if (rc != 0) {
     std::printf("Error: %s\n", vsrmc_last_error());
     exit_code = rc == VSRMC_E_EVAL ? 12 : 1;
-  } else if (violated) {
+  } else if (violated || probed_violation) {
     const char* names[2] = {"AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"};
     for (int b = 0; b < 2; b++)
       if (info.viol_mask & (1 << b)) std::printf("Error: Invariant %s is violated.\n", names[b]);
@@ -221,7 +249,9 @@ int main(int argc, char** argv) {
     uint64_t cap_w = (viol_level + 2) * (uint64_t)lay.max_record_words, n_states = 0;
     std::vector<uint64_t> words(cap_w), off(viol_level + 2);
     std::vector<int32_t> acts(viol_level + 2);
-    if (vsrmc_checker_trace(c, (int32_t)viol_level, viol_index, words.data(), cap_w, off.data(), acts.data(), off.size(), &n_states) != 0) {
+    if ((probed_violation ? vsrmc_checker_probe_trace(c, words.data(), cap_w, off.data(), acts.data(), off.size(), &n_states)
+                          : vsrmc_checker_trace(c, (int32_t)viol_level, viol_index, words.data(), cap_w, off.data(), acts.data(), off.size(),
+                                                &n_states)) != 0) {
       std::printf("Error: %s\n", vsrmc_last_error());
       exit_code = 1;
     } else {
