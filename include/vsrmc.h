@@ -119,9 +119,9 @@ typedef struct vsrmc_options {
                                     follow the same switch. */
   int32_t filter_log2;           /* sharded single-pass runs: entries (8 B) of this rank's sent-filter = 2^filter_log2;
                                     0 = table_log2 */
-  int32_t host_frontier;         /* 1: the two record buffers (frontier_words each) are pinned HOST memory that the kernels
-                                    read and write over PCIe; refs, fingerprints, trace log and seen-set stay in HBM.  For
-                                    frontiers beyond 288 GB (≙ TLC's DiskStateQueue) */
+  int32_t host_frontier;         /* bit 0 / bit 1: the first (levels 1, 3, 5, ...) / second (levels 2, 4, ...) record buffer is
+                                    pinned HOST memory that the kernels read and write over PCIe (3 = both); refs, fingerprints,
+                                    trace log and seen-set stay in HBM.  For frontiers beyond 288 GB (≙ TLC's DiskStateQueue) */
   int32_t reserved0;
   uint64_t frontier_words_b;     /* capacity of the SECOND record buffer (levels 2, 4, 6, ...); 0 = frontier_words.  Level sizes
                                     grow geometrically, so the last two levels differ by that factor: size the buffers apart */
@@ -182,6 +182,13 @@ void vsrmc_checker_destroy(vsrmc_checker* c);
  * with "frontier full".  info: level (the probed one), generated, viol_fp / viol_mask, viol_index = index of the violator's
  * PARENT in the newest level, pending = violating successors seen.  vsrmc_checker_probe_trace: Init .. violator. */
 int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info);
+/* Two levels beyond the last materialised one: level L+1 becomes a VIRTUAL level (fingerprints claimed, invariants checked, exact
+ * count, no records), then the newest level is expanded a second time in slices — the successors that won their slot are written
+ * to the idle next buffer and at once expanded in probe mode (level L+2), then dropped.  Costs one extra expansion of the newest
+ * level and no memory beyond a slice.  virt: level L+1 (n_new exact); probe: level L+2.  A violation in either is reported there
+ * (viol_index = index in the newest level of the violator's parent resp. grandparent); vsrmc_checker_probe_trace gives the
+ * counter-example.  The search cannot continue afterwards. */
+int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_level_info* probe);
 int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
                                   uint64_t cap_states, uint64_t* n_states);
 

@@ -591,7 +591,7 @@ def test_probe_after_frontier_full_and_host_frontier(vt, orc):
     p = small.probe()
     assert p["level"] == lvl + 1 and p["viol_mask"] == 0 and p["generated"] == gen[lvl - 1]
     small.close()
-    host = vt.ModelChecker(m, table_log2=22, frontier_words=1 << 26, frontier_states=1 << 21, host_frontier=True)
+    host = vt.ModelChecker(m, table_log2=22, frontier_words=1 << 26, frontier_states=1 << 21, host_frontier=1, frontier_words_b=1 << 25)
     for _ in range(13):
         host.step()
     assert (host.level, host.distinct) == (ref.level, ref.distinct)
@@ -600,3 +600,43 @@ def test_probe_after_frontier_full_and_host_frontier(vt, orc):
     assert len(host.trace(host.level, host.find_fp(fp))) == host.level
     host.close()
     ref.close()
+
+
+def test_probe2_virtual_level_plus_probe_level(vt, orc):
+    """Stop after level 26 of config 2.  probe2(): level 27 as a virtual level (exact count, no records), level 28 probed over
+    slices of regenerated level-27 states -> the golden violating fingerprint, exact per-level figures, a 28-state
+    counter-example the oracle accepts.  Small buffers force many slices."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_violation.json")) as f:
+        fx = json.load(f)
+    P = orc.Params(3, 1, 2, 2)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=30, frontier_words=int(2.4e9), frontier_states=1 << 26, pending_entries=1 << 20,
+                         trace_entries=int(2.4e8))
+    while mc.level < 26:
+        assert mc.step()["viol_mask"] == 0
+    v, p = mc.probe2()
+    assert v["level"] == 27 and v["viol_mask"] == 0
+    assert (v["n_new"], v["generated"], v["deadlocks"]) == tuple(fx["levels"][26][k] for k in ("n_new", "generated", "deadlocks"))
+    assert v["distinct"] == sum(l["n_new"] for l in fx["levels"][:27])
+    assert p["level"] == 28 and p["viol_mask"] == 1 and p["viol_fp"] == int(fx["viol_fp"], 16)
+    assert (p["generated"], p["deadlocks"]) == (fx["levels"][27]["generated"], fx["levels"][27]["deadlocks"])
+    tr = mc.probe_trace()
+    assert len(tr) == 28
+    _check_walk_with_oracle(orc, P, tr, 1)
+    fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
+    assert int(fps[0]) == p["viol_fp"]
+    with pytest.raises(vt.VsrmcError):
+        mc.step()                                                # the seen-set holds a level that has no frontier
+    mc.close()
+    # the violation sits in the virtual level itself when the run stops one level later
+    mc = vt.ModelChecker(m, table_log2=30, frontier_words=int(3.2e9), frontier_states=1 << 27, pending_entries=1 << 20,
+                         trace_entries=1 << 29)
+    while mc.level < 27:
+        mc.step()
+    v, p = mc.probe2()
+    assert v["level"] == 28 and v["viol_mask"] == 1 and v["viol_fp"] == int(fx["viol_fp"], 16) and v["n_new"] == fx["levels"][27]["n_new"]
+    assert p["level"] == 0
+    tr = mc.probe_trace()
+    assert len(tr) == 28
+    _check_walk_with_oracle(orc, P, tr, 1)
+    mc.close()

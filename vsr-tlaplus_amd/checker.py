@@ -265,7 +265,8 @@ class ModelChecker:
         o.trace_entries = trace_entries
         o.exact_ties = int(exact_ties)
         o.frontier_words_b = frontier_words_b         # second record buffer (levels 2, 4, ...); 0 = frontier_words
-        o.host_frontier = int(host_frontier)     # records in pinned host memory, read / written over PCIe (≙ DiskStateQueue)
+        # bit mask: record buffer 0 (levels 1, 3, ...) / 1 (levels 2, 4, ...) in pinned host memory (≙ DiskStateQueue); True = both
+        o.host_frontier = 3 if host_frontier is True else int(host_frontier)
         self.options = o
         self._h = C.c_void_p()
         if recover is None:
@@ -378,10 +379,22 @@ class ModelChecker:
             self.violation = dict(level=d["level"], index=None, fp=d["viol_fp"], mask=d["viol_mask"], probed=True)
         return d
 
+    def probe2(self):
+        """Two levels beyond the newest one without storing either: level+1 as a virtual level (fingerprints claimed, exact count,
+        invariants), level+2 as a probe over slices of regenerated level+1 states.  -> (virtual level dict, probe level dict)"""
+        v, p = capi.LevelInfo(), capi.LevelInfo()
+        check(capi.load().vsrmc_checker_probe2(self._h, C.byref(v), C.byref(p)))
+        dv, dp = v.as_dict(), p.as_dict()
+        for d in (dv, dp):
+            d["ancestor_index"] = d.pop("viol_index")
+            if d["viol_mask"] and self.violation is None:
+                self.violation = dict(level=d["level"], index=None, fp=d["viol_fp"], mask=d["viol_mask"], probed=True)
+        return dv, dp
+
     def probe_trace(self):
         """The counter-example of the violation probe() reported: [(action name, record)] from Init to the violator."""
         lay = self.model.layout
-        n_max = self.level + 2
+        n_max = self.level + 3
         cap_w = (n_max + 1) * int(lay.max_record_words)
         words = np.zeros(cap_w, dtype=np.uint64)
         off = np.zeros(n_max + 2, dtype=np.uint64)

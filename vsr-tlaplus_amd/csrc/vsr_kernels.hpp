@@ -47,6 +47,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
 __host__ __device__ __forceinline__ int owner_of(u64 fp, int world) { return (int)(((fp >> 40) & 0xFFFFFF) % (u64)world); }
 
+enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #define VSR_TILE_MAX 128     // frontier records staged per block iteration: 64 or 128 (kernel parameter `tile`)
 #define VSR_BLOCK 256
 #define VSR_CAND_CAP 2048    // enabled instances per tile the LDS work list can hold
@@ -198,9 +199,15 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
          // fused + sharded (world > 1): successors owned by another rank pass the rank's sent-filter, are written to the local
          // next frontier SPECULATIVELY and announced to their owner; cand_idx remembers where, for k_apply_verdict
          u64* filter, u64 fmask, u64* cand_idx, u32 cchunk /* candidate entries a block reserves per owner and global atomic */,
-         // probe level (fused, unsharded): nothing is inserted or written; every successor that is not a state of an EARLIER level
-         // gets its invariants checked, violators go to the `pending` list as (fp, key) pairs (n_pending counts them)
-         int probe) {
+         // fused, unsharded passes that do not materialise a level the normal way (vsrmc_checker_probe / _probe2):
+         //   MODE_PROBE   nothing is inserted or written; every successor that is not a state of an EARLIER level gets its
+         //                invariants checked
+         //   MODE_INSERT  "virtual level": fingerprints are claimed (min-merged keys, as always) and the invariants of the
+         //                new states checked, but no record, ref or trace key is written; ctl->n_new = exact number of new states
+         //   MODE_REGEN   re-expansion of (a slice of) the same parents after a MODE_INSERT pass: the successor whose key IS
+         //                the slot's final meta word — exactly one per new state — is written to the next frontier
+         // violators of PROBE / INSERT go to the `pending` list as (fp, key) pairs (n_pending counts them).
+         int mode, u64 p_offset /* index of parent 0 of this launch in its level (slices) */) {
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
@@ -373,7 +380,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
     __syncthreads();
 
     const u64 t_3 = __builtin_readcyclecounter();
-    if (fused && !probe) {
+    if (fused && (mode == MODE_NORMAL || mode == MODE_REGEN)) {
       // ---- reserve room for this tile's successors (upper bounds: ncand states, s_wneed words) in the block's chunks
       if (s_ich_used + ncand > ichunk) {                        // block-uniform
         const u32 used = s_ich_used;
@@ -445,7 +452,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       u64 fp;
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
-      const u64 key = meta_make(level, ak, rank, p_base + (u64)p, ord);
+      const u64 key = meta_make(level, ak, rank, p_offset + p_base + (u64)p, ord);
       const u64 a_2 = __builtin_readcyclecounter();
       if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
       if (!fused && world > 1) {                                // sharded seen-set, exact scheme: route to the owner of fp
@@ -464,7 +471,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
           continue;
         }
       }
-      if (fused && probe) {
+      if (fused && mode == MODE_PROBE) {
         u64 m = META_EMPTY;
         const bool seen = probe_lookup(table, tmask, fp, &m, &my_probes) && meta_level(m) < level;
         if (!seen) {
@@ -497,6 +504,9 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
           __hip_atomic_store(fs, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           remote = true;
           do_write = true;
+        } else if (mode == MODE_REGEN) {
+          u64 m = META_EMPTY;
+          do_write = probe_lookup(table, tmask, fp, &m, &my_probes) && m == key;
         } else {
           bool claimed, full;
           table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, &my_probes, &full);
@@ -505,6 +515,21 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
             continue;
           }
           do_write = claimed;
+        }
+        if (do_write && mode == MODE_INSERT) {                  // virtual level: the state is counted and checked, not stored
+          const int bad = check_invariants_child(M, rec, D);
+          if (bad) {
+            const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
+            if (i < pending_cap) {
+              pending[2 * i] = fp;
+              pending[2 * i + 1] = key;
+            }
+            atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
+            atomicOr(&ctl->viol_mask, (u32)bad);
+          }
+          my_maxbag = my_maxbag > (u32)hdr_nmsg(D.hdr) ? my_maxbag : (u32)hdr_nmsg(D.hdr);
+          my_words++;                                           // counts states in this mode
+          do_write = false;
         }
         const u64 a_3 = __builtin_readcyclecounter();
         if (tid == 0) s_acc[12] += a_3 - a_2;
@@ -660,7 +685,7 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
       }
       if (tid == 0) {
         if (s_acc[8]) atomicAdd((unsigned long long*)&ctl->ties, s_acc[8]);
-        if (s_acc[9]) atomicAdd((unsigned long long*)&ctl->rec_words, s_acc[9]);
+        if (s_acc[9]) atomicAdd((unsigned long long*)(mode == MODE_INSERT ? &ctl->n_new : &ctl->rec_words), s_acc[9]);
         if (s_maxbag_out) atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)s_maxbag_out);
       }
     } else {

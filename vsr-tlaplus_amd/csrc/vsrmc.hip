@@ -852,7 +852,8 @@ struct vsrmc_checker {
   bool level_fused = false;              // the level in flight is a single-pass level
   int failed_code = 0;                   // device ERR_* that stopped the search (failed == 1)
   u64 probe_key = ~(u64)0;               // vsrmc_checker_probe: trace key (parent index, ordinal) of the reported violator
-  bool host_frontier = false;            // the two record buffers live in pinned host memory (zero-copy over PCIe)
+  u64 probe_key2 = ~(u64)0;              // vsrmc_checker_probe2: key of the second probed step (parent = a state of the virtual level)
+  int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
   u64 words_cap(int b) const { return (b == 1 && opt.frontier_words_b) ? opt.frontier_words_b : opt.frontier_words; }
 };
 
@@ -893,7 +894,7 @@ int checker_seed(vsrmc_checker* c) {
   c->total_generated = 0;
   c->failed = 0;
   c->failed_code = 0;
-  c->probe_key = ~(u64)0;
+  c->probe_key = c->probe_key2 = ~(u64)0;
   c->level_base.assign(1, 0);
   c->level_size.assign(1, c->n_frontier);
   return 0;
@@ -937,11 +938,11 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
   u64 slots = (u64)1 << o->table_log2;
   c->tmask = slots - 1;
   hipError_t e = hipMalloc((void**)&c->table, slots * sizeof(Slot));
-  c->host_frontier = o->host_frontier != 0;
+  c->host_frontier = o->host_frontier & 3;
   for (int b = 0; b < 2 && e == hipSuccess; b++) {
     // host_frontier: the records stay in pinned host memory and the kernels read / write them over PCIe (zero-copy); the
     // refs, fingerprints, trace log and the seen-set stay in HBM.  For state spaces whose frontier outgrows the 288 GB.
-    if (c->host_frontier) e = hipHostMalloc((void**)&c->words[b], c->words_cap(b) * 8, hipHostMallocMapped | hipHostMallocPortable);
+    if ((c->host_frontier >> b) & 1) e = hipHostMalloc((void**)&c->words[b], c->words_cap(b) * 8, hipHostMallocMapped | hipHostMallocPortable);
     else e = hipMalloc((void**)&c->words[b], c->words_cap(b) * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&c->off[b], (o->frontier_states + 1) * 8);
   }
@@ -991,7 +992,7 @@ int level_error(vsrmc_checker* c, const LevelCtl& h, int new_level) {
 }
 
 // phase 1: k_expand over the current frontier.  io == nullptr: unsharded.
-int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, bool probe = false) {
+int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NORMAL) {
   const Model& M = c->model.M;
   HIPCHK(hipSetDevice(c->opt.device));
   if (c->level + 1 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
@@ -1040,12 +1041,12 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, bool probe = false)
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
-                         wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk, probe ? 1 : 0);
+                         wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk, mode, (u64)0);
     else
       hipLaunchKernelGGL(k_expand<false>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
-                         0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap, nullptr, 0, nullptr, 0, 0);
+                         0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap, nullptr, 0, nullptr, 0, 0, (u64)0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -1200,6 +1201,162 @@ static int32_t step_local(vsrmc_checker* c, vsrmc_level_info* info) {
   return 0;
 }
 
+namespace {
+// One single-pass launch over an arbitrary source (a slice of the newest level, or the partial next frontier a MODE_REGEN
+// slice just wrote), unsharded.  Resets the level counters, returns them in c->h.  Destination = the next-frontier buffers.
+int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 n_parents, u64 p_offset, int level, int mode) {
+  const Model& M = c->model.M;
+  std::memset(&c->h, 0, sizeof(c->h));
+  c->h.viol_fp = ~(u64)0;
+  HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
+  if (n_parents > 0) {
+    const int tile = M.R <= 3 ? 128 : 64;
+    const u64 ntiles = (n_parents + tile - 1) / tile;
+    const u32 ccap = tile == 128 ? 1536u : (u32)VSR_CAND_CAP;
+    const size_t lds = (size_t)tile * c->lds_stride * 8 + 2 * (size_t)ccap * 4;
+    const int nxt = c->cur ^ 1;
+    u64 nx_cap = c->opt.frontier_states;
+    if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
+    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 2);
+    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
+    const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
+    const u32 wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(k_expand<true>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
+                       c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, c->lds_stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
+                       c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr,
+                       ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0, mode, p_offset);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (n_parents > 0) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->expand_ms += ms;
+  }
+  if (c->h.err) return level_error(c, c->h, level);
+  if (c->h.ties) {
+    c->failed = 1;
+    return fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables (SURVEY F2)");
+  }
+  return 0;
+}
+
+// smallest-fingerprint violator of the (fp, key) list a PROBE / INSERT pass left in c->pending; among equal fps the smallest key
+int min_violator(vsrmc_checker* c, u64 fp_min, u64* key) {
+  *key = ~(u64)0;
+  const u64 n = std::min<u64>(c->h.n_pending, std::min<u64>(c->opt.pending_entries, (u64)1 << 20));
+  std::vector<u64> list(2 * n);
+  if (n) HIPCHK(hipMemcpy(list.data(), c->pending, 16 * n, hipMemcpyDeviceToHost));
+  for (u64 i = 0; i < n; i++)
+    if (list[2 * i] == fp_min && list[2 * i + 1] < *key) *key = list[2 * i + 1];
+  return 0;
+}
+}  // namespace
+
+// Two levels beyond the last materialised one.  Level L+1 becomes a VIRTUAL level: its fingerprints are claimed and its states'
+// invariants checked (MODE_INSERT), but no record is stored.  Then the newest level is expanded AGAIN, slice by slice: the
+// successors that won their slot (key == final meta word, exactly one per new state) are written to the otherwise idle next
+// buffer (MODE_REGEN) and immediately expanded in probe mode (MODE_PROBE, level L+2), after which the slice's records are
+// dropped.  Cost: the newest level is expanded twice; memory: none beyond one slice.  virt = level L+1, probe = level L+2.
+int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_level_info* probe) {
+  if (!c || !virt || !probe) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
+  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  if (c->level + 2 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
+  HIPCHK(hipSetDevice(c->opt.device));
+  std::memset(virt, 0, sizeof(*virt));
+  std::memset(probe, 0, sizeof(*probe));
+  virt->viol_fp = virt->viol_index = probe->viol_fp = probe->viol_index = ~(u64)0;
+  c->probe_key = c->probe_key2 = ~(u64)0;
+  const double t0 = now_s();
+  c->expand_ms = 0;
+  // ---- pass 1: the virtual level
+  int rc = expand_pass(c, c->words[c->cur], c->off[c->cur], c->n_frontier, 0, c->level + 1, MODE_INSERT);
+  c->failed = 1;                                               // whatever happens next, the seen-set now holds a level that has no frontier:
+  c->failed_code = 0;                                          // stepping on is impossible
+  if (rc) return rc;
+  virt->level = c->level + 1;
+  virt->frontier = c->n_frontier;
+  virt->generated = c->h.generated;
+  virt->deadlocks = c->h.deadlocks;
+  virt->n_new = c->h.n_new;
+  virt->distinct = c->distinct + c->h.n_new;
+  virt->total_generated = c->total_generated + c->h.generated;
+  virt->probes = c->h.probes;
+  virt->max_bag = c->h.max_bag;
+  virt->expand_ms = c->expand_ms;
+  virt->seconds = now_s() - t0;
+  const u64 gen1 = c->h.generated;
+  if (c->h.viol_fp != ~(u64)0) {                               // a violation already in level L+1: one probed step
+    virt->viol_fp = c->h.viol_fp;
+    virt->viol_mask = (int32_t)c->h.viol_mask;
+    rc = min_violator(c, c->h.viol_fp, &c->probe_key);
+    if (rc) return rc;
+    if (c->probe_key != ~(u64)0) virt->viol_index = meta_pidx(c->probe_key);
+    return 0;
+  }
+  // ---- pass 2: slices of the newest level -> their part of level L+1 -> probe of level L+2
+  const double t1 = now_s();
+  c->expand_ms = 0;
+  const int nxt = c->cur ^ 1;
+  const u64 g = std::max<u64>(1, (gen1 + c->n_frontier - 1) / std::max<u64>(1, c->n_frontier));   // successors per parent, rounded up
+  u64 nx_cap = c->opt.frontier_states;
+  nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
+  // a slice may not produce more than a quarter of the next buffers (index range and words), chunk slack included
+  u64 slice = std::min<u64>(nx_cap / (4 * g), c->words_cap(nxt) / (4 * g * (u64)c->lds_stride));
+  slice = std::max<u64>(128, slice & ~(u64)127);
+  u64 best_fp = ~(u64)0, gen2 = 0, dead2 = 0, seen_bad = 0, probes2 = 0, regen = 0;
+  u32 mask2 = 0;
+  for (u64 a = 0; a < c->n_frontier; a += slice) {
+    const u64 n = std::min<u64>(slice, c->n_frontier - a);
+    rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, c->level + 1, MODE_REGEN);
+    if (rc) return rc;
+    const u64 part_n = c->h.n_new;                             // index range of this slice's part of level L+1
+    regen += c->h.rec_words;
+    rc = expand_pass(c, c->words[nxt], c->off[nxt], part_n, 0, c->level + 2, MODE_PROBE);
+    if (rc) return rc;
+    gen2 += c->h.generated;
+    dead2 += c->h.deadlocks;
+    probes2 += c->h.probes;
+    seen_bad += c->h.n_pending;
+    if (c->h.viol_fp != ~(u64)0) {
+      mask2 |= c->h.viol_mask;
+      if (c->h.viol_fp < best_fp) {
+        u64 k2 = ~(u64)0, k1 = ~(u64)0;
+        rc = min_violator(c, c->h.viol_fp, &k2);
+        if (rc) return rc;
+        if (k2 != ~(u64)0) {                                    // its parent is state pidx(k2) of this slice's part: the parent's own key
+          HIPCHK(hipMemcpy(&k1, c->tr_all + c->tr_base0() + meta_pidx(k2), 8, hipMemcpyDeviceToHost));
+          best_fp = c->h.viol_fp;
+          c->probe_key = k1;
+          c->probe_key2 = k2;
+        }
+      }
+    }
+  }
+  probe->level = c->level + 2;
+  probe->frontier = virt->n_new;
+  probe->generated = gen2;
+  probe->deadlocks = dead2;
+  probe->probes = probes2;
+  probe->pending = seen_bad;
+  probe->record_words = regen;
+  probe->distinct = virt->distinct;
+  probe->total_generated = virt->total_generated + gen2;
+  probe->expand_ms = c->expand_ms;
+  probe->seconds = now_s() - t1;
+  if (best_fp != ~(u64)0) {
+    probe->viol_fp = best_fp;
+    probe->viol_mask = (int32_t)mask2;
+    probe->viol_index = meta_pidx(c->probe_key);               // index (in the newest level) of the violator's GRANDPARENT
+  }
+  return 0;
+}
+
 // Probe level: expand the newest level WITHOUT storing its successors — every successor that is not a state of an earlier
 // level gets its invariants checked, nothing is inserted into the seen-set, no frontier is written.  The search cannot
 // continue afterwards (the level does not exist), but a violation one level beyond what memory can hold is found and its
@@ -1209,8 +1366,8 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
   if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
   if (c->failed && c->failed_code != ERR_FRONTIER_FULL) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   c->failed = 0;
-  c->probe_key = ~(u64)0;
-  int rc = phase_expand(c, nullptr, true);
+  c->probe_key = c->probe_key2 = ~(u64)0;
+  int rc = phase_expand(c, nullptr, MODE_PROBE);
   if (rc) return rc;
   std::memset(info, 0, sizeof(*info));
   info->level = c->level + 1;
@@ -1246,7 +1403,8 @@ int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t ca
   if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->probe_key == ~(u64)0) return fail(VSRMC_E_STATE, "no violation recorded by vsrmc_checker_probe");
   if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
-  const int level = c->level, nsteps = level;                   // level - 1 logged steps + the probed one
+  const int extra = c->probe_key2 != ~(u64)0 ? 2 : 1;
+  const int level = c->level, nsteps = level - 1 + extra;       // level - 1 logged steps + the probed one(s)
   HIPCHK(hipSetDevice(c->opt.device));
   std::vector<u32> ords((size_t)nsteps);
   if (level > 1) {
@@ -1260,7 +1418,8 @@ int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t ca
     (void)hipFree(d_ords);
     if (ords[0] == 0xFFFFFFFFu) return fail(VSRMC_E_STATE, "the trace log does not hold the violator's parent");
   }
-  ords[(size_t)nsteps - 1] = (u32)meta_ord(c->probe_key);
+  ords[(size_t)level - 1] = (u32)meta_ord(c->probe_key);
+  if (extra == 2) ords[(size_t)level] = (u32)meta_ord(c->probe_key2);
   return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), nsteps, words, cap_words, off, actions, cap_states, n_states);
 }
 
@@ -1792,7 +1951,7 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
   (void)hipSetDevice(c->opt.device);
   if (c->table) (void)hipFree(c->table);
   for (int b = 0; b < 2; b++) {
-    if (c->words[b]) (void)(c->host_frontier ? hipHostFree(c->words[b]) : hipFree(c->words[b]));
+    if (c->words[b]) (void)(((c->host_frontier >> b) & 1) ? hipHostFree(c->words[b]) : hipFree(c->words[b]));
     if (c->off[b]) (void)hipFree(c->off[b]);
   }
   if (c->lvl_fp) (void)hipFree(c->lvl_fp);

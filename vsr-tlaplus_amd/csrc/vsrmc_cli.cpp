@@ -169,7 +169,7 @@ int main(int argc, char** argv) {
   vsrmc_options_default(&o);
   o.device = device;
   o.table_log2 = table_log2;
-  o.host_frontier = host_frontier ? 1 : 0;
+  o.host_frontier = host_frontier ? 3 : 0;
   o.frontier_words = (uint64_t)(frontier_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);
   o.frontier_words_b = (uint64_t)(frontier_b_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);   // 0 = like the first
   o.frontier_states = o.frontier_words / 24;
