@@ -83,7 +83,7 @@ except vt.VsrmcError as e:
 dt = time.time() - t0
 print(json.dumps(dict(summary=True, stop=why, depth=mc.level, distinct=mc.distinct, seconds=round(dt, 3),
                       states_per_s=round(mc.distinct / dt, 1), violation=mc.violation)))
-if mc.violation and not a.no_trace:
+if mc.violation and not a.no_trace and not mc.violation.get("probed"):
     tr = mc.trace(mc.violation["level"], mc.violation["index"])
     print("trace length", len(tr), [t[0] for t in tr])
     print(m.format_state(tr[-1][1]))
