@@ -640,3 +640,15 @@ def test_probe2_virtual_level_plus_probe_level(vt, orc):
     assert len(tr) == 28
     _check_walk_with_oracle(orc, P, tr, 1)
     mc.close()
+
+
+def test_cli_probe2_and_probe_last(vt, tmp_path):
+    """vsrmc -probe2At / -probeLast / -hostFrontierMask on config 1 (76 states, depth 14, no violation) and on a cfg that violates."""
+    import subprocess
+    from test_host_cpu import _cfg
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cfg = _cfg(tmp_path, R=2, vals="v1", L=1)
+    r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01", "-probe2At", "9", "-hostFrontierMask", "1"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Virtual(9):" in r.stdout and "Probe(10):" in r.stdout and "No violation up to level 10" in r.stdout

@@ -30,6 +30,9 @@ static void usage() {
       "                    its last state violates\n"
       "  -hostFrontier     keep the two record buffers (-frontierGiB each) in pinned host memory, read / written over PCIe\n"
       "                    (state spaces whose frontier outgrows HBM; TLC's DiskStateQueue)\n"
+      "  -hostFrontierMask M   the same per buffer: bit 0 = first buffer (levels 1, 3, ..), bit 1 = second (levels 2, 4, ..)\n"
+      "  -probe2At N       when level N-1 is complete: level N as a VIRTUAL level (seen-set entries and invariants only) and level N+1\n"
+      "                    as a PROBE level (nothing stored) — two levels beyond the last frontier that fits; the search ends there\n"
       "  -probeLast        when the next level does not fit the frontier buffers, still check its states' invariants without\n"
       "                    storing them (finds a violation one level beyond memory; the search ends there)\n"
       "  -checkpoint FILE  write a checkpoint between levels, at most every -checkpointMinutes M (default 30; 0 = after every level)\n"
@@ -46,7 +49,7 @@ int main(int argc, char** argv) {
   unsigned sim_walkers = 1u << 17;
   unsigned long long sim_seed = 1;
   double sim_seconds = 60.0;
-  int max_depth = 1 << 30, device = 0, table_log2 = 28;
+  int max_depth = 1 << 30, device = 0, table_log2 = 28, probe2_at = 0, host_mask = 0;
   double frontier_gib = 8.0, frontier_b_gib = 0.0;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -62,6 +65,8 @@ int main(int argc, char** argv) {
     else if (a == "-noTLA") no_tla = true;
     else if (a == "-hostFrontier") host_frontier = true;
     else if (a == "-probeLast") probe_last = true;
+    else if (a == "-probe2At" && i + 1 < argc) probe2_at = std::atoi(argv[++i]);
+    else if (a == "-hostFrontierMask" && i + 1 < argc) host_mask = std::atoi(argv[++i]);
     else if (a == "-validateTrace" && i + 1 < argc) trace_file = argv[++i];
     else if (a == "-checkpoint" && i + 1 < argc) chk_file = argv[++i];
     else if (a == "-checkpointMinutes" && i + 1 < argc) chk_minutes = std::atof(argv[++i]);
@@ -169,7 +174,7 @@ int main(int argc, char** argv) {
   vsrmc_options_default(&o);
   o.device = device;
   o.table_log2 = table_log2;
-  o.host_frontier = host_frontier ? 3 : 0;
+  o.host_frontier = host_frontier ? 3 : (host_mask & 3);
   o.frontier_words = (uint64_t)(frontier_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);
   o.frontier_words_b = (uint64_t)(frontier_b_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);   // 0 = like the first
   o.frontier_states = o.frontier_words / 24;
@@ -196,6 +201,35 @@ int main(int argc, char** argv) {
   uint64_t viol_level = 0, viol_index = 0;
   int depth = info.level;
   while (depth < max_depth) {
+    if (probe2_at > 0 && depth + 1 == probe2_at) {
+      vsrmc_level_info vi, pi;
+      rc = vsrmc_checker_probe2(c, &vi, &pi);
+      if (rc != 0) break;
+      double dtp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      std::printf("Virtual(%d): %llu states generated, %llu distinct states found, %llu states in the level (not stored). (%.2f s)\n", vi.level,
+                  (unsigned long long)vi.total_generated, (unsigned long long)vi.distinct, (unsigned long long)vi.n_new, dtp);
+      info.total_generated = vi.total_generated;
+      info.distinct = vi.distinct;
+      info.n_new = vi.n_new;
+      depth = vi.level;
+      if (vi.viol_mask) {
+        probed_violation = true;
+        info.viol_mask = vi.viol_mask;
+        viol_level = (uint64_t)vi.level;
+      } else {
+        std::printf("Probe(%d): %llu states generated from %llu states, %llu violating successors seen. (%.2f s)\n", pi.level,
+                    (unsigned long long)pi.generated, (unsigned long long)pi.frontier, (unsigned long long)pi.pending, dtp);
+        info.total_generated = pi.total_generated;
+        if (pi.viol_mask) {
+          probed_violation = true;
+          info.viol_mask = pi.viol_mask;
+          viol_level = (uint64_t)pi.level;
+        } else {
+          std::printf("No violation up to level %d; the search is incomplete beyond it.\n", pi.level);
+        }
+      }
+      break;
+    }
     rc = vsrmc_checker_step(c, &info);
     if (rc == VSRMC_E_REP && probe_last && std::strstr(vsrmc_last_error(), "device error 21") != nullptr) {
       // the level does not fit: probe it (invariants only, nothing stored)
