@@ -217,6 +217,17 @@ def test_bfs_config5_prefix(vt, orc):
     assert level == 7
 
 
+def test_bfs_four_replicas_and_symmetry_off_prefixes(vt, orc):
+    """an even replica count (f = 2, f + 1 = 3 of 4; 4-word replica blocks, 95-word LDS slots) and the 3-replica config without
+    SYMMETRY (1 permutation hashed)"""
+    total, level = _compare_levels(vt, orc, (4, 1, 2, 2), 8)
+    assert level == 8
+    total, level = _compare_levels(vt, orc, (3, 1, 2, 2), 10, symmetry=False)
+    assert level == 10
+    total, level = _compare_levels(vt, orc, (4, 1, 1, 3), 9, exact_ties=True)
+    assert level == 9
+
+
 def test_bfs_config4_assume_commit_number_prefix(vt, orc):
     _compare_levels(vt, orc, (3, 2, 3, 3), 7, assume_commit_number=True)
 
