@@ -879,7 +879,7 @@ int checker_seed(vsrmc_checker* c) {
   if (c->filter) HIPCHK(hipMemsetAsync(c->filter, 0, (c->fmask + 1) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(LevelCtl), c->stream));
   if (mine) {
-    HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyDefault, c->stream));   // the buffer may be pinned host memory
     HIPCHK(hipMemcpyAsync(c->off[0], &zero, 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->tr_all, c->ctl);
     HIPCHK(hipGetLastError());
@@ -1614,7 +1614,7 @@ int32_t vsrmc_shard_append(vsrmc_checker* c, const uint64_t* d_words, uint64_t n
     return fail(VSRMC_E_REP, "frontier / trace buffers full while appending received records");
   }
   const int nxt = c->cur ^ 1;
-  HIPCHK(hipMemcpyAsync(c->words[nxt] + c->nx_w, d_words, n_words * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->words[nxt] + c->nx_w, d_words, n_words * 8, hipMemcpyDefault, c->stream));
   hipLaunchKernelGGL(k_append_fixup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->off[nxt] + c->nx_n,
                      c->lvl_fp + c->nx_n, c->tr_all ? c->tr_all + c->tr_base + c->nx_n : nullptr, d_off, d_fp, d_key, n, c->nx_w);
   HIPCHK(hipGetLastError());
@@ -1641,7 +1641,7 @@ struct ChkHeader {
 bool dev_to_file(FILE* f, const void* d_ptr, u64 bytes, std::vector<char>& buf) {
   for (u64 pos = 0; pos < bytes; pos += buf.size()) {
     const u64 k = std::min<u64>(buf.size(), bytes - pos);
-    if (hipMemcpy(buf.data(), (const char*)d_ptr + pos, k, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(buf.data(), (const char*)d_ptr + pos, k, hipMemcpyDefault) != hipSuccess) return false;
     if (std::fwrite(buf.data(), 1, k, f) != k) return false;
   }
   return true;
@@ -1650,7 +1650,7 @@ bool file_to_dev(FILE* f, void* d_ptr, u64 bytes, std::vector<char>& buf) {
   for (u64 pos = 0; pos < bytes; pos += buf.size()) {
     const u64 k = std::min<u64>(buf.size(), bytes - pos);
     if (std::fread(buf.data(), 1, k, f) != k) return false;
-    if (hipMemcpy((char*)d_ptr + pos, buf.data(), k, hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemcpy((char*)d_ptr + pos, buf.data(), k, hipMemcpyDefault) != hipSuccess) return false;
   }
   return true;
 }
@@ -1856,7 +1856,7 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
   }
   std::vector<u64> dev(hi + (u64)M.fixed + 256);
   u64 take = std::min<u64>(dev.size(), c->words_cap(c->cur));
-  HIPCHK(hipMemcpy(dev.data(), c->words[c->cur], take * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(dev.data(), c->words[c->cur], take * 8, hipMemcpyDefault));
   u64 pos = 0, k = 0;
   for (u64 i = 0; i < c->n_frontier; i++) {
     if (!valid[i]) continue;
