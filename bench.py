@@ -97,6 +97,43 @@ def run_single(args):
     return elapsed, S, m
 
 
+def run_config3(args):
+    """--workload config3: the reference README's defect configuration (BASELINE configs[2]) on ONE GPU, BFS to its first violation.
+    Levels 2-22 are materialised (level 22: 164 GB of records in pinned host memory, read / written over PCIe), level 23 is a
+    virtual level, level 24 a probe level.  Needs ~210 GB of host memory and ~200 GB of HBM; not the default."""
+    import numpy as np
+    import vsr_tlaplus_amd as vt
+    with open(os.path.join(ROOT, "tests", "golden", "config3_violation.json")) as f:
+        fx = json.load(f)
+    m = vt.Model.from_constants(R=3, C_=1, n=3, L=3)
+    t_setup = time.perf_counter()
+    mc = vt.ModelChecker(m, device=0, table_log2=32, frontier_words=int(2 ** 33.65), frontier_words_b=int(2 ** 34.6),
+                         frontier_states=int(2 ** 29.05), pending_entries=1 << 20, keep_trace=True, trace_entries=int(2 ** 30.2),
+                         host_frontier=2)
+    t_setup = time.perf_counter() - t_setup
+    t0 = time.perf_counter()
+    generated = 0
+    while mc.level < 22:
+        d = mc.step()
+        generated += d["generated"]
+        assert d["viol_mask"] == 0 and d["n_new"] == fx["levels"][d["level"] - 1]["n_new"]
+    v, p = mc.probe2()
+    tr = mc.probe_trace()
+    dt = time.perf_counter() - t0
+    assert v["n_new"] == fx["levels"][22]["n_new"] and p["viol_mask"] == 1 and "%016x" % p["viol_fp"] == fx["viol_fp"] and len(tr) == 24
+    fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
+    assert int(fps[0]) == p["viol_fp"]
+    print(json.dumps({
+        "metric": "time-to-first-violation, VSR 3-replica README defect config (BFS, trace reconstructed)", "value": round(dt, 3), "unit": "s",
+        "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": round(1e3 * dt, 1), "higher_is_better": False, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2,v3} StartViewOnTimerLimit=3 (BASELINE configs[2], "
+                               "README:13-18), VIEW+SYMMETRY, to the first violation at depth 24: levels 2-22 materialised (level 22 in "
+                               "pinned host memory), level 23 virtual, level 24 probed"},
+        "distinct_states_through_level_23": v["distinct"], "distinct_states_per_s": round(v["distinct"] / dt, 1),
+        "generated": generated + v["generated"] + p["generated"], "setup_seconds": round(t_setup, 1)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,7 +141,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["config2", "config3"], default="config2",
+                    help="config2 (default) = BASELINE's 1-GPU configuration; config3 = the README defect config to its violation (one GPU, "
+                         "host-resident level 22; minutes of setup, ~210 GB of host memory)")
     args = ap.parse_args()
+    if args.workload == "config3":
+        return run_config3(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("VSR_BENCH_SHARDED"):   # VSR_BENCH_SHARDED=1: the N > 1 leg on one rank
         from vsr_tlaplus_amd import sharded_bench
