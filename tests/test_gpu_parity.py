@@ -663,3 +663,17 @@ def test_cli_probe2_and_probe_last(vt, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Virtual(9):" in r.stdout and "Probe(10):" in r.stdout and "No violation up to level 10" in r.stdout
+
+
+def test_exists_on_majority_fails_at_depth_19_on_the_shipped_constants(vt, orc):
+    """The stricter invariant the shipped VSR.cfg keeps commented out (AcknowledgedWritesExistOnMajority, VSR.tla:937-943) is
+    violated after 9 327 854 distinct states, at depth 19; the oracle accepts the 19-state counter-example and its verdict."""
+    P = orc.Params(3, 1, 2, 2, invariant_mask=2)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2, invariant_mask=2)
+    mc = vt.ModelChecker(m, table_log2=26, frontier_words=1 << 28, frontier_states=1 << 23, trace_entries=1 << 25)
+    assert mc.run() == "violation"
+    assert (mc.level, mc.distinct, mc.violation["mask"]) == (19, 9327854, 2)
+    tr = mc.trace(mc.violation["level"], mc.violation["index"])
+    assert len(tr) == 19
+    _check_walk_with_oracle(orc, P, tr, 2)
+    mc.close()
