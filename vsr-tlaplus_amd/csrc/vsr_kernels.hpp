@@ -189,9 +189,12 @@ __device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp,
 // -----------------------------------------------------------------------------------------------------------------
 // k_expand
 // -----------------------------------------------------------------------------------------------------------------
-template <bool FUSED>
+// SPEC = R * 100 + C * 10 + |Values| of a configuration the kernel is specialised for (0 = generic): the constants of the model
+// become compile-time constants of this instantiation (every device function below is inlined), so loops over replicas,
+// clients, values and permutations unroll without predicates and strides fold into addresses.
+template <bool FUSED, int SPEC = 0>
 __global__ void __launch_bounds__(VSR_BLOCK, FUSED ? 2 : 3)
-k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
+k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
          // fused single-pass mode (nx_words != nullptr): the lane that inserts a fingerprint writes the successor at once
@@ -208,6 +211,19 @@ k_expand(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_o
          //                the slot's final meta word — exactly one per new state — is written to the next frontier
          // violators of PROBE / INSERT go to the `pending` list as (fp, key) pairs (n_pending counts them).
          int mode, u64 p_offset /* index of parent 0 of this launch in its level (slices) */) {
+  Model M = Marg;
+  if constexpr (SPEC != 0) {
+    constexpr int SR = SPEC / 100, SC = (SPEC / 10) % 10, SN = SPEC % 10;
+    M.R = SR;
+    M.C = SC;
+    M.n = SN;
+    M.wpr = 1 + (SR + 2) / 2;
+    M.h0 = 1 + SR * M.wpr;
+    M.m0 = 4 * SR + SR * SC * SN;
+    if (Marg.np == 1) M.np = 1;                                // symmetry off: block-uniform, still cheap
+    else M.np = SN == 1 ? 1 : SN == 2 ? 2 : 6;
+    M.fixed = M.h0 + M.np;
+  }
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal

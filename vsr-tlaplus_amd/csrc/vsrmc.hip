@@ -851,6 +851,12 @@ struct vsrmc_checker {
   u64 cand_idx_cap = 0;
   bool level_fused = false;              // the level in flight is a single-pass level
   int failed_code = 0;                   // device ERR_* that stopped the search (failed == 1)
+  // the single-pass kernel of this model (a specialised instantiation when there is one) and its launch shape
+  void* fused_kernel = nullptr;
+  int fused_tile = 128;
+  u32 fused_ccap = 1536;
+  size_t fused_lds = 0;
+  unsigned fused_blocks_per_cu = 2;
   u64 probe_key = ~(u64)0;               // vsrmc_checker_probe: trace key (parent index, ordinal) of the reported violator
   u64 probe_key2 = ~(u64)0;              // vsrmc_checker_probe2: key of the second probed step (parent = a state of the virtual level)
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
@@ -858,6 +864,45 @@ struct vsrmc_checker {
 };
 
 namespace {
+typedef void (*ExpandKernel)(Model, const u64*, const u64*, u64, int, int, Slot*, u64, u64*, u64, LevelCtl*, int, int, u64*, u64, u32, u64*,
+                             u64, u64*, u64, u64*, u64*, u32, u32, int, u32, u64*, u64, u64*, u32, int, u64);
+// k_expand<true, SPEC>: the configurations of BASELINE.json (and their small neighbours used by the tests) have their own
+// instantiation with the model constants folded in; anything else runs the generic one.
+ExpandKernel fused_kernel_for(const Model& M) {
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 211: return k_expand<true, 211>;
+    case 212: return k_expand<true, 212>;
+    case 311: return k_expand<true, 311>;
+    case 312: return k_expand<true, 312>;
+    case 313: return k_expand<true, 313>;
+    case 323: return k_expand<true, 323>;
+    case 412: return k_expand<true, 412>;
+    case 512: return k_expand<true, 512>;
+    default: return k_expand<true, 0>;
+  }
+}
+// Launch shape of the single-pass kernel: 64-record tiles when three blocks of them fit a CU (registers and LDS), else 128-record
+// tiles (R <= 3) at two blocks per CU; R >= 4 records need 95-word LDS slots: 64-record tiles.
+int choose_fused_shape(vsrmc_checker* c) {
+  const Model& M = c->model.M;
+  c->fused_kernel = (void*)fused_kernel_for(M);
+  auto occupancy = [&](int tile, u32 ccap, size_t* lds) {
+    *lds = (size_t)tile * c->lds_stride * 8 + 2 * (size_t)ccap * 4;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c->fused_kernel, VSR_BLOCK, *lds) != hipSuccess) nb = 0;
+    return nb;
+  };
+  size_t lds64 = 0, lds128 = 0;
+  const int occ64 = occupancy(64, (u32)VSR_CAND_CAP, &lds64);
+  const int occ128 = M.R <= 3 ? occupancy(128, 1536u, &lds128) : 0;
+  if (M.R <= 3 && occ64 < 3 && occ128 >= 1) {
+    c->fused_tile = 128; c->fused_ccap = 1536u; c->fused_lds = lds128; c->fused_blocks_per_cu = (unsigned)std::min(occ128, 2);
+  } else {
+    c->fused_tile = 64; c->fused_ccap = (u32)VSR_CAND_CAP; c->fused_lds = lds64; c->fused_blocks_per_cu = (unsigned)std::max(1, std::min(occ64, 3));
+  }
+  return 0;
+}
+
 // Put the checker in its initial state (ModelChecker.doInit): empty seen-set, Init in frontier 0 and in the set.
 int checker_seed(vsrmc_checker* c) {
   const Model& M = c->model.M;
@@ -964,6 +1009,7 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     vsrmc_checker_destroy(c);
     return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
+  choose_fused_shape(c);
   rc = checker_seed(c);
   if (rc) { vsrmc_checker_destroy(c); return rc; }
   *out = c;
@@ -1004,11 +1050,11 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
   c->level_fused = !c->opt.exact_ties;
   if (c->n_frontier > 0) {
     // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
-    const int tile = M.R <= 3 ? 128 : 64;
+    const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
+    const int tile = fused ? c->fused_tile : (M.R <= 3 ? 128 : 64);
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
     // every block reserves pending-list room in chunks: the list must hold one chunk per block beyond the real entries
     const u32 pchunk = c->opt.pending_entries >= ((u64)1 << 24) ? 8192u : (u32)VSR_CAND_CAP;
-    const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
     if (fused && io && c->cand_idx_cap < (u64)c->opt.world * io->cand_cap) {
       if (c->cand_idx) (void)hipFree(c->cand_idx);
       c->cand_idx = nullptr;
@@ -1018,7 +1064,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     }
     unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 3);
     if (!fused) grid = (unsigned)std::min<u64>(grid, std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));   // the pending list is only used by the two-kernel scheme
-    const u32 ccap = tile == 128 ? 1536u : (u32)VSR_CAND_CAP;   // keeps two blocks per CU in LDS at 128 records per tile
+    const u32 ccap = fused ? c->fused_ccap : (tile == 128 ? 1536u : (u32)VSR_CAND_CAP);   // 128-record tiles: two blocks per CU in LDS
     size_t lds = (size_t)tile * c->lds_stride * 8 + 2 * (size_t)ccap * 4;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     // fused single-pass mode (unsharded, not exact_ties): the lane that inserts a fingerprint writes the successor itself
@@ -1031,13 +1077,13 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     if (fused) {
       // persistent blocks (2 resident per CU: 225 VGPRs, 79 KB LDS): every block leaves one partly used index chunk and
       // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
-      grid = (unsigned)std::min<u64>(grid, (u64)c->num_cus * 2);
+      grid = (unsigned)std::min<u64>(grid, (u64)c->num_cus * c->fused_blocks_per_cu);
       grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
       ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
       wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     }
     if (fused)
-      hipLaunchKernelGGL(k_expand<true>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+      hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
@@ -1210,19 +1256,19 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
   c->h.viol_fp = ~(u64)0;
   HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
   if (n_parents > 0) {
-    const int tile = M.R <= 3 ? 128 : 64;
+    const int tile = c->fused_tile;
     const u64 ntiles = (n_parents + tile - 1) / tile;
-    const u32 ccap = tile == 128 ? 1536u : (u32)VSR_CAND_CAP;
-    const size_t lds = (size_t)tile * c->lds_stride * 8 + 2 * (size_t)ccap * 4;
+    const u32 ccap = c->fused_ccap;
+    const size_t lds = c->fused_lds;
     const int nxt = c->cur ^ 1;
     u64 nx_cap = c->opt.frontier_states;
     if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
-    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 2);
+    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * c->fused_blocks_per_cu);
     grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
     const u32 wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(k_expand<true>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
+    hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, c->lds_stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
                        c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr,
                        ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0, mode, p_offset);
