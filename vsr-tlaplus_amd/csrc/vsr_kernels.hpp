@@ -193,7 +193,7 @@ __device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp,
 // become compile-time constants of this instantiation (every device function below is inlined), so loops over replicas,
 // clients, values and permutations unroll without predicates and strides fold into addresses.
 template <bool FUSED, int SPEC = 0>
-__global__ void __launch_bounds__(VSR_BLOCK, FUSED ? 2 : 3)
+__global__ void __launch_bounds__(VSR_BLOCK, FUSED ? (SPEC ? 4 : 2) : 3)
 k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
@@ -275,6 +275,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       const u64 ref = fr_off[p_base + tid];
       s_ref[tid] = ref;
       if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
+      if ((int)(ref & 255) > stride) raise_error(ctl, ERR_INTERNAL, (p_base + (u64)tid) << 16);   // LDS slots sized for shorter records
     }
     __syncthreads();
     for (int half = 0; half < tile; half += 64)

@@ -853,10 +853,8 @@ struct vsrmc_checker {
   int failed_code = 0;                   // device ERR_* that stopped the search (failed == 1)
   // the single-pass kernel of this model (a specialised instantiation when there is one) and its launch shape
   void* fused_kernel = nullptr;
-  int fused_tile = 128;
-  u32 fused_ccap = 1536;
-  size_t fused_lds = 0;
-  unsigned fused_blocks_per_cu = 2;
+  u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
+  bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
   u64 probe_key = ~(u64)0;               // vsrmc_checker_probe: trace key (parent index, ordinal) of the reported violator
   u64 probe_key2 = ~(u64)0;              // vsrmc_checker_probe2: key of the second probed step (parent = a state of the virtual level)
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
@@ -881,26 +879,37 @@ ExpandKernel fused_kernel_for(const Model& M) {
     default: return k_expand<true, 0>;
   }
 }
-// Launch shape of the single-pass kernel: 64-record tiles when three blocks of them fit a CU (registers and LDS), else 128-record
-// tiles (R <= 3) at two blocks per CU; R >= 4 records need 95-word LDS slots: 64-record tiles.
-int choose_fused_shape(vsrmc_checker* c) {
+// Launch shape of the single-pass kernel for one launch.  The LDS slot of a record only has to hold the longest record of the
+// level that is being expanded (stride = fixed words + its largest bag, made odd: conflict-free columns), not the format's
+// worst case, so deep levels of small bags leave room for more resident blocks.  64-record tiles when that gives at least
+// three blocks per CU (registers and LDS, asked from the runtime), else 128-record tiles (R <= 3) at two.
+struct FusedShape {
+  int tile;
+  u32 ccap;
+  int stride;
+  size_t lds;
+  unsigned blocks_per_cu;
+};
+FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source) {
   const Model& M = c->model.M;
-  c->fused_kernel = (void*)fused_kernel_for(M);
+  FusedShape f;
+  f.stride = (int)std::min<u64>((u64)c->lds_stride, (u64)((M.fixed + (int)std::min<u64>(max_bag_of_source, 255)) | 1));
   auto occupancy = [&](int tile, u32 ccap, size_t* lds) {
-    *lds = (size_t)tile * c->lds_stride * 8 + 2 * (size_t)ccap * 4;
+    *lds = (size_t)tile * f.stride * 8 + 2 * (size_t)ccap * 4;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c->fused_kernel, VSR_BLOCK, *lds) != hipSuccess) nb = 0;
     return nb;
   };
   size_t lds64 = 0, lds128 = 0;
-  const int occ64 = occupancy(64, (u32)VSR_CAND_CAP, &lds64);
+  const u32 ccap64 = M.R <= 3 ? 1536u : (u32)VSR_CAND_CAP;      // work-list entries per tile (24 resp. 32 per record)
+  const int occ64 = occupancy(64, ccap64, &lds64);
   const int occ128 = M.R <= 3 ? occupancy(128, 1536u, &lds128) : 0;
   if (M.R <= 3 && occ64 < 3 && occ128 >= 1) {
-    c->fused_tile = 128; c->fused_ccap = 1536u; c->fused_lds = lds128; c->fused_blocks_per_cu = (unsigned)std::min(occ128, 2);
+    f.tile = 128; f.ccap = 1536u; f.lds = lds128; f.blocks_per_cu = (unsigned)std::min(occ128, 2);
   } else {
-    c->fused_tile = 64; c->fused_ccap = (u32)VSR_CAND_CAP; c->fused_lds = lds64; c->fused_blocks_per_cu = (unsigned)std::max(1, std::min(occ64, 3));
+    f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, 4));
   }
-  return 0;
+  return f;
 }
 
 // Put the checker in its initial state (ModelChecker.doInit): empty seen-set, Init in frontier 0 and in the set.
@@ -938,6 +947,8 @@ int checker_seed(vsrmc_checker* c) {
   c->distinct = mine ? 1 : 0;
   c->total_generated = 0;
   c->failed = 0;
+  c->cur_max_bag = 0;
+  c->bag_known = true;
   c->failed_code = 0;
   c->probe_key = c->probe_key2 = ~(u64)0;
   c->level_base.assign(1, 0);
@@ -1009,7 +1020,7 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     vsrmc_checker_destroy(c);
     return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
-  choose_fused_shape(c);
+  c->fused_kernel = (void*)fused_kernel_for(M);
   rc = checker_seed(c);
   if (rc) { vsrmc_checker_destroy(c); return rc; }
   *out = c;
@@ -1051,7 +1062,10 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
   if (c->n_frontier > 0) {
     // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
     const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
-    const int tile = fused ? c->fused_tile : (M.R <= 3 ? 128 : 64);
+    // sharded: records arrive from other ranks (rebalancing), the local maximum says nothing -> the format's capacity
+    const FusedShape fs = fused_shape(c, (c->bag_known && c->opt.world == 1) ? c->cur_max_bag : (u64)M.max_bag);
+    const int tile = fused ? fs.tile : (M.R <= 3 ? 128 : 64);
+    const int stride = fused ? fs.stride : c->lds_stride;
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
     // every block reserves pending-list room in chunks: the list must hold one chunk per block beyond the real entries
     const u32 pchunk = c->opt.pending_entries >= ((u64)1 << 24) ? 8192u : (u32)VSR_CAND_CAP;
@@ -1064,8 +1078,8 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     }
     unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 3);
     if (!fused) grid = (unsigned)std::min<u64>(grid, std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));   // the pending list is only used by the two-kernel scheme
-    const u32 ccap = fused ? c->fused_ccap : (tile == 128 ? 1536u : (u32)VSR_CAND_CAP);   // 128-record tiles: two blocks per CU in LDS
-    size_t lds = (size_t)tile * c->lds_stride * 8 + 2 * (size_t)ccap * 4;
+    const u32 ccap = fused ? fs.ccap : (tile == 128 ? 1536u : (u32)VSR_CAND_CAP);   // 128-record tiles: two blocks per CU in LDS
+    size_t lds = (size_t)tile * stride * 8 + 2 * (size_t)ccap * 4;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     // fused single-pass mode (unsharded, not exact_ties): the lane that inserts a fingerprint writes the successor itself
     const int nxt = c->cur ^ 1;
@@ -1077,7 +1091,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     if (fused) {
       // persistent blocks (2 resident per CU: 225 VGPRs, 79 KB LDS): every block leaves one partly used index chunk and
       // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
-      grid = (unsigned)std::min<u64>(grid, (u64)c->num_cus * c->fused_blocks_per_cu);
+      grid = (unsigned)std::min<u64>((u64)ntiles, (u64)c->num_cus * fs.blocks_per_cu);
       grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
       ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
       wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
@@ -1085,7 +1099,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     if (fused)
       hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
-                         c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
+                         stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
                          wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk, mode, (u64)0);
     else
@@ -1199,6 +1213,8 @@ int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
     c->n_frontier = c->nx_n;
     c->n_valid = n_new;
     c->cur_w = c->nx_w;
+    c->cur_max_bag = h.max_bag;
+    c->bag_known = c->opt.world == 1;
   } else {
     c->n_frontier = 0;
     c->n_valid = 0;
@@ -1250,26 +1266,28 @@ static int32_t step_local(vsrmc_checker* c, vsrmc_level_info* info) {
 namespace {
 // One single-pass launch over an arbitrary source (a slice of the newest level, or the partial next frontier a MODE_REGEN
 // slice just wrote), unsharded.  Resets the level counters, returns them in c->h.  Destination = the next-frontier buffers.
-int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 n_parents, u64 p_offset, int level, int mode) {
+int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 n_parents, u64 p_offset, int level, int mode,
+                u64 src_max_bag) {
   const Model& M = c->model.M;
   std::memset(&c->h, 0, sizeof(c->h));
   c->h.viol_fp = ~(u64)0;
   HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
   if (n_parents > 0) {
-    const int tile = c->fused_tile;
+    const FusedShape fs = fused_shape(c, src_max_bag);
+    const int tile = fs.tile;
     const u64 ntiles = (n_parents + tile - 1) / tile;
-    const u32 ccap = c->fused_ccap;
-    const size_t lds = c->fused_lds;
+    const u32 ccap = fs.ccap;
+    const size_t lds = fs.lds;
     const int nxt = c->cur ^ 1;
     u64 nx_cap = c->opt.frontier_states;
     if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
-    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * c->fused_blocks_per_cu);
+    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * fs.blocks_per_cu);
     grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
     const u32 wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
-                       c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, c->lds_stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
+                       c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
                        c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr,
                        ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0, mode, p_offset);
     HIPCHK(hipGetLastError());
@@ -1321,7 +1339,7 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   const double t0 = now_s();
   c->expand_ms = 0;
   // ---- pass 1: the virtual level
-  int rc = expand_pass(c, c->words[c->cur], c->off[c->cur], c->n_frontier, 0, c->level + 1, MODE_INSERT);
+  int rc = expand_pass(c, c->words[c->cur], c->off[c->cur], c->n_frontier, 0, c->level + 1, MODE_INSERT, c->bag_known ? c->cur_max_bag : (u64)c->model.M.max_bag);
   c->failed = 1;                                               // whatever happens next, the seen-set now holds a level that has no frontier:
   c->failed_code = 0;                                          // stepping on is impossible
   if (rc) return rc;
@@ -1336,7 +1354,7 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   virt->max_bag = c->h.max_bag;
   virt->expand_ms = c->expand_ms;
   virt->seconds = now_s() - t0;
-  const u64 gen1 = c->h.generated;
+  const u64 gen1 = c->h.generated, virt_max_bag = c->h.max_bag;
   if (c->h.viol_fp != ~(u64)0) {                               // a violation already in level L+1: one probed step
     virt->viol_fp = c->h.viol_fp;
     virt->viol_mask = (int32_t)c->h.viol_mask;
@@ -1359,11 +1377,11 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   u32 mask2 = 0;
   for (u64 a = 0; a < c->n_frontier; a += slice) {
     const u64 n = std::min<u64>(slice, c->n_frontier - a);
-    rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, c->level + 1, MODE_REGEN);
+    rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, c->level + 1, MODE_REGEN, c->bag_known ? c->cur_max_bag : (u64)c->model.M.max_bag);
     if (rc) return rc;
     const u64 part_n = c->h.n_new;                             // index range of this slice's part of level L+1
     regen += c->h.rec_words;
-    rc = expand_pass(c, c->words[nxt], c->off[nxt], part_n, 0, c->level + 2, MODE_PROBE);
+    rc = expand_pass(c, c->words[nxt], c->off[nxt], part_n, 0, c->level + 2, MODE_PROBE, virt_max_bag);
     if (rc) return rc;
     gen2 += c->h.generated;
     dead2 += c->h.deadlocks;
@@ -1830,6 +1848,7 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
     vsrmc_checker_destroy(c);
     return fail(VSRMC_E_CFG, std::string("reading the checkpoint ") + path + " failed");
   }
+  c->bag_known = false;                                        // the header does not carry it: LDS slots at the format's capacity
   c->level = h.level;
   c->n_frontier = h.n_frontier;
   c->n_valid = h.n_valid;
