@@ -189,6 +189,23 @@ __device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp,
 // -----------------------------------------------------------------------------------------------------------------
 // k_expand
 // -----------------------------------------------------------------------------------------------------------------
+// Overwrite the structural constants of a private copy of the model with the compile-time constants of SPEC (see k_expand).
+template <int SPEC>
+__device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
+  if constexpr (SPEC != 0) {
+    constexpr int SR = SPEC / 100, SC = (SPEC / 10) % 10, SN = SPEC % 10;
+    M.R = SR;
+    M.C = SC;
+    M.n = SN;
+    M.wpr = 1 + (SR + 2) / 2;
+    M.h0 = 1 + SR * M.wpr;
+    M.m0 = 4 * SR + SR * SC * SN;
+    if (Marg.np == 1) M.np = 1;                                // symmetry off: block-uniform, still cheap
+    else M.np = SN == 1 ? 1 : SN == 2 ? 2 : 6;
+    M.fixed = M.h0 + M.np;
+  }
+}
+
 // SPEC = R * 100 + C * 10 + |Values| of a configuration the kernel is specialised for (0 = generic): the constants of the model
 // become compile-time constants of this instantiation (every device function below is inlined), so loops over replicas,
 // clients, values and permutations unroll without predicates and strides fold into addresses.
@@ -212,18 +229,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
          // violators of PROBE / INSERT go to the `pending` list as (fp, key) pairs (n_pending counts them).
          int mode, u64 p_offset /* index of parent 0 of this launch in its level (slices) */) {
   Model M = Marg;
-  if constexpr (SPEC != 0) {
-    constexpr int SR = SPEC / 100, SC = (SPEC / 10) % 10, SN = SPEC % 10;
-    M.R = SR;
-    M.C = SC;
-    M.n = SN;
-    M.wpr = 1 + (SR + 2) / 2;
-    M.h0 = 1 + SR * M.wpr;
-    M.m0 = 4 * SR + SR * SC * SN;
-    if (Marg.np == 1) M.np = 1;                                // symmetry off: block-uniform, still cheap
-    else M.np = SN == 1 ? 1 : SN == 2 ? 2 : 6;
-    M.fixed = M.h0 + M.np;
-  }
+  specialise<SPEC>(M, Marg);
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
@@ -1272,9 +1278,12 @@ __device__ __forceinline__ u64 sim_rng(u64* s) {   // xorshift64*
   return x * 0x2545F4914F6CDD1DULL;
 }
 
+template <int SPEC>
 __global__ void __launch_bounds__(64)
-k_simulate(Model M, const u64* __restrict__ init_rec, int init_len, u64* walker_words, int stride, u32* walker_depth,
+k_simulate(Model Marg, const u64* __restrict__ init_rec, int init_len, u64* walker_words, int stride, u32* walker_depth,
            u16* walker_ords, u64* walker_rng, u32 n_walkers, int max_depth, int steps_per_launch, SimCtl* ctl) {
+  Model M = Marg;
+  specialise<SPEC>(M, Marg);
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_walkers) return;
   u64* w = walker_words + (u64)t * stride;

@@ -787,9 +787,17 @@ extern "C" int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t
   }
   HIPCHK(hipMemcpy(d_rng, rng.data(), (u64)n_walkers * 8, hipMemcpyHostToDevice));
   SimCtl h;
+  typedef void (*SimKernel)(Model, const u64*, int, u64*, int, u32*, u16*, u64*, u32, int, int, SimCtl*);
+  SimKernel sim_kernel = k_simulate<0>;
+  switch (M.R * 100 + M.C * 10 + M.n) {                        // the same per-configuration instantiations as k_expand
+    case 312: sim_kernel = k_simulate<312>; break;
+    case 313: sim_kernel = k_simulate<313>; break;
+    case 512: sim_kernel = k_simulate<512>; break;
+    default: break;
+  }
   double t0 = now_s();
   while (true) {
-    hipLaunchKernelGGL(k_simulate, dim3((n_walkers + 63) / 64), dim3(64), 0, 0, M, d_init, len, d_words, stride, d_depth, d_ords, d_rng,
+    hipLaunchKernelGGL(sim_kernel, dim3((n_walkers + 63) / 64), dim3(64), 0, 0, M, d_init, len, d_words, stride, d_depth, d_ords, d_rng,
                        n_walkers, max_depth, 64, d_ctl);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost));
