@@ -766,11 +766,14 @@ __device__ __forceinline__ void lds_wave_sync() {   // orders this wave's LDS wr
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+template <int SPEC>
 __global__ void __launch_bounds__(VSR_MAT_BLOCK)
-k_materialize(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, const u64* __restrict__ pending,
+k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, const u64* __restrict__ pending,
               u64 n_pending, const Slot* __restrict__ table, u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap,
               u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w, int stride,
               u32 ichunk /* state indices per reservation, >= 64 */, u32 wchunk /* words per reservation, >= 64 * stride */) {
+  Model M = Marg;
+  specialise<SPEC>(M, Marg);
   extern __shared__ u64 s_slot[];                              // 64 slots of `stride` words
   const int lane = threadIdx.x;
   // This wave's private chunks of the output (wave-uniform values): state indices [idx_base, idx_base + idx_left) and

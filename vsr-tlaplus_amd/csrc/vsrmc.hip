@@ -874,6 +874,26 @@ typedef void (*ExpandKernel)(Model, const u64*, const u64*, u64, int, int, Slot*
                              u64, u64*, u64, u64*, u64*, u32, u32, int, u32, u64*, u64, u64*, u32, int, u64);
 // k_expand<true, SPEC>: the configurations of BASELINE.json (and their small neighbours used by the tests) have their own
 // instantiation with the model constants folded in; anything else runs the generic one.
+ExpandKernel exact_kernel_for(const Model& M) {               // two-kernel levels: k_expand<false, SPEC>
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 211: return k_expand<false, 211>;
+    case 312: return k_expand<false, 312>;
+    case 313: return k_expand<false, 313>;
+    case 512: return k_expand<false, 512>;
+    default: return k_expand<false, 0>;
+  }
+}
+typedef void (*MaterializeKernel)(Model, const u64*, const u64*, const u64*, u64, const Slot*, u64*, u64, u64*, u64, u64*, u64*, LevelCtl*,
+                                  const uint8_t*, u64*, u64*, int, u32, u32);
+MaterializeKernel materialize_kernel_for(const Model& M) {
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 211: return k_materialize<211>;
+    case 312: return k_materialize<312>;
+    case 313: return k_materialize<313>;
+    case 512: return k_materialize<512>;
+    default: return k_materialize<0>;
+  }
+}
 ExpandKernel fused_kernel_for(const Model& M) {
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 211: return k_expand<true, 211>;
@@ -1111,7 +1131,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
                          wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk, mode, (u64)0);
     else
-      hipLaunchKernelGGL(k_expand<false>, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+      hipLaunchKernelGGL(exact_kernel_for(M), dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
                          0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap, nullptr, 0, nullptr, 0, 0, (u64)0);
@@ -1155,7 +1175,7 @@ int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t
   unsigned grid = (unsigned)grid64;
   size_t lds = (size_t)VSR_MAT_BLOCK * c->lds_stride * 8;
   HIPCHK(hipEventRecord(c->ev[2], c->stream));
-  hipLaunchKernelGGL(k_materialize, dim3(grid), dim3(VSR_MAT_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], entries, n,
+  hipLaunchKernelGGL(materialize_kernel_for(M), dim3(grid), dim3(VSR_MAT_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], entries, n,
                      c->table, t_words, t_words_cap, t_off, t_cap, t_fp, t_key, c->ctl, verdict, cnt_n, cnt_w, c->lds_stride, ichunk, wchunk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev[3], c->stream));
