@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 CONFIG = dict(R=3, C=1, n=2, L=2)                     # BASELINE.json configs[1] = /root/reference/.../VSR.cfg:4-8
 EXPECT = dict(distinct=319228361, depth=28, viol_fp=0x22239cb457b78204)   # tests/golden/config2_violation.json
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TABLE_LOG2 = 31                                       # seen-set: 2^31 slots x 16 B = 32 GiB of the 288 GB (load 0.15 at the end)
+TABLE_LOG2 = int(os.environ.get("VSR_BENCH_TABLE_LOG2", 31))   # seen-set: 2^31 slots x 16 B = 32 GiB of the 288 GB (load 0.15 at the end)
 
 
 def cpu_baseline(seconds=15.0):
