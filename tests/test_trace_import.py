@@ -155,3 +155,35 @@ def test_cli_validate_trace(vt, golden_trace, tmp_path):
     assert "24 states read" in r.stdout and "The trace is a behaviour of the model." in r.stdout
     assert "Its last state violates invariant AcknowledgedWriteNotLost." in r.stdout
     assert "State 24: <%s>" % golden_trace["states"][-1]["action"] in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_dump_is_readable_and_complete(vt, tmp_path):
+    """vsrmc -dump writes every distinct state in TLC's -dump text form; the product's reader takes it back and the set of
+    fingerprints is the oracle's whole state space of config 1 (76 states) — the file a maintainer with a JVM would diff
+    against `tlc2.TLC -dump` to pin parity with TLC itself."""
+    from oracle import orc
+    from test_host_cpu import _cfg
+    cfg = _cfg(tmp_path, R=2, vals="v1", L=1)
+    out = tmp_path / "states.dump"
+    r = subprocess.run([os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc"), "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01",
+                        "-dump", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "76 states dumped" in r.stdout, r.stdout + r.stderr
+    text = out.read_text()
+    assert text.startswith("State 1:\n/\\ aux_client_acked = <<>>\n") and text.count("\nState ") == 75
+    m = vt.Model.from_constants(R=2, C_=1, n=1, L=1)
+    states = m.parse_states(text)
+    assert len(states) == 76 and np.array_equal(states[0][1], m.init_state())
+    words = np.concatenate([rec for _, rec in states])
+    off = np.cumsum([0] + [len(rec) for _, rec in states]).astype(np.uint64)
+    fps, _ = m.fingerprints(words, off)
+    P = orc.Params(2, 1, 1, 1)
+    ob = orc.Bfs(P)
+    want = []
+    level = 1
+    while True:
+        want += [int(x) for x in ob.level_fps(level)]
+        if ob.step() == 0:
+            break
+        level += 1
+    assert sorted(int(x) for x in fps) == sorted(want) and len(set(want)) == 76

@@ -35,6 +35,8 @@ static void usage() {
       "                    as a PROBE level (nothing stored) — two levels beyond the last frontier that fits; the search ends there\n"
       "  -probeLast        when the next level does not fit the frontier buffers, still check its states' invariants without\n"
       "                    storing them (finds a violation one level beyond memory; the search ends there)\n"
+      "  -dump FILE        write every distinct state in the text form of `tlc2.TLC -dump` (State k: + /\\ var = value conjuncts), level by\n"
+      "                    level; for cross-checking small configurations against a real TLC run (refused beyond -dumpMax states, 1e6)\n"
       "  -checkpoint FILE  write a checkpoint between levels, at most every -checkpointMinutes M (default 30; 0 = after every level)\n"
       "  -recover FILE     continue the search a checkpoint stopped at (same constants; buffer sizes may differ)\n"
       "  -noTLA            do not read / hash-check the .tla file (only the cfg)\n"
@@ -42,7 +44,8 @@ static void usage() {
 }
 
 int main(int argc, char** argv) {
-  std::string cfg, tla, trace_file, chk_file, recover_file;
+  std::string cfg, tla, trace_file, chk_file, recover_file, dump_file;
+  unsigned long long dump_max = 1000000ull, dumped = 0;
   double chk_minutes = 30.0;
   bool check_deadlock = false, no_tla = false, json = false, simulate = false, host_frontier = false, probe_last = false;
   int sim_depth = 100;
@@ -71,6 +74,8 @@ int main(int argc, char** argv) {
     else if (a == "-checkpoint" && i + 1 < argc) chk_file = argv[++i];
     else if (a == "-checkpointMinutes" && i + 1 < argc) chk_minutes = std::atof(argv[++i]);
     else if (a == "-recover" && i + 1 < argc) recover_file = argv[++i];
+    else if (a == "-dump" && i + 1 < argc) dump_file = argv[++i];
+    else if (a == "-dumpMax" && i + 1 < argc) dump_max = std::strtoull(argv[++i], nullptr, 10);
     else if (a == "-simulate") simulate = true;
     else if (a == "-depth" && i + 1 < argc) sim_depth = std::atoi(argv[++i]);
     else if (a == "-walkers" && i + 1 < argc) sim_walkers = (unsigned)std::strtoul(argv[++i], nullptr, 10);
@@ -197,6 +202,43 @@ int main(int argc, char** argv) {
   else std::printf("Recovered from %s: level %d, %llu distinct states found, %llu states left on queue.\n", recover_file.c_str(), info.level,
                    (unsigned long long)info.distinct, (unsigned long long)info.n_new);
   int rc = 0;
+  FILE* dump = nullptr;
+  if (!dump_file.empty()) {
+    dump = std::fopen(dump_file.c_str(), "w");
+    if (!dump) { std::fprintf(stderr, "Error: cannot write %s\n", dump_file.c_str()); return 1; }
+  }
+  // the newest level in TLC's -dump text form: "State k:" + one "/\ var = value" conjunct per variable
+  auto dump_level = [&](uint64_t n_states) -> bool {
+    if (!dump || n_states == 0) return true;
+    if (dumped + n_states > dump_max) {
+      std::fprintf(stderr, "Error: -dump stops at %llu states (-dumpMax)\n", dump_max);
+      return false;
+    }
+    std::vector<uint64_t> words(n_states * (uint64_t)lay.max_record_words), off(n_states + 1);
+    uint64_t n = 0;
+    if (vsrmc_checker_frontier(c, words.data(), words.size(), off.data(), off.size(), &n) != 0) return false;
+    for (uint64_t t = 0; t < n; t++) {
+      int64_t need = 0;
+      vsrmc_model_format_state(m, &words[off[t]], nullptr, 0, &need);
+      std::string buf((size_t)need, '\0');
+      vsrmc_model_format_state(m, &words[off[t]], &buf[0], need, &need);
+      std::fprintf(dump, "State %llu:\n", ++dumped);
+      size_t pos = 0;
+      while (pos < buf.size()) {                              // "[\nvar |-> value,\n...\n]" -> conjuncts
+        size_t eol = buf.find('\n', pos);
+        if (eol == std::string::npos) eol = buf.size();
+        std::string line = buf.substr(pos, eol - pos);
+        pos = eol + 1;
+        size_t arrow = line.find(" |-> ");
+        if (arrow == std::string::npos) continue;             // the brackets
+        if (!line.empty() && line.back() == ',') line.pop_back();
+        std::fprintf(dump, "/\\ %s = %s\n", line.substr(0, arrow).c_str(), line.substr(arrow + 5).c_str());
+      }
+      std::fprintf(dump, "\n");
+    }
+    return true;
+  };
+  if (dump && recover_file.empty() && !dump_level(1)) return 1;
   bool violated = false, deadlocked = false, probed_violation = false;
   uint64_t viol_level = 0, viol_index = 0;
   int depth = info.level;
@@ -260,6 +302,7 @@ int main(int argc, char** argv) {
     else if (info.n_new)
       std::printf("Progress(%d): %llu states generated, %llu distinct states found, %llu states left on queue. (%.2f s)\n", info.level,
                   (unsigned long long)info.total_generated, (unsigned long long)info.distinct, (unsigned long long)info.n_new, dt);
+    if (!dump_level(info.n_new)) { rc = -1; break; }
     if (info.viol_mask) { violated = true; viol_level = (uint64_t)info.level; viol_index = info.viol_index; break; }
     if (check_deadlock && info.deadlocks) { deadlocked = true; break; }
     if (info.n_new == 0) break;
@@ -308,6 +351,10 @@ int main(int argc, char** argv) {
               (unsigned long long)info.distinct, (unsigned long long)(info.n_new));
   std::printf("The depth of the complete state graph search is %d.\nFinished in %.3f s (%.3g distinct states/s).\n", depth, dt,
               dt > 0 ? (double)info.distinct / dt : 0.0);
+  if (dump) {
+    std::fclose(dump);
+    std::printf("%llu states dumped to %s.\n", dumped, dump_file.c_str());
+  }
   vsrmc_checker_destroy(c);
   vsrmc_model_destroy(m);
   return exit_code;
