@@ -154,3 +154,19 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
     assert "Error: Invariant AcknowledgedWriteNotLost is violated." in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert "State 1: <Initial predicate>" in r.stdout and "State 28: <" in r.stdout and "State 29: <" not in r.stdout
     assert "319228361 distinct states found" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4])
+def test_bench_sharded_leg_at_full_scale(world):
+    """`bench.py --gpus N` (the driver's scaling run) with N ranks sharing this GPU over gloo: the whole 319 M-state workload
+    with the buffer sizes the leg computes for that world size; bench asserts the distinct-state count, the depth, the
+    violating fingerprint and the trace replay itself."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29680 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", VSR_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["launches"] >= 27

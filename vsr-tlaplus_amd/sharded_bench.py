@@ -30,21 +30,23 @@ def main(args, CONFIG, EXPECT):
         else:
             dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    # slack: hash imbalance between shards, plus the unused tails of the per-wave output chunks (k_materialize reserves
-    # indices / words in chunks; up to 1280 waves x (1024 indices, 65536 words) per target and level stay unused)
+    # slack 1.4: frontier imbalance between ranks (rebalancing tolerates 25 %) and the speculative successors that lose (≈ 5 %).
+    # On top of that every resident block of k_expand leaves one partly used index chunk (<= 8192 indices) and one word chunk
+    # (<= 262144 words) behind per level: up to 4 blocks per CU.
     slack = 1.4
+    blocks = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+    tail_idx, tail_words = blocks * 8192, blocks * 262144
     per_rank = lambda x, extra=0: int(x / world * slack) + extra + (1 << 16)   # noqa: E731
     per_pair = lambda x, extra=0: int(x / world / world * slack) + extra + (1 << 16)   # noqa: E731
-    tail_idx, tail_words = 1280 * 1024, 1280 * 65536
     m = vt.Model.from_constants(R=CONFIG["R"], C_=CONFIG["C"], n=CONFIG["n"], L=CONFIG["L"])
     table_log2 = max(20, int(math.ceil(math.log2(4.4 * TOTAL / world))))
     eng = sharded.HipShardEngine(
-        m, rank, world, device=local_rank, table_log2=table_log2, frontier_words=per_rank(MAX_WORDS, world * tail_words),
-        frontier_states=per_rank(MAX_NEW, world * tail_idx), pending_entries=1 << 16,   # single-pass levels: no pending list
+        m, rank, world, device=local_rank, table_log2=table_log2, frontier_words=per_rank(MAX_WORDS, 2 * tail_words),
+        frontier_states=per_rank(MAX_NEW, 2 * tail_idx), pending_entries=1 << 16,   # single-pass levels: no pending list
         cand_cap=per_pair(MAX_GENERATED), filter_log2=max(20, int(math.ceil(math.log2(2.0 * TOTAL / world)))),
         # records stay with their generator; these two only bound one rebalancing move to one peer (early, small levels)
         rec_cap=1 << 22, rec_words_cap=1 << 28,
-        keep_trace=True, trace_entries=per_rank(TOTAL, 30 * world * tail_idx))
+        keep_trace=True, trace_entries=per_rank(TOTAL, 16 * tail_idx))
     x = sharded.Exchanger()
     S = dict(alg_bytes=0.0, launches=0, distinct=0, ttfv=[])
     moved = [0]
