@@ -183,7 +183,7 @@ int main(int argc, char** argv) {
   o.frontier_words = (uint64_t)(frontier_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);
   o.frontier_words_b = (uint64_t)(frontier_b_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);   // 0 = like the first
   o.frontier_states = o.frontier_words / 24;
-  o.pending_entries = o.frontier_states * 3;
+  o.pending_entries = (uint64_t)1 << 20;   // single-pass levels keep no pending list (the buffer only collects violators of probe levels)
   // one entry per state plus the unused tails of the per-block index chunks (<= 4096 per block per level, 510 levels at most)
   o.trace_entries = ((uint64_t)1 << table_log2) / 2 + ((uint64_t)1 << 21);
   vsrmc_checker* c = nullptr;
