@@ -1830,7 +1830,9 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
     std::fclose(f);
     return fail(VSRMC_E_CFG, "the checkpoint was written for different model constants");
   }
-  if (h.n_frontier > o->frontier_states || h.cur_w > o->frontier_words || 2 * h.table_entries > ((u64)1 << o->table_log2) ||
+  const int buf_of_level = (h.level - 1) & 1;                   // level L lives in record buffer (L - 1) mod 2, also after recovery
+  const u64 cap_of_buf = (buf_of_level == 1 && o->frontier_words_b) ? o->frontier_words_b : o->frontier_words;
+  if (h.n_frontier > o->frontier_states || h.cur_w > cap_of_buf || 2 * h.table_entries > ((u64)1 << o->table_log2) ||
       (o->keep_trace && h.trace_entries == 0 && h.level > 1)) {
     std::fclose(f);
     return fail(VSRMC_E_ARG, "the options are too small for this checkpoint (frontier, table) or ask for a trace log it does not have");
@@ -1864,9 +1866,9 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
   if (ok) ok = hipMemcpy(&terr, d_err, 4, hipMemcpyDeviceToHost) == hipSuccess && terr == 0;
   if (d_in) (void)hipFree(d_in);
   if (d_err) (void)hipFree(d_err);
-  c->cur = 0;
-  ok = ok && file_to_dev(f, c->words[0], h.cur_w * 8, buf);
-  ok = ok && file_to_dev(f, c->off[0], h.n_frontier * 8, buf);
+  c->cur = buf_of_level;
+  ok = ok && file_to_dev(f, c->words[c->cur], h.cur_w * 8, buf);
+  ok = ok && file_to_dev(f, c->off[c->cur], h.n_frontier * 8, buf);
   ok = ok && file_to_dev(f, c->lvl_fp, h.n_frontier * 8, buf);
   if (h.trace_entries) {
     if (c->tr_all) ok = ok && file_to_dev(f, c->tr_all, h.trace_entries * 8, buf);
