@@ -504,7 +504,16 @@ def test_checkpoint_and_recover_continue_to_the_same_result(vt, orc, tmp_path):
     path = str(tmp_path / "run.chk")
     a.save(path)
     fps7 = a.level_fps()
+    a.step()
+    path8 = str(tmp_path / "run8.chk")                           # an even level lives in the second record buffer
+    a.save(path8)
     a.close()
+    b8 = vt.ModelChecker(m, table_log2=21, frontier_words=1 << 24, frontier_words_b=1 << 25, frontier_states=1 << 19, recover=path8)
+    assert b8.level == 8
+    for _ in range(4):
+        b8.step()
+    assert (b8.level, b8.distinct) == (ref.level, ref.distinct) and np.array_equal(b8.level_fps(), ref.level_fps())
+    b8.close()
     # recover into a checker with a different table size and different capacities
     b = vt.ModelChecker(m, table_log2=21, frontier_words=1 << 24, frontier_states=1 << 19, recover=path)
     assert (b.level, b.distinct) == (7, sum(l["n_new"] for l in ref.levels[:7]))
