@@ -347,6 +347,11 @@ int main(int argc, char** argv) {
   } else if (info.n_new == 0) {
     std::printf("Model checking completed. No error has been found.\n");
   }
+  {  // TLC prints the same estimate: every generated state that was judged "seen" could be a 64-bit fingerprint collision
+    const double n = (double)info.distinct, g = (double)info.total_generated;
+    std::printf("The probability of a fingerprint collision hiding a state is estimated (optimistically) at %.1e.\n",
+                n * (g > n ? g - n : 0.0) / 18446744073709551616.0);
+  }
   std::printf("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)info.total_generated,
               (unsigned long long)info.distinct, (unsigned long long)(info.n_new));
   std::printf("The depth of the complete state graph search is %d.\nFinished in %.3f s (%.3g distinct states/s).\n", depth, dt,
