@@ -227,3 +227,12 @@ def test_cli_help_and_cfg_errors(vt, tmp_path):
     assert r.returncode == 0 and "-config" in r.stdout
     r = subprocess.run([cli, "-config", _cfg(tmp_path, restart=2), "VSR.tla", "-noTLA"], capture_output=True, text=True)
     assert r.returncode != 0 and "RestartEmptyLimit" in (r.stderr + r.stdout)
+
+
+def test_make_cfg_tool_writes_a_cfg_the_loader_accepts(vt, tmp_path):
+    import subprocess
+    out = tmp_path / "gen.cfg"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_cfg.py"), str(out), "3", "1", "v1, v2, v3", "3"], check=True)
+    lay = vt.Model.load(str(out)).layout
+    assert (lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit) == (3, 1, 3, 3)
+    assert lay.symmetry == 1 and lay.permutations == 6 and lay.invariant_mask == 1
