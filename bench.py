@@ -173,7 +173,7 @@ def main():
                      "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3)}},
     }
     # HBM traffic of the same kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
-    tpath = os.path.join(ROOT, "profiles", "r01f_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01g_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             t = json.load(f)

@@ -209,10 +209,10 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
 // SPEC = R * 100 + C * 10 + |Values| of a configuration the kernel is specialised for (0 = generic): the constants of the model
 // become compile-time constants of this instantiation (every device function below is inlined), so loops over replicas,
 // clients, values and permutations unroll without predicates and strides fold into addresses.
-template <bool FUSED, int SPEC = 0>
+template <bool FUSED, int SPEC = 0, bool PLAIN = false>
 __global__ void __launch_bounds__(VSR_BLOCK, FUSED ? (SPEC ? 4 : 2) : 3)
 k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
-         Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world, u64* cand_send,
+         Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world_arg, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
          // fused single-pass mode (nx_words != nullptr): the lane that inserts a fingerprint writes the successor at once
          u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u64* lvl_tr, u32 ichunk, u32 wchunk, int tile, u32 ccap /* work-list capacity per tile */,
@@ -227,7 +227,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
          //   MODE_REGEN   re-expansion of (a slice of) the same parents after a MODE_INSERT pass: the successor whose key IS
          //                the slot's final meta word — exactly one per new state — is written to the next frontier
          // violators of PROBE / INSERT go to the `pending` list as (fp, key) pairs (n_pending counts them).
-         int mode, u64 p_offset /* index of parent 0 of this launch in its level (slices) */) {
+         int mode_arg, u64 p_offset /* index of parent 0 of this launch in its level (slices) */) {
+  // PLAIN: the unsharded, ordinary level — the probe / virtual-level modes and the sharded branches are compiled out (11 % less
+  // code: the specialised kernel then fits the 64-KB instruction cache with room to spare)
+  const int mode = PLAIN ? (int)MODE_NORMAL : mode_arg;
+  const int world = PLAIN ? 1 : world_arg;
   Model M = Marg;
   specialise<SPEC>(M, Marg);
   extern __shared__ u64 smem[];

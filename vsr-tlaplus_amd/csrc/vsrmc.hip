@@ -861,6 +861,7 @@ struct vsrmc_checker {
   int failed_code = 0;                   // device ERR_* that stopped the search (failed == 1)
   // the single-pass kernel of this model (a specialised instantiation when there is one) and its launch shape
   void* fused_kernel = nullptr;
+  void* plain_kernel = nullptr;          // the same without modes / sharding, when the configuration has one (ordinary unsharded levels)
   u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
   bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
   u64 probe_key = ~(u64)0;               // vsrmc_checker_probe: trace key (parent index, ordinal) of the reported violator
@@ -892,6 +893,14 @@ MaterializeKernel materialize_kernel_for(const Model& M) {
     case 313: return k_materialize<313>;
     case 512: return k_materialize<512>;
     default: return k_materialize<0>;
+  }
+}
+ExpandKernel plain_kernel_for(const Model& M) {               // unsharded ordinary levels: modes and sharding compiled out
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 312: return k_expand<true, 312, true>;
+    case 313: return k_expand<true, 313, true>;
+    case 512: return k_expand<true, 512, true>;
+    default: return nullptr;
   }
 }
 ExpandKernel fused_kernel_for(const Model& M) {
@@ -1049,6 +1058,7 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
   c->fused_kernel = (void*)fused_kernel_for(M);
+  c->plain_kernel = (void*)plain_kernel_for(M);
   rc = checker_seed(c);
   if (rc) { vsrmc_checker_destroy(c); return rc; }
   *out = c;
@@ -1125,7 +1135,8 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
       wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     }
     if (fused)
-      hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+      hipLaunchKernelGGL((ExpandKernel)((!io && mode == MODE_NORMAL && c->plain_kernel) ? c->plain_kernel : c->fused_kernel), dim3(grid),
+                         dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
