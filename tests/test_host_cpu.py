@@ -14,7 +14,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-VSR_CFG_TEXT = """\\* SPECIFICATION
+VSR_CFG_TEXT = """\\* (test template in the layout of a TLC cfg: comment lines, blank lines, multi-line INVARIANT list)
 
 CONSTANTS
     ReplicaCount = %(R)d
@@ -43,15 +43,14 @@ INIT Init
 NEXT Next
 
 VIEW view
-\\* use symmValues when only using a set larger than one for the Values constant
+\\* symmetry reduction needs at least two model values
 %(symmetry)s
 
-\\* PROPERTY
-\\* Uncomment the previous line and add property names
+\\* (no temporal properties: safety checking only)
 
 INVARIANT
 AcknowledgedWriteNotLost
-\\* AcknowledgedWritesExistOnMajority \\* less strict than AcknowledgedWriteNotLost
+\\* AcknowledgedWritesExistOnMajority \\* kept out by default, enabled by some tests through the line below
 %(extra)s
 """
 
