@@ -13,7 +13,7 @@
 // exists in this image, and the reference pins no TLC version, fingerprints or state counts
 // (SURVEY.md §8c).  What pins this oracle:
 //   * the reference's only golden vector, state_transfer_violation_trace.txt (24 states), replayed
-//     step-by-step (tests/test_golden_trace.py, fixtures in tests/golden/);
+//     step-by-step (tests/test_oracle_golden.py, fixtures in tests/golden/);
 //   * an independently written Python restatement (oracle/pyoracle.py) that canonicalises by explicit
 //     value comparison instead of hashing, compared on whole small state spaces.
 //
