@@ -147,6 +147,11 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
     r = run(_cfg(tmp_path, R=2, vals="v1", L=1), "-replicateBelow", "8")
     assert "Model checking completed. No error has been found." in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert "76 distinct states found" in r.stdout and "search is 14" in r.stdout and "[sharded]" in r.stdout
+    # the same through `vsrmc -gpus 2` (the C++ front end re-executes itself under torch.distributed.run)
+    r = subprocess.run([os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc"), "-config", _cfg(tmp_path, R=2, vals="v1", L=1), "-noTLA", "-gpus", "2",
+                        "-backend", "gloo", "-tableLog2", "20", "-frontierGiB", "0.05", "-replicateBelow", "8"], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_PORT="29672"))
+    assert "76 distinct states found" in r.stdout and "[sharded]" in r.stdout and "2 rank(s)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     # the shipped VSR.cfg constants: the run ends in the depth-28 violation of AcknowledgedWriteNotLost (319 M states)
     d2 = tmp_path / "c2"
     d2.mkdir()

@@ -12,6 +12,7 @@
 #include <sstream>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/vsrmc.h"
 
@@ -22,6 +23,9 @@ static void usage() {
       "  -deadlock         do not check for deadlock (default)      -checkDeadlock   report the first terminal state\n"
       "  -maxDepth N       stop after N BFS levels (Init = level 1)\n"
       "  -device D         HIP device ordinal (default 0)\n"
+      "  -gpus N           N > 1: run the sharded checker on N GPUs of this node (re-executes as\n"
+      "                    python3 -m torch.distributed.run ... -m vsr_tlaplus_amd.sharded_cli with the other arguments;\n"
+      "                    -tableLog2 / -frontierGiB are then PER RANK; see that module for -replicateBelow, -backend, -exactTies)\n"
       "  -tableLog2 N      seen-set slots = 2^N x 16 B (default 28)\n"
       "  -frontierGiB G    size of each of the two frontier buffers (default 8); -frontierBGiB G: the second one (levels 2, 4, ..)\n"
       "  -simulate         random walks instead of BFS (TLC -simulate): -depth N (default 100) -walkers N (131072) -seed S -maxSeconds T\n"
@@ -43,7 +47,32 @@ static void usage() {
       "  -json             one JSON object per level on stdout instead of TLC-style progress lines\n");
 }
 
+// -gpus N: hand the run to the multi-GPU front end (one process per GPU under torch.distributed.run)
+static int exec_sharded(int argc, char** argv, int gpus_at) {
+  std::string exe = argv[0];
+  char real[4096];
+  ssize_t n = readlink("/proc/self/exe", real, sizeof(real) - 1);
+  if (n > 0) { real[n] = 0; exe = real; }
+  std::string root = exe.substr(0, exe.find_last_of('/'));          // .../vsr-tlaplus_amd
+  root = root.substr(0, root.find_last_of('/'));                    // repository root (holds the vsr_tlaplus_amd import shim)
+  const char* old = getenv("PYTHONPATH");
+  setenv("PYTHONPATH", old && *old ? (root + ":" + old).c_str() : root.c_str(), 1);
+  const char* port = getenv("MASTER_PORT");
+  std::vector<std::string> args = {"python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", argv[gpus_at + 1],
+                                   "--master-addr", "127.0.0.1", "--master-port", port ? port : "29500", "-m", "vsr_tlaplus_amd.sharded_cli"};
+  for (int i = 1; i < argc; i++)
+    if (i != gpus_at && i != gpus_at + 1) args.push_back(argv[i]);
+  std::vector<char*> cargs;
+  for (auto& a : args) cargs.push_back(const_cast<char*>(a.c_str()));
+  cargs.push_back(nullptr);
+  execvp("python3", cargs.data());
+  std::perror("vsrmc: cannot start python3");
+  return 1;
+}
+
 int main(int argc, char** argv) {
+  for (int i = 1; i + 1 < argc; i++)
+    if (std::string(argv[i]) == "-gpus" && std::atoi(argv[i + 1]) > 1) return exec_sharded(argc, argv, i);
   std::string cfg, tla, trace_file, chk_file, recover_file, dump_file;
   unsigned long long dump_max = 1000000ull, dumped = 0;
   double chk_minutes = 30.0;
@@ -62,6 +91,7 @@ int main(int argc, char** argv) {
     else if (a == "-checkDeadlock") check_deadlock = true;
     else if (a == "-maxDepth" && i + 1 < argc) max_depth = std::atoi(argv[++i]);
     else if (a == "-device" && i + 1 < argc) device = std::atoi(argv[++i]);
+    else if (a == "-gpus" && i + 1 < argc) ++i;                   // 1: this process
     else if (a == "-tableLog2" && i + 1 < argc) table_log2 = std::atoi(argv[++i]);
     else if (a == "-frontierGiB" && i + 1 < argc) frontier_gib = std::atof(argv[++i]);
     else if (a == "-frontierBGiB" && i + 1 < argc) frontier_b_gib = std::atof(argv[++i]);
