@@ -67,7 +67,8 @@ def replay_walks_with_oracle(ranks, params):
 
 
 @pytest.mark.parametrize("world,params,max_depth,rb", [(2, (2, 1, 2, 2), 40, 0), (3, (2, 1, 1, 1), 40, 0), (2, (3, 1, 2, 2), 7, 0),
-                                                       (2, (2, 1, 2, 2), 40, 30), (3, (2, 1, 2, 2), 40, 10 ** 9)])
+                                                       (2, (2, 1, 2, 2), 40, 30), (3, (2, 1, 2, 2), 40, 10 ** 9),
+                                                       (4, (2, 1, 2, 2), 40, 20)])
 def test_sharded_level_loop_matches_single_process_oracle(tmp_path, world, params, max_depth, rb):
     """rb = replicate_below: 0 = sharded from Init on, 30 = the ranks explore the first levels on their own and partition the
     first level with >= 30 new states, 10^9 = never sharded (every rank explores everything)"""
