@@ -8,13 +8,13 @@ package tlc2.tool;
 public final class GpuModelChecker {
     static { System.loadLibrary("vsrmc_jni"); }
 
-    // --- natives (java/jni/vsrmc_jni.c would implement them exactly like the FPSet ones) -------------------------------
+    // --- natives (java/jni/vsrmc_jni.c) --------------------------------------------------------------------------------
     private static native long modelLoad(String tlaPath, String cfgPath);                 // vsrmc_model_load
     private static native long checkerCreate(long model, int device, int tableLog2, long frontierWords,
                                              long frontierStates, long pendingEntries, long traceEntries);   // vsrmc_checker_create
     /** one BFS level; out = {level, nNew, distinct, totalGenerated, violMask, violIndex, deadlocks}; returns the C ABI code */
     private static native int checkerStep(long checker, long[] out);                      // vsrmc_checker_step
-    private static native String[] checkerTrace(long checker, int level, long index);     // vsrmc_checker_trace + format_state
+    private static native String[] checkerTrace(long checker, long model, int level, long index);   // vsrmc_checker_trace + format_state
     private static native String[] simulate(long model, int device, int walkers, int depth, long seed, double maxSeconds);
     private static native String lastError();                                             // vsrmc_last_error
 
@@ -54,7 +54,7 @@ public final class GpuModelChecker {
                               info[0], info[3], info[2], info[1]);
             if (info[4] != 0) {
                 System.out.println("Error: Invariant AcknowledgedWriteNotLost is violated.\nError: The behavior up to this point is:");
-                for (String s : checkerTrace(mc, (int) info[0], info[5])) System.out.println(s);
+                for (String s : checkerTrace(mc, model, (int) info[0], info[5])) System.out.println(s);
                 System.exit(12);
             }
             if (checkDeadlock && info[6] != 0) { System.out.println("Error: Deadlock reached."); System.exit(11); }
