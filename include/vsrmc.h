@@ -262,6 +262,9 @@ int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t n_walkers,
  * fingerprints then sit in every rank's table, owners included, which is all the protocol needs.) */
 int32_t vsrmc_shard_local_step(vsrmc_checker* c, vsrmc_level_info* info);
 int32_t vsrmc_shard_partition(vsrmc_checker* c, uint64_t* n_kept);
+/* after vsrmc_shard_commit / _local_step: the largest bag (vsrmc_level_info.max_bag) of the new level over ALL ranks, so that the next
+ * expansion can size its LDS record slots for the level (optional; without it the format's worst case is used) */
+int32_t vsrmc_shard_set_max_bag(vsrmc_checker* c, uint64_t max_bag);
 typedef struct vsrmc_shard_io {
   uint64_t* cand_send;           /* [world][cand_cap][2]  (fp, key) */
   uint64_t cand_cap;             /* entries per owner */

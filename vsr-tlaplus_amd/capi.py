@@ -105,6 +105,7 @@ SYMBOLS = {
     "vsrmc_shard_commit": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_shard_local_step": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_shard_partition": (C.c_int32, [V, C.POINTER(C.c_uint64)]),
+    "vsrmc_shard_set_max_bag": (C.c_int32, [V, C.c_uint64]),
 }
 
 _lib = None

@@ -1101,7 +1101,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
     const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
     // sharded: records arrive from other ranks (rebalancing), the local maximum says nothing -> the format's capacity
-    const FusedShape fs = fused_shape(c, (c->bag_known && c->opt.world == 1) ? c->cur_max_bag : (u64)M.max_bag);
+    const FusedShape fs = fused_shape(c, c->bag_known ? c->cur_max_bag : (u64)M.max_bag);
     const int tile = fused ? fs.tile : (M.R <= 3 ? 128 : 64);
     const int stride = fused ? fs.stride : c->lds_stride;
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
@@ -1537,6 +1537,16 @@ int32_t vsrmc_shard_local_step(vsrmc_checker* c, vsrmc_level_info* info) {
   if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   return step_local(c, info);
+}
+
+// Sharded runs: the largest bag among the records of the newest level over ALL ranks (records move between ranks when the
+// frontiers are rebalanced, so a rank's own maximum is not enough).  Lets the next k_expand size its LDS record slots for the
+// level instead of the format's worst case; without this call the worst case is used.
+int32_t vsrmc_shard_set_max_bag(vsrmc_checker* c, uint64_t max_bag) {
+  if (!c) return fail(VSRMC_E_ARG, "NULL argument");
+  c->cur_max_bag = max_bag;
+  c->bag_known = true;
+  return 0;
 }
 
 int32_t vsrmc_shard_partition(vsrmc_checker* c, uint64_t* n_kept) {

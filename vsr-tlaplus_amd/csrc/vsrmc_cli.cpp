@@ -215,7 +215,7 @@ int main(int argc, char** argv) {
   o.frontier_states = o.frontier_words / 24;
   o.pending_entries = (uint64_t)1 << 20;   // single-pass levels keep no pending list (the buffer only collects violators of probe levels)
   // one entry per state plus the unused tails of the per-block index chunks (<= 4096 per block per level, 510 levels at most)
-  o.trace_entries = ((uint64_t)1 << table_log2) / 2 + ((uint64_t)1 << 21);
+  o.trace_entries = ((uint64_t)1 << table_log2) / 2 + ((uint64_t)1 << 28);   // + chunk tails: <= 1024 blocks x 8192 indices x ~30 large levels
   vsrmc_checker* c = nullptr;
   if ((recover_file.empty() ? vsrmc_checker_create(m, &o, &c) : vsrmc_checker_load(m, &o, recover_file.c_str(), &c)) != 0) {
     std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());

@@ -178,6 +178,8 @@ class ShardedChecker:
 
     def _step_replicated(self):
         info = self.e.local_step()
+        if hasattr(self.e, "set_max_bag"):                      # replicated phase: every rank sees the same level
+            self.e.set_max_bag(info.get("max_bag", 0))
         self.level += 1
         self.n_frontier = info["n_new"]
         self.distinct += info["n_new"]
@@ -255,7 +257,9 @@ class ShardedChecker:
         viol_fp = info["viol_fp"] if info["viol_mask"] else U64_MAX
         # one all-gather carries every per-level figure (a 64-bit fingerprint travels as two 32-bit halves: int64 tensors)
         rows = x.allgather([info["n_new"], info["generated"], info["deadlocks"], info["pending"], viol_fp >> 32,
-                            viol_fp & 0xFFFFFFFF, err, info["viol_mask"]])
+                            viol_fp & 0xFFFFFFFF, err, info["viol_mask"], info.get("max_bag", 0)])
+        if hasattr(e, "set_max_bag"):                           # the level's largest bag over all ranks: LDS slot size of the next level
+            e.set_max_bag(max(r[8] for r in rows))
         self._raise_if(max(r[6] for r in rows), "append")
         s = [sum(r[k] for r in rows) for k in range(4)]
         gviol = min((r[4] << 32) | r[5] for r in rows)
@@ -427,6 +431,9 @@ class HipShardEngine:
         n = C.c_uint64()
         check(capi.load().vsrmc_shard_partition(self._h, C.byref(n)))
         return n.value
+
+    def set_max_bag(self, max_bag):
+        check(capi.load().vsrmc_shard_set_max_bag(self._h, int(max_bag)))
 
     def find_fp(self, fp):
         idx = C.c_uint64()

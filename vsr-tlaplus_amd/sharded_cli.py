@@ -92,7 +92,10 @@ def main(argv=None):
         m, rank, world, device=local_rank, table_log2=opt["table_log2"], frontier_words=words, frontier_states=states,
         pending_entries=max(1 << 16, 3 * states if opt["exact"] else 0), cand_cap=int(1.5 * states / world) + (1 << 16),
         rec_cap=max(1 << 12, states // 8), rec_words_cap=max(1 << 16, words // 8), keep_trace=True,
-        trace_entries=(1 << opt["table_log2"]) // 2 + (1 << 21), exact_ties=opt["exact"])
+        # one entry per state the rank ends up holding, plus the unused tails of the index chunks its resident blocks leave behind
+        # per level (<= 4 blocks per CU x 8192 indices), for some thirty large levels
+        trace_entries=(1 << opt["table_log2"]) // 2 + 32 * 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count * 8192,
+        exact_ties=opt["exact"])
     sc = sharded.ShardedChecker(eng, sharded.Exchanger(), replicate_below=opt["replicate_below"])
     say("vsrmc: VSR.tla lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), invariant "
         "mask %d; %d rank(s), backend %s" % (lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
