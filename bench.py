@@ -7,7 +7,7 @@
 One "step" = one complete run of the hot path: level-synchronous BFS of VSR.tla under the shipped VSR.cfg constants
 (BASELINE.json configs[1]: ReplicaCount=3, ClientCount=1, Values={v1,v2}, StartViewOnTimerLimit=2, VIEW + SYMMETRY on,
 INVARIANT AcknowledgedWriteNotLost) from Init until the level that contains the first invariant violation is complete —
-28 levels, 319 228 361 distinct states, 942 M successors generated; the seen-set is cleared at the start of every step,
+28 levels, 319 228 361 distinct states, 885 M successors generated; the seen-set is cleared at the start of every step,
 HBM allocations are reused.  Inputs are the model itself (deterministic, no data files): "synthetic" in the contract's
 sense.  Timed region: barrier + torch.cuda.synchronize() on both sides, max over ranks, exactly K steps.
 
@@ -28,7 +28,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIG = dict(R=3, C=1, n=2, L=2)                     # BASELINE.json configs[1] = /root/reference/.../VSR.cfg:4-8
-EXPECT = dict(distinct=319228361, depth=28, viol_fp=0x22239cb457b78204)   # tests/golden/config2_violation.json
+FP_VERSION = 2                                        # fingerprint function of this build (oracle/vsr_oracle.hpp FP_VERSION)
+
+
+def load_expect():
+    """What a run must reproduce, from the CPU ORACLE's run of the whole workload (tools/make_oracle_levels.py ->
+    tests/golden/oracle_levels_config2*.json): level sizes, generated / deadlock counts and largest bags of all 28 levels (valid for
+    any fingerprint function), and — from a fixture made with this build's fingerprint function — the per-level xor / sum of the
+    fingerprints and the violating fingerprint."""
+    g = os.path.join(ROOT, "tests", "golden")
+    for name in ("oracle_levels_config2.json", "oracle_levels_config2_fpv1.json"):
+        if os.path.exists(os.path.join(g, name)):
+            with open(os.path.join(g, name)) as f:
+                d = json.load(f)
+            same_fp = d.get("fp_version", 1) == FP_VERSION
+            return dict(distinct=d["distinct"], depth=d["depth"], levels=d["levels"], fixture=name,
+                        viol_fp=int(d["viol_fp"], 16) if same_fp else None, checksums=same_fp)
+    raise SystemExit("no oracle fixture for the bench workload under tests/golden/")
+
+
+EXPECT = load_expect()
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TABLE_LOG2 = int(os.environ.get("VSR_BENCH_TABLE_LOG2", 31))   # seen-set: 2^31 slots x 16 B = 32 GiB of the 288 GB (load 0.15 at the end)
 
@@ -57,12 +76,21 @@ def run_single(args):
                          pending_entries=1 << 28, keep_trace=True, trace_entries=1 << 29)
     S = dict(expand_ms=0.0, mat_ms=0.0, launches=0, alg_bytes=0.0, distinct=0, generated=0, ttfv=[], words=0)
 
-    def one_run(record):
+    def one_run(record, verify=False):
         mc.reset()
         t0 = time.perf_counter()
         cur_words = int(m.layout.fixed_words) + int(m.layout.permutations)      # Init record, device layout
         while True:
             d = mc.step()
+            want = EXPECT["levels"][d["level"] - 1] if d["n_new"] else None     # every run, every level: the oracle's figures
+            assert want is None or (d["n_new"], d["generated"], d["deadlocks"], d["max_bag"]) == \
+                (want["new"], want["generated"], want["deadlocks"], want["max_bag"]), (d["level"], d["n_new"], d["generated"])
+            if verify and want is not None:                                    # untimed run: per-action counts, fingerprint checksums
+                assert [int(x) for x in d["act_generated"][1:16]] == want["act_generated"][1:16], d["level"]
+                x, sm, cnt = mc.level_checksum()
+                assert cnt == want["new"]
+                if EXPECT["checksums"]:
+                    assert ("%016x" % x, "%016x" % sm) == (want["fp_xor"], want["fp_sum"]), d["level"]
             if record and d["frontier"]:
                 S["expand_ms"] += d["expand_ms"]
                 S["mat_ms"] += d["materialize_ms"]
@@ -81,11 +109,12 @@ def run_single(args):
             assert len(tr) == mc.violation["level"]
         dt = time.perf_counter() - t0
         assert mc.distinct == EXPECT["distinct"] and mc.level == EXPECT["depth"], (mc.distinct, mc.level)
-        assert mc.violation and mc.violation["fp"] == EXPECT["viol_fp"]
+        assert mc.violation and (EXPECT["viol_fp"] is None or mc.violation["fp"] == EXPECT["viol_fp"])
         if record:
             S["distinct"] += mc.distinct
             S["ttfv"].append(dt)
 
+    one_run(False, verify=True)                                                # untimed: the whole workload against the oracle fixture
     for _ in range(args.warmup):
         one_run(False)
     torch.cuda.synchronize()

@@ -160,9 +160,17 @@ int32_t vsrmc_checker_reset(vsrmc_checker* c);
 int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info);
 /* sorted fingerprints of the newest level */
 int32_t vsrmc_checker_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, uint64_t* n);
+/* xor, sum (mod 2^64) and number of the fingerprints of the newest level, computed on the device (order-independent checksums
+ * of a level's fingerprint SET: what the whole-workload fixtures of the CPU oracle hold per level) */
+int32_t vsrmc_checker_level_checksum(vsrmc_checker* c, uint64_t* fp_xor, uint64_t* fp_sum, uint64_t* n_states);
 /* the newest level in wire layout (≙ StateQueue.sDequeue(int) without removal) */
 int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, uint64_t cap_states,
                                uint64_t* n);
+/* the states of the newest level in which at least one instance of an action of `action_mask` (bit a = action id a, the order of
+ * `Next`, VSR.tla:896-918) is enabled — at most max_states of them, wire layout; *n_matching = how many there are in all
+ * (≙ TLC's per-action coverage, as a filter) */
+int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t max_states, uint64_t* words, uint64_t cap_words,
+                             uint64_t* off, uint64_t* n_states, uint64_t* n_matching);
 /* ≙ TLCTrace.getTrace: the path Init .. state `index` of level `level`; records in wire layout, one action id per
  * state (0 = Initial predicate) */
 int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words,

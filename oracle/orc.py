@@ -52,8 +52,12 @@ def lib():
         L.orc_bfs_frontier.restype = C.c_longlong
         L.orc_bfs_frontier.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
         L.orc_bfs_trace_fps.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        assert L.orc_fp_version() == FP_VERSION, "oracle/orc.py and oracle/vsr_oracle.hpp disagree on FP_VERSION"
         _lib = L
     return _lib
+
+
+FP_VERSION = 2     # == vsr_oracle.hpp FP_VERSION (checked when the library loads): which fingerprint function fixtures were made with
 
 
 class OracleError(Exception):

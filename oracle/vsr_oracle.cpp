@@ -824,8 +824,8 @@ State decode(const Params& P, const u64* rec, int* nwords) {
 // Fingerprint of the canonical VIEW (DESIGN.md "Fingerprint").
 //   view (VSR.tla:149-150) = every variable except aux_svc, aux_restart, aux_client_acked;
 //   symmetry (VSR.tla:151)  = min over all permutations pi of Values of the hash of pi(view).
-// The hash is a SUM over components (one per replica column, one per bag entry) so that it does not
-// depend on the storage order of the bag and so that the HIP path can update it incrementally.
+// The hash is a SUM over components (one per word of a replica column, salted with its position, and one per bag entry) so
+// that it does not depend on the storage order of the bag and so that the HIP path can update it incrementally.
 // =============================================================================================
 u64 fmix64(u64 x) {
   x ^= x >> 33;
@@ -836,7 +836,8 @@ u64 fmix64(u64 x) {
   return x;
 }
 static const u64 SALT_MSG = 0x9E3779B97F4A7C15ULL;
-static u64 salt_rep(int r) { return fmix64(0xA0761D6478BD642FULL + (u64)r); }
+// position salt of word k of replica r's column (Zobrist-style: every (position, word) pair contributes one independent term)
+static u64 salt_word(int r, int k) { return fmix64(0xA0761D6478BD642FULL + (u64)(8 * r + k)); }
 
 static u64 view_hash(const Params& P, const State& s) {
   std::vector<u64> rec;
@@ -845,9 +846,7 @@ static u64 view_hash(const Params& P, const State& s) {
   u64 sum = 0;
   for (int r = 1; r <= P.R; r++) {
     const u64* b = &rec[1 + (size_t)(r - 1) * wpr];
-    u64 h = fmix64(b[0] ^ salt_rep(r));
-    for (int k = 1; k < wpr; k++) h = fmix64(h ^ b[k]);
-    sum += h;
+    for (int k = 0; k < wpr; k++) sum += fmix64(b[k] ^ salt_word(r, k));
   }
   for (size_t j = fixed_words(P); j < rec.size(); j++) sum += fmix64(rec[j] ^ SALT_MSG);
   return sum;

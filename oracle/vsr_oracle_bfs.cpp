@@ -186,6 +186,7 @@ int fail(int code, const std::string& msg) {
 extern "C" {
 
 const char* orc_last_error() { return g_err.c_str(); }
+int orc_fp_version() { return FP_VERSION; }
 
 int orc_layout(const int* params, int* wpr, int* fixed) {
   Params P = params_from(params);

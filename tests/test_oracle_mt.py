@@ -1,5 +1,5 @@
 """The multi-threaded oracle driver (oracle/vsr_oracle_mt, used by bench.py's cpu_baseline leg) against the single-threaded
-oracle and its committed per-level fixtures: identical new / generated / deadlock counts per level for any thread count."""
+oracle and its committed per-level fixtures: identical new / generated / deadlock counts and fingerprint xor / sum per level for any thread count."""
 import json
 import subprocess
 
@@ -20,9 +20,11 @@ def test_mt_oracle_reproduces_the_level_fixtures(golden_counts, threads):
     g = golden_counts["config2 (3,1,{v1,v2},2)"]
     levels, summary = _run([3, 1, 2, 2, "--threads", threads, "--max-depth", 12])
     assert summary["threads"] == threads and summary["stop"] == "max-depth" and summary["error"] == ""
-    for lv, want in zip(levels, g["levels"][1:]):
-        assert (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["ties"]) == \
-               (want["level"], want["new"], want["generated"], want["deadlocks"], 0)
+    assert len(levels) == 12
+    for lv, want in zip(levels, g["levels"]):
+        assert (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["ties"], lv["fp_xor"], lv["fp_sum"]) == \
+               (want["level"], want["new"], want["generated"], want["deadlocks"], 0, want["fp_xor"], want["fp_sum"])
+        assert sum(lv["act_generated"]) == lv["generated"]
     assert summary["distinct"] == sum(w["new"] for w in g["levels"][:12])
 
 

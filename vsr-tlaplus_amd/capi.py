@@ -79,6 +79,8 @@ SYMBOLS = {
     "vsrmc_checker_destroy": (None, [V]),
     "vsrmc_model_replay": (C.c_int32, [V, C.c_int32, V, C.c_int32, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_trace_entry": (C.c_int32, [V, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_level_checksum": (C.c_int32, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_select": (C.c_int32, [V, C.c_uint32, C.c_uint64, V, C.c_uint64, V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vsrmc_checker_find_fp": (C.c_int32, [V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_check": (C.c_int32, [V, C.c_int32, C.c_double, C.POINTER(C.c_int32), C.POINTER(LevelInfo)]),
     "vsrmc_queue_create": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(V)]),

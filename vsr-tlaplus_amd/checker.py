@@ -349,6 +349,23 @@ class ModelChecker:
         check(capi.load().vsrmc_checker_frontier(self._h, _p(words), cap_w, _p(off), len(off), C.byref(n)))
         return words[: int(off[n.value])].copy(), off[: n.value + 1].copy()
 
+    def level_checksum(self):
+        """(xor, sum mod 2^64, count) of the newest level's fingerprints, computed on the device."""
+        x, s_, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(capi.load().vsrmc_checker_level_checksum(self._h, C.byref(x), C.byref(s_), C.byref(n)))
+        return x.value, s_.value, n.value
+
+    def select(self, action_mask, max_states=4096):
+        """States of the newest level in which an action of `action_mask` (bit a = action id a) is enabled
+        -> (words, off, n_matching): at most max_states wire records, and how many such states the level has."""
+        cap_w = int(max_states) * int(self.model.layout.max_record_words) + 16
+        words = np.zeros(cap_w, dtype=np.uint64)
+        off = np.zeros(int(max_states) + 1, dtype=np.uint64)
+        n, total = C.c_uint64(), C.c_uint64()
+        check(capi.load().vsrmc_checker_select(self._h, int(action_mask), int(max_states), _p(words), cap_w, _p(off), C.byref(n),
+                                               C.byref(total)))
+        return words[: int(off[n.value])], off[: n.value + 1], total.value
+
     def find_fp(self, fp):
         """Index (in the newest level's index range) of the state with fingerprint `fp`, or None."""
         idx = C.c_uint64()

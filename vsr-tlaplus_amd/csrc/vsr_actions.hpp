@@ -582,30 +582,57 @@ VSR_HD u32 guard_slot(const Model& M, PTR rec, int slot, int* kind0) {
   return guard_slot_pre(M, rec, rec[0], Areg, slot, kind0);
 }
 
-// Incremental view hashes of the child: Hc[i] = Hp[i] - hash(old replica block) + hash(new) + bag patch deltas.
-template <typename PTR>
-VSR_HD void hash_child(const Model& M, PTR rec, const Delta& D, u64* Hc) {
-  PTR pb = rec + 1 + (D.r - 1) * M.wpr;
-  bool rep_changed = (pb[0] != D.rep[0]) | (pb[1] != D.rep[1]) | (pb[2] != D.rep[2]);
-  if (M.wpr > 3) rep_changed |= (pb[3] != D.rep[3]);
-  u64 ha_old = 0, ha_new = 0;
-  if (rep_changed) {
-    ha_old = fmix64(pb[0] ^ salt_rep_of(D.r));
-    ha_new = fmix64(D.rep[0] ^ salt_rep_of(D.r));
+// Incremental view hashes of the child: Hc[i] = Hp[i] + sum over the changed words of (new term - old term).  A word without
+// values (no in-use log entry byte: every A word, SVC / PrepareOk / GetState messages, empty DVC slots) has the same term under
+// every permutation: it is hashed once (`dinv`), not once per permutation.
+template <int K>
+VSR_HD void hash_word_delta(const Model& M, u64 w_old, u64 w_new, int r, u64& dinv, u64* d) {
+  if (w_old == w_new) return;
+  constexpr u64 m01 = K == 0 ? (u64)0 : K == 1 ? LOGB_REP1 : LOGB_REPK;
+  const u64 s = salt_word<K>(r);
+  if (K == 0 || !(word_has_values(w_old, m01) | word_has_values(w_new, m01))) {
+    dinv += fmix64(w_new ^ s) - fmix64(w_old ^ s);
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     if (i >= M.np) break;
-    u32 pt = M.pitab[i];
-    u64 h = rec[M.h0 + i];
-    if (rep_changed) h += hash_rep_tail(M, ha_new, D.rep, pt) - hash_rep_tail(M, ha_old, pb, pt);
+    const u32 pt = M.pitab[i];
+    d[i] += fmix64(permute_word(w_new, m01, pt) ^ s) - fmix64(permute_word(w_old, m01, pt) ^ s);
+  }
+}
+VSR_HD void hash_msg_term(const Model& M, u64 w, bool add, u64& dinv, u64* d) {
+  if (!word_has_values(w, LOGB_MSG)) {
+    const u64 h = fmix64(w ^ SALT_MSG);
+    dinv += add ? h : (u64)0 - h;
+    return;
+  }
 #pragma unroll
-    for (int k = 0; k < VSR_NSLOT; k++)
-      if ((D.used >> k) & 1) {
-        h += hash_msg(D.pnew[k], pt);
-        if (D.pj[k] >= 0) h -= hash_msg(D.pold[k], pt);
-      }
-    Hc[i] = h;
+  for (int i = 0; i < 6; i++) {
+    if (i >= M.np) break;
+    const u64 h = hash_msg(w, M.pitab[i]);
+    d[i] += add ? h : (u64)0 - h;
+  }
+}
+template <typename PTR>
+VSR_HD void hash_child(const Model& M, PTR rec, const Delta& D, u64* Hc) {
+  PTR pb = rec + 1 + (D.r - 1) * M.wpr;
+  u64 dinv = 0;
+  u64 d[6] = {0, 0, 0, 0, 0, 0};
+  hash_word_delta<0>(M, pb[0], D.rep[0], D.r, dinv, d);
+  hash_word_delta<1>(M, pb[1], D.rep[1], D.r, dinv, d);
+  if (M.wpr > 2) hash_word_delta<2>(M, pb[2], D.rep[2], D.r, dinv, d);
+  if (M.wpr > 3) hash_word_delta<3>(M, pb[3], D.rep[3], D.r, dinv, d);
+#pragma unroll
+  for (int k = 0; k < VSR_NSLOT; k++)
+    if ((D.used >> k) & 1) {
+      hash_msg_term(M, D.pnew[k], true, dinv, d);
+      if (D.pj[k] >= 0) hash_msg_term(M, D.pold[k], false, dinv, d);
+    }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (i >= M.np) break;
+    Hc[i] = rec[M.h0 + i] + dinv + d[i];
   }
 }
 

@@ -203,6 +203,11 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
     if (Marg.np == 1) M.np = 1;                                // symmetry off: block-uniform, still cheap
     else M.np = SN == 1 ? 1 : SN == 2 ? 2 : 6;
     M.fixed = M.h0 + M.np;
+    // the permutation table in build_model's order (identity first): compile-time constants, so that permute_word's select
+    // masks fold (np == 1 only ever looks at entry 0)
+    M.pitab[0] = 0x24u;
+    if (SN == 2) M.pitab[1] = 0x21u;
+    if (SN == 3) { M.pitab[1] = 0x18u; M.pitab[2] = 0x21u; M.pitab[3] = 0x09u; M.pitab[4] = 0x12u; M.pitab[5] = 0x06u; }
   }
 }
 
@@ -238,7 +243,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
   u32* s_cand2 = s_cand + ccap;                        // the same, sorted by action
-  __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out;
+  __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out, s_skip;
   __shared__ u32 s_alive[VSR_TILE_MAX];
   __shared__ u64 s_ref[VSR_TILE_MAX];
   __shared__ u32 s_kcount[16], s_kbase[16];
@@ -274,7 +279,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     const u64 p_base = tile_i * (u64)tile;
     const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
     const u64 t_0 = __builtin_readcyclecounter();
-    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; }
+    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; }
     if (tid < tile) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
     __syncthreads();
@@ -431,6 +436,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         if (tid == 0) {
           u64 nb = atomicAdd((unsigned long long*)&ctl->words_new, (unsigned long long)wchunk);
           if (nb + wchunk > nx_words_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
+          // a tile whose successors cannot fit even a fresh chunk would run into the next block's chunk: the host sizes
+          // wchunk >= ccap * (stride + 5) so that this cannot happen; refuse instead of corrupting records if it ever does
+          if (s_wneed > wchunk) { raise_error(ctl, ERR_FRONTIER_FULL, p_base); s_skip = 1; }
           s_wch_base = nb;
           s_wch_used = 0;
         }
@@ -459,7 +467,8 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     __syncthreads();
     // ---- apply + fingerprint + seen-set claim: one lane per enabled instance
     u32 my_probes = 0, my_maxbag = 0, my_words = 0;
-    for (u32 c = tid; c < ncand; c += VSR_BLOCK) {
+    const u32 ncand_apply = s_skip ? 0u : ncand;                // s_skip: the tile was refused (see the word-chunk reservation)
+    for (u32 c = tid; c < ncand_apply; c += VSR_BLOCK) {
       const u32 code = s_cand2[c];
       const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
       const u64* rec = s_rec + p * stride;
@@ -960,6 +969,29 @@ __global__ void k_count_valid(const u64* __restrict__ refs, u64 n, u64* out) {
   if ((threadIdx.x & 63) == 0 && c) atomicAdd((unsigned long long*)out, (unsigned long long)c);
 }
 
+// xor / sum (mod 2^64) / count of the fingerprints of a level's index range (0 = unused index): out[0..2]
+__global__ void k_level_checksum(const u64* __restrict__ fps, u64 n, u64* out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  u64 x = 0, s = 0, c = 0;
+  for (; i < n; i += stride) {
+    const u64 f = fps[i];
+    x ^= f;
+    s += f;
+    c += f != 0 ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    x ^= __shfl_down(x, o);
+    s += __shfl_down(s, o);
+    c += __shfl_down(c, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (x) atomicXor((unsigned long long*)&out[0], (unsigned long long)x);
+    if (s) atomicAdd((unsigned long long*)&out[1], (unsigned long long)s);
+    if (c) atomicAdd((unsigned long long*)&out[2], (unsigned long long)c);
+  }
+}
+
 // empty seen-set: fp = 0, meta = all ones
 __global__ void k_table_init(Slot* table, u64 slots) {
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (u64)gridDim.x * blockDim.x) {
@@ -1167,6 +1199,30 @@ __global__ void k_trace_walk(const u64* tr_all, const u64* level_base, int level
     }
     ords[l - 2] = (u32)meta_ord(key);
     idx = meta_pidx(key);
+  }
+}
+
+// k_select: indices of the frontier records in which at least one instance of an action of `action_mask` (bit a = action id a)
+// is enabled — TLC's per-action coverage, as a filter.  One lane per record, guards only (guard_slot: the same statement of the
+// guards k_expand enumerates with).  counters[0] = matching records (all of them), out_idx holds the first out_cap that arrived.
+__global__ void k_select(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n, u32 action_mask, u64* out_idx,
+                         u64 out_cap, u64* counters) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 ref = fr_off[i];
+  if (!ref) return;
+  const u64* rec = fr_words + (ref >> 8);
+  const int nslots = M.m0 + hdr_nmsg(rec[0]);
+  bool hit = false;
+  for (int slot = 0; slot < nslots && !hit; slot++) {
+    int kind0 = 0;
+    const u32 mask = guard_slot(M, rec, slot, &kind0);
+    if ((mask & 1u) && ((action_mask >> kind0) & 1u)) hit = true;
+    if ((mask & ~1u) && ((action_mask >> A_SendGetState) & 1u)) hit = true;
+  }
+  if (hit) {
+    const u64 k = wave_alloc(&counters[0]);
+    if (k < out_cap) out_idx[k] = i;
   }
 }
 

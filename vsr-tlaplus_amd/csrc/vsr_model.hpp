@@ -68,7 +68,6 @@ struct Model {
   int m0;                // first message-bound ordinal = 4R + R*C*n
   u32 primtab;           // Primary(v) for v = 0..7, 3 bits each (a table: `%` by a run-time R costs ~20 instructions)
   u32 pitab[6];          // permutation i: pi[v] in bits 2v..2v+1
-  u64 salt_rep[6];       // per-replica hash salt, index r (1..R)
 };
 
 static const u64 SALT_MSG = 0x9E3779B97F4A7C15ULL;
@@ -87,8 +86,22 @@ VSR_HD u64 fmix64(u64 x) {
   return x;
 }
 
-// per-replica hash salt (computed, not tabulated: a per-lane table index would force the table into scratch memory)
-VSR_HD u64 salt_rep_of(int r) { return fmix64(0xA0761D6478BD642FULL + (u64)r); }
+// Position salt of word k of replica r's block: fmix64(0xA0761D6478BD642F + 8 r + k), folded at compile time and picked with a
+// select chain over r (a per-lane table index would force the table into scratch memory; computing it costs one fmix64 per use).
+constexpr u64 fmix64_c(u64 x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+template <int K>
+VSR_HD u64 salt_word(int r) {
+  constexpr u64 B = 0xA0761D6478BD642FULL + (u64)K;
+  constexpr u64 s1 = fmix64_c(B + 8), s2 = fmix64_c(B + 16), s3 = fmix64_c(B + 24), s4 = fmix64_c(B + 32), s5 = fmix64_c(B + 40);
+  return r == 1 ? s1 : r == 2 ? s2 : r == 3 ? s3 : r == 4 ? s4 : s5;
+}
 
 // ---- header -------------------------------------------------------------------------------------------------
 VSR_HD int hdr_nmsg(u64 h) { return (int)(h & 0xFF); }
@@ -179,13 +192,21 @@ VSR_HD u64 permute_word(u64 w, u64 m01, u32 pt) {
 // hash of one bag word under permutation pt
 VSR_HD u64 hash_msg(u64 w, u32 pt) { return fmix64(permute_word(w, LOGB_MSG, pt) ^ SALT_MSG); }
 
-// hash of one replica block (wpr words at b) under permutation pt; h_a = fmix64(b[0] ^ salt_rep[r]) is
-// permutation-invariant (the A word holds no values) and is passed in.
+// does a word hold any value (an in-use log entry byte)?  If not, its hash term is the same under every permutation.
+VSR_HD bool word_has_values(u64 w, u64 m01) { return ((w | (w >> 1) | (w >> 2)) & m01) != 0; }
+
+// Zobrist-style view hash: H_pi = sum over the words of the replica blocks of fmix64(pi(word) ^ salt(position))
+//                                + sum over the bag of fmix64(pi(word) ^ SALT_MSG)
+// hash term of word K of replica r's block under permutation pt
+template <int K>
+VSR_HD u64 hash_rep_word(u64 w, int r, u32 pt) {
+  return fmix64(permute_word(w, K == 0 ? (u64)0 : K == 1 ? LOGB_REP1 : LOGB_REPK, pt) ^ salt_word<K>(r));
+}
 template <typename PTR>
-VSR_HD u64 hash_rep_tail(const Model& M, u64 h_a, PTR b, u32 pt) {
-  u64 h = fmix64(h_a ^ permute_word(b[1], LOGB_REP1, pt));
-  if (M.wpr > 2) h = fmix64(h ^ permute_word(b[2], LOGB_REPK, pt));   // written out: b may be a register array
-  if (M.wpr > 3) h = fmix64(h ^ permute_word(b[3], LOGB_REPK, pt));
+VSR_HD u64 hash_rep_block(const Model& M, PTR b, int r, u32 pt) {
+  u64 h = hash_rep_word<0>(b[0], r, pt) + hash_rep_word<1>(b[1], r, pt);
+  if (M.wpr > 2) h += hash_rep_word<2>(b[2], r, pt);              // written out: b may be a register array
+  if (M.wpr > 3) h += hash_rep_word<3>(b[3], r, pt);
   return h;
 }
 
@@ -203,10 +224,7 @@ VSR_HD void hash_full(const Model& M, PTR rec, u64* H) {
   for (int i = 0; i < M.np; i++) {
     u32 pt = M.pitab[i];
     u64 sum = 0;
-    for (int r = 1; r <= M.R; r++) {
-      PTR b = rec + 1 + (r - 1) * M.wpr;
-      sum += hash_rep_tail(M, fmix64(b[0] ^ salt_rep_of(r)), b, pt);
-    }
+    for (int r = 1; r <= M.R; r++) sum += hash_rep_block(M, rec + 1 + (r - 1) * M.wpr, r, pt);
     for (int j = 0; j < nmsg; j++) sum += hash_msg(rec[M.fixed + j], pt);
     H[i] = sum;
   }

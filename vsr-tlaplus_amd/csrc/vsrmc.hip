@@ -130,7 +130,6 @@ int build_model(int R, int C, int n, int L, int restart, int symmetry, int inv_m
   M.m0 = 4 * R + R * C * n;
   M.primtab = 0;
   for (int v = 1; v <= 7; v++) M.primtab |= (u32)(1 + ((v - 1) % R)) << (3 * v);   // Primary(v) == 1 + ((v - 1) % ReplicaCount), VSR.tla:287-288
-  for (int r = 0; r < 6; r++) M.salt_rep[r] = fmix64(0xA0761D6478BD642FULL + (u64)r);
   out->symmetry = symmetry ? 1 : 0;
   out->value_names.clear();
   for (int v = 0; v < n; v++) out->value_names.push_back("v" + std::to_string(v + 1));
@@ -1016,6 +1015,8 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
       o->pending_entries < 4 * (uint64_t)VSR_CAND_CAP)
     return fail(VSRMC_E_ARG, "bad options");
   if (o->world < 1 || o->world > 8 || o->rank < 0 || o->rank >= o->world) return fail(VSRMC_E_ARG, "bad rank / world (1..8 ranks)");
+  // the trace key packs the parent's index of its level into 32 bits (meta_make): a larger index range would bleed into the ordinal
+  if (o->frontier_states > ((uint64_t)1 << 32)) return fail(VSRMC_E_ARG, "frontier_states > 2^32: a level's index range must fit the 32-bit parent index of the trace key");
   int rc = check_device(o->device);
   if (rc) return rc;
   vsrmc_checker* c = new vsrmc_checker();
@@ -1131,8 +1132,14 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
       // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
       grid = (unsigned)std::min<u64>((u64)ntiles, (u64)c->num_cus * fs.blocks_per_cu);
       grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
+      // a tile's successors (at most ccap records of at most stride + 5 words each) must fit one word chunk, and every block
+      // may leave one partly used chunk behind: fewer blocks if the buffer is too small for that
+      // (a buffer too small even for one such chunk keeps going with what it has: the kernel refuses a tile that does not fit
+      // its chunk with ERR_FRONTIER_FULL instead of writing past it)
+      const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(stride + 5));
+      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, c->words_cap(nxt) / (4 * wmin)));
       ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
-      wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
+      wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     }
     if (fused)
       hipLaunchKernelGGL((ExpandKernel)((!io && mode == MODE_NORMAL && c->plain_kernel) ? c->plain_kernel : c->fused_kernel), dim3(grid),
@@ -1322,8 +1329,10 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
     unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * fs.blocks_per_cu);
     grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
+    const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(fs.stride + 5));   // see phase_expand
+    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, c->words_cap(nxt) / (4 * wmin)));
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
-    const u32 wchunk = (u32)std::max<u64>(16384, std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
+    const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
@@ -1798,8 +1807,12 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   const u64 slots = c->tmask + 1, win = std::min<u64>(slots, (u64)1 << 26);
   Slot* d_out = nullptr;
   u64* d_cnt = nullptr;
-  HIPCHK(hipMalloc((void**)&d_out, win * sizeof(Slot)));
-  HIPCHK(hipMalloc((void**)&d_cnt, 8));
+  if (hipMalloc((void**)&d_out, win * sizeof(Slot)) != hipSuccess || hipMalloc((void**)&d_cnt, 8) != hipSuccess) {
+    if (d_out) (void)hipFree(d_out);
+    std::fclose(f);                                             // no early return leaves the file open or the .tmp behind
+    std::remove(tmp.c_str());
+    return fail(VSRMC_E_HIP, "hipMalloc of the checkpoint export window failed");
+  }
   ok = std::fwrite(&h, sizeof(h), 1, f) == 1;                   // rewritten at the end with table_entries
   ok = ok && std::fwrite(c->level_base.data(), 8, c->level_base.size(), f) == c->level_base.size();
   ok = ok && std::fwrite(c->level_size.data(), 8, c->level_size.size(), f) == c->level_size.size();
@@ -1841,9 +1854,15 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
     level_size.resize(h.n_levels);
     ok = std::fread(level_base.data(), 8, h.n_levels, f) == h.n_levels && std::fread(level_size.data(), 8, h.n_levels, f) == h.n_levels;
   }
+  // header invariants (a truncated or foreign file must not become an inconsistent checker): one level_base / level_size entry
+  // per level, fewer than 511 levels, no more states than indices, and a trace log that ends where the newest level ends
+  if (ok)
+    ok = h.level >= 1 && h.level < 511 && (u64)h.level == h.n_levels && h.n_valid <= h.n_frontier && (level_size.back() == h.n_frontier || h.n_frontier == 0) &&
+         (h.trace_entries == 0 || level_base.back() + level_size.back() == h.trace_entries);
+  for (u64 l = 1; ok && l < h.n_levels; l++) ok = level_base[l] == level_base[l - 1] + level_size[l - 1];
   if (!ok) {
     std::fclose(f);
-    return fail(VSRMC_E_CFG, std::string(path) + " is not a vsrmc checkpoint");
+    return fail(VSRMC_E_CFG, std::string(path) + " is not a (consistent) vsrmc checkpoint");
   }
   const Model& M = m->M;
   const int32_t consts[8] = {M.R, M.C, M.n, M.L, m->symmetry, M.inv_mask, M.assume_commit, M.np};
@@ -1954,6 +1973,26 @@ int32_t vsrmc_checker_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, u
   return 0;
 }
 
+int32_t vsrmc_checker_level_checksum(vsrmc_checker* c, uint64_t* fp_xor, uint64_t* fp_sum, uint64_t* n_states) {
+  if (!c || !fp_xor || !fp_sum || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
+  *fp_xor = *fp_sum = *n_states = 0;
+  if (c->n_frontier == 0) return 0;
+  HIPCHK(hipSetDevice(c->opt.device));
+  u64* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 24));
+  u64 h[3] = {0, 0, 0};
+  bool ok = hipMemsetAsync(d, 0, 24, c->stream) == hipSuccess;
+  hipLaunchKernelGGL(k_level_checksum, dim3(2048), dim3(256), 0, c->stream, c->lvl_fp, c->n_frontier, d);
+  ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+       hipMemcpy(h, d, 24, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) return fail(VSRMC_E_HIP, "k_level_checksum failed");
+  *fp_xor = h[0];
+  *fp_sum = h[1];
+  *n_states = h[2];
+  return 0;
+}
+
 int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, uint64_t cap_states,
                                uint64_t* n) {
   if (!c || !n || !words || !off) return fail(VSRMC_E_ARG, "NULL argument");
@@ -1985,6 +2024,52 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
   }
   off[k] = pos;
   *n = k;
+  return 0;
+}
+
+// The states of the newest level in which an action of `action_mask` is enabled (wire layout), at most max_states of them;
+// *n_matching = how many there are in all.  ≙ TLC's action coverage, used as a filter (directed parity tests, debugging).
+int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t max_states, uint64_t* words, uint64_t cap_words,
+                             uint64_t* off, uint64_t* n_states, uint64_t* n_matching) {
+  if (!c || !words || !off || !n_states || !n_matching) return fail(VSRMC_E_ARG, "NULL argument");
+  const Model& M = c->model.M;
+  *n_states = *n_matching = 0;
+  off[0] = 0;
+  if (c->n_frontier == 0 || max_states == 0) return 0;
+  HIPCHK(hipSetDevice(c->opt.device));
+  u64 *d_idx = nullptr, *d_cnt = nullptr;
+  HIPCHK(hipMalloc((void**)&d_idx, max_states * 8));
+  if (hipMalloc((void**)&d_cnt, 8) != hipSuccess || hipMemset(d_cnt, 0, 8) != hipSuccess) {
+    (void)hipFree(d_idx);
+    return fail(VSRMC_E_HIP, "hipMalloc failed");
+  }
+  hipLaunchKernelGGL(k_select, dim3((unsigned)((c->n_frontier + 255) / 256)), dim3(256), 0, c->stream, M, c->words[c->cur], c->off[c->cur],
+                     c->n_frontier, action_mask, d_idx, max_states, d_cnt);
+  u64 cnt = 0;
+  bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+            hipMemcpy(&cnt, d_cnt, 8, hipMemcpyDeviceToHost) == hipSuccess;
+  const u64 k = std::min<u64>(cnt, max_states);
+  std::vector<u64> idx(k);
+  ok = ok && (k == 0 || hipMemcpy(idx.data(), d_idx, k * 8, hipMemcpyDeviceToHost) == hipSuccess);
+  (void)hipFree(d_idx);
+  (void)hipFree(d_cnt);
+  if (!ok) return fail(VSRMC_E_HIP, "k_select failed");
+  std::sort(idx.begin(), idx.end());
+  std::vector<u64> rec(256);
+  u64 pos = 0;
+  for (u64 q = 0; q < k; q++) {
+    u64 ref = 0;
+    HIPCHK(hipMemcpy(&ref, c->off[c->cur] + idx[q], 8, hipMemcpyDeviceToHost));
+    const u64 len = ref & 255;
+    HIPCHK(hipMemcpy(rec.data(), c->words[c->cur] + (ref >> 8), len * 8, hipMemcpyDefault));
+    const u64 wl = (u64)M.h0 + hdr_nmsg(rec[0]);
+    if (pos + wl > cap_words) return fail(VSRMC_E_ARG, "buffers too small");
+    device_to_wire(M, rec.data(), words + pos);
+    pos += wl;
+    off[q + 1] = pos;
+  }
+  *n_states = k;
+  *n_matching = cnt;
   return 0;
 }
 

@@ -73,7 +73,7 @@ def main(args, CONFIG, EXPECT):
                 assert len(tr) == sc.violation["level"]
         dt = time.perf_counter() - t0
         assert sc.distinct == EXPECT["distinct"] and sc.level == EXPECT["depth"], (sc.distinct, sc.level)
-        assert sc.violation and sc.violation["fp"] == EXPECT["viol_fp"]
+        assert sc.violation and (EXPECT["viol_fp"] is None or sc.violation["fp"] == EXPECT["viol_fp"])
         moved[0] = sc.moved
         if record:
             S["distinct"] += sc.distinct
