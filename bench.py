@@ -52,13 +52,34 @@ HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM
 TABLE_LOG2 = int(os.environ.get("VSR_BENCH_TABLE_LOG2", 31))   # seen-set: 2^31 slots x 16 B = 32 GiB of the 288 GB (load 0.15 at the end)
 
 
+def usable_cpus():
+    """Hardware threads this process may actually use: the affinity mask, capped by the container's CPU quota (cgroup v2
+    cpu.max / v1 cfs quota).  The GPU box shows 256 logical CPUs but grants 16 CPUs' worth of time: 256 oracle threads then
+    run SLOWER than 16 (measured: 1.0e6 vs 2.4e6 states/s)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return min(n, 256)
+
+
 def cpu_baseline(seconds=15.0):
-    """CPU oracle (oracle/vsr_oracle_mt: the restatement of VSR.tla spread over std::thread workers sharing 64 seen-set
-    shards, the way TLC spreads Worker threads over an FPSet) on the same config, all host cores, for a bounded time."""
+    """CPU oracle (oracle/vsr_oracle_mt: the restatement of VSR.tla spread over std::thread workers sharing one lock-free
+    seen-set, the way TLC spreads Worker threads over an FPSet) on the same config, on every CPU the container may use, for a
+    bounded time."""
     exe = os.path.join(ROOT, "oracle", "build", "vsr_oracle_mt")
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
-    threads = min(os.cpu_count() or 1, 256)
+    threads = usable_cpus()
     out = subprocess.run([exe, str(CONFIG["R"]), str(CONFIG["C"]), str(CONFIG["n"]), str(CONFIG["L"]), "--threads", str(threads),
                           "--max-seconds", str(seconds), "--quiet"], capture_output=True, text=True, check=True).stdout
     s = json.loads(out.strip().splitlines()[-1])

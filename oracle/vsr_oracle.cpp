@@ -7,6 +7,19 @@
 
 namespace vsr_oracle {
 
+Params params_from_array(const int* p) {
+  Params P;
+  P.R = p[0];
+  P.C = p[1];
+  P.n = p[2];
+  P.L = p[3];
+  P.restart_limit = p[4];
+  P.assume_commit_number = p[5] != 0;
+  P.symmetry = p[6] != 0;
+  P.invariant_mask = p[7];
+  return P;
+}
+
 const char* const ACTION_NAMES[16] = {
     "Initial predicate", "TimerSendSVC", "ReceiveHigherSVC", "ReceiveMatchingSVC", "SendDVC",
     "ReceiveHigherDVC", "ReceiveMatchingDVC", "SendSV", "ReceiveSV", "ReceiveClientRequest",

@@ -46,6 +46,8 @@ struct Params {
                            // bit2 NoLogDivergence (vacuous, VSR.tla:931), bit3 TestInv
 };
 
+Params params_from_array(const int* p);   // {R, C, n, L, restart_limit, assume_commit_number, symmetry, invariant_mask}
+
 enum { Normal = 0, ViewChange = 1, Recovering = 2 };                       // VSR.tla:99-101
 enum { T_SVC = 1, T_PREPARE = 2, T_PREPAREOK = 3, T_DVC = 4, T_SV = 5,      // VSR.tla:104-115 (live ones)
        T_GETSTATE = 6, T_NEWSTATE = 7 };

@@ -12,26 +12,21 @@
 #include <thread>
 #include <unordered_map>
 
-#include "vsr_oracle.hpp"
+// The driver is model-independent: it is compiled once per restatement (ORACLE_HPP / ORACLE_NS: vsr_oracle.hpp = VSR.tla, the
+// default; vrst_oracle.hpp = analysis/03-state-transfer/VR_STATE_TRANSFER.tla -> liborc2.so, vrst_oracle, vrst_oracle_mt).
+#ifndef ORACLE_HPP
+#define ORACLE_HPP "vsr_oracle.hpp"
+#define ORACLE_NS vsr_oracle
+#endif
+#include ORACLE_HPP
 
-using namespace vsr_oracle;
+using namespace ORACLE_NS;
 
 namespace {
 
 thread_local std::string g_err;
 
-Params params_from(const int* p) {
-  Params P;
-  P.R = p[0];
-  P.C = p[1];
-  P.n = p[2];
-  P.L = p[3];
-  P.restart_limit = p[4];
-  P.assume_commit_number = p[5] != 0;
-  P.symmetry = p[6] != 0;
-  P.invariant_mask = p[7];
-  return P;
-}
+Params params_from(const int* p) { return params_from_array(p); }
 
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -30,9 +30,13 @@
 #include <thread>
 #include <vector>
 
-#include "vsr_oracle.hpp"
+#ifndef ORACLE_HPP          // model-independent driver, compiled once per restatement (see vsr_oracle_bfs.cpp)
+#define ORACLE_HPP "vsr_oracle.hpp"
+#define ORACLE_NS vsr_oracle
+#endif
+#include ORACLE_HPP
 
-using namespace vsr_oracle;
+using namespace ORACLE_NS;
 
 namespace {
 
@@ -115,7 +119,9 @@ int main(int argc, char** argv) {
     else if (a == "--inv-mask" && i + 1 < argc) P.invariant_mask = std::atoi(argv[++i]);
     else if (a == "--count-only-from" && i + 1 < argc) count_only_from = std::atoi(argv[++i]);
     else if (a == "--no-symmetry") P.symmetry = false;
+#ifndef ORACLE_VRST
     else if (a == "--assume-commit-number") P.assume_commit_number = true;
+#endif
     else if (a == "--quiet") quiet = true;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvsrmc.so")
+LIB_PATH = os.environ.get("VSRMC_LIB") or os.path.join(HERE, "libvsrmc.so")   # VSRMC_LIB: an experimental build of the same library (tools/ab_build.sh)
 
 u64p = C.POINTER(C.c_uint64)
 
