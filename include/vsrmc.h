@@ -56,6 +56,12 @@ int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model
 int32_t vsrmc_model_from_constants(int32_t replica_count, int32_t client_count, int32_t value_count,
                                    int32_t start_view_on_timer_limit, int32_t restart_empty_limit, int32_t symmetry,
                                    int32_t invariant_mask, int32_t assume_commit_number, vsrmc_model** out);
+/* The second model this build lowers: analysis/03-state-transfer/VR_STATE_TRANSFER.tla under the constants of
+ * VR_STATE_TRANSFER.cfg:4-7.  invariant_mask: 1 AcknowledgedWriteNotLost, 2 AcknowledgedWritesExistOnMajority, 4 NoLogDivergence,
+ * 8 CommitNumberNeverHigherThanOpNumber (the shipped cfg checks 2 + 4 + 8).  vsrmc_model_load recognises either module by the
+ * SHA-256 of the .tla (or, without a .tla, by the cfg's constants); every other entry point takes either model. */
+int32_t vsrmc_model2_from_constants(int32_t replica_count, int32_t value_count, int32_t start_view_on_timer_limit,
+                                    int32_t no_progress_change_limit, int32_t symmetry, int32_t invariant_mask, vsrmc_model** out);
 int32_t vsrmc_model_info(const vsrmc_model* m, vsrmc_layout* out);
 /* Init (VSR.tla:323-348) in wire layout */
 int32_t vsrmc_model_init_state(const vsrmc_model* m, uint64_t* rec, int32_t cap_words, int32_t* n_words);

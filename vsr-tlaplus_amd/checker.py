@@ -51,6 +51,14 @@ class Model:
                                                      int(assume_commit_number), C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def second_model(cls, R=3, n=2, L=2, no_progress_limit=0, symmetry=False, invariant_mask=14):
+        """analysis/03-state-transfer/VR_STATE_TRANSFER.tla under the constants of its cfg (the shipped one: 3, {v1,v2}, 2, 0;
+        INVARIANT AcknowledgedWritesExistOnMajority, NoLogDivergence, CommitNumberNeverHigherThanOpNumber = mask 14)."""
+        h = C.c_void_p()
+        check(capi.load().vsrmc_model2_from_constants(R, n, L, no_progress_limit, int(symmetry), invariant_mask, C.byref(h)))
+        return cls(h)
+
     def init_state(self):
         out = np.zeros(256, dtype=np.uint64)
         n = C.c_int32()

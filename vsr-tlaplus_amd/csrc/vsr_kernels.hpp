@@ -14,8 +14,50 @@
 #include <hip/hip_runtime.h>
 
 #include "vsr_actions.hpp"
+#include "vrst_actions.hpp"
 
 namespace vsr {
+
+// The model a kernel instantiation checks: 0 = VSR.tla (vsr_actions.hpp), 1 = analysis/03-state-transfer/VR_STATE_TRANSFER.tla
+// (vrst_actions.hpp).  Everything above the action table — staging, enumeration, sort, seen-set, frontier, trace — is shared.
+template <int MODEL>
+struct ModelOps;
+template <>
+struct ModelOps<0> {
+  template <bool GUARD_ONLY, typename PTR>
+  static VSR_HD bool gen_(const Model& M, PTR rec, int ord, Delta& D) { return gen<GUARD_ONLY>(M, rec, ord, D); }
+  template <typename PTR>
+  static VSR_HD u32 guard_pre(const Model& M, PTR rec, u64 hdr, const u64* Areg, int slot, int* kind0, int info) {
+    return guard_slot_pre(M, rec, hdr, Areg, slot, kind0, info);
+  }
+  template <typename PTR>
+  static VSR_HD u32 guard(const Model& M, PTR rec, int slot, int* kind0) { return guard_slot(M, rec, slot, kind0); }
+  static VSR_HD int other_kind(int) { return A_SendGetState; }    // bits 1.. of a slot: SendGetState(r, rDest, m), one per destination
+  template <typename PTR>
+  static VSR_HD void hash_child_(const Model& M, PTR rec, const Delta& D, u64* Hc) { hash_child(M, rec, D, Hc); }
+  template <typename PTR>
+  static VSR_HD void hash_full_(const Model& M, PTR rec, u64* H) { hash_full(M, rec, H); }
+  template <typename PTR>
+  static VSR_HD int invariants(const Model& M, PTR rec, const Delta& D) { return check_invariants_child(M, rec, D); }
+};
+template <>
+struct ModelOps<1> {
+  template <bool GUARD_ONLY, typename PTR>
+  static VSR_HD bool gen_(const Model& M, PTR rec, int ord, Delta& D) { return vrst::gen<GUARD_ONLY>(M, rec, ord, D); }
+  template <typename PTR>
+  static VSR_HD u32 guard_pre(const Model& M, PTR rec, u64, const u64*, int slot, int* kind0, int) {
+    return vrst::guard_slot(M, rec, slot, kind0);
+  }
+  template <typename PTR>
+  static VSR_HD u32 guard(const Model& M, PTR rec, int slot, int* kind0) { return vrst::guard_slot(M, rec, slot, kind0); }
+  static VSR_HD int other_kind(int kind0) { return kind0; }       // bits 1.. of a slot: the same action taken by another replica (AnyDest)
+  template <typename PTR>
+  static VSR_HD void hash_child_(const Model& M, PTR rec, const Delta& D, u64* Hc) { vrst::hash_child(M, rec, D, Hc); }
+  template <typename PTR>
+  static VSR_HD void hash_full_(const Model& M, PTR rec, u64* H) { vrst::hash_full(M, rec, H); }
+  template <typename PTR>
+  static VSR_HD int invariants(const Model& M, PTR rec, const Delta& D) { return vrst::check_invariants_child(M, rec, D); }
+};
 
 struct Slot {       // one seen-set slot: 16 bytes, fp == 0 means empty
   u64 fp;
@@ -192,16 +234,23 @@ __device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp,
 // Overwrite the structural constants of a private copy of the model with the compile-time constants of SPEC (see k_expand).
 template <int SPEC>
 __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
-  if constexpr (SPEC != 0) {
-    constexpr int SR = SPEC / 100, SC = (SPEC / 10) % 10, SN = SPEC % 10;
+  constexpr int MODEL = SPEC / 1000, S = SPEC % 1000;
+  if constexpr (S != 0) {
+    constexpr int SR = S / 100, SC = (S / 10) % 10, SN = S % 10;
     M.R = SR;
     M.C = SC;
     M.n = SN;
-    M.wpr = 1 + (SR + 2) / 2;
+    if constexpr (MODEL == 0) {
+      M.wpr = 1 + (SR + 2) / 2;
+      M.m0 = 4 * SR + SR * SC * SN;
+      if (Marg.np == 1) M.np = 1;                              // symmetry off: block-uniform, still cheap
+      else M.np = SN == 1 ? 1 : SN == 2 ? 2 : 6;
+    } else {                                                   // the second model: one word per replica, no clients, no symmetry
+      M.wpr = 1;
+      M.m0 = 4 * SR + SR * SN;
+      M.np = 1;
+    }
     M.h0 = 1 + SR * M.wpr;
-    M.m0 = 4 * SR + SR * SC * SN;
-    if (Marg.np == 1) M.np = 1;                                // symmetry off: block-uniform, still cheap
-    else M.np = SN == 1 ? 1 : SN == 2 ? 2 : 6;
     M.fixed = M.h0 + M.np;
     // the permutation table in build_model's order (identity first): compile-time constants, so that permute_word's select
     // masks fold (np == 1 only ever looks at entry 0)
@@ -211,7 +260,8 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
   }
 }
 
-// SPEC = R * 100 + C * 10 + |Values| of a configuration the kernel is specialised for (0 = generic): the constants of the model
+// SPEC = model * 1000 + R * 100 + C * 10 + |Values| of a configuration the kernel is specialised for (S = SPEC % 1000 = 0: generic
+// in the constants, still specific to the model): the constants of the model
 // become compile-time constants of this instantiation (every device function below is inlined), so loops over replicas,
 // clients, values and permutations unroll without predicates and strides fold into addresses.
 template <bool FUSED, int SPEC = 0, bool PLAIN = false>
@@ -239,6 +289,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   const int world = PLAIN ? 1 : world_arg;
   Model M = Marg;
   specialise<SPEC>(M, Marg);
+  typedef ModelOps<SPEC / 1000> Ops;
   extern __shared__ u64 smem[];
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
@@ -267,7 +318,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   const int tshift = tile == 128 ? 7 : 6;
   if (tid < 32) s_acc[tid] = 0;
   if (tid == 0) s_maxbag_out = 0;
-  if (tid < 64) s_slotinfo[tid] = tid < M.m0 ? slot_info(M, tid) : 0;
+  if (tid < 64) s_slotinfo[tid] = (SPEC / 1000 == 0 && tid < M.m0) ? slot_info(M, tid) : 0;
   if (tid == 0) {                                              // "no chunk yet"
     s_chunk_base = 0; s_chunk_used = pchunk;
     s_ich_base = 0; s_ich_used = ichunk; s_wch_base = 0; s_wch_used = wchunk;
@@ -361,7 +412,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           const int slot = item >> tshift;
           masks[u] = 0;
           kinds[u] = 0;
-          if (item < nitems && mine_valid) masks[u] = guard_slot_pre(M, rec_mine, hdr_mine, Areg, slot, &kinds[u], s_slotinfo[slot & 63]);
+          if (item < nitems && mine_valid) masks[u] = Ops::guard_pre(M, rec_mine, hdr_mine, Areg, slot, &kinds[u], s_slotinfo[slot & 63]);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -373,7 +424,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           while (mask) {
             const int k = __ffs((int)mask) - 1;
             mask &= mask - 1;
-            const int kind = k == 0 ? kinds[u] : A_SendGetState;   // bits 1.. = SendGetState, one per destination
+            const int kind = k == 0 ? kinds[u] : Ops::other_kind(kinds[u]);
             atomicAdd(&s_kcount[kind], 1u);
             u32 idx;
             if (nmine < PRIV) idx = (u32)tid * PRIV + nmine;
@@ -474,7 +525,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       const u64* rec = s_rec + p * stride;
       Delta D;
       const u64 a_0 = __builtin_readcyclecounter();
-      if (!gen<false>(M, rec, ord, D) || D.action != (int)(code >> 18)) {
+      if (!Ops::template gen_<false>(M, rec, ord, D) || D.action != (int)(code >> 18)) {
         raise_error(ctl, ERR_INTERNAL, ((p_base + (u64)p) << 16) | (u64)ord);
         continue;
       }
@@ -484,7 +535,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
       const u64 a_1 = __builtin_readcyclecounter();
       u64 Hc[6];
-      hash_child(M, rec, D, Hc);
+      Ops::hash_child_(M, rec, D, Hc);
       u64 fp;
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
@@ -511,7 +562,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         u64 m = META_EMPTY;
         const bool seen = probe_lookup(table, tmask, fp, &m, &my_probes) && meta_level(m) < level;
         if (!seen) {
-          const int bad = check_invariants_child(M, rec, D);
+          const int bad = Ops::invariants(M, rec, D);
           if (bad) {
             const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
             if (i < pending_cap) {
@@ -553,7 +604,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           do_write = claimed;
         }
         if (do_write && mode == MODE_INSERT) {                  // virtual level: the state is counted and checked, not stored
-          const int bad = check_invariants_child(M, rec, D);
+          const int bad = Ops::invariants(M, rec, D);
           if (bad) {
             const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
             if (i < pending_cap) {
@@ -590,8 +641,8 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           out[0] = D.hdr;
           u64* ob = out + 1 + (D.r - 1) * M.wpr;
           ob[0] = D.rep[0];
-          ob[1] = D.rep[1];
-          ob[2] = D.rep[2];
+          if (M.wpr > 1) ob[1] = D.rep[1];
+          if (M.wpr > 2) ob[2] = D.rep[2];
           if (M.wpr > 3) ob[3] = D.rep[3];
 #pragma unroll
           for (int k = 0; k < 6; k++)
@@ -606,7 +657,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           nx_off[idx] = (dst << 8) | (u64)clen;
           lvl_fp[idx] = fp;
           if (lvl_tr) lvl_tr[idx] = key;
-          const int bad = check_invariants_child(M, rec, D);
+          const int bad = Ops::invariants(M, rec, D);
           if (bad && !remote) {
             atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
             atomicOr(&ctl->viol_mask, (u32)bad);
@@ -787,6 +838,7 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
               u32 ichunk /* state indices per reservation, >= 64 */, u32 wchunk /* words per reservation, >= 64 * stride */) {
   Model M = Marg;
   specialise<SPEC>(M, Marg);
+  typedef ModelOps<SPEC / 1000> Ops;
   extern __shared__ u64 s_slot[];                              // 64 slots of `stride` words
   const int lane = threadIdx.x;
   // This wave's private chunks of the output (wave-uniform values): state indices [idx_base, idx_base + idx_left) and
@@ -843,20 +895,20 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
     if (win) {
       u64* rec = s_slot + lane * stride;
       Delta D;
-      gen<false>(M, (const u64*)rec, meta_ord(key), D);
+      Ops::template gen_<false>(M, (const u64*)rec, meta_ord(key), D);
       u64 Hc[6];
-      hash_child(M, (const u64*)rec, D, Hc);
+      Ops::hash_child_(M, (const u64*)rec, D, Hc);
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
-      bad = check_invariants_child(M, (const u64*)rec, D);
+      bad = Ops::invariants(M, (const u64*)rec, D);
       nbag = hdr_nmsg(D.hdr);
       clen = M.fixed + nbag;
       if (clen > stride) clen = stride;                        // cannot happen: gen() raised ERR_REP_BAG in k_expand
       rec[0] = D.hdr;
       u64* pb = rec + 1 + (D.r - 1) * M.wpr;
       pb[0] = D.rep[0];
-      pb[1] = D.rep[1];
-      pb[2] = D.rep[2];
+      if (M.wpr > 1) pb[1] = D.rep[1];
+      if (M.wpr > 2) pb[2] = D.rep[2];
       if (M.wpr > 3) pb[3] = D.rep[3];
 #pragma unroll
       for (int k = 0; k < 6; k++)
@@ -1205,6 +1257,7 @@ __global__ void k_trace_walk(const u64* tr_all, const u64* level_base, int level
 // k_select: indices of the frontier records in which at least one instance of an action of `action_mask` (bit a = action id a)
 // is enabled — TLC's per-action coverage, as a filter.  One lane per record, guards only (guard_slot: the same statement of the
 // guards k_expand enumerates with).  counters[0] = matching records (all of them), out_idx holds the first out_cap that arrived.
+template <int MODEL>
 __global__ void k_select(Model M, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n, u32 action_mask, u64* out_idx,
                          u64 out_cap, u64* counters) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1216,9 +1269,9 @@ __global__ void k_select(Model M, const u64* __restrict__ fr_words, const u64* _
   bool hit = false;
   for (int slot = 0; slot < nslots && !hit; slot++) {
     int kind0 = 0;
-    const u32 mask = guard_slot(M, rec, slot, &kind0);
+    const u32 mask = ModelOps<MODEL>::guard(M, rec, slot, &kind0);
     if ((mask & 1u) && ((action_mask >> kind0) & 1u)) hit = true;
-    if ((mask & ~1u) && ((action_mask >> A_SendGetState) & 1u)) hit = true;
+    if ((mask & ~1u) && ((action_mask >> ModelOps<MODEL>::other_kind(kind0)) & 1u)) hit = true;
   }
   if (hit) {
     const u64 k = wave_alloc(&counters[0]);
@@ -1279,6 +1332,7 @@ __global__ void k_fpset_contains(const Slot* table, u64 tmask, const u64* fps, u
 // One lane per parent; out_meta has 8 words per successor:
 //   [parent index, ordinal, action id, fingerprint, auxkey, violated-invariant mask, error code, word offset]
 // -----------------------------------------------------------------------------------------------------------------
+template <int MODEL>
 __global__ void k_successors(Model M, const u64* words, const u64* off, u64 n, u64* out_words, u64 out_words_cap,
                              u64* out_meta, u64 out_cap, u64* counters /* [0] successors, [1] words, [2] overflow */) {
   u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1287,10 +1341,10 @@ __global__ void k_successors(Model M, const u64* words, const u64* off, u64 n, u
   int nords = ord_count(M, hdr_nmsg(rec[0]));
   for (int ord = 0; ord < nords; ord++) {
     Delta D;
-    if (!gen<true>(M, rec, ord, D)) continue;
-    gen<false>(M, rec, ord, D);
+    if (!ModelOps<MODEL>::template gen_<true>(M, rec, ord, D)) continue;
+    ModelOps<MODEL>::template gen_<false>(M, rec, ord, D);
     u64 Hc[6];
-    hash_child(M, rec, D, Hc);
+    ModelOps<MODEL>::hash_child_(M, rec, D, Hc);
     u64 fp;
     u32 ak;
     canonical_fp(M, D.hdr, Hc, &fp, &ak);
@@ -1309,7 +1363,7 @@ __global__ void k_successors(Model M, const u64* words, const u64* off, u64 n, u
     m[2] = (u64)D.action;
     m[3] = fp;
     m[4] = ak;
-    m[5] = D.err ? 0 : (u64)check_invariants_child(M, rec, D);
+    m[5] = D.err ? 0 : (u64)ModelOps<MODEL>::invariants(M, rec, D);
     m[6] = (u64)D.err;
     m[7] = w;
   }
@@ -1347,6 +1401,7 @@ k_simulate(Model Marg, const u64* __restrict__ init_rec, int init_len, u64* walk
            u16* walker_ords, u64* walker_rng, u32 n_walkers, int max_depth, int steps_per_launch, SimCtl* ctl) {
   Model M = Marg;
   specialise<SPEC>(M, Marg);
+  typedef ModelOps<SPEC / 1000> Ops;
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_walkers) return;
   u64* w = walker_words + (u64)t * stride;
@@ -1366,7 +1421,7 @@ k_simulate(Model Marg, const u64* __restrict__ init_rec, int init_len, u64* walk
     int total = 0;
     for (int slot = 0; slot < nslots; slot++) {
       int kind0;
-      total += __builtin_popcount(guard_slot(M, (const u64*)w, slot, &kind0));
+      total += __builtin_popcount(Ops::guard(M, (const u64*)w, slot, &kind0));
     }
     if (total == 0) {                                           // terminal state: the walk ends (TLC -deadlock)
       depth = 0xFFFFFFFFu;
@@ -1375,7 +1430,7 @@ k_simulate(Model Marg, const u64* __restrict__ init_rec, int init_len, u64* walk
     int pick = (int)(sim_rng(&rng) % (u64)total), ord = -1;
     for (int slot = 0; slot < nslots && ord < 0; slot++) {
       int kind0;
-      u32 mask = guard_slot(M, (const u64*)w, slot, &kind0);
+      u32 mask = Ops::guard(M, (const u64*)w, slot, &kind0);
       const int c = __builtin_popcount(mask);
       if (pick >= c) { pick -= c; continue; }
       while (pick--) mask &= mask - 1;
@@ -1383,7 +1438,7 @@ k_simulate(Model Marg, const u64* __restrict__ init_rec, int init_len, u64* walk
       ord = slot < M.m0 ? slot : M.m0 + (slot - M.m0) * (M.R + 1) + k;
     }
     Delta D;
-    if (ord < 0 || !gen<false>(M, (const u64*)w, ord, D)) {
+    if (ord < 0 || !Ops::template gen_<false>(M, (const u64*)w, ord, D)) {
       atomicExch(&ctl->viol_mask, 0x80000000u | (u32)ERR_INTERNAL);
       atomicExch(&ctl->found, 2u);
       break;
@@ -1396,14 +1451,14 @@ k_simulate(Model Marg, const u64* __restrict__ init_rec, int init_len, u64* walk
       }
       break;
     }
-    const int bad = check_invariants_child(M, (const u64*)w, D);
+    const int bad = Ops::invariants(M, (const u64*)w, D);
     // apply the step in place
     const int plen = M.fixed + hdr_nmsg(w[0]);
     w[0] = D.hdr;
     u64* pb = w + 1 + (D.r - 1) * M.wpr;
     pb[0] = D.rep[0];
-    pb[1] = D.rep[1];
-    pb[2] = D.rep[2];
+    if (M.wpr > 1) pb[1] = D.rep[1];
+    if (M.wpr > 2) pb[2] = D.rep[2];
     if (M.wpr > 3) pb[3] = D.rep[3];
     int a = 0;
 #pragma unroll
@@ -1431,17 +1486,19 @@ k_simulate(Model Marg, const u64* __restrict__ init_rec, int init_len, u64* walk
 }
 
 // k_hash_records: fill in the H words of device-layout records (used when records enter through the C ABI)
+template <int MODEL>
 __global__ void k_hash_records(Model M, u64* words, const u64* off, u64 n) {
   u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   u64* rec = words + off[p];
   u64 H[6];
-  hash_full(M, (const u64*)rec, H);
+  ModelOps<MODEL>::hash_full_(M, (const u64*)rec, H);
   for (int i = 0; i < M.np; i++) rec[M.h0 + i] = H[i];
 }
 
 // k_replay: re-execute a path of ordinals starting from the record at out_words[0..).  Record t+1 = ord[t] applied
 // to record t.  out_meta per step: [action id, fingerprint, invariant mask, error].
+template <int MODEL>
 __global__ void k_replay(Model M, u64* out_words, u64* out_off, const u32* ords, int nsteps, u64* out_meta) {
   if (threadIdx.x || blockIdx.x) return;
   u64 pos = 0;
@@ -1450,23 +1507,23 @@ __global__ void k_replay(Model M, u64* out_words, u64* out_off, const u32* ords,
     const u64* rec = out_words + pos;
     u64 next = pos + (u64)(M.fixed + hdr_nmsg(rec[0]));
     Delta D;
-    bool en = gen<true>(M, rec, (int)ords[t], D);
+    bool en = ModelOps<MODEL>::template gen_<true>(M, rec, (int)ords[t], D);
     if (!en) {
       out_meta[4 * t + 3] = 0xFFFF;
       out_off[t + 1] = next;
       for (int k = t + 1; k < nsteps; k++) out_off[k + 1] = next;
       return;
     }
-    gen<false>(M, rec, (int)ords[t], D);
+    ModelOps<MODEL>::template gen_<false>(M, rec, (int)ords[t], D);
     u64 Hc[6];
-    hash_child(M, rec, D, Hc);
+    ModelOps<MODEL>::hash_child_(M, rec, D, Hc);
     u64 fp;
     u32 ak;
     canonical_fp(M, D.hdr, Hc, &fp, &ak);
     write_child_serial(M, rec, D, Hc, out_words + next);
     out_meta[4 * t + 0] = (u64)D.action;
     out_meta[4 * t + 1] = fp;
-    out_meta[4 * t + 2] = (u64)check_invariants_child(M, rec, D);
+    out_meta[4 * t + 2] = (u64)ModelOps<MODEL>::invariants(M, rec, D);
     out_meta[4 * t + 3] = (u64)D.err;
     out_off[t + 1] = next;
     pos = next;

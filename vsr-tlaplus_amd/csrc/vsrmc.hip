@@ -16,6 +16,7 @@
 
 #include "../../include/vsrmc.h"
 #include "vsr_format.hpp"
+#include "vrst_format.hpp"
 #include "vsr_parse.hpp"
 #include "vsr_kernels.hpp"
 
@@ -85,6 +86,8 @@ std::string sha256_hex(const std::string& data) {
 
 // SHA-256 of the one module this build lowers: /root/reference/vsr-revisited/paper/VSR.tla (970 lines)
 const char* const VSR_TLA_SHA256 = "f37efb7b055316624c885e2805550097fa609864b1b7a782279c189f8e2dbf22";
+// ... and of the second one: /root/reference/vsr-revisited/paper/analysis/03-state-transfer/VR_STATE_TRANSFER.tla (948 lines)
+const char* const VRST_TLA_SHA256 = "e716e3e04a9f9284d9e2df039271a37d4974c1d32d19dbe54a8da5de46331eee";
 
 }  // namespace
 
@@ -136,6 +139,33 @@ int build_model(int R, int C, int n, int L, int restart, int symmetry, int inv_m
   return 0;
 }
 
+// The second model (VR_STATE_TRANSFER.tla): one word per replica, no clients, no symmetry (vrst_actions.hpp)
+int build_model2(int R, int n, int L, int no_progress_limit, int symmetry, int inv_mask, vsrmc_model* out) {
+  if (R < 2 || R > 5 || n < 1 || n > 3 || L < 0 || L > 6)
+    return fail(VSRMC_E_CFG, "model constants outside the supported bounds (ReplicaCount 2..5, |Values| 1..3, StartViewOnTimerLimit 0..6)");
+  if (no_progress_limit != 0)
+    return fail(VSRMC_E_CFG, "NoProgressChangeLimit > 0 is not supported: NoProgressChange (VR_STATE_TRANSFER.tla:765-776) is not lowered");
+  if (symmetry)
+    return fail(VSRMC_E_CFG, "SYMMETRY is not lowered for VR_STATE_TRANSFER.tla (VR_STATE_TRANSFER.cfg:25-27 keeps it commented out)");
+  Model& M = out->M;
+  std::memset(&M, 0, sizeof(M));
+  M.model_id = 1;
+  M.R = R; M.C = 0; M.n = n; M.L = L;
+  M.wpr = 1;
+  M.h0 = 1 + R;
+  M.np = 1;
+  M.pitab[0] = 0x24u;                                            // the identity
+  M.fixed = M.h0 + 1;
+  M.inv_mask = inv_mask;
+  M.max_bag = 63 - M.fixed;
+  M.m0 = 4 * R + R * n;
+  for (int v = 1; v <= 7; v++) M.primtab |= (u32)(1 + ((v - 1) % R)) << (3 * v);   // Primary(v), VR_STATE_TRANSFER.tla:233-234
+  out->symmetry = 0;
+  out->value_names.clear();
+  for (int v = 0; v < n; v++) out->value_names.push_back("v" + std::to_string(v + 1));
+  return 0;
+}
+
 std::string strip(const std::string& s) {
   size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
   return a == std::string::npos ? "" : s.substr(a, b - a + 1);
@@ -158,6 +188,10 @@ int device_to_wire(const Model& M, const u64* dev, u64* wire) {
 
 void init_record_wire(const Model& M, std::vector<u64>& rec) {   // Init, VSR.tla:323-348
   rec.assign(M.h0, 0);
+  if (M.model_id == 1) {                                         // Init, VR_STATE_TRANSFER.tla:267-283
+    for (int r = 1; r <= M.R; r++) rec[r] = a_set_lnv(a_set_view(a_set_status(0, vrst::ST2_NORMAL), 1), 1);   // view 1, last normal view 1
+    return;
+  }
   for (int r = 1; r <= M.R; r++) {
     u64 A = 0;
     A = a_set_status(A, ST_NORMAL);        // rep_status = Normal            :328
@@ -165,6 +199,12 @@ void init_record_wire(const Model& M, std::vector<u64>& rec) {   // Init, VSR.tl
     for (int c = 1; c <= M.C; c++) A = a_set_ctrow(A, c, ct_make(0, 0, 1));   // EmptyClientTableRow :318-321
     rec[1 + (r - 1) * M.wpr] = A;          // everything else 0 / empty      :329-343
   }
+}
+
+// view hashes of a device-layout record on the host (pure arithmetic, the same functions the kernels run)
+void hash_full_host(const Model& M, const u64* rec, u64* H) {
+  if (M.model_id == 1) vrst::hash_full(M, rec, H);
+  else hash_full(M, rec, H);
 }
 
 }  // namespace
@@ -189,25 +229,39 @@ int32_t vsrmc_model_from_constants(int32_t R, int32_t C, int32_t n, int32_t L, i
   return 0;
 }
 
+int32_t vsrmc_model2_from_constants(int32_t R, int32_t n, int32_t L, int32_t no_progress_limit, int32_t symmetry, int32_t inv_mask,
+                                    vsrmc_model** out) {
+  if (!out) return fail(VSRMC_E_ARG, "out is NULL");
+  vsrmc_model* m = new vsrmc_model();
+  int rc = build_model2(R, n, L, no_progress_limit, symmetry, inv_mask, m);
+  if (rc) { delete m; return rc; }
+  *out = m;
+  return 0;
+}
+
 // The TLC cfg grammar as used by VSR.cfg:1-39: CONSTANTS (name = int | name = {mv, ...} | name = mv), INIT, NEXT,
 // VIEW, SYMMETRY, INVARIANT[S] (multi-line list), CHECK_DEADLOCK, `\*` comments.  SPECIFICATION / PROPERTY are refused.
 int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model** out) {
   if (!cfg_path || !out) return fail(VSRMC_E_ARG, "cfg_path / out is NULL");
+  int module = -1;                                               // 0 = VSR.tla, 1 = VR_STATE_TRANSFER.tla, -1 = decided by the cfg
   if (tla_path) {
+    module = 0;
     std::ifstream f(tla_path, std::ios::binary);
     if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + tla_path);
     std::stringstream ss;
     ss << f.rdbuf();
     std::string dig = sha256_hex(ss.str());
-    if (dig != VSR_TLA_SHA256)
-      return fail(VSRMC_E_CFG, std::string(tla_path) + ": sha256 " + dig + " is not the VSR.tla this build lowers (" +
-                                   VSR_TLA_SHA256 + "); refusing to check a module the action table was not derived from");
+    if (dig == VRST_TLA_SHA256) module = 1;
+    else if (dig != VSR_TLA_SHA256)
+      return fail(VSRMC_E_CFG, std::string(tla_path) + ": sha256 " + dig + " is neither the VSR.tla (" + VSR_TLA_SHA256 +
+                                   ") nor the VR_STATE_TRANSFER.tla (" + VRST_TLA_SHA256 +
+                                   ") this build lowers; refusing to check a module the action table was not derived from");
   }
   std::ifstream f(cfg_path);
   if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + cfg_path);
   std::map<std::string, std::string> consts;
   std::vector<std::string> invariants;
-  std::string init, next, view, symmetry, line, section;
+  std::string init, next, view, symmetry, spec, line, section;
   int check_deadlock = 0;   // TLC's default is TRUE; the BASELINE runs use -deadlock, see DESIGN.md
   int lineno = 0;
   static const char* KW[] = {"CONSTANTS", "CONSTANT", "INIT", "NEXT", "VIEW", "SYMMETRY", "INVARIANTS", "INVARIANT",
@@ -227,7 +281,8 @@ int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model
       if (is_kw) {
         section = tok;
         rest = strip(rest.substr(tok.size()));
-        if (section == "SPECIFICATION" || section == "PROPERTY" || section == "PROPERTIES" || section == "CONSTRAINT" ||
+        if (section == "SPECIFICATION") continue;                  // VR_STATE_TRANSFER.cfg:21 `SPECIFICATION Spec`; checked below
+        if (section == "PROPERTY" || section == "PROPERTIES" || section == "CONSTRAINT" ||
             section == "CONSTRAINTS" || section == "ACTION_CONSTRAINT" || section == "ACTION_CONSTRAINTS" ||
             section == "ALIAS" || section == "POSTCONDITION")
           return fail(VSRMC_E_CFG, std::string(cfg_path) + ":" + std::to_string(lineno) + ": " + section +
@@ -241,7 +296,8 @@ int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model
         std::string name = strip(rest.substr(0, eq)), val = strip(rest.substr(eq + 1));
         consts[name] = val;
         rest.clear();
-      } else if (section == "INIT") { init = tok; rest = strip(rest.substr(tok.size())); }
+      } else if (section == "SPECIFICATION") { spec = tok; rest = strip(rest.substr(tok.size())); }
+      else if (section == "INIT") { init = tok; rest = strip(rest.substr(tok.size())); }
       else if (section == "NEXT") { next = tok; rest = strip(rest.substr(tok.size())); }
       else if (section == "VIEW") { view = tok; rest = strip(rest.substr(tok.size())); }
       else if (section == "SYMMETRY") { symmetry = tok; rest = strip(rest.substr(tok.size())); }
@@ -260,6 +316,55 @@ int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model
     *v = (int)x;
     return true;
   };
+  if (module < 0) module = consts.count("NoProgressChangeLimit") ? 1 : 0;   // no module given: the cfg's constants tell them apart
+  if (module == 1) {  // ---- VR_STATE_TRANSFER.cfg
+    int R2, L2, npl;
+    if (!need_int("ReplicaCount", &R2) || !need_int("StartViewOnTimerLimit", &L2) || !need_int("NoProgressChangeLimit", &npl))
+      return fail(VSRMC_E_CFG, std::string(cfg_path) + ": CONSTANTS must bind ReplicaCount, StartViewOnTimerLimit, "
+                                   "NoProgressChangeLimit to integers (VR_STATE_TRANSFER.cfg:4-7)");
+    std::vector<std::string> values2;
+    auto itv = consts.find("Values");
+    if (itv == consts.end() || itv->second.size() < 2 || itv->second.front() != '{' || itv->second.back() != '}')
+      return fail(VSRMC_E_CFG, std::string(cfg_path) + ": CONSTANTS must bind Values to a set of model values (VR_STATE_TRANSFER.cfg:5)");
+    {
+      std::string body = itv->second.substr(1, itv->second.size() - 2), item;
+      std::stringstream ss(body);
+      while (std::getline(ss, item, ',')) {
+        item = strip(item);
+        if (!item.empty()) values2.push_back(item);
+      }
+    }
+    static const char* SELF2[] = {"Normal", "ViewChange", "StateTransfer", "PrepareMsg", "PrepareOkMsg", "StartViewChangeMsg",
+                                  "DoViewChangeMsg", "StartViewMsg", "GetStateMsg", "NewStateMsg", "Nil", "AnyDest"};
+    for (const char* sname : SELF2) {
+      auto it = consts.find(sname);
+      if (it == consts.end() || it->second != sname)
+        return fail(VSRMC_E_CFG, std::string(cfg_path) + ": constant " + sname + " must be bound to the model value " + sname +
+                                     " (VR_STATE_TRANSFER.cfg:8-19)");
+    }
+    if (!((spec == "Spec" && init.empty() && next.empty()) || (spec.empty() && init == "Init" && next == "Next")))
+      return fail(VSRMC_E_CFG, std::string(cfg_path) + ": expected SPECIFICATION Spec (VR_STATE_TRANSFER.cfg:21; LivenessSpec and "
+                                   "PROPERTY checking are not lowered) or INIT Init / NEXT Next");
+    if (view != "view") return fail(VSRMC_E_CFG, std::string(cfg_path) + ": expected VIEW view (VR_STATE_TRANSFER.cfg:23)");
+    int mask2 = 0;
+    for (const std::string& iv : invariants) {
+      if (iv == "AcknowledgedWriteNotLost") mask2 |= 1;                  // VR_STATE_TRANSFER.tla:830-835
+      else if (iv == "AcknowledgedWritesExistOnMajority") mask2 |= 2;   // :818-824
+      else if (iv == "NoLogDivergence") mask2 |= 4;                     // :806-811
+      else if (iv == "CommitNumberNeverHigherThanOpNumber") mask2 |= 8; // :845-847
+      else if (iv == "TestInv") mask2 |= 0;                             // :849 (TRUE)
+      else return fail(VSRMC_E_CFG, std::string(cfg_path) + ": unknown INVARIANT " + iv);
+    }
+    vsrmc_model* m2 = new vsrmc_model();
+    int rc2 = build_model2(R2, (int)values2.size(), L2, npl, symmetry.empty() ? 0 : 1, mask2, m2);
+    if (rc2) { delete m2; return rc2; }
+    m2->value_names = values2;
+    m2->check_deadlock = check_deadlock;
+    *out = m2;
+    return 0;
+  }
+  if (!spec.empty())
+    return fail(VSRMC_E_CFG, std::string(cfg_path) + ": SPECIFICATION is not supported for VSR.tla (VSR.cfg:26-27 uses INIT / NEXT)");
   int R, C, L, restart;
   if (!need_int("ReplicaCount", &R) || !need_int("ClientCount", &C) || !need_int("StartViewOnTimerLimit", &L) ||
       !need_int("RestartEmptyLimit", &restart))
@@ -334,7 +439,7 @@ int32_t vsrmc_model_init_state(const vsrmc_model* m, uint64_t* rec, int32_t cap,
 
 int32_t vsrmc_model_format_state(const vsrmc_model* m, const uint64_t* rec, char* buf, int64_t cap, int64_t* n) {
   if (!m || !rec || !n) return fail(VSRMC_E_ARG, "NULL argument");
-  std::string s = format_state_tlc(m->M, m->value_names, rec);
+  std::string s = m->M.model_id == 1 ? vrst::format_state_tlc(m->M, m->value_names, rec) : format_state_tlc(m->M, m->value_names, rec);
   *n = (int64_t)s.size() + 1;
   if (buf && cap >= *n) std::memcpy(buf, s.c_str(), s.size() + 1);
   else if (buf && cap > 0) return fail(VSRMC_E_ARG, "buffer too small");
@@ -483,7 +588,7 @@ int upload_records(const Model& M, const u64* words, const u64* off, u64 n, u64*
   HIPCHK(hipMalloc((void**)d_off, (n + 1) * 8));
   HIPCHK(hipMemcpy(*d_words, dev.data(), dev.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(*d_off, doff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_hash_records, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, *d_words, *d_off, n);
+  hipLaunchKernelGGL((M.model_id == 1 ? k_hash_records<1> : k_hash_records<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, *d_words, *d_off, n);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -510,7 +615,7 @@ int32_t vsrmc_expand_batch(const vsrmc_model* m, int32_t device, const uint64_t*
   HIPCHK(hipMalloc((void**)&d_om, std::max<u64>(out_cap, 1) * 64));
   HIPCHK(hipMalloc((void**)&d_cnt, 32));
   HIPCHK(hipMemset(d_cnt, 0, 32));
-  hipLaunchKernelGGL(k_successors, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, d_words, d_off, n, d_ow, dev_words_cap,
+  hipLaunchKernelGGL((M.model_id == 1 ? k_successors<1> : k_successors<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, d_words, d_off, n, d_ow, dev_words_cap,
                      d_om, out_cap, d_cnt);
   HIPCHK(hipGetLastError());
   u64 cnt[4];
@@ -788,6 +893,8 @@ extern "C" int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t
   SimCtl h;
   typedef void (*SimKernel)(Model, const u64*, int, u64*, int, u32*, u16*, u64*, u32, int, int, SimCtl*);
   SimKernel sim_kernel = k_simulate<0>;
+  if (M.model_id == 1) sim_kernel = k_simulate<1000>;
+  else
   switch (M.R * 100 + M.C * 10 + M.n) {                        // the same per-configuration instantiations as k_expand
     case 312: sim_kernel = k_simulate<312>; break;
     case 313: sim_kernel = k_simulate<313>; break;
@@ -875,6 +982,7 @@ typedef void (*ExpandKernel)(Model, const u64*, const u64*, u64, int, int, Slot*
 // k_expand<true, SPEC>: the configurations of BASELINE.json (and their small neighbours used by the tests) have their own
 // instantiation with the model constants folded in; anything else runs the generic one.
 ExpandKernel exact_kernel_for(const Model& M) {               // two-kernel levels: k_expand<false, SPEC>
+  if (M.model_id == 1) return k_expand<false, 1000>;
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 211: return k_expand<false, 211>;
     case 312: return k_expand<false, 312>;
@@ -886,6 +994,7 @@ ExpandKernel exact_kernel_for(const Model& M) {               // two-kernel leve
 typedef void (*MaterializeKernel)(Model, const u64*, const u64*, const u64*, u64, const Slot*, u64*, u64, u64*, u64, u64*, u64*, LevelCtl*,
                                   const uint8_t*, u64*, u64*, int, u32, u32);
 MaterializeKernel materialize_kernel_for(const Model& M) {
+  if (M.model_id == 1) return k_materialize<1000>;
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 211: return k_materialize<211>;
     case 312: return k_materialize<312>;
@@ -895,6 +1004,7 @@ MaterializeKernel materialize_kernel_for(const Model& M) {
   }
 }
 ExpandKernel plain_kernel_for(const Model& M) {               // unsharded ordinary levels: modes and sharding compiled out
+  if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true> : nullptr;   // the shipped VR_STATE_TRANSFER.cfg
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 312: return k_expand<true, 312, true>;
     case 313: return k_expand<true, 313, true>;
@@ -903,6 +1013,7 @@ ExpandKernel plain_kernel_for(const Model& M) {               // unsharded ordin
   }
 }
 ExpandKernel fused_kernel_for(const Model& M) {
+  if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302> : k_expand<true, 1000>;
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 211: return k_expand<true, 211>;
     case 212: return k_expand<true, 212>;
@@ -958,7 +1069,7 @@ int checker_seed(vsrmc_checker* c) {
   init_record_wire(M, wire);
   int len = wire_to_device(M, wire.data(), dev.data());
   u64 H[6];
-  hash_full(M, (const u64*)dev.data(), H);   // pure arithmetic on the constant Init record (same code as the kernels)
+  hash_full_host(M, (const u64*)dev.data(), H);   // pure arithmetic on the constant Init record (same code as the kernels)
   for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
   u64 zero = (u64)len, init_fp = 0;                            // ref of record 0: offset 0, length len
   u32 init_ak = 0;
@@ -2043,7 +2154,7 @@ int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t ma
     (void)hipFree(d_idx);
     return fail(VSRMC_E_HIP, "hipMalloc failed");
   }
-  hipLaunchKernelGGL(k_select, dim3((unsigned)((c->n_frontier + 255) / 256)), dim3(256), 0, c->stream, M, c->words[c->cur], c->off[c->cur],
+  hipLaunchKernelGGL((M.model_id == 1 ? k_select<1> : k_select<0>), dim3((unsigned)((c->n_frontier + 255) / 256)), dim3(256), 0, c->stream, M, c->words[c->cur], c->off[c->cur],
                      c->n_frontier, action_mask, d_idx, max_states, d_cnt);
   u64 cnt = 0;
   bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
@@ -2094,12 +2205,12 @@ int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t*
   init_record_wire(M, wire);
   int len = wire_to_device(M, wire.data(), dev.data());
   u64 H[6];
-  hash_full(M, (const u64*)dev.data(), H);
+  hash_full_host(M, (const u64*)dev.data(), H);
   for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
   HIPCHK(hipMemcpy(d_w, dev.data(), len * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(d_m, 0, (u64)std::max(nsteps, 1) * 32));
   if (nsteps > 0) HIPCHK(hipMemcpy(d_ords, ords, (u64)nsteps * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_replay, dim3(1), dim3(64), 0, 0, M, d_w, d_o, d_ords, nsteps, d_m);
+  hipLaunchKernelGGL((M.model_id == 1 ? k_replay<1> : k_replay<0>), dim3(1), dim3(64), 0, 0, M, d_w, d_o, d_ords, nsteps, d_m);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   std::vector<u64> hw(maxw), ho(level + 1), hm((size_t)std::max(nsteps, 1) * 4);
