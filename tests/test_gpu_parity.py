@@ -289,9 +289,10 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, key):
     p = g["params"]
     m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=p["n"], L=p["L"], symmetry=p["symmetry"], invariant_mask=p["inv_mask"])
     biggest = max(lv["new"] for lv in g["levels"])
-    words = int(biggest * (m.layout.max_record_words * 0.62) * 1.15) + (1 << 29)     # + the blocks' partly used chunks
+    # record = fixed words + H words + at most the largest bag; + the partly used chunks every block leaves behind (words and indices)
+    words = int(biggest * (m.layout.fixed_words + m.layout.permutations + g["max_bag"]) * 1.1) + (1 << 29)
     mc = vt.ModelChecker(m, table_log2=max(20, int(np.ceil(np.log2(2.5 * g["distinct"])))), frontier_words=words,
-                         frontier_states=int(biggest * 1.2) + (1 << 16), pending_entries=1 << 15, keep_trace=False)
+                         frontier_states=int(biggest * 1.3) + (1 << 24), pending_entries=1 << 15, keep_trace=False)
     assert mc.level_checksum()[2] == 1
     for lv in g["levels"][1:]:
         d = mc.step()

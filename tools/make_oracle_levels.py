@@ -30,13 +30,15 @@ def main():
     ap.add_argument("--max-depth", type=int, default=0)
     ap.add_argument("--max-seconds", type=float, default=0)
     ap.add_argument("--count-only-from", type=int, default=0)
-    ap.add_argument("--inv-mask", type=int, default=1)
+    ap.add_argument("--inv-mask", type=int, default=0, help="default: the shipped cfg's invariants (model 1: 1, model 2: 14)")
+    ap.add_argument("--model", type=int, default=1, help="1 = VSR.tla (vsr_oracle_mt), 2 = analysis/03-state-transfer/VR_STATE_TRANSFER.tla (vrst_oracle_mt)")
     ap.add_argument("--no-symmetry", action="store_true")
     ap.add_argument("--label", default="")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
-    exe = os.path.join(ROOT, "oracle", "build", "vsr_oracle_mt")
+    exe = os.path.join(ROOT, "oracle", "build", "vsr_oracle_mt" if a.model == 1 else "vrst_oracle_mt")
+    a.inv_mask = a.inv_mask or (1 if a.model == 1 else 14)
     cmd = [exe, str(a.R), str(a.C), str(a.n), str(a.L), "--inv-mask", str(a.inv_mask)]
     if a.threads:
         cmd += ["--threads", str(a.threads)]
@@ -55,12 +57,14 @@ def main():
         """(re)write the output file; before the oracle's summary line arrives the file says stop = "running" — a run that is
         killed (timeout) still leaves every completed level behind"""
         out = dict(
-            source="CPU oracle: oracle/vsr_oracle_mt (multi-threaded driver over oracle/vsr_oracle.cpp, the restatement of VSR.tla) — "
+            source="CPU oracle: oracle/%s (multi-threaded driver over oracle/%s) — " % (
+                       ("vsr_oracle_mt", "vsr_oracle.cpp, the restatement of VSR.tla") if a.model == 1 else
+                       ("vrst_oracle_mt", "vrst_oracle.cpp, the restatement of VR_STATE_TRANSFER.tla")) +
                    "`%s`, %s threads on %s (%d logical CPUs), %.1f s; written by tools/make_oracle_levels.py"
-                   % (" ".join(["vsr_oracle_mt"] + cmd[1:]), summary.get("threads", a.threads or "all"), platform.processor() or platform.machine(),
+                   % (" ".join([os.path.basename(exe)] + cmd[1:]), summary.get("threads", a.threads or "all"), platform.processor() or platform.machine(),
                       os.cpu_count() or 0, time.time() - t0),
             label=a.label or "(%d,%d,%d values,%d)" % (a.R, a.C, a.n, a.L),
-            params=dict(R=a.R, C=a.C, n=a.n, L=a.L, symmetry=not a.no_symmetry, inv_mask=a.inv_mask),
+            model=a.model, params=dict(R=a.R, C=a.C, n=a.n, L=a.L, symmetry=(not a.no_symmetry) and a.model == 1, inv_mask=a.inv_mask),
             stop=summary.get("stop", "running"), depth=summary.get("depth", len(levels)),
             distinct=summary.get("distinct", sum(lv["new"] for lv in levels)),
             generated=summary.get("generated", sum(lv["generated"] for lv in levels)),
