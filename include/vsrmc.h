@@ -114,10 +114,10 @@ typedef struct vsrmc_options {
   int32_t table_log2;            /* seen-set slots = 2^table_log2 (16 B each) */
   uint64_t frontier_words;       /* capacity of each of the two frontier buffers, in 8-byte words */
   uint64_t frontier_states;      /* capacity of each frontier in states */
-  uint64_t pending_entries;      /* capacity of the per-level pending list (16 B each) */
-  int32_t keep_trace;            /* 1 = keep the (parent, ordinal) log in HBM for counter-examples (TLCTrace) */
+  uint64_t pending_entries;      /* capacity of the per-level pending list (24 B each; only the exact scheme fills it) */
+  int32_t keep_trace;            /* ignored (kept for ABI stability): predecessor pointers live in the seen-set slots, always */
   int32_t rank, world;           /* shard of the seen-set owned by this process (world = 1: everything) */
-  uint64_t trace_entries;        /* capacity of that log in states (8 B each); 0 = 8 x frontier_states */
+  uint64_t trace_entries;        /* ignored (there is no separate trace log any more) */
   int32_t exact_ties;            /* 0 (default): single-pass levels — the lane that inserts a fingerprint writes the successor;
                                     a same-level VIEW collision with different aux variables (never observed) stops the run
                                     with VSRMC_E_STATE.  1: two-kernel levels (k_expand + k_materialize) that arbitrate
@@ -177,15 +177,24 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
  * (≙ TLC's per-action coverage, as a filter) */
 int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t max_states, uint64_t* words, uint64_t cap_words,
                              uint64_t* off, uint64_t* n_states, uint64_t* n_matching);
-/* ≙ TLCTrace.getTrace: the path Init .. state `index` of level `level`; records in wire layout, one action id per
- * state (0 = Initial predicate) */
+/* ≙ TLCTrace.getTrace: the path Init .. state `index` of the NEWEST level (level must be the current one); records in wire
+ * layout, one action id per state (0 = Initial predicate).  The path is a function of the state alone: every state's slot in the
+ * seen-set names the ordinal of the step that discovers it and its parent — of all (parent, instance) pairs of the previous
+ * level that produce it the one with the smallest (canonical auxkey, ordinal, parent fingerprint) — so the same counter-example
+ * comes back in every run, on any number of GPUs, in either level scheme. */
 int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words,
                             uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
+/* the same for any state of any completed level, addressed by its fingerprint */
+int32_t vsrmc_checker_trace_fp(vsrmc_checker* c, int32_t level, uint64_t fp, uint64_t* words, uint64_t cap_words,
+                               uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
 /* forward half of TLCTrace.getTrace on its own: re-execute `nsteps` ordinals from Init */
 int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t* ords, int32_t nsteps, uint64_t* words,
                            uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
-/* one entry of the trace log: key = level(9) | auxkey(9) | ordinal(11) | parent index(32) | rank(3) */
-int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* key);
+/* one step of a trace walk through this checker's (shard of the) seen-set — what a walk that crosses ranks is made of.
+ * by_low_bits = 0: the slot of fingerprint `key`; 1: the slot of the level-`level` state whose fingerprint ends in the 35 bits
+ * `key`.  meta = level(9) << 55 | auxkey(9) << 46 | ordinal(10) << 36 | parent fingerprint bits(35) << 1 | taken(1). */
+int32_t vsrmc_checker_lookup(vsrmc_checker* c, uint64_t key, int32_t level, int32_t by_low_bits, int32_t* found, uint64_t* fp,
+                             uint64_t* meta);
 /* index of fingerprint `fp` in the newest level (~0 if absent) */
 int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index);
 void vsrmc_checker_destroy(vsrmc_checker* c);
@@ -262,7 +271,7 @@ int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t n_walkers,
  *                               when they are out of balance, moves records in bulk:
  *      vsrmc_shard_export       copy the valid records of an index window into send streams and invalidate them here
  *      [all-to-all of the streams]
- *      vsrmc_shard_append       per received stream: copy into the next frontier, publish refs / fps / trace keys
+ *      vsrmc_shard_append       per received stream: copy into the next frontier, publish refs / fps
  *   7. vsrmc_shard_commit       swap the frontiers; local statistics (the caller all-reduces them)
  * With exact_ties = 0 (default) the levels are single-pass: in step 1 a successor owned by another rank that passes this
  * rank's sent-filter (exact repeats are dropped there) is written to the local next frontier SPECULATIVELY and announced;
@@ -287,11 +296,11 @@ int32_t vsrmc_shard_expand(vsrmc_checker* c, const vsrmc_shard_io* io, uint64_t*
 int32_t vsrmc_shard_claim(vsrmc_checker* c, const uint64_t* d_cand_recv, uint64_t n, uint8_t* d_verdict);
 int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, const uint8_t* d_verdict_in /* [world][cand_cap] */);
 int32_t vsrmc_shard_count(vsrmc_checker* c, uint64_t* n_valid, uint64_t* n_range);
-/* streams: d_words (device layout records, contiguous), d_off (ref = word offset in d_words << 8 | length), d_fp, d_key */
+/* streams: d_words (device layout records, contiguous), d_off (ref = word offset in d_words << 8 | length), d_fp */
 int32_t vsrmc_shard_export(vsrmc_checker* c, uint64_t first, uint64_t n, uint64_t* d_words, uint64_t words_cap, uint64_t* d_off,
-                           uint64_t* d_fp, uint64_t* d_key, uint64_t cap, uint64_t* n_out, uint64_t* words_out);
+                           uint64_t* d_fp, uint64_t cap, uint64_t* n_out, uint64_t* words_out);
 int32_t vsrmc_shard_append(vsrmc_checker* c, const uint64_t* d_words, uint64_t n_words, const uint64_t* d_off,
-                           const uint64_t* d_fp, const uint64_t* d_key, uint64_t n);
+                           const uint64_t* d_fp, uint64_t n);
 int32_t vsrmc_shard_commit(vsrmc_checker* c, vsrmc_level_info* info);
 
 #ifdef __cplusplus

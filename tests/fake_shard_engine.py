@@ -21,14 +21,13 @@ def _u64(t):
 class FakeShardEngine:
     def __init__(self, params, rank, world, owner_of):
         self.P, self.rank, self.world, self.owner_of = params, rank, world, owner_of
-        self.seen = {}            # fp -> best key (level << 55 | auxkey << 46 | ord << 35 | pidx << 3 | rank)
+        self.seen = {}            # fp -> best key (level << 55 | auxkey << 46 | ordinal << 36 | parent fingerprint bits(35) << 1)
         self.level = 1
         init = orc.init_record(params)
         fp, ak = orc.fingerprint(params, init)
         # replicated start: Init on every rank (sharded.ShardedChecker partitions when its replicated phase ends)
         self.frontier, self.fps = [init], [fp]
         self.seen[fp] = self._key(1, ak, 0, 0)
-        self.trace = [[self.seen[fp]]]
         self.total = len(self.frontier)
         self._err = ""
 
@@ -44,13 +43,13 @@ class FakeShardEngine:
 
     def partition(self):
         keep = set(i for i, f in enumerate(self.fps) if f is not None and self.owner_of(f, self.world) == self.rank)
-        # indices stay what they were (the trace log is addressed by index): withdrawn states become holes
+        # withdrawn states become holes of the index range, as in the product engine
         self.frontier = [self.frontier[i] if i in keep else None for i in range(len(self.frontier))]
         self.fps = [self.fps[i] if self.frontier[i] is not None else None for i in range(len(self.fps))]
         return len(keep)
 
-    def _key(self, level, ak, pidx, ordinal):
-        return (level << 55) | (ak << 46) | (ordinal << 35) | (pidx << 3) | self.rank
+    def _key(self, level, ak, parent_fp, ordinal):
+        return (level << 55) | (ak << 46) | (ordinal << 36) | ((parent_fp & ((1 << 35) - 1)) << 1)
 
     def error_text(self):
         return self._err
@@ -70,7 +69,8 @@ class FakeShardEngine:
         self.generated = self.deadlocks = 0
         self.local_pending, self.sent = [], [[] for _ in range(self.world)]
         self.succ_cache = {}
-        for pidx, rec in enumerate(self.frontier):
+        self.where = {}           # (fp, key) -> (parent index, ordinal): the generator's own bookkeeping (the product keeps it
+        for pidx, rec in enumerate(self.frontier):          # beside the candidate lists; it never crosses ranks)
             if rec is None:                                     # withdrawn by partition()
                 continue
             succ = orc.successors(self.P, rec)
@@ -78,7 +78,8 @@ class FakeShardEngine:
             self.generated += len(succ)
             self.deadlocks += 0 if succ else 1
             for k, s in enumerate(succ):
-                key = self._key(self.level + 1, s["auxkey"], pidx, k)
+                key = self._key(self.level + 1, s["auxkey"], self.fps[pidx], k)
+                self.where.setdefault((s["fp"], key), (pidx, k))
                 o = self.owner_of(s["fp"], self.world)
                 if o == self.rank:
                     if self._claim(s["fp"], key):
@@ -98,23 +99,25 @@ class FakeShardEngine:
         verdict = [1 if a and self.seen[fp] == key else 0 for a, (fp, key) in zip(alive, self.recv)]
         return torch.tensor(verdict, dtype=torch.uint8), 0
 
-    def _record_of(self, key):
-        pidx, k = (key >> 3) & 0xFFFFFFFF, (key >> 35) & 2047
+    def _record_of(self, fp, key):
+        pidx, k = self.where[(fp, key)]
         return self.succ_cache[pidx][k]
 
     def materialize(self, verdicts):
-        self.next_frontier, self.next_fps, self.next_keys = [], [], []
+        self.next_frontier, self.next_fps = [], []
         self.viol_fp, self.viol_mask, self.max_bag = U64_MAX, 0, 0
+        done = set()                                            # exactly-once: candidates with equal (fp, key) are one state
         for fp, key in self.local_pending:
-            if self.seen[fp] == key:
-                self._emit_local(self._record_of(key), key)
+            if self.seen[fp] == key and (fp, key) not in done:
+                done.add((fp, key))
+                self._emit_local(self._record_of(fp, key), key)
         for o in range(self.world):
             if o != self.rank and self.sent[o]:
                 v = [int(x) for x in verdicts[o].cpu()]
                 assert len(v) == len(self.sent[o])
                 for (fp, key), win in zip(self.sent[o], v):
                     if win:
-                        self._emit_local(self._record_of(key), key)     # the record stays with its generator
+                        self._emit_local(self._record_of(fp, key), key)     # the record stays with its generator
         return 0
 
     def count(self):
@@ -122,17 +125,16 @@ class FakeShardEngine:
 
     def empty_streams(self):
         z = torch.zeros(0, dtype=torch.int64)
-        return (z, z, z, z)
+        return (z, z, z)
 
     def export(self, first, n):
-        words, off, fps, keys = [], [], [], []
+        words, off, fps = [], [], []
         for i in range(first, first + n):
             off.append(len(words))
             words.extend(int(w) for w in self.next_frontier[i])
             fps.append(self.next_fps[i])
-            keys.append(self.next_keys[i])
-        del self.next_frontier[first: first + n], self.next_fps[first: first + n], self.next_keys[first: first + n]
-        return (_i64(words), _i64(off), _i64(fps), _i64(keys)), 0
+        del self.next_frontier[first: first + n], self.next_fps[first: first + n]
+        return (_i64(words), _i64(off), _i64(fps)), 0
 
     def _inv(self, s):
         if s["inv"]:
@@ -143,30 +145,30 @@ class FakeShardEngine:
         self._inv(s)
         self.next_frontier.append(np.array(s["words"], dtype=np.uint64))
         self.next_fps.append(s["fp"])
-        self.next_keys.append(key)
 
-    def append(self, words, off, fp, key):
-        w, o, f, k = _u64(words), _u64(off), _u64(fp), _u64(key)
+    def append(self, words, off, fp):
+        w, o, f = _u64(words), _u64(off), _u64(fp)
         bounds = o + [len(w)]
         for i in range(len(o)):
             self.next_frontier.append(np.array(w[bounds[i]: bounds[i + 1]], dtype=np.uint64))
             self.next_fps.append(f[i])
-            self.next_keys.append(k[i])
         return 0
 
     def commit(self):
         self.frontier, self.fps = self.next_frontier, self.next_fps
-        self.trace.append(self.next_keys)
         self.level += 1
         self.total += len(self.frontier)
         return dict(n_new=len(self.frontier), expand_ms=0.0, materialize_ms=0.0, generated=self.generated, deadlocks=self.deadlocks,
                     pending=len(self.local_pending), viol_fp=self.viol_fp, viol_mask=self.viol_mask, max_bag=0)
 
-    def find_fp(self, fp):
-        return self.fps.index(fp) if fp in self.fps else None
-
-    def trace_entry(self, level, index):
-        return self.trace[level - 1][index]
+    def lookup(self, key, level, by_low_bits):
+        """one step of a trace walk through this rank's part of the seen-set -> (fingerprint, meta) or None"""
+        if not by_low_bits:
+            return (key, self.seen[key]) if key in self.seen else None
+        for fp, meta in self.seen.items():
+            if (fp & ((1 << 35) - 1)) == key and (meta >> 55) == level:
+                return (fp, meta)
+        return None
 
     def level_fps(self):
         return np.array(sorted(f for f in self.fps if f is not None), dtype=np.uint64)

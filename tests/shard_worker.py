@@ -42,13 +42,14 @@ def main():
     # trace of the last state of the deepest non-empty local level (every rank takes part in every walk)
     walks = []
     for r in range(world):
-        # rank r nominates its state with the largest fingerprint; states are addressed by their index in the level's
-        # index range (which may contain unused slots), found by fingerprint
+        # rank r nominates its state with the largest fingerprint; states are addressed by fingerprint
         mine = eng.level_fps()
-        idx = eng.find_fp(int(mine[-1])) if (rank == r and len(mine)) else -1
-        idx = sc.x.allreduce([idx if idx is not None else -1], dist.ReduceOp.MAX)[0]
-        if idx >= 0:
-            walks.append(dict(rank=r, level=sc.level, index=idx, ords=sc.trace_ordinals(sc.level, r, idx)))
+        fp = int(mine[-1]) if (rank == r and len(mine)) else 0
+        hi, lo = sc.x.allreduce([fp >> 32, fp & 0xFFFFFFFF], dist.ReduceOp.MAX) if world > 1 else (fp >> 32, fp & 0xFFFFFFFF)
+        # (the two halves come from the same rank: every other rank contributes zeros)
+        fp = (hi << 32) | lo
+        if fp:
+            walks.append(dict(rank=r, level=sc.level, fp="%016x" % fp, ords=sc.trace_ordinals(sc.level, fp)))
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks,
                        bytes_sent=sc.x.bytes_sent, moved=sc.moved), f)

@@ -310,6 +310,28 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, key):
     mc.close()
 
 
+def test_counterexample_is_the_same_in_every_run_and_scheme(vt, orc):
+    """The counter-example is a function of the state space, not of the run: every state's seen-set slot names, of all (parent,
+    instance) pairs that produce it, the one with the smallest (canonical auxkey, ordinal, parent fingerprint), and the reported
+    violator is the one with the smallest fingerprint.  Two single-pass runs (racy insertion order, racy frontier order) and one
+    exact two-kernel run return the identical 19-state path for AcknowledgedWritesExistOnMajority on the shipped constants."""
+    P = orc.Params(3, 1, 2, 2, invariant_mask=2)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2, invariant_mask=2)
+    paths = []
+    for exact in (False, False, True):
+        mc = vt.ModelChecker(m, table_log2=26, frontier_words=1 << 28, frontier_states=1 << 23, pending_entries=1 << 24, exact_ties=exact)
+        assert mc.run() == "violation" and (mc.level, mc.distinct, mc.violation["mask"]) == (19, 9327854, 2)
+        tr = mc.trace(mc.violation["level"], mc.violation["index"])
+        same = mc.trace_fp(mc.violation["level"], mc.violation["fp"])
+        assert [a for a, _ in tr] == [a for a, _ in same] and all(np.array_equal(x[1], y[1]) for x, y in zip(tr, same))
+        paths.append([(a, tuple(int(x) for x in w)) for a, w in tr])
+        mid = mc.lookup(mc.violation["fp"])
+        assert mid is not None and mid[0] == mc.violation["fp"] and (mid[1] >> 55) == 19
+        mc.close()
+    assert paths[0] == paths[1] == paths[2] and len(paths[0]) == 19
+    _check_walk_with_oracle(orc, P, [(a, np.array(w, dtype=np.uint64)) for a, w in paths[0]], 2)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # TLCTrace.getTrace
 # ---------------------------------------------------------------------------------------------------------------------

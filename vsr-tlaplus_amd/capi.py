@@ -79,7 +79,9 @@ SYMBOLS = {
                                         C.POINTER(C.c_uint64)]),
     "vsrmc_checker_destroy": (None, [V]),
     "vsrmc_model_replay": (C.c_int32, [V, C.c_int32, V, C.c_int32, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
-    "vsrmc_checker_trace_entry": (C.c_int32, [V, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_trace_fp": (C.c_int32, [V, C.c_int32, C.c_uint64, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_lookup": (C.c_int32, [V, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64)]),
     "vsrmc_checker_level_checksum": (C.c_int32, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vsrmc_checker_select": (C.c_int32, [V, C.c_uint32, C.c_uint64, V, C.c_uint64, V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vsrmc_checker_find_fp": (C.c_int32, [V, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -102,9 +104,9 @@ SYMBOLS = {
     "vsrmc_shard_claim": (C.c_int32, [V, V, C.c_uint64, V]),
     "vsrmc_shard_materialize": (C.c_int32, [V, C.POINTER(ShardIO), V]),
     "vsrmc_shard_count": (C.c_int32, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "vsrmc_shard_export": (C.c_int32, [V, C.c_uint64, C.c_uint64, V, C.c_uint64, V, V, V, C.c_uint64, C.POINTER(C.c_uint64),
+    "vsrmc_shard_export": (C.c_int32, [V, C.c_uint64, C.c_uint64, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64)]),
-    "vsrmc_shard_append": (C.c_int32, [V, V, C.c_uint64, V, V, V, C.c_uint64]),
+    "vsrmc_shard_append": (C.c_int32, [V, V, C.c_uint64, V, V, C.c_uint64]),
     "vsrmc_shard_commit": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_shard_local_step": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_shard_partition": (C.c_int32, [V, C.POINTER(C.c_uint64)]),

@@ -380,8 +380,25 @@ class ModelChecker:
         check(capi.load().vsrmc_checker_find_fp(self._h, int(fp), C.byref(idx)))
         return None if idx.value == (1 << 64) - 1 else idx.value
 
+    def trace_fp(self, level, fp):
+        """TLCTrace.getTrace for the level-`level` state with fingerprint `fp` (any completed level)."""
+        lay = self.model.layout
+        cap_w = (level + 1) * int(lay.max_record_words)
+        words = np.zeros(cap_w, dtype=np.uint64)
+        off = np.zeros(level + 2, dtype=np.uint64)
+        acts = np.zeros(level + 2, dtype=np.int32)
+        n = C.c_uint64()
+        check(capi.load().vsrmc_checker_trace_fp(self._h, level, int(fp), _p(words), cap_w, _p(off), _p(acts), len(off), C.byref(n)))
+        return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(n.value)]
+
+    def lookup(self, key, level=0, by_low_bits=False):
+        """one step of a trace walk through the seen-set -> (fingerprint, meta) or None"""
+        found, fp, meta = C.c_int32(), C.c_uint64(), C.c_uint64()
+        check(capi.load().vsrmc_checker_lookup(self._h, int(key), int(level), int(by_low_bits), C.byref(found), C.byref(fp), C.byref(meta)))
+        return (fp.value, meta.value) if found.value else None
+
     def trace(self, level, index):
-        """TLCTrace.getTrace -> list of (action name, record words) from Init to the given state."""
+        """TLCTrace.getTrace -> list of (action name, record words) from Init to state `index` of the newest level."""
         lay = self.model.layout
         cap_w = (level + 1) * int(lay.max_record_words)
         words = np.zeros(cap_w, dtype=np.uint64)

@@ -164,7 +164,7 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32
 }
 
 // Lookup without insertion (probe level, vsrmc_checker_probe): is fp in the table, and with which meta word?
-__device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp, u64* meta, u32* nprobe) {
+__device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp, u64* meta, u32* nprobe, u64* slot_out = nullptr) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   u64 i = fp & mask;
   for (u32 lines = 0; lines < 2048; lines++) {
@@ -178,6 +178,7 @@ __device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp
       (*nprobe)++;
       if (sk.x == fp) {
         *meta = sk.y;
+        if (slot_out) *slot_out = lb + k;
         return true;
       }
       if (sk.x == 0) return false;
@@ -270,7 +271,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world_arg, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
          // fused single-pass mode (nx_words != nullptr): the lane that inserts a fingerprint writes the successor at once
-         u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u64* lvl_tr, u32 ichunk, u32 wchunk, int tile, u32 ccap /* work-list capacity per tile */,
+         u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap, u64* lvl_fp, u32 ichunk, u32 wchunk, int tile, u32 ccap /* work-list capacity per tile */,
          // fused + sharded (world > 1): successors owned by another rank pass the rank's sent-filter, are written to the local
          // next frontier SPECULATIVELY and announced to their owner; cand_idx remembers where, for k_apply_verdict
          u64* filter, u64 fmask, u64* cand_idx, u32 cchunk /* candidate entries a block reserves per owner and global atomic */,
@@ -297,6 +298,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out, s_skip;
   __shared__ u32 s_alive[VSR_TILE_MAX];
   __shared__ u64 s_ref[VSR_TILE_MAX];
+  __shared__ u64 s_pfp[VSR_TILE_MAX];                          // canonical fingerprint of every staged record (the parent part of its successors' keys)
   __shared__ u32 s_kcount[16], s_kbase[16];
   __shared__ int s_slotinfo[64];                               // decode of the replica-bound slots (m0 <= 50), see slot_info()
   // per-block accumulators (flushed once at the end: no hot global counters inside the tile loop)
@@ -371,6 +373,13 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
       }
     __syncthreads();
+    if (tid < np_tile && s_ref[tid] != 0) {                     // the parent's own fingerprint, from the view hashes it carries
+      const u64* r0 = s_rec + tid * stride;
+      u64 pf;
+      u32 pa;
+      canonical_fp(M, r0[0], r0 + M.h0, &pf, &pa);
+      s_pfp[tid] = pf;
+    }
 
     const u64 t_1 = __builtin_readcyclecounter();
     // ---- enumerate enabled instances, slot-major: item = slot * 64 + record, so the 64 lanes of a wave evaluate the same
@@ -471,7 +480,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         for (u32 k = used + tid; k < ichunk; k += VSR_BLOCK) {  // unused indices of the old chunk: invalid refs
           nx_off[base + k] = 0;
           lvl_fp[base + k] = 0;
-          if (lvl_tr) lvl_tr[base + k] = ~(u64)0;
         }
         __syncthreads();
         if (tid == 0) {
@@ -501,7 +509,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     if (!fused && s_chunk_used + ncand > pchunk) {          // block-uniform
       const u32 used = s_chunk_used;
       const u64 base = s_chunk_base;
-      for (u32 k = used + tid; k < pchunk && used < pchunk; k += VSR_BLOCK) pending[2 * (base + k) + 1] = ~(u64)0;
+      for (u32 k = used + tid; k < pchunk && used < pchunk; k += VSR_BLOCK) pending[3 * (base + k) + 1] = ~(u64)0;
       __syncthreads();
       if (tid == 0) {
         u64 nb = atomicAdd((unsigned long long*)&ctl->n_pending, (unsigned long long)pchunk);
@@ -539,7 +547,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       u64 fp;
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
-      const u64 key = meta_make(level, ak, rank, p_offset + p_base + (u64)p, ord);
+      const u64 key = meta_make(level, ak, ord, s_pfp[p]);
       const u64 a_2 = __builtin_readcyclecounter();
       if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
       if (!fused && world > 1) {                                // sharded seen-set, exact scheme: route to the owner of fp
@@ -551,6 +559,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
               if (i < cand_cap) {
                 cand_send[2 * ((u64)o * cand_cap + i)] = fp;
                 cand_send[2 * ((u64)o * cand_cap + i) + 1] = key;
+                cand_idx[(u64)o * cand_cap + i] = p_offset + p_base + (u64)p;   // the parent, for k_materialize on this rank
               } else {
                 raise_error(ctl, ERR_FRONTIER_FULL, i);
               }
@@ -593,7 +602,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           do_write = true;
         } else if (mode == MODE_REGEN) {
           u64 m = META_EMPTY;
-          do_write = probe_lookup(table, tmask, fp, &m, &my_probes) && m == key;
+          u64 slot_i = 0;
+          do_write = probe_lookup(table, tmask, fp, &m, &my_probes, &slot_i) && m == key &&
+                     atomicCAS((unsigned long long*)&table[slot_i].meta, (unsigned long long)key, (unsigned long long)(key | META_TAKEN)) == key;
         } else {
           bool claimed, full;
           table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, &my_probes, &full);
@@ -656,7 +667,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             }
           nx_off[idx] = (dst << 8) | (u64)clen;
           lvl_fp[idx] = fp;
-          if (lvl_tr) lvl_tr[idx] = key;
           const int bad = Ops::invariants(M, rec, D);
           if (bad && !remote) {
             atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
@@ -708,8 +718,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         if (lane == leader) b = atomicAdd(&s_tile_cursor, (u32)__popcll(active));
         b = __shfl(b, leader);
         const u64 i = s_chunk_base + s_tile_base + b + (u32)__popcll(active & (((u64)1 << lane) - 1));
-        pending[2 * i] = slot;
-        pending[2 * i + 1] = key;
+        pending[3 * i] = slot;
+        pending[3 * i + 1] = key;
+        pending[3 * i + 2] = p_offset + p_base + (u64)p;
       }
     }
     const u64 t_4 = __builtin_readcyclecounter();
@@ -755,7 +766,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       for (u32 k = used + tid; k < ichunk; k += VSR_BLOCK) {
         nx_off[base + k] = 0;
         lvl_fp[base + k] = 0;
-        if (lvl_tr) lvl_tr[base + k] = ~(u64)0;
       }
       if (world > 1) {
         __syncthreads();
@@ -778,7 +788,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     } else {
       const u32 used = s_chunk_used;
       const u64 base = s_chunk_base;
-      for (u32 k = used + tid; k < pchunk; k += VSR_BLOCK) pending[2 * (base + k) + 1] = ~(u64)0;
+      for (u32 k = used + tid; k < pchunk; k += VSR_BLOCK) pending[3 * (base + k) + 1] = ~(u64)0;
     }
     if (tid == 0) {
       if (s_acc[0]) atomicAdd((unsigned long long*)&ctl->generated, s_acc[0]);
@@ -833,9 +843,12 @@ __device__ __forceinline__ void lds_wave_sync() {   // orders this wave's LDS wr
 template <int SPEC>
 __global__ void __launch_bounds__(VSR_MAT_BLOCK)
 k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, const u64* __restrict__ pending,
-              u64 n_pending, const Slot* __restrict__ table, u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap,
-              u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w, int stride,
-              u32 ichunk /* state indices per reservation, >= 64 */, u32 wchunk /* words per reservation, >= 64 * stride */) {
+              u64 n_pending, Slot* table, u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap,
+              u64* lvl_fp, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w, int stride,
+              u32 ichunk /* state indices per reservation, >= 64 */, u32 wchunk /* words per reservation, >= 64 * stride */,
+              // entry i = pending[es * i ..): (slot or fingerprint, key[, parent index]); the parent's index in the frontier comes
+              // from the entry's third word (local pending list, es = 3) or from pidx_arr[i] (candidates sent to a remote owner, es = 2)
+              int es, const u64* __restrict__ pidx_arr) {
   Model M = Marg;
   specialise<SPEC>(M, Marg);
   typedef ModelOps<SPEC / 1000> Ops;
@@ -856,12 +869,15 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
     u64 key = 0, src = 0;
     int plen = 0;
     if (i < n_pending) {
-      key = pending[2 * i + 1];
+      key = pending[(u64)es * i + 1];
       if (key != ~(u64)0) {                                     // ~0 = unused entry of a block's chunk
-        // winner test: the owner's verdict (sharded, remote owner) or the slot's final meta word (local owner); the
-        // parent's ref is fetched alongside, not after (one HBM latency, not two)
-        const u64 ref = fr_off[meta_pidx(key)];
-        win = verdict ? (verdict[i] != 0) : (table[pending[2 * i]].meta == key);
+        // winner test: the owner's verdict (sharded, remote owner) or the slot's final meta word (local owner) — taken with a
+        // compare-and-swap key -> key | taken, so that a state is materialised exactly once; the parent's ref is fetched
+        // alongside, not after (one HBM latency, not two)
+        const u64 ref = fr_off[pidx_arr ? pidx_arr[i] : pending[(u64)es * i + 2]];
+        if (verdict) win = verdict[i] != 0;
+        else win = atomicCAS((unsigned long long*)&table[pending[(u64)es * i]].meta, (unsigned long long)key,
+                             (unsigned long long)(key | META_TAKEN)) == key;
         src = ref >> 8;
         plen = (int)(ref & 255);
         if (plen > stride) plen = stride;
@@ -980,7 +996,6 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
     if (win) {
       nx_off[idx] = (dst << 8) | (u64)clen;
       lvl_fp[idx] = fp;
-      if (lvl_tr) lvl_tr[idx] = key;
       if (bad) {
         atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
         atomicOr(&ctl->viol_mask, (u32)bad);
@@ -1007,7 +1022,6 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
   for (u32 k = lane; k < idx_left; k += 64) {
     nx_off[idx_base + k] = 0;
     lvl_fp[idx_base + k] = 0;
-    if (lvl_tr) lvl_tr[idx_base + k] = ~(u64)0;
   }
 }
 
@@ -1067,12 +1081,13 @@ __global__ void k_claim_batch(Slot* table, u64 tmask, const u64* __restrict__ en
   atomicAdd((unsigned long long*)&ctl->probes, (unsigned long long)np);
 }
 // k_verdict: after every claim of the level has landed: did candidate i win its slot?
-__global__ void k_verdict(const Slot* __restrict__ table, const u64* __restrict__ entries, const u64* __restrict__ rslot, u64 n,
-                          uint8_t* verdict) {
+__global__ void k_verdict(Slot* table, const u64* __restrict__ entries, const u64* __restrict__ rslot, u64 n, uint8_t* verdict) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64 s = rslot[i];
-  verdict[i] = (s != ~(u64)0 && table[s].meta == entries[2 * i + 1]) ? 1 : 0;
+  const u64 key = entries[2 * i + 1];
+  verdict[i] = (s != ~(u64)0 && atomicCAS((unsigned long long*)&table[s].meta, (unsigned long long)key,
+                                          (unsigned long long)(key | META_TAKEN)) == key) ? 1 : 0;
 }
 // Single-pass (fused) flavour of the owner's side: the candidate that INSERTS the fingerprint wins, every other candidate
 // of the same fingerprint loses — the same rule k_expand<true> applies to the successors this rank owns itself, which are
@@ -1102,7 +1117,7 @@ __global__ void k_claim_batch_fused(Slot* table, u64 tmask, const u64* __restric
 // written speculatively at state index cand_idx[i] (bits 62..63: violated-invariant mask); losers are withdrawn (invalid
 // ref, exactly like an unused index), winners that violate an invariant are reported now.
 __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __restrict__ cand_idx, const uint8_t* __restrict__ verdict,
-                                u64 n, u64* nx_off, u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl) {
+                                u64 n, u64* nx_off, u64* lvl_fp, LevelCtl* ctl) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 fp = entries[2 * i];
@@ -1118,7 +1133,6 @@ __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __re
   } else {
     nx_off[idx] = 0;
     lvl_fp[idx] = 0;
-    if (lvl_tr) lvl_tr[idx] = ~(u64)0;
   }
 }
 // k_partition: end of the replicated phase of a sharded run (every rank explored the small early levels by itself): keep
@@ -1136,23 +1150,22 @@ __global__ void k_partition(u64* off, u64* lvl_fp, u64 n, int rank, int world, u
   for (int o = 32; o > 0; o >>= 1) keep += __shfl_down(keep, o);
   if ((threadIdx.x & 63) == 0 && keep) atomicAdd((unsigned long long*)counter, (unsigned long long)keep);
 }
-// k_append_fixup: records received from a peer were copied to nx_words[base_words ..); publish their offsets,
-// fingerprints and trace keys at state indices n0 ..
-__global__ void k_append_fixup(u64* nx_off, u64* lvl_fp, u64* lvl_tr, const u64* __restrict__ rel_off,
-                               const u64* __restrict__ fps, const u64* __restrict__ keys, u64 n, u64 base_words) {
+// k_append_fixup: records received from a peer were copied to nx_words[base_words ..); publish their offsets and
+// fingerprints at state indices n0 .. (the predecessor pointers live in the owners' table slots and do not move)
+__global__ void k_append_fixup(u64* nx_off, u64* lvl_fp, const u64* __restrict__ rel_off, const u64* __restrict__ fps, u64 n,
+                               u64 base_words) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   nx_off[i] = rel_off[i] ? rel_off[i] + (base_words << 8) : 0;   // refs are (word offset << 8 | length); 0 stays invalid
   lvl_fp[i] = fps[i];
-  if (lvl_tr) lvl_tr[i] = keys[i];
 }
 
 // k_export: rebalancing between ranks — move the valid records of the index window [first, first + n) of the (new) frontier
 // into contiguous send streams and invalidate them here (ref = 0, fp = 0).  One wave per block, lane per index; records
 // are copied cooperatively (lane k moves word k).  counters[0] = records exported, counters[1] = words exported.
 __global__ void __launch_bounds__(64)
-k_export(const u64* __restrict__ nx_words, u64* nx_off, u64* lvl_fp, const u64* __restrict__ lvl_tr, u64 first, u64 n,
-         u64* out_words, u64 out_words_cap, u64* out_off, u64* out_fp, u64* out_key, u64 out_cap, u64* counters, u32* err) {
+k_export(const u64* __restrict__ nx_words, u64* nx_off, u64* lvl_fp, u64 first, u64 n,
+         u64* out_words, u64 out_words_cap, u64* out_off, u64* out_fp, u64 out_cap, u64* counters, u32* err) {
   const int lane = threadIdx.x;
   const u64 i = (u64)blockIdx.x * 64 + lane;
   u64 ref = 0;
@@ -1190,7 +1203,6 @@ k_export(const u64* __restrict__ nx_words, u64* nx_off, u64* lvl_fp, const u64* 
     const u64 k = kb + (u64)__popcll(wmask & (((u64)1 << lane) - 1));
     out_off[k] = (dst << 8) | (u64)len;
     out_fp[k] = lvl_fp[first + i];
-    out_key[k] = lvl_tr ? lvl_tr[first + i] : 0;
     nx_off[first + i] = 0;
     lvl_fp[first + i] = 0;
   }
@@ -1223,35 +1235,67 @@ __global__ void k_table_import(Slot* table, u64 tmask, const Slot* __restrict__ 
 }
 
 // Seed the search with the initial state (ModelChecker.doInit): record already in frontier slot 0.
-__global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl_fp, u64* lvl_tr, LevelCtl* ctl) {
+__global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl_fp, LevelCtl* ctl) {
   if (threadIdx.x || blockIdx.x) return;
   u64 fp;
   u32 ak;
   canonical_fp(M, rec[0], rec + M.h0, &fp, &ak);
-  u64 key = meta_make(1, ak, 0, 0, 0);
+  u64 key = meta_make(1, ak, 0, 0);
   bool found_old, full;
   u32 np = 0;
   table_claim(table, tmask, fp, key, 1, &found_old, &np, &full);
   lvl_fp[0] = fp;
-  if (lvl_tr) lvl_tr[0] = key;
   ctl->n_new = 1;
   ctl->words_new = (u64)(M.fixed + hdr_nmsg(rec[0]));
 }
 
-// TLCTrace.getTrace, backwards half: follow the (parent index, ordinal) log from state `idx` of level `level` to Init.
-// tr_all holds one meta key per state, level l (1-based) starting at level_base[l-1]; ords[l-2] = ordinal of the step
-// into level l.
-__global__ void k_trace_walk(const u64* tr_all, const u64* level_base, int level, u64 idx, u32* ords) {
+// Slot of the state whose fingerprint has the low bits `pfp` and whose level is `level` (the parent a meta word names): linear
+// probing stores a fingerprint at or after its home slot fp & mask with no empty slot in between, and the home slot only needs
+// the bits the meta word keeps (table_log2 <= 35).  ~0 = no such state.
+__device__ __forceinline__ u64 find_by_low_bits(const Slot* table, u64 tmask, u64 pfp, int level) {
+  u64 i = pfp & tmask;
+  for (u64 step = 0; step <= tmask; step++, i = (i + 1) & tmask) {
+    const u64 f = table[i].fp;
+    if (f == 0) return ~(u64)0;
+    if ((f & PFP_MASK) == pfp && meta_level(table[i].meta) == level) return i;
+  }
+  return ~(u64)0;
+}
+__device__ __forceinline__ u64 find_exact(const Slot* table, u64 tmask, u64 fp) {
+  u64 i = fp & tmask;
+  for (u64 step = 0; step <= tmask; step++, i = (i + 1) & tmask) {
+    const u64 f = table[i].fp;
+    if (f == 0) return ~(u64)0;
+    if (f == fp) return i;
+  }
+  return ~(u64)0;
+}
+// TLCTrace.getTrace, backwards half: follow the predecessor pointers in the seen-set from the state with fingerprint `fp` of
+// level `level` back to Init.  ords[l-2] = ordinal of the step into level l; fps[l-1] = fingerprint of the path's level-l state.
+// ords[0] = 0xFFFFFFFF on a broken chain (cannot happen on a table the search itself filled).
+__global__ void k_trace_walk(const Slot* table, u64 tmask, u64 fp, int level, u32* ords, u64* fps) {
   if (threadIdx.x || blockIdx.x) return;
-  for (int l = level; l >= 2; l--) {
-    u64 key = tr_all[level_base[l - 1] + idx];
-    if (key == ~(u64)0 || meta_level(key) != l) {              // an unused index of a wave's chunk, not a state
+  u64 slot = find_exact(table, tmask, fp);
+  for (int l = level; l >= 1; l--) {
+    if (slot == ~(u64)0 || meta_level(table[slot].meta) != l) {
       ords[0] = 0xFFFFFFFFu;
       return;
     }
-    ords[l - 2] = (u32)meta_ord(key);
-    idx = meta_pidx(key);
+    fps[l - 1] = table[slot].fp;
+    if (l == 1) break;
+    const u64 m = table[slot].meta;
+    ords[l - 2] = (u32)meta_ord(m);
+    slot = find_by_low_bits(table, tmask, meta_pfp(m), l - 1);
   }
+}
+// one step of the same walk, for walks that cross ranks (sharded runs): mode 0: exact fingerprint -> (fp, meta); mode 1: low
+// fingerprint bits + level -> (fp, meta).  out[0] = found (0 / 1), out[1] = fingerprint, out[2] = meta.
+__global__ void k_table_lookup(const Slot* table, u64 tmask, u64 key, int level, int mode, u64* out) {
+  if (threadIdx.x || blockIdx.x) return;
+  const u64 slot = mode == 0 ? find_exact(table, tmask, key) : find_by_low_bits(table, tmask, key & PFP_MASK, level);
+  out[0] = slot != ~(u64)0 ? 1 : 0;
+  out[1] = slot != ~(u64)0 ? table[slot].fp : 0;
+  out[2] = slot != ~(u64)0 ? table[slot].meta : 0;
 }
 
 // k_select: indices of the frontier records in which at least one instance of an action of `action_mask` (bit a = action id a)

@@ -945,16 +945,12 @@ struct vsrmc_checker {
   int num_cus = 256;
   int lds_stride = 65;
   int failed = 0;
-  u64* tr_all = nullptr;                 // TLCTrace: one meta key (parent index, ordinal) per state, level after level
-  u64 trace_cap = 0;
-  u64* d_level_base = nullptr;           // device copy of level_base (512 entries)
-  std::vector<u64> level_base;           // index of the first state of each level in tr_all
-  std::vector<u64> level_size;
+  // TLCTrace: there is no separate log — a state's slot in the seen-set holds the ordinal of the step that discovered it and
+  // 35 bits of its parent's fingerprint (meta word, vsr_model.hpp); traces are walked through the table (k_trace_walk)
   // state of the level in flight (between the phases)
   LevelCtl h;
   double t_level0 = 0, expand_ms = 0, materialize_ms = 0;
-  u64 tr_base = 0, nx_n = 0, nx_w = 0;
-  u64 tr_base0() const { return level_base.back() + level_size.back(); }
+  u64 nx_n = 0, nx_w = 0;
   u64 n_valid = 1;                       // states in the newest level (n_frontier is its index range, holes included)
   u64 cur_w = 0;                         // words of the current frontier buffer in use (chunk slack included)
   u64* rslot = nullptr;                  // sharded: slot of every received candidate
@@ -970,15 +966,17 @@ struct vsrmc_checker {
   void* plain_kernel = nullptr;          // the same without modes / sharding, when the configuration has one (ordinary unsharded levels)
   u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
   bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
-  u64 probe_key = ~(u64)0;               // vsrmc_checker_probe: trace key (parent index, ordinal) of the reported violator
-  u64 probe_key2 = ~(u64)0;              // vsrmc_checker_probe2: key of the second probed step (parent = a state of the virtual level)
+  // vsrmc_checker_probe / _probe2: where the reported violator's counter-example is walked from — the fingerprint of the deepest
+  // state of the path that is IN the seen-set, its level, and the ordinal of the one probed step beyond it (-1: none)
+  u64 probe_fp = 0;
+  int probe_level = 0, probe_extra_ord = -1;
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
   u64 words_cap(int b) const { return (b == 1 && opt.frontier_words_b) ? opt.frontier_words_b : opt.frontier_words; }
 };
 
 namespace {
 typedef void (*ExpandKernel)(Model, const u64*, const u64*, u64, int, int, Slot*, u64, u64*, u64, LevelCtl*, int, int, u64*, u64, u32, u64*,
-                             u64, u64*, u64, u64*, u64*, u32, u32, int, u32, u64*, u64, u64*, u32, int, u64);
+                             u64, u64*, u64, u64*, u32, u32, int, u32, u64*, u64, u64*, u32, int, u64);
 // k_expand<true, SPEC>: the configurations of BASELINE.json (and their small neighbours used by the tests) have their own
 // instantiation with the model constants folded in; anything else runs the generic one.
 ExpandKernel exact_kernel_for(const Model& M) {               // two-kernel levels: k_expand<false, SPEC>
@@ -991,8 +989,8 @@ ExpandKernel exact_kernel_for(const Model& M) {               // two-kernel leve
     default: return k_expand<false, 0>;
   }
 }
-typedef void (*MaterializeKernel)(Model, const u64*, const u64*, const u64*, u64, const Slot*, u64*, u64, u64*, u64, u64*, u64*, LevelCtl*,
-                                  const uint8_t*, u64*, u64*, int, u32, u32);
+typedef void (*MaterializeKernel)(Model, const u64*, const u64*, const u64*, u64, Slot*, u64*, u64, u64*, u64, u64*, LevelCtl*,
+                                  const uint8_t*, u64*, u64*, int, u32, u32, int, const u64*);
 MaterializeKernel materialize_kernel_for(const Model& M) {
   if (M.model_id == 1) return k_materialize<1000>;
   switch (M.R * 100 + M.C * 10 + M.n) {
@@ -1082,7 +1080,7 @@ int checker_seed(vsrmc_checker* c) {
   if (mine) {
     HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyDefault, c->stream));   // the buffer may be pinned host memory
     HIPCHK(hipMemcpyAsync(c->off[0], &zero, 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->tr_all, c->ctl);
+    hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->ctl);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1097,9 +1095,9 @@ int checker_seed(vsrmc_checker* c) {
   c->cur_max_bag = 0;
   c->bag_known = true;
   c->failed_code = 0;
-  c->probe_key = c->probe_key2 = ~(u64)0;
-  c->level_base.assign(1, 0);
-  c->level_size.assign(1, c->n_frontier);
+  c->probe_fp = 0;
+  c->probe_level = 0;
+  c->probe_extra_ord = -1;
   return 0;
 }
 }  // namespace
@@ -1126,8 +1124,9 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
       o->pending_entries < 4 * (uint64_t)VSR_CAND_CAP)
     return fail(VSRMC_E_ARG, "bad options");
   if (o->world < 1 || o->world > 8 || o->rank < 0 || o->rank >= o->world) return fail(VSRMC_E_ARG, "bad rank / world (1..8 ranks)");
-  // the trace key packs the parent's index of its level into 32 bits (meta_make): a larger index range would bleed into the ordinal
-  if (o->frontier_states > ((uint64_t)1 << 32)) return fail(VSRMC_E_ARG, "frontier_states > 2^32: a level's index range must fit the 32-bit parent index of the trace key");
+  // a state's predecessor pointer keeps 35 bits of the parent's fingerprint, from which the walk derives the parent's home slot
+  if (o->table_log2 > 35) return fail(VSRMC_E_ARG, "table_log2 > 35: the home slot of a parent must follow from the 35 fingerprint bits its children keep");
+  if (m->M.m0 + m->M.max_bag * (m->M.R + 1) >= 1024) return fail(VSRMC_E_ARG, "ordinals of this model do not fit the 10-bit field of the meta word");
   int rc = check_device(o->device);
   if (rc) return rc;
   vsrmc_checker* c = new vsrmc_checker();
@@ -1152,17 +1151,12 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     if (e == hipSuccess) e = hipMalloc((void**)&c->off[b], (o->frontier_states + 1) * 8);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&c->lvl_fp, o->frontier_states * 8);
-  if (o->keep_trace) {
-    c->trace_cap = o->trace_entries ? o->trace_entries : 8 * o->frontier_states;
-    if (e == hipSuccess) e = hipMalloc((void**)&c->tr_all, c->trace_cap * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_level_base, 512 * 8);
-  }
   if (e == hipSuccess && o->world > 1 && !o->exact_ties) {
     const int fl = o->filter_log2 > 0 ? o->filter_log2 : o->table_log2;
     c->fmask = ((u64)1 << fl) - 1;
     e = hipMalloc((void**)&c->filter, (c->fmask + 1) * 8);
   }
-  if (e == hipSuccess) e = hipMalloc((void**)&c->pending, o->pending_entries * 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->pending, o->pending_entries * 24);   // (slot, key, parent index) entries of the exact scheme
   if (e == hipSuccess) e = hipMalloc((void**)&c->ctl, sizeof(LevelCtl));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_find, 8);
   if (e != hipSuccess) {
@@ -1219,7 +1213,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
     // every block reserves pending-list room in chunks: the list must hold one chunk per block beyond the real entries
     const u32 pchunk = c->opt.pending_entries >= ((u64)1 << 24) ? 8192u : (u32)VSR_CAND_CAP;
-    if (fused && io && c->cand_idx_cap < (u64)c->opt.world * io->cand_cap) {
+    if (io && c->cand_idx_cap < (u64)c->opt.world * io->cand_cap) {   // per announced candidate: where it was written (fused) / its parent (exact)
       if (c->cand_idx) (void)hipFree(c->cand_idx);
       c->cand_idx = nullptr;
       c->cand_idx_cap = 0;
@@ -1233,8 +1227,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     // fused single-pass mode (unsharded, not exact_ties): the lane that inserts a fingerprint writes the successor itself
     const int nxt = c->cur ^ 1;
-    u64 nx_cap = c->opt.frontier_states;                       // the trace log bounds the level as well
-    if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
+    const u64 nx_cap = c->opt.frontier_states;
     u32 ichunk = 0, wchunk = 0, cchunk = 0;
     if (fused && io)   // candidate entries a block reserves per owner at a time: <= 1/4 of a bucket in total over all blocks
       cchunk = (u32)std::max<u64>(16, std::min<u64>(512, io->cand_cap / (4 * (u64)c->num_cus * 2)));
@@ -1257,13 +1250,13 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
                          dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
-                         c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr, ichunk,
+                         c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, ichunk,
                          wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk, mode, (u64)0);
     else
       hipLaunchKernelGGL(exact_kernel_for(M), dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
-                         0, nullptr, 0, nullptr, nullptr, 0, 0, tile, ccap, nullptr, 0, nullptr, 0, 0, (u64)0);
+                         0, nullptr, 0, nullptr, 0, 0, tile, ccap, nullptr, 0, io ? c->cand_idx : nullptr, 0, 0, (u64)0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -1274,7 +1267,6 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->expand_ms = ms;
   }
-  c->tr_base = c->tr_base0();
   c->nx_n = c->nx_w = 0;
   if (c->h.err) return level_error(c, c->h, c->level + 1);
   if (!c->opt.exact_ties) {                                    // fused: the level is already materialised (sharded: speculatively)
@@ -1292,7 +1284,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
 
 // phase 2: k_materialize over a list of (slot-or-fp, key) entries into one target (next frontier or a peer's bucket)
 int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t* verdict, u64* t_words, u64 t_words_cap,
-                      u64* t_off, u64 t_cap, u64* t_fp, u64* t_key, u64* cnt_n, u64* cnt_w) {
+                      u64* t_off, u64 t_cap, u64* t_fp, u64* cnt_n, u64* cnt_w, int entry_words, const u64* pidx_arr) {
   if (n == 0) return 0;
   const Model& M = c->model.M;
   // persistent waves: each keeps private output chunks, so the grid is sized to what is resident (LDS: 5 waves / CU)
@@ -1305,7 +1297,8 @@ int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t
   size_t lds = (size_t)VSR_MAT_BLOCK * c->lds_stride * 8;
   HIPCHK(hipEventRecord(c->ev[2], c->stream));
   hipLaunchKernelGGL(materialize_kernel_for(M), dim3(grid), dim3(VSR_MAT_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], entries, n,
-                     c->table, t_words, t_words_cap, t_off, t_cap, t_fp, t_key, c->ctl, verdict, cnt_n, cnt_w, c->lds_stride, ichunk, wchunk);
+                     c->table, t_words, t_words_cap, t_off, t_cap, t_fp, c->ctl, verdict, cnt_n, cnt_w, c->lds_stride, ichunk, wchunk,
+                     entry_words, pidx_arr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev[3], c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1318,11 +1311,10 @@ int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t
 // materialise the local pending list straight into the next frontier (self bucket)
 int phase_materialize_local(vsrmc_checker* c) {
   u64 n_pending = std::min<u64>(c->h.n_pending, c->opt.pending_entries);
-  u64 nx_cap = c->opt.frontier_states;                         // the trace log bounds the level as well
-  if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base ? c->trace_cap - c->tr_base : 0);
+  const u64 nx_cap = c->opt.frontier_states;
   const int nxt = c->cur ^ 1;
   int rc = phase_materialize(c, c->pending, n_pending, nullptr, c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap,
-                             c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base : nullptr, &c->ctl->n_new, &c->ctl->words_new);
+                             c->lvl_fp, &c->ctl->n_new, &c->ctl->words_new, 3, nullptr);
   if (rc) return rc;
   HIPCHK(hipMemcpy(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost));
   if (c->h.err) return level_error(c, c->h, c->level + 1);
@@ -1362,8 +1354,6 @@ int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
   info->words_new = c->nx_w;
   info->record_words = h.rec_words;
   if (n_new > 0 || c->opt.world > 1) {   // sharded: levels stay aligned across ranks even when this shard got nothing
-    c->level_base.push_back(c->tr_base);
-    c->level_size.push_back(c->nx_n);
     c->cur ^= 1;
     c->level += 1;
     c->distinct += n_new;
@@ -1436,8 +1426,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 ccap = fs.ccap;
     const size_t lds = fs.lds;
     const int nxt = c->cur ^ 1;
-    u64 nx_cap = c->opt.frontier_states;
-    if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
+    const u64 nx_cap = c->opt.frontier_states;
     unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * fs.blocks_per_cu);
     grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
     const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(fs.stride + 5));   // see phase_expand
@@ -1447,7 +1436,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
-                       c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base0() : nullptr,
+                       c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp,
                        ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0, mode, p_offset);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -1464,6 +1453,46 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     c->failed = 1;
     return fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables (SURVEY F2)");
   }
+  return 0;
+}
+
+// one step of a trace walk through the seen-set (k_table_lookup): by_low_bits = 0: the slot of fingerprint `key`; 1: the slot of
+// the level-`level` state whose fingerprint ends in the 35 bits `key` (what a child's meta word knows of its parent)
+int table_lookup(vsrmc_checker* c, u64 key, int level, int by_low_bits, bool* found, u64* fp, u64* meta) {
+  u64* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 24));
+  hipLaunchKernelGGL(k_table_lookup, dim3(1), dim3(64), 0, c->stream, c->table, c->tmask, key, level, by_low_bits, d);
+  u64 h[3] = {0, 0, 0};
+  const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+                  hipMemcpy(h, d, 24, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) return fail(VSRMC_E_HIP, "k_table_lookup failed");
+  *found = h[0] != 0;
+  *fp = h[1];
+  *meta = h[2];
+  return 0;
+}
+// TLCTrace.getTrace, backwards half: the ordinals of the path Init -> the level-`level` state with fingerprint `fp`
+int walk_trace(vsrmc_checker* c, u64 fp, int level, std::vector<u32>* ords) {
+  ords->assign((size_t)std::max(level - 1, 0), 0);
+  if (level < 1) return fail(VSRMC_E_ARG, "no such level");
+  u32* d_ords = nullptr;
+  u64* d_fps = nullptr;
+  HIPCHK(hipMalloc((void**)&d_ords, (u64)level * 4));
+  if (hipMalloc((void**)&d_fps, (u64)level * 8) != hipSuccess) {
+    (void)hipFree(d_ords);
+    return fail(VSRMC_E_HIP, "hipMalloc failed");
+  }
+  bool ok = hipMemsetAsync(d_ords, 0, (u64)level * 4, c->stream) == hipSuccess;
+  hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->table, c->tmask, fp, level, d_ords, d_fps);
+  ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+  std::vector<u32> h((size_t)level);
+  ok = ok && hipMemcpy(h.data(), d_ords, (u64)level * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d_ords);
+  (void)hipFree(d_fps);
+  if (!ok) return fail(VSRMC_E_HIP, "k_trace_walk failed");
+  if (h[0] == 0xFFFFFFFFu) return fail(VSRMC_E_STATE, "the seen-set holds no path from Init to this state at this level");
+  for (int l = 2; l <= level; l++) (*ords)[(size_t)l - 2] = h[(size_t)l - 2];
   return 0;
 }
 
@@ -1487,14 +1516,15 @@ int min_violator(vsrmc_checker* c, u64 fp_min, u64* key) {
 int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_level_info* probe) {
   if (!c || !virt || !probe) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
-  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   if (c->level + 2 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
   HIPCHK(hipSetDevice(c->opt.device));
   std::memset(virt, 0, sizeof(*virt));
   std::memset(probe, 0, sizeof(*probe));
   virt->viol_fp = virt->viol_index = probe->viol_fp = probe->viol_index = ~(u64)0;
-  c->probe_key = c->probe_key2 = ~(u64)0;
+  c->probe_fp = 0;
+  c->probe_level = 0;
+  c->probe_extra_ord = -1;
   const double t0 = now_s();
   c->expand_ms = 0;
   // ---- pass 1: the virtual level
@@ -1517,9 +1547,9 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   if (c->h.viol_fp != ~(u64)0) {                               // a violation already in level L+1: one probed step
     virt->viol_fp = c->h.viol_fp;
     virt->viol_mask = (int32_t)c->h.viol_mask;
-    rc = min_violator(c, c->h.viol_fp, &c->probe_key);
-    if (rc) return rc;
-    if (c->probe_key != ~(u64)0) virt->viol_index = meta_pidx(c->probe_key);
+    c->probe_fp = c->h.viol_fp;                                 // the virtual level's states are in the seen-set: walk from the violator itself
+    c->probe_level = c->level + 1;
+    c->probe_extra_ord = -1;
     return 0;
   }
   // ---- pass 2: slices of the newest level -> their part of level L+1 -> probe of level L+2
@@ -1527,8 +1557,7 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   c->expand_ms = 0;
   const int nxt = c->cur ^ 1;
   const u64 g = std::max<u64>(1, (gen1 + c->n_frontier - 1) / std::max<u64>(1, c->n_frontier));   // successors per parent, rounded up
-  u64 nx_cap = c->opt.frontier_states;
-  nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base0() ? c->trace_cap - c->tr_base0() : 0);
+  const u64 nx_cap = c->opt.frontier_states;
   // a slice may not produce more than a quarter of the next buffers (index range and words), chunk slack included
   u64 slice = std::min<u64>(nx_cap / (4 * g), c->words_cap(nxt) / (4 * g * (u64)c->lds_stride));
   slice = std::max<u64>(128, slice & ~(u64)127);
@@ -1549,14 +1578,20 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
     if (c->h.viol_fp != ~(u64)0) {
       mask2 |= c->h.viol_mask;
       if (c->h.viol_fp < best_fp) {
-        u64 k2 = ~(u64)0, k1 = ~(u64)0;
+        u64 k2 = ~(u64)0;
         rc = min_violator(c, c->h.viol_fp, &k2);
         if (rc) return rc;
-        if (k2 != ~(u64)0) {                                    // its parent is state pidx(k2) of this slice's part: the parent's own key
-          HIPCHK(hipMemcpy(&k1, c->tr_all + c->tr_base0() + meta_pidx(k2), 8, hipMemcpyDeviceToHost));
-          best_fp = c->h.viol_fp;
-          c->probe_key = k1;
-          c->probe_key2 = k2;
+        if (k2 != ~(u64)0) {                                    // its parent is a state of the virtual level: in the seen-set, found by its fingerprint bits
+          bool found = false;
+          u64 pfp = 0, pmeta = 0;
+          rc = table_lookup(c, meta_pfp(k2), c->level + 1, 1, &found, &pfp, &pmeta);
+          if (rc) return rc;
+          if (found) {
+            best_fp = c->h.viol_fp;
+            c->probe_fp = pfp;
+            c->probe_level = c->level + 1;
+            c->probe_extra_ord = meta_ord(k2);
+          }
         }
       }
     }
@@ -1575,7 +1610,6 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   if (best_fp != ~(u64)0) {
     probe->viol_fp = best_fp;
     probe->viol_mask = (int32_t)mask2;
-    probe->viol_index = meta_pidx(c->probe_key);               // index (in the newest level) of the violator's GRANDPARENT
   }
   return 0;
 }
@@ -1589,7 +1623,9 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
   if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
   if (c->failed && c->failed_code != ERR_FRONTIER_FULL) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   c->failed = 0;
-  c->probe_key = c->probe_key2 = ~(u64)0;
+  c->probe_fp = 0;
+  c->probe_level = 0;
+  c->probe_extra_ord = -1;
   int rc = phase_expand(c, nullptr, MODE_PROBE);
   if (rc) return rc;
   std::memset(info, 0, sizeof(*info));
@@ -1611,12 +1647,20 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
     info->viol_fp = c->h.viol_fp;
     info->viol_mask = (int32_t)c->h.viol_mask;
     // the violator that is reported: smallest fingerprint; among its (fp, key) entries the smallest key
-    const u64 n = std::min<u64>(c->h.n_pending, std::min<u64>(c->opt.pending_entries, (u64)1 << 20));
-    std::vector<u64> list(2 * n);
-    HIPCHK(hipMemcpy(list.data(), c->pending, 16 * n, hipMemcpyDeviceToHost));
-    for (u64 i = 0; i < n; i++)
-      if (list[2 * i] == c->h.viol_fp && list[2 * i + 1] < c->probe_key) c->probe_key = list[2 * i + 1];
-    if (c->probe_key != ~(u64)0) info->viol_index = meta_pidx(c->probe_key);   // index of its PARENT in the newest level
+    u64 key = ~(u64)0;
+    rc = min_violator(c, c->h.viol_fp, &key);
+    if (rc) return rc;
+    if (key != ~(u64)0) {                                       // its parent: the newest level's state with these fingerprint bits
+      bool found = false;
+      u64 pfp = 0, pmeta = 0;
+      rc = table_lookup(c, meta_pfp(key), c->level, 1, &found, &pfp, &pmeta);
+      if (rc) return rc;
+      if (found) {
+        c->probe_fp = pfp;
+        c->probe_level = c->level;
+        c->probe_extra_ord = meta_ord(key);
+      }
+    }
   }
   return 0;
 }
@@ -1624,26 +1668,13 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
 int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
                                   uint64_t cap_states, uint64_t* n_states) {
   if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
-  if (c->probe_key == ~(u64)0) return fail(VSRMC_E_STATE, "no violation recorded by vsrmc_checker_probe");
-  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
-  const int extra = c->probe_key2 != ~(u64)0 ? 2 : 1;
-  const int level = c->level, nsteps = level - 1 + extra;       // level - 1 logged steps + the probed one(s)
+  if (c->probe_fp == 0) return fail(VSRMC_E_STATE, "no violation recorded by vsrmc_checker_probe");
   HIPCHK(hipSetDevice(c->opt.device));
-  std::vector<u32> ords((size_t)nsteps);
-  if (level > 1) {
-    u32* d_ords = nullptr;
-    HIPCHK(hipMalloc((void**)&d_ords, (u64)(level - 1) * 4));
-    HIPCHK(hipMemcpy(c->d_level_base, c->level_base.data(), c->level_base.size() * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->tr_all, c->d_level_base, level, meta_pidx(c->probe_key), d_ords);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(ords.data(), d_ords, (u64)(level - 1) * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_ords);
-    if (ords[0] == 0xFFFFFFFFu) return fail(VSRMC_E_STATE, "the trace log does not hold the violator's parent");
-  }
-  ords[(size_t)level - 1] = (u32)meta_ord(c->probe_key);
-  if (extra == 2) ords[(size_t)level] = (u32)meta_ord(c->probe_key2);
-  return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), nsteps, words, cap_words, off, actions, cap_states, n_states);
+  std::vector<u32> ords;
+  int rc = walk_trace(c, c->probe_fp, c->probe_level, &ords);   // Init .. the deepest state of the path that is in the seen-set
+  if (rc) return rc;
+  if (c->probe_extra_ord >= 0) ords.push_back((u32)c->probe_extra_ord);   // ... and the probed step beyond it
+  return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), (int32_t)ords.size(), words, cap_words, off, actions, cap_states, n_states);
 }
 
 int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
@@ -1754,8 +1785,7 @@ int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, cons
       if (n == 0) continue;
       if (!d_verdict_in) return fail(VSRMC_E_ARG, "verdicts missing");
       hipLaunchKernelGGL(k_apply_verdict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, io->cand_send + 2 * (u64)o * io->cand_cap,
-                         c->cand_idx + (u64)o * io->cand_cap, d_verdict_in + (u64)o * io->cand_cap, n, c->off[nxt], c->lvl_fp,
-                         c->tr_all ? c->tr_all + c->tr_base : nullptr, c->ctl);
+                         c->cand_idx + (u64)o * io->cand_cap, d_verdict_in + (u64)o * io->cand_cap, n, c->off[nxt], c->lvl_fp, c->ctl);
       HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
@@ -1776,15 +1806,14 @@ int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, cons
   }
   int rc = phase_materialize_local(c);
   const int nxt = c->cur ^ 1;
-  u64 nx_cap = c->opt.frontier_states;
-  if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base ? c->trace_cap - c->tr_base : 0);
+  const u64 nx_cap = c->opt.frontier_states;
   for (int o = 0; o < c->opt.world && !rc; o++) {
     if (o == c->opt.rank) continue;
     u64 n = std::min<u64>(c->h.cand_cnt[o], io->cand_cap);
     if (n && !d_verdict_in) return fail(VSRMC_E_ARG, "verdicts missing");
     rc = phase_materialize(c, io->cand_send + 2 * (u64)o * io->cand_cap, n, d_verdict_in + (u64)o * io->cand_cap, c->words[nxt],
-                           c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, c->tr_all ? c->tr_all + c->tr_base : nullptr,
-                           &c->ctl->n_new, &c->ctl->words_new);
+                           c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, &c->ctl->n_new, &c->ctl->words_new, 2,
+                           c->cand_idx + (u64)o * io->cand_cap);
   }
   if (rc) return rc;
   HIPCHK(hipMemcpy(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost));
@@ -1810,19 +1839,18 @@ int32_t vsrmc_shard_count(vsrmc_checker* c, uint64_t* n_valid, uint64_t* n_range
 }
 
 int32_t vsrmc_shard_export(vsrmc_checker* c, uint64_t first, uint64_t n, uint64_t* d_words, uint64_t words_cap, uint64_t* d_off,
-                           uint64_t* d_fp, uint64_t* d_key, uint64_t cap, uint64_t* n_out, uint64_t* words_out) {
+                           uint64_t* d_fp, uint64_t cap, uint64_t* n_out, uint64_t* words_out) {
   if (!c || !n_out || !words_out) return fail(VSRMC_E_ARG, "NULL argument");
   *n_out = *words_out = 0;
   if (n == 0) return 0;
-  if (!d_words || !d_off || !d_fp || !d_key || first + n > c->nx_n) return fail(VSRMC_E_ARG, "bad export window");
+  if (!d_words || !d_off || !d_fp || first + n > c->nx_n) return fail(VSRMC_E_ARG, "bad export window");
   HIPCHK(hipSetDevice(c->opt.device));
   const int nxt = c->cur ^ 1;
   u64* d_cnt = nullptr;
   HIPCHK(hipMalloc((void**)&d_cnt, 32));
   HIPCHK(hipMemsetAsync(d_cnt, 0, 32, c->stream));
   hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->words[nxt], c->off[nxt] + 0, c->lvl_fp,
-                     c->tr_all ? c->tr_all + c->tr_base : nullptr, first, n, d_words, words_cap, d_off, d_fp, d_key, cap, d_cnt,
-                     (u32*)(d_cnt + 2));
+                     first, n, d_words, words_cap, d_off, d_fp, cap, d_cnt, (u32*)(d_cnt + 2));
   HIPCHK(hipGetLastError());
   u64 h[4];
   HIPCHK(hipMemcpyAsync(h, d_cnt, 32, hipMemcpyDeviceToHost, c->stream));
@@ -1835,21 +1863,20 @@ int32_t vsrmc_shard_export(vsrmc_checker* c, uint64_t first, uint64_t n, uint64_
 }
 
 int32_t vsrmc_shard_append(vsrmc_checker* c, const uint64_t* d_words, uint64_t n_words, const uint64_t* d_off,
-                           const uint64_t* d_fp, const uint64_t* d_key, uint64_t n) {
+                           const uint64_t* d_fp, uint64_t n) {
   if (!c) return fail(VSRMC_E_ARG, "NULL argument");
   if (n == 0) return 0;
-  if (!d_words || !d_off || !d_fp || !d_key) return fail(VSRMC_E_ARG, "NULL argument");
+  if (!d_words || !d_off || !d_fp) return fail(VSRMC_E_ARG, "NULL argument");
   HIPCHK(hipSetDevice(c->opt.device));
-  u64 nx_cap = c->opt.frontier_states;
-  if (c->tr_all) nx_cap = std::min<u64>(nx_cap, c->trace_cap > c->tr_base ? c->trace_cap - c->tr_base : 0);
+  const u64 nx_cap = c->opt.frontier_states;
   if (c->nx_n + n > nx_cap || c->nx_w + n_words > c->words_cap(c->cur ^ 1)) {
     c->failed = 1;
-    return fail(VSRMC_E_REP, "frontier / trace buffers full while appending received records");
+    return fail(VSRMC_E_REP, "frontier buffers full while appending received records");
   }
   const int nxt = c->cur ^ 1;
   HIPCHK(hipMemcpyAsync(c->words[nxt] + c->nx_w, d_words, n_words * 8, hipMemcpyDefault, c->stream));
   hipLaunchKernelGGL(k_append_fixup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->off[nxt] + c->nx_n,
-                     c->lvl_fp + c->nx_n, c->tr_all ? c->tr_all + c->tr_base + c->nx_n : nullptr, d_off, d_fp, d_key, n, c->nx_w);
+                     c->lvl_fp + c->nx_n, d_off, d_fp, n, c->nx_w);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   c->nx_n += n;
@@ -1866,7 +1893,7 @@ int32_t vsrmc_shard_commit(vsrmc_checker* c, vsrmc_level_info* info) {
 // ---- checkpoint / recover ≙ TLC's checkpoints (ModelChecker.checkpoint: FPSet.beginChkpt/commitChkpt, StateQueue, TLCTrace) ----
 namespace {
 struct ChkHeader {
-  char magic[8];                 // "VSRMCCK1"
+  char magic[8];                 // "VSRMCCK2" (1 = the format with a separate trace log and index-based meta words)
   int32_t consts[8];             // R, C, n, L, symmetry, inv_mask, assume_commit, np
   int32_t level, cur_unused;
   u64 n_frontier, n_valid, cur_w, distinct, total_generated, n_levels, table_entries, trace_entries;
@@ -1901,7 +1928,7 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   if (!f) return fail(VSRMC_E_CFG, "cannot write " + tmp);
   ChkHeader h;
   std::memset(&h, 0, sizeof(h));
-  std::memcpy(h.magic, "VSRMCCK1", 8);
+  std::memcpy(h.magic, "VSRMCCK2", 8);
   const int32_t consts[8] = {M.R, M.C, M.n, M.L, c->model.symmetry, M.inv_mask, M.assume_commit, M.np};
   std::memcpy(h.consts, consts, sizeof(consts));
   h.level = c->level;
@@ -1910,8 +1937,8 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   h.cur_w = c->cur_w;
   h.distinct = c->distinct;
   h.total_generated = c->total_generated;
-  h.n_levels = c->level_base.size();
-  h.trace_entries = c->tr_all ? c->tr_base0() : 0;
+  h.n_levels = (u64)c->level;
+  h.trace_entries = 0;                                          // the predecessor pointers travel inside the seen-set slots
   std::vector<char> buf((size_t)64 << 20);
   bool ok = true;
   // the seen-set: occupied slots only, window by window (the export buffer holds one window)
@@ -1925,8 +1952,6 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
     return fail(VSRMC_E_HIP, "hipMalloc of the checkpoint export window failed");
   }
   ok = std::fwrite(&h, sizeof(h), 1, f) == 1;                   // rewritten at the end with table_entries
-  ok = ok && std::fwrite(c->level_base.data(), 8, c->level_base.size(), f) == c->level_base.size();
-  ok = ok && std::fwrite(c->level_size.data(), 8, c->level_size.size(), f) == c->level_size.size();
   u64 total = 0;
   for (u64 first = 0; first < slots && ok; first += win) {
     u64 cnt = 0;
@@ -1941,7 +1966,6 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   ok = ok && dev_to_file(f, c->words[c->cur], c->cur_w * 8, buf);
   ok = ok && dev_to_file(f, c->off[c->cur], c->n_frontier * 8, buf);
   ok = ok && dev_to_file(f, c->lvl_fp, c->n_frontier * 8, buf);
-  if (c->tr_all) ok = ok && dev_to_file(f, c->tr_all, h.trace_entries * 8, buf);
   h.table_entries = total;
   ok = ok && std::fseek(f, 0, SEEK_SET) == 0 && std::fwrite(&h, sizeof(h), 1, f) == 1;
   ok = (std::fclose(f) == 0) && ok;
@@ -1958,19 +1982,9 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
   FILE* f = std::fopen(path, "rb");
   if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + path);
   ChkHeader h;
-  std::vector<u64> level_base, level_size;
-  bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VSRMCCK1", 8) == 0 && h.n_levels >= 1 && h.n_levels < 512;
-  if (ok) {
-    level_base.resize(h.n_levels);
-    level_size.resize(h.n_levels);
-    ok = std::fread(level_base.data(), 8, h.n_levels, f) == h.n_levels && std::fread(level_size.data(), 8, h.n_levels, f) == h.n_levels;
-  }
-  // header invariants (a truncated or foreign file must not become an inconsistent checker): one level_base / level_size entry
-  // per level, fewer than 511 levels, no more states than indices, and a trace log that ends where the newest level ends
-  if (ok)
-    ok = h.level >= 1 && h.level < 511 && (u64)h.level == h.n_levels && h.n_valid <= h.n_frontier && (level_size.back() == h.n_frontier || h.n_frontier == 0) &&
-         (h.trace_entries == 0 || level_base.back() + level_size.back() == h.trace_entries);
-  for (u64 l = 1; ok && l < h.n_levels; l++) ok = level_base[l] == level_base[l - 1] + level_size[l - 1];
+  bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VSRMCCK2", 8) == 0;
+  // header invariants (a truncated or foreign file must not become an inconsistent checker)
+  if (ok) ok = h.level >= 1 && h.level < 511 && (u64)h.level == h.n_levels && h.n_valid <= h.n_frontier && h.trace_entries == 0;
   if (!ok) {
     std::fclose(f);
     return fail(VSRMC_E_CFG, std::string(path) + " is not a (consistent) vsrmc checkpoint");
@@ -1983,21 +1997,15 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
   }
   const int buf_of_level = (h.level - 1) & 1;                   // level L lives in record buffer (L - 1) mod 2, also after recovery
   const u64 cap_of_buf = (buf_of_level == 1 && o->frontier_words_b) ? o->frontier_words_b : o->frontier_words;
-  if (h.n_frontier > o->frontier_states || h.cur_w > cap_of_buf || 2 * h.table_entries > ((u64)1 << o->table_log2) ||
-      (o->keep_trace && h.trace_entries == 0 && h.level > 1)) {
+  if (h.n_frontier > o->frontier_states || h.cur_w > cap_of_buf || 2 * h.table_entries > ((u64)1 << o->table_log2)) {
     std::fclose(f);
-    return fail(VSRMC_E_ARG, "the options are too small for this checkpoint (frontier, table) or ask for a trace log it does not have");
+    return fail(VSRMC_E_ARG, "the options are too small for this checkpoint (frontier, table)");
   }
   vsrmc_checker* c = nullptr;
   int rc = vsrmc_checker_create(m, o, &c);
   if (rc) {
     std::fclose(f);
     return rc;
-  }
-  if (c->tr_all && h.trace_entries > c->trace_cap) {
-    std::fclose(f);
-    vsrmc_checker_destroy(c);
-    return fail(VSRMC_E_ARG, "trace_entries too small for this checkpoint");
   }
   std::vector<char> buf((size_t)64 << 20);
   // the seen-set: empty it (create seeded Init), re-insert the saved slots
@@ -2021,9 +2029,6 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
   ok = ok && file_to_dev(f, c->words[c->cur], h.cur_w * 8, buf);
   ok = ok && file_to_dev(f, c->off[c->cur], h.n_frontier * 8, buf);
   ok = ok && file_to_dev(f, c->lvl_fp, h.n_frontier * 8, buf);
-  if (h.trace_entries) {
-    if (c->tr_all) ok = ok && file_to_dev(f, c->tr_all, h.trace_entries * 8, buf);
-  }
   std::fclose(f);
   if (!ok) {
     vsrmc_checker_destroy(c);
@@ -2036,8 +2041,6 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
   c->cur_w = h.cur_w;
   c->distinct = h.distinct;
   c->total_generated = h.total_generated;
-  c->level_base = level_base;
-  c->level_size = level_size;
   *out = c;
   return 0;
 }
@@ -2060,13 +2063,14 @@ int32_t vsrmc_checker_find_fp(vsrmc_checker* c, uint64_t fp, uint64_t* index) {
   return find_fp_newest(c, fp, index);
 }
 
-int32_t vsrmc_checker_trace_entry(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* key) {
-  if (!c || !key) return fail(VSRMC_E_ARG, "NULL argument");
-  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
-  if (level < 1 || level > (int)c->level_base.size() || index >= c->level_size[level - 1]) return fail(VSRMC_E_ARG, "no such state");
+int32_t vsrmc_checker_lookup(vsrmc_checker* c, uint64_t key, int32_t level, int32_t by_low_bits, int32_t* found, uint64_t* fp,
+                             uint64_t* meta) {
+  if (!c || !found || !fp || !meta) return fail(VSRMC_E_ARG, "NULL argument");
   HIPCHK(hipSetDevice(c->opt.device));
-  HIPCHK(hipMemcpy(key, c->tr_all + c->level_base[level - 1] + index, 8, hipMemcpyDeviceToHost));
-  return 0;
+  bool f = false;
+  int rc = table_lookup(c, key, level, by_low_bits, &f, fp, meta);
+  *found = f ? 1 : 0;
+  return rc;
 }
 
 int32_t vsrmc_checker_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, uint64_t* n) {
@@ -2234,28 +2238,28 @@ int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t*
   return 0;
 }
 
+int32_t vsrmc_checker_trace_fp(vsrmc_checker* c, int32_t level, uint64_t fp, uint64_t* words, uint64_t cap_words, uint64_t* off,
+                               int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
+  if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: walk the predecessor pointers with vsrmc_checker_lookup on every rank");
+  if (level < 1 || level > c->level) return fail(VSRMC_E_ARG, "no such level");
+  HIPCHK(hipSetDevice(c->opt.device));
+  std::vector<u32> ords;
+  int rc = walk_trace(c, fp, level, &ords);                    // through the seen-set, back to Init, on the device
+  if (rc) return rc;
+  return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), (int32_t)ords.size(), words, cap_words, off, actions, cap_states, n_states);
+}
+
 int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words, uint64_t* off,
                             int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
   if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
-  if (!c->tr_all) return fail(VSRMC_E_STATE, "created with keep_trace = 0");
-  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: walk the log with vsrmc_checker_trace_entry on the owning ranks");
-  if (level < 1 || level > (int)c->level_base.size() || index >= c->level_size[level - 1])
-    return fail(VSRMC_E_ARG, "no such state");
-  int nsteps = level - 1;
+  if (level != c->level || index >= c->n_frontier)
+    return fail(VSRMC_E_ARG, "no such state: states are addressed by index in the newest level only (older ones: vsrmc_checker_trace_fp)");
   HIPCHK(hipSetDevice(c->opt.device));
-  std::vector<u32> ords(std::max(nsteps, 1));
-  if (nsteps > 0) {   // walk the (parent index, ordinal) log back to Init on the device
-    u32* d_ords = nullptr;
-    HIPCHK(hipMalloc((void**)&d_ords, (u64)nsteps * 4));
-    HIPCHK(hipMemcpy(c->d_level_base, c->level_base.data(), c->level_base.size() * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->tr_all, c->d_level_base, level, index, d_ords);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(ords.data(), d_ords, (u64)nsteps * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_ords);
-    if (ords[0] == 0xFFFFFFFFu) return fail(VSRMC_E_ARG, "no such state: the index is an unused slot of the level's index range");
-  }
-  return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), nsteps, words, cap_words, off, actions, cap_states, n_states);
+  u64 fp = 0;
+  HIPCHK(hipMemcpy(&fp, c->lvl_fp + index, 8, hipMemcpyDeviceToHost));
+  if (fp == 0) return fail(VSRMC_E_ARG, "no such state: the index is an unused slot of the level's index range");
+  return vsrmc_checker_trace_fp(c, level, fp, words, cap_words, off, actions, cap_states, n_states);
 }
 
 void vsrmc_checker_destroy(vsrmc_checker* c) {
@@ -2267,8 +2271,6 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
     if (c->off[b]) (void)hipFree(c->off[b]);
   }
   if (c->lvl_fp) (void)hipFree(c->lvl_fp);
-  if (c->tr_all) (void)hipFree(c->tr_all);
-  if (c->d_level_base) (void)hipFree(c->d_level_base);
   if (c->pending) (void)hipFree(c->pending);
   if (c->ctl) (void)hipFree(c->ctl);
   if (c->d_find) (void)hipFree(c->d_find);

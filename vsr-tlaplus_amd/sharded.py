@@ -143,10 +143,11 @@ class ShardedChecker:
         claim(cands (n,2))                -> (uint8 verdict tensor (n,), err)
         materialize(verdicts per peer)    -> err                       (winners go to the local next frontier)
         count()                           -> (valid states, index range) of the local next frontier
-        export(first, n)                  -> ((words, off, fp, key) tensors, err): records of an index window, removed locally
-        append(words, off, fp, key)       -> err
+        export(first, n)                  -> ((words, off, fp) tensors, err): records of an index window, removed locally
+        append(words, off, fp)            -> err
         commit()                          -> dict(n_new, generated, deadlocks, viol_fp, viol_mask, max_bag, ...)
-        find_fp(fp) -> index or None ; trace_entry(level, index) -> key ; error_text()
+        lookup(key, level, by_low_bits)   -> (fingerprint, meta) or None: one step of a trace walk through this rank's seen-set
+        error_text()
         local_step()                      -> dict like commit(): one whole level on this rank alone (replicated phase)
         partition()                       -> states of the current frontier this rank keeps (its own)
 
@@ -190,10 +191,7 @@ class ShardedChecker:
         if info["n_new"]:
             self.levels.append(out)
         if viol is not None and self.violation is None:
-            # every rank holds the state; rank 0's copy (and its private trace log) is the one that gets walked
-            self.violation = dict(level=self.level, rank=0, index=self.e.find_fp(viol) if self.rank == 0 else -1, fp=viol,
-                                  mask=info["viol_mask"])
-            self.violation["index"] = self.x.allreduce([self.violation["index"]], dist.ReduceOp.MAX)[0]
+            self.violation = dict(level=self.level, fp=viol, mask=info["viol_mask"])    # every rank holds the state
         elif info["n_new"] >= self.replicate_below:
             self._end_replicated()
         return out
@@ -226,14 +224,14 @@ class ShardedChecker:
             hi -= width
             send[dst] = streams
         got = []
-        for s in range(4):                                      # words, off, fp, key
+        for s in range(3):                                      # words, off, fp
             r, err, _ = x.exchange([send[p][s] for p in range(w)], err)
             got.append(r)
         self._raise_if(err, "rebalance")
         err = 0
         for p in range(w):
             if p != me and got[1][p].shape[0]:
-                err = max(err, e.append(got[0][p], got[1][p], got[2][p], got[3][p]))
+                err = max(err, e.append(got[0][p], got[1][p], got[2][p]))
                 self.moved += int(got[1][p].shape[0])
         return err
 
@@ -271,13 +269,11 @@ class ShardedChecker:
         if s[0]:
             self.levels.append(out)
         if gviol != U64_MAX and self.violation is None:
-            idx = e.find_fp(gviol)
-            where = x.allreduce([me if idx is not None else -1, idx if idx is not None else -1], dist.ReduceOp.MAX)
             mask = 0
             for r in rows:
                 if ((r[4] << 32) | r[5]) == gviol:
                     mask |= r[7]
-            self.violation = dict(level=self.level, rank=where[0], index=where[1], fp=gviol, mask=mask)
+            self.violation = dict(level=self.level, fp=gviol, mask=mask)
         return out
 
     def run(self, max_depth=None, stop_on_violation=True):
@@ -290,16 +286,27 @@ class ShardedChecker:
             if self.violation is not None and stop_on_violation:
                 return "violation"
 
-    def trace_ordinals(self, level, rank, index):
-        """Walk the distributed (parent rank, parent index, ordinal) log back to Init; every rank must call this."""
+    def _agree(self, hit):
+        """hit = (a, b) 64-bit values on the rank(s) that found something, None elsewhere -> the pair on every rank (or None).
+        64-bit values cross ranks as 32-bit halves (signed int64 all-reduce); ranks that hold the same state hold the same pair."""
+        a, b = hit if hit is not None else (0, 0)
+        parts = self.x.allreduce([1 if hit is not None else 0, a >> 32, a & 0xFFFFFFFF, b >> 32, b & 0xFFFFFFFF], dist.ReduceOp.MAX)
+        return ((parts[1] << 32) | parts[2], (parts[3] << 32) | parts[4]) if parts[0] else None
+
+    def trace_ordinals(self, level, fp):
+        """Walk the predecessor pointers — they live in the seen-set slots, i.e. on the owner of each state — from the level-`level`
+        state with fingerprint `fp` back to Init; every rank must call this.  Two small all-reduces per level.
+        meta = level(9) << 55 | auxkey(9) << 46 | ordinal(10) << 36 | parent fingerprint bits(35) << 1 | taken(1)."""
         ords = []
         for l in range(level, 1, -1):
-            key = self.e.trace_entry(l, index) if rank == self.rank else 0
-            # a 64-bit key crosses ranks as two 32-bit halves (signed int64 all-reduce)
-            parts = self.x.allreduce([key >> 32, key & 0xFFFFFFFF], dist.ReduceOp.MAX)
-            key = (parts[0] << 32) | parts[1]
-            ords.append((key >> 35) & 2047)                    # key = level(9) | auxkey(9) | ordinal(11) | parent index(32) | rank(3)
-            rank, index = key & 7, (key >> 3) & 0xFFFFFFFF
+            hit = self._agree(self.e.lookup(fp, l, False))
+            if hit is None or (hit[1] >> 55) != l:
+                raise ShardError("trace walk: no level-%d state with fingerprint %016x in any shard" % (l, fp))
+            ords.append((hit[1] >> 36) & 1023)
+            parent = self._agree(self.e.lookup((hit[1] >> 1) & ((1 << 35) - 1), l - 1, True))
+            if parent is None:
+                raise ShardError("trace walk: the parent of %016x is in no shard" % fp)
+            fp = parent[0]
         return ords[::-1]
 
 
@@ -383,28 +390,26 @@ class HipShardEngine:
 
     def empty_streams(self):
         z = torch.zeros(0, dtype=torch.int64, device=self.dev)
-        return (z, z, z, z)
+        return (z, z, z)
 
     def export(self, first, n):
         words = torch.empty(self.rec_words_cap, dtype=torch.int64, device=self.dev)
         off = torch.empty(self.rec_cap, dtype=torch.int64, device=self.dev)
         fp = torch.empty(self.rec_cap, dtype=torch.int64, device=self.dev)
-        key = torch.empty(self.rec_cap, dtype=torch.int64, device=self.dev)
         torch.cuda.synchronize(self.dev)
         no, nw = C.c_uint64(), C.c_uint64()
         err = self._call(capi.load().vsrmc_shard_export(self._h, first, n, C.c_void_p(words.data_ptr()), self.rec_words_cap,
-                                                        C.c_void_p(off.data_ptr()), C.c_void_p(fp.data_ptr()),
-                                                        C.c_void_p(key.data_ptr()), self.rec_cap, C.byref(no), C.byref(nw)))
+                                                        C.c_void_p(off.data_ptr()), C.c_void_p(fp.data_ptr()), self.rec_cap,
+                                                        C.byref(no), C.byref(nw)))
         if err:
             return self.empty_streams(), err
-        return (words[: nw.value], off[: no.value], fp[: no.value], key[: no.value]), 0
+        return (words[: nw.value], off[: no.value], fp[: no.value]), 0
 
-    def append(self, words, off, fp, key):
-        words, off, fp, key = words.contiguous(), off.contiguous(), fp.contiguous(), key.contiguous()
+    def append(self, words, off, fp):
+        words, off, fp = words.contiguous(), off.contiguous(), fp.contiguous()
         torch.cuda.synchronize(self.dev)
         return self._call(capi.load().vsrmc_shard_append(self._h, C.c_void_p(words.data_ptr()), int(words.shape[0]),
-                                                         C.c_void_p(off.data_ptr()), C.c_void_p(fp.data_ptr()),
-                                                         C.c_void_p(key.data_ptr()), int(off.shape[0])))
+                                                         C.c_void_p(off.data_ptr()), C.c_void_p(fp.data_ptr()), int(off.shape[0])))
 
     def commit(self):
         info = capi.LevelInfo()
@@ -440,10 +445,11 @@ class HipShardEngine:
         check(capi.load().vsrmc_checker_find_fp(self._h, fp, C.byref(idx)))
         return None if idx.value == U64_MAX else idx.value
 
-    def trace_entry(self, level, index):
-        key = C.c_uint64()
-        check(capi.load().vsrmc_checker_trace_entry(self._h, level, index, C.byref(key)))
-        return key.value
+    def lookup(self, key, level, by_low_bits):
+        found, fp, meta = C.c_int32(), C.c_uint64(), C.c_uint64()
+        check(capi.load().vsrmc_checker_lookup(self._h, int(key), int(level), int(bool(by_low_bits)), C.byref(found), C.byref(fp),
+                                               C.byref(meta)))
+        return (fp.value, meta.value) if found.value else None
 
     def level_fps(self):
         rc, n = self._frontier_counts()

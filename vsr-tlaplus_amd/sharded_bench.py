@@ -67,7 +67,7 @@ def main(args, CONFIG, EXPECT):
             if d["n_new"] == 0 or sc.violation is not None:
                 break
         if sc.violation is not None:                          # counter-example reconstructed = found
-            ords = sc.trace_ordinals(sc.violation["level"], sc.violation["rank"], sc.violation["index"])
+            ords = sc.trace_ordinals(sc.violation["level"], sc.violation["fp"])
             if rank == 0:
                 tr = sharded.replay(m, ords, device=local_rank)
                 assert len(tr) == sc.violation["level"]
