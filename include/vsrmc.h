@@ -179,20 +179,24 @@ int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t ma
                              uint64_t* off, uint64_t* n_states, uint64_t* n_matching);
 /* ≙ TLCTrace.getTrace: the path Init .. state `index` of the NEWEST level (level must be the current one); records in wire
  * layout, one action id per state (0 = Initial predicate).  The path is a function of the state alone: every state's slot in the
- * seen-set names the ordinal of the step that discovers it and its parent — of all (parent, instance) pairs of the previous
- * level that produce it the one with the smallest (canonical auxkey, ordinal, parent fingerprint) — so the same counter-example
- * comes back in every run, on any number of GPUs, in either level scheme. */
+ * seen-set names its parent — of all states of the previous level that produce it the one with the smallest (canonical auxkey,
+ * fingerprint) — and the step between two states of the path is the enabled instance with the smallest ordinal that leads from
+ * one to the other; so the same counter-example comes back in every run, on any number of GPUs, in either level scheme. */
 int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words,
                             uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
 /* the same for any state of any completed level, addressed by its fingerprint */
 int32_t vsrmc_checker_trace_fp(vsrmc_checker* c, int32_t level, uint64_t fp, uint64_t* words, uint64_t cap_words,
                                uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
-/* forward half of TLCTrace.getTrace on its own: re-execute `nsteps` ordinals from Init */
+/* forward half of TLCTrace.getTrace for a path given by the fingerprints of its states (fps[0] = Init's): at every step the
+ * successor with the next fingerprint is taken — what a walk through the seen-set (vsrmc_checker_lookup) yields */
+int32_t vsrmc_model_replay_fps(const vsrmc_model* m, int32_t device, const uint64_t* fps, int32_t n_fps, uint64_t* words,
+                               uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
+/* the same for a path of ordinals (simulation walks): re-execute `nsteps` ordinals from Init */
 int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t* ords, int32_t nsteps, uint64_t* words,
                            uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
 /* one step of a trace walk through this checker's (shard of the) seen-set — what a walk that crosses ranks is made of.
- * by_low_bits = 0: the slot of fingerprint `key`; 1: the slot of the level-`level` state whose fingerprint ends in the 35 bits
- * `key`.  meta = level(9) << 55 | auxkey(9) << 46 | ordinal(10) << 36 | parent fingerprint bits(35) << 1 | taken(1). */
+ * by_low_bits = 0: the slot of fingerprint `key`; 1: the slot of the level-`level` state whose fingerprint ends in the 45 bits
+ * `key`.  meta = level(9) << 55 | auxkey(9) << 46 | parent fingerprint bits(45) << 1 | taken(1). */
 int32_t vsrmc_checker_lookup(vsrmc_checker* c, uint64_t key, int32_t level, int32_t by_low_bits, int32_t* found, uint64_t* fp,
                              uint64_t* meta);
 /* index of fingerprint `fp` in the newest level (~0 if absent) */

@@ -79,6 +79,8 @@ public class GpuFPSet extends FPSet {
         return bv;
     }
 
+    // NOTE: fingerprint 0 is the device table's empty-slot sentinel; put / contains remap it to 1 (k_fpset_put, k_fpset_contains), so
+    // the two TLC fingerprints 0 and 1 share a slot — one possible false "seen" in 2^64, the same order as a fingerprint collision.
     @Override
     public long size() { return size0(handle); }
 
@@ -91,9 +93,14 @@ public class GpuFPSet extends FPSet {
     @Override
     public void exit(boolean cleanup) throws IOException { close(); }
 
-    @Override public void beginChkpt() { throw new UnsupportedOperationException("checkpointing is out of scope"); }
-    @Override public void commitChkpt() { throw new UnsupportedOperationException("checkpointing is out of scope"); }
-    @Override public void recover() { throw new UnsupportedOperationException("checkpointing is out of scope"); }
+    // TLC checkpoints periodically by default (every 30 minutes): these hooks must not abort a long run.  The set lives in HBM
+    // and this shim does not persist it — begin / commit are no-ops (a `-recover` of such a checkpoint finds an empty set and is
+    // refused below); the native checker's own checkpoint (vsrmc_checker_save / _load) is the supported way to stop and resume.
+    @Override public void beginChkpt() { }
+    @Override public void commitChkpt() { }
+    @Override public void recover() throws IOException {
+        throw new IOException("GpuFPSet does not persist fingerprints across TLC checkpoints; resume with the native checker's -recover");
+    }
     @Override public void beginChkpt(String filename) { beginChkpt(); }
     @Override public void commitChkpt(String filename) { commitChkpt(); }
     @Override public void recover(String filename) { recover(); }

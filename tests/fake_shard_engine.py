@@ -21,7 +21,7 @@ def _u64(t):
 class FakeShardEngine:
     def __init__(self, params, rank, world, owner_of):
         self.P, self.rank, self.world, self.owner_of = params, rank, world, owner_of
-        self.seen = {}            # fp -> best key (level << 55 | auxkey << 46 | ordinal << 36 | parent fingerprint bits(35) << 1)
+        self.seen = {}            # fp -> best key (level << 55 | auxkey << 46 | parent fingerprint bits(45) << 1)
         self.level = 1
         init = orc.init_record(params)
         fp, ak = orc.fingerprint(params, init)
@@ -49,7 +49,7 @@ class FakeShardEngine:
         return len(keep)
 
     def _key(self, level, ak, parent_fp, ordinal):
-        return (level << 55) | (ak << 46) | (ordinal << 36) | ((parent_fp & ((1 << 35) - 1)) << 1)
+        return (level << 55) | (ak << 46) | ((parent_fp & ((1 << 45) - 1)) << 1)
 
     def error_text(self):
         return self._err
@@ -96,7 +96,12 @@ class FakeShardEngine:
         vals = _u64(cands)
         self.recv = [(vals[2 * i], vals[2 * i + 1]) for i in range(len(vals) // 2)]
         alive = [self._claim(fp, key) for fp, key in self.recv]
-        verdict = [1 if a and self.seen[fp] == key else 0 for a, (fp, key) in zip(alive, self.recv)]
+        verdict, taken = [], set()                              # exactly-once: of equal (fp, key) candidates one is told "yes"
+        for a, (fp, key) in zip(alive, self.recv):
+            win = a and self.seen[fp] == key and fp not in taken
+            if win:
+                taken.add(fp)
+            verdict.append(1 if win else 0)
         return torch.tensor(verdict, dtype=torch.uint8), 0
 
     def _record_of(self, fp, key):
@@ -166,7 +171,7 @@ class FakeShardEngine:
         if not by_low_bits:
             return (key, self.seen[key]) if key in self.seen else None
         for fp, meta in self.seen.items():
-            if (fp & ((1 << 35) - 1)) == key and (meta >> 55) == level:
+            if (fp & ((1 << 45) - 1)) == key and (meta >> 55) == level:
                 return (fp, meta)
         return None
 

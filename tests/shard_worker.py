@@ -49,7 +49,7 @@ def main():
         # (the two halves come from the same rank: every other rank contributes zeros)
         fp = (hi << 32) | lo
         if fp:
-            walks.append(dict(rank=r, level=sc.level, fp="%016x" % fp, ords=sc.trace_ordinals(sc.level, fp)))
+            walks.append(dict(rank=r, level=sc.level, fp="%016x" % fp, fps=["%016x" % f for f in sc.trace_fps(sc.level, fp)]))
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks,
                        bytes_sent=sc.x.bytes_sent, moved=sc.moved), f)

@@ -55,15 +55,18 @@ def check_against_oracle(ranks, params, max_depth):
 
 
 def replay_walks_with_oracle(ranks, params):
-    """every distributed trace walk is a valid path: applying the i-th successor (the fake engine's ordinal) from Init"""
+    """every distributed trace walk is a valid path: from Init, every state of the path is a successor of the one before"""
     from oracle import orc
     P = orc.Params(*params)
     for w in ranks[0]["walks"]:
         rec = orc.init_record(P)
-        for k in w["ords"]:
-            rec = orc.successors(P, rec)[k]["words"]
-        fp, _ = orc.fingerprint(P, rec)
-        assert "%016x" % fp in ranks[w["rank"]]["levels"][-1]["fps"]
+        path = [int(f, 16) for f in w["fps"]]
+        assert len(path) == w["level"] and orc.fingerprint(P, rec)[0] == path[0]
+        for f in path[1:]:
+            nxt = [s["words"] for s in orc.successors(P, rec) if s["fp"] == f]
+            assert nxt, "a state of the walk is not a successor of its predecessor"
+            rec = nxt[0]
+        assert w["fp"] == w["fps"][-1] and w["fp"] in ranks[w["rank"]]["levels"][-1]["fps"]
 
 
 @pytest.mark.parametrize("world,params,max_depth,rb", [(2, (2, 1, 2, 2), 40, 0), (3, (2, 1, 1, 1), 40, 0), (2, (3, 1, 2, 2), 7, 0),
@@ -126,7 +129,7 @@ def test_sharded_hip_engine_on_one_gpu(tmp_path, engine, world, params, depth, r
     from vsr_tlaplus_amd import sharded
     m = vt.Model.from_constants(R=params[0], C_=params[1], n=params[2], L=params[3])
     for w in ranks[0]["walks"]:
-        tr = sharded.replay(m, w["ords"])
+        tr = sharded.replay_fps(m, [int(f, 16) for f in w["fps"]])
         assert len(tr) == w["level"]
         words = tr[-1][1]
         fps, _ = m.fingerprints(words, np.array([0, len(words)], dtype=np.uint64))

@@ -79,6 +79,7 @@ SYMBOLS = {
                                         C.POINTER(C.c_uint64)]),
     "vsrmc_checker_destroy": (None, [V]),
     "vsrmc_model_replay": (C.c_int32, [V, C.c_int32, V, C.c_int32, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_model_replay_fps": (C.c_int32, [V, C.c_int32, V, C.c_int32, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_trace_fp": (C.c_int32, [V, C.c_int32, C.c_uint64, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_lookup": (C.c_int32, [V, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]),

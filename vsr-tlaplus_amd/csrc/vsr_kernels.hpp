@@ -547,7 +547,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       u64 fp;
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
-      const u64 key = meta_make(level, ak, ord, s_pfp[p]);
+      const u64 key = meta_make(level, ak, s_pfp[p]);
       const u64 a_2 = __builtin_readcyclecounter();
       if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
       if (!fused && world > 1) {                                // sharded seen-set, exact scheme: route to the owner of fp
@@ -559,7 +559,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
               if (i < cand_cap) {
                 cand_send[2 * ((u64)o * cand_cap + i)] = fp;
                 cand_send[2 * ((u64)o * cand_cap + i) + 1] = key;
-                cand_idx[(u64)o * cand_cap + i] = p_offset + p_base + (u64)p;   // the parent, for k_materialize on this rank
+                cand_idx[(u64)o * cand_cap + i] = origin_make(p_offset + p_base + (u64)p, ord);   // where it comes from, for k_materialize on this rank
               } else {
                 raise_error(ctl, ERR_FRONTIER_FULL, i);
               }
@@ -720,7 +720,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         const u64 i = s_chunk_base + s_tile_base + b + (u32)__popcll(active & (((u64)1 << lane) - 1));
         pending[3 * i] = slot;
         pending[3 * i + 1] = key;
-        pending[3 * i + 2] = p_offset + p_base + (u64)p;
+        pending[3 * i + 2] = origin_make(p_offset + p_base + (u64)p, ord);
       }
     }
     const u64 t_4 = __builtin_readcyclecounter();
@@ -846,8 +846,8 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
               u64 n_pending, Slot* table, u64* nx_words, u64 nx_words_cap, u64* nx_off, u64 nx_cap,
               u64* lvl_fp, LevelCtl* ctl, const uint8_t* __restrict__ verdict, u64* cnt_n, u64* cnt_w, int stride,
               u32 ichunk /* state indices per reservation, >= 64 */, u32 wchunk /* words per reservation, >= 64 * stride */,
-              // entry i = pending[es * i ..): (slot or fingerprint, key[, parent index]); the parent's index in the frontier comes
-              // from the entry's third word (local pending list, es = 3) or from pidx_arr[i] (candidates sent to a remote owner, es = 2)
+              // entry i = pending[es * i ..): (slot or fingerprint, key[, origin]); origin = parent index | ordinal << 40 comes from
+              // the entry's third word (local pending list, es = 3) or from pidx_arr[i] (candidates sent to a remote owner, es = 2)
               int es, const u64* __restrict__ pidx_arr) {
   Model M = Marg;
   specialise<SPEC>(M, Marg);
@@ -866,7 +866,7 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
     const u64 i = it * nthreads + (u64)blockIdx.x * VSR_MAT_BLOCK + lane;
     const u64 c_0 = __builtin_readcyclecounter();
     bool win = false;
-    u64 key = 0, src = 0;
+    u64 key = 0, src = 0, origin = 0;
     int plen = 0;
     if (i < n_pending) {
       key = pending[(u64)es * i + 1];
@@ -874,7 +874,8 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
         // winner test: the owner's verdict (sharded, remote owner) or the slot's final meta word (local owner) — taken with a
         // compare-and-swap key -> key | taken, so that a state is materialised exactly once; the parent's ref is fetched
         // alongside, not after (one HBM latency, not two)
-        const u64 ref = fr_off[pidx_arr ? pidx_arr[i] : pending[(u64)es * i + 2]];
+        origin = pidx_arr ? pidx_arr[i] : pending[(u64)es * i + 2];
+        const u64 ref = fr_off[origin_pidx(origin)];
         if (verdict) win = verdict[i] != 0;
         else win = atomicCAS((unsigned long long*)&table[pending[(u64)es * i]].meta, (unsigned long long)key,
                              (unsigned long long)(key | META_TAKEN)) == key;
@@ -911,7 +912,7 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
     if (win) {
       u64* rec = s_slot + lane * stride;
       Delta D;
-      Ops::template gen_<false>(M, (const u64*)rec, meta_ord(key), D);
+      Ops::template gen_<false>(M, (const u64*)rec, origin_ord(origin), D);
       u64 Hc[6];
       Ops::hash_child_(M, (const u64*)rec, D, Hc);
       u32 ak;
@@ -1240,7 +1241,7 @@ __global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl
   u64 fp;
   u32 ak;
   canonical_fp(M, rec[0], rec + M.h0, &fp, &ak);
-  u64 key = meta_make(1, ak, 0, 0);
+  u64 key = meta_make(1, ak, 0);
   bool found_old, full;
   u32 np = 0;
   table_claim(table, tmask, fp, key, 1, &found_old, &np, &full);
@@ -1251,7 +1252,7 @@ __global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl
 
 // Slot of the state whose fingerprint has the low bits `pfp` and whose level is `level` (the parent a meta word names): linear
 // probing stores a fingerprint at or after its home slot fp & mask with no empty slot in between, and the home slot only needs
-// the bits the meta word keeps (table_log2 <= 35).  ~0 = no such state.
+// the bits the meta word keeps (table_log2 <= 36 < 45).  ~0 = no such state.
 __device__ __forceinline__ u64 find_by_low_bits(const Slot* table, u64 tmask, u64 pfp, int level) {
   u64 i = pfp & tmask;
   for (u64 step = 0; step <= tmask; step++, i = (i + 1) & tmask) {
@@ -1271,25 +1272,22 @@ __device__ __forceinline__ u64 find_exact(const Slot* table, u64 tmask, u64 fp) 
   return ~(u64)0;
 }
 // TLCTrace.getTrace, backwards half: follow the predecessor pointers in the seen-set from the state with fingerprint `fp` of
-// level `level` back to Init.  ords[l-2] = ordinal of the step into level l; fps[l-1] = fingerprint of the path's level-l state.
-// ords[0] = 0xFFFFFFFF on a broken chain (cannot happen on a table the search itself filled).
-__global__ void k_trace_walk(const Slot* table, u64 tmask, u64 fp, int level, u32* ords, u64* fps) {
+// level `level` back to Init.  fps[l-1] = fingerprint of the path's level-l state; fps[0] = 0 on a broken chain (cannot happen
+// on a table the search itself filled).
+__global__ void k_trace_walk(const Slot* table, u64 tmask, u64 fp, int level, u64* fps) {
   if (threadIdx.x || blockIdx.x) return;
   u64 slot = find_exact(table, tmask, fp);
   for (int l = level; l >= 1; l--) {
     if (slot == ~(u64)0 || meta_level(table[slot].meta) != l) {
-      ords[0] = 0xFFFFFFFFu;
+      fps[0] = 0;
       return;
     }
     fps[l - 1] = table[slot].fp;
-    if (l == 1) break;
-    const u64 m = table[slot].meta;
-    ords[l - 2] = (u32)meta_ord(m);
-    slot = find_by_low_bits(table, tmask, meta_pfp(m), l - 1);
+    if (l > 1) slot = find_by_low_bits(table, tmask, meta_pfp(table[slot].meta), l - 1);
   }
 }
-// one step of the same walk, for walks that cross ranks (sharded runs): mode 0: exact fingerprint -> (fp, meta); mode 1: low
-// fingerprint bits + level -> (fp, meta).  out[0] = found (0 / 1), out[1] = fingerprint, out[2] = meta.
+// one step of the same walk, for walks that cross ranks (sharded runs): mode 0: exact fingerprint -> (fp, meta); mode 1: the 45
+// low fingerprint bits a child keeps of its parent + the parent's level -> (fp, meta).  out[0] = found (0 / 1), out[1] = fingerprint, out[2] = meta.
 __global__ void k_table_lookup(const Slot* table, u64 tmask, u64 key, int level, int mode, u64* out) {
   if (threadIdx.x || blockIdx.x) return;
   const u64 slot = mode == 0 ? find_exact(table, tmask, key) : find_by_low_bits(table, tmask, key & PFP_MASK, level);
@@ -1540,10 +1538,13 @@ __global__ void k_hash_records(Model M, u64* words, const u64* off, u64 n) {
   for (int i = 0; i < M.np; i++) rec[M.h0 + i] = H[i];
 }
 
-// k_replay: re-execute a path of ordinals starting from the record at out_words[0..).  Record t+1 = ord[t] applied
-// to record t.  out_meta per step: [action id, fingerprint, invariant mask, error].
+// k_replay: re-execute a path starting from the record at out_words[0..).  Record t+1 = the successor of record t named by
+// ords[t] (fps == nullptr: a path of ordinals — simulation walks), or the successor whose fingerprint is fps[t + 1] (a path of
+// fingerprints — what a trace walk through the seen-set yields; of several instances with that successor the smallest ordinal is
+// taken, the state is the same).  out_meta per step: [action id, fingerprint, invariant mask, error]; ords_out[t] (may be null) =
+// the ordinal taken.
 template <int MODEL>
-__global__ void k_replay(Model M, u64* out_words, u64* out_off, const u32* ords, int nsteps, u64* out_meta) {
+__global__ void k_replay(Model M, u64* out_words, u64* out_off, const u32* ords, int nsteps, u64* out_meta, const u64* fps, u32* ords_out) {
   if (threadIdx.x || blockIdx.x) return;
   u64 pos = 0;
   out_off[0] = 0;
@@ -1551,19 +1552,40 @@ __global__ void k_replay(Model M, u64* out_words, u64* out_off, const u32* ords,
     const u64* rec = out_words + pos;
     u64 next = pos + (u64)(M.fixed + hdr_nmsg(rec[0]));
     Delta D;
-    bool en = ModelOps<MODEL>::template gen_<true>(M, rec, (int)ords[t], D);
+    u64 Hc[6];
+    u64 fp = 0;
+    u32 ak = 0;
+    bool en = false;
+    int ord = 0;
+    if (fps) {
+      const int nords = ord_count(M, hdr_nmsg(rec[0]));
+      for (ord = 0; ord < nords && !en; ord++) {
+        if (!ModelOps<MODEL>::template gen_<true>(M, rec, ord, D)) continue;
+        ModelOps<MODEL>::template gen_<false>(M, rec, ord, D);
+        if (D.err) continue;
+        ModelOps<MODEL>::hash_child_(M, rec, D, Hc);
+        canonical_fp(M, D.hdr, Hc, &fp, &ak);
+        if (fp == fps[t + 1]) {
+          en = true;
+          break;
+        }
+      }
+    } else {
+      ord = (int)ords[t];
+      en = ModelOps<MODEL>::template gen_<true>(M, rec, ord, D);
+      if (en) {
+        ModelOps<MODEL>::template gen_<false>(M, rec, ord, D);
+        ModelOps<MODEL>::hash_child_(M, rec, D, Hc);
+        canonical_fp(M, D.hdr, Hc, &fp, &ak);
+      }
+    }
     if (!en) {
       out_meta[4 * t + 3] = 0xFFFF;
       out_off[t + 1] = next;
       for (int k = t + 1; k < nsteps; k++) out_off[k + 1] = next;
       return;
     }
-    ModelOps<MODEL>::template gen_<false>(M, rec, (int)ords[t], D);
-    u64 Hc[6];
-    ModelOps<MODEL>::hash_child_(M, rec, D, Hc);
-    u64 fp;
-    u32 ak;
-    canonical_fp(M, D.hdr, Hc, &fp, &ak);
+    if (ords_out) ords_out[t] = (u32)ord;
     write_child_serial(M, rec, D, Hc, out_words + next);
     out_meta[4 * t + 0] = (u64)D.action;
     out_meta[4 * t + 1] = fp;

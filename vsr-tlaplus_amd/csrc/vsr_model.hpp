@@ -249,24 +249,29 @@ VSR_HD void canonical_fp(const Model& M, u64 hdr, const u64* H, u64* fp, u32* au
 }
 
 // ---- meta word of a seen-set slot: smaller = wins the slot --------------------------------------------------------------
-//   level(9) << 55 | canonical auxkey(9) << 46 | ordinal(10) << 36 | low 35 bits of the PARENT's fingerprint << 1 | taken(1)
-// Every field is a property of the (parent state, action instance) pair itself — no buffer index, no rank — so the meta word a
-// level's candidates min-merge into a slot is the same in every run, on any number of GPUs, in any scheme: (i) shallower levels
-// always win (F2: the first discoverer keeps its aux values), (ii) same-level duplicates resolve to the smallest canonical
-// auxkey, then the smallest ordinal, then the parent with the smallest fingerprint bits, (iii) the slot IS the predecessor
-// pointer of its state (TLCTrace): the ordinal of the step and 35 bits of where it came from — the trace is walked through the
-// table (k_trace_walk), there is no separate log.  `taken` is set by the one candidate that materialises the state in the
-// schemes that pick the winner after the level (exact levels, MODE_REGEN): a compare-and-swap key -> key | 1 makes that
-// exactly-once even if two candidates ever carried the same 64 bits.
+//   level(9) << 55 | canonical auxkey(9) << 46 | low 45 bits of the PARENT's fingerprint << 1 | taken(1)
+// Every field is a property of the states themselves — no buffer index, no rank, no ordinal (an ordinal names a position in the
+// parent record's bag, and the order of a bag depends on which candidate materialised the parent) — so the meta word a level's
+// candidates min-merge into a slot is the same in every run, on any number of GPUs, in any scheme: (i) shallower levels always
+// win (F2: the first discoverer keeps its aux values), (ii) same-level duplicates resolve to the smallest canonical auxkey, then
+// to the parent with the smallest fingerprint bits, (iii) the slot IS the predecessor pointer of its state (TLCTrace): a trace
+// is the chain of fingerprints walked through the table (k_trace_walk) and re-executed forwards by searching, at every step, the
+// successor with the next fingerprint (k_replay_fps); there is no separate log.  `taken` is set by the one candidate that
+// materialises the state in the schemes that pick the winner after the level (exact levels, MODE_REGEN): a compare-and-swap
+// key -> key | 1 makes that exactly-once when several candidates carry the same 64 bits (two instances of one parent with the
+// same successor do).
 static const u64 META_EMPTY = ~(u64)0;
 static const u64 META_TAKEN = 1;
-static const u64 PFP_MASK = ((u64)1 << 35) - 1;
-VSR_HD u64 meta_make(int level, u32 auxkey, int ord, u64 parent_fp) {
-  return ((u64)level << 55) | ((u64)auxkey << 46) | ((u64)ord << 36) | ((parent_fp & PFP_MASK) << 1);
+static const u64 PFP_MASK = ((u64)1 << 45) - 1;
+VSR_HD u64 meta_make(int level, u32 auxkey, u64 parent_fp) {
+  return ((u64)level << 55) | ((u64)auxkey << 46) | ((parent_fp & PFP_MASK) << 1);
 }
 VSR_HD int meta_level(u64 m) { return (int)(m >> 55); }
 VSR_HD int meta_auxkey(u64 m) { return (int)((m >> 46) & 511); }
-VSR_HD int meta_ord(u64 m) { return (int)((m >> 36) & 1023); }
 VSR_HD u64 meta_pfp(u64 m) { return (m >> 1) & PFP_MASK; }
+// what the generator keeps beside a candidate of the schemes that materialise after the level: parent index | ordinal << 40
+VSR_HD u64 origin_make(u64 pidx, int ord) { return pidx | ((u64)ord << 40); }
+VSR_HD u64 origin_pidx(u64 o) { return o & (((u64)1 << 40) - 1); }
+VSR_HD int origin_ord(u64 o) { return (int)(o >> 40); }
 
 }  // namespace vsr

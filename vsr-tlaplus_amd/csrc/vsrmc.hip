@@ -945,8 +945,8 @@ struct vsrmc_checker {
   int num_cus = 256;
   int lds_stride = 65;
   int failed = 0;
-  // TLCTrace: there is no separate log — a state's slot in the seen-set holds the ordinal of the step that discovered it and
-  // 35 bits of its parent's fingerprint (meta word, vsr_model.hpp); traces are walked through the table (k_trace_walk)
+  // TLCTrace: there is no separate log — a state's slot in the seen-set names its parent:
+  // 45 bits of its parent's fingerprint (meta word, vsr_model.hpp); traces are walked through the table (k_trace_walk)
   // state of the level in flight (between the phases)
   LevelCtl h;
   double t_level0 = 0, expand_ms = 0, materialize_ms = 0;
@@ -967,9 +967,9 @@ struct vsrmc_checker {
   u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
   bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
   // vsrmc_checker_probe / _probe2: where the reported violator's counter-example is walked from — the fingerprint of the deepest
-  // state of the path that is IN the seen-set, its level, and the ordinal of the one probed step beyond it (-1: none)
-  u64 probe_fp = 0;
-  int probe_level = 0, probe_extra_ord = -1;
+  // state of the path that is IN the seen-set, its level, and the fingerprint of the one probed state beyond it (0: none)
+  u64 probe_fp = 0, probe_extra_fp = 0;
+  int probe_level = 0;
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
   u64 words_cap(int b) const { return (b == 1 && opt.frontier_words_b) ? opt.frontier_words_b : opt.frontier_words; }
 };
@@ -1097,7 +1097,7 @@ int checker_seed(vsrmc_checker* c) {
   c->failed_code = 0;
   c->probe_fp = 0;
   c->probe_level = 0;
-  c->probe_extra_ord = -1;
+  c->probe_extra_fp = 0;
   return 0;
 }
 }  // namespace
@@ -1124,9 +1124,7 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
       o->pending_entries < 4 * (uint64_t)VSR_CAND_CAP)
     return fail(VSRMC_E_ARG, "bad options");
   if (o->world < 1 || o->world > 8 || o->rank < 0 || o->rank >= o->world) return fail(VSRMC_E_ARG, "bad rank / world (1..8 ranks)");
-  // a state's predecessor pointer keeps 35 bits of the parent's fingerprint, from which the walk derives the parent's home slot
-  if (o->table_log2 > 35) return fail(VSRMC_E_ARG, "table_log2 > 35: the home slot of a parent must follow from the 35 fingerprint bits its children keep");
-  if (m->M.m0 + m->M.max_bag * (m->M.R + 1) >= 1024) return fail(VSRMC_E_ARG, "ordinals of this model do not fit the 10-bit field of the meta word");
+    if (o->frontier_states > ((uint64_t)1 << 40)) return fail(VSRMC_E_ARG, "frontier_states > 2^40");   // origin word: parent index | ordinal << 40
   int rc = check_device(o->device);
   if (rc) return rc;
   vsrmc_checker* c = new vsrmc_checker();
@@ -1457,7 +1455,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
 }
 
 // one step of a trace walk through the seen-set (k_table_lookup): by_low_bits = 0: the slot of fingerprint `key`; 1: the slot of
-// the level-`level` state whose fingerprint ends in the 35 bits `key` (what a child's meta word knows of its parent)
+// the level-`level` state whose fingerprint ends in the 45 bits `key` (what a child's meta word knows of its parent)
 int table_lookup(vsrmc_checker* c, u64 key, int level, int by_low_bits, bool* found, u64* fp, u64* meta) {
   u64* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, 24));
@@ -1472,27 +1470,19 @@ int table_lookup(vsrmc_checker* c, u64 key, int level, int by_low_bits, bool* fo
   *meta = h[2];
   return 0;
 }
-// TLCTrace.getTrace, backwards half: the ordinals of the path Init -> the level-`level` state with fingerprint `fp`
-int walk_trace(vsrmc_checker* c, u64 fp, int level, std::vector<u32>* ords) {
-  ords->assign((size_t)std::max(level - 1, 0), 0);
+// TLCTrace.getTrace, backwards half: the fingerprints of the path Init -> the level-`level` state with fingerprint `fp`
+int walk_trace(vsrmc_checker* c, u64 fp, int level, std::vector<u64>* fps) {
   if (level < 1) return fail(VSRMC_E_ARG, "no such level");
-  u32* d_ords = nullptr;
+  fps->assign((size_t)level, 0);
   u64* d_fps = nullptr;
-  HIPCHK(hipMalloc((void**)&d_ords, (u64)level * 4));
-  if (hipMalloc((void**)&d_fps, (u64)level * 8) != hipSuccess) {
-    (void)hipFree(d_ords);
-    return fail(VSRMC_E_HIP, "hipMalloc failed");
-  }
-  bool ok = hipMemsetAsync(d_ords, 0, (u64)level * 4, c->stream) == hipSuccess;
-  hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->table, c->tmask, fp, level, d_ords, d_fps);
-  ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
-  std::vector<u32> h((size_t)level);
-  ok = ok && hipMemcpy(h.data(), d_ords, (u64)level * 4, hipMemcpyDeviceToHost) == hipSuccess;
-  (void)hipFree(d_ords);
+  HIPCHK(hipMalloc((void**)&d_fps, (u64)level * 8));
+  bool ok = hipMemsetAsync(d_fps, 0, (u64)level * 8, c->stream) == hipSuccess;
+  hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->table, c->tmask, fp, level, d_fps);
+  ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+       hipMemcpy(fps->data(), d_fps, (u64)level * 8, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(d_fps);
   if (!ok) return fail(VSRMC_E_HIP, "k_trace_walk failed");
-  if (h[0] == 0xFFFFFFFFu) return fail(VSRMC_E_STATE, "the seen-set holds no path from Init to this state at this level");
-  for (int l = 2; l <= level; l++) (*ords)[(size_t)l - 2] = h[(size_t)l - 2];
+  if ((*fps)[0] == 0) return fail(VSRMC_E_STATE, "the seen-set holds no path from Init to this state at this level");
   return 0;
 }
 
@@ -1524,7 +1514,7 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   virt->viol_fp = virt->viol_index = probe->viol_fp = probe->viol_index = ~(u64)0;
   c->probe_fp = 0;
   c->probe_level = 0;
-  c->probe_extra_ord = -1;
+  c->probe_extra_fp = 0;
   const double t0 = now_s();
   c->expand_ms = 0;
   // ---- pass 1: the virtual level
@@ -1549,7 +1539,7 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
     virt->viol_mask = (int32_t)c->h.viol_mask;
     c->probe_fp = c->h.viol_fp;                                 // the virtual level's states are in the seen-set: walk from the violator itself
     c->probe_level = c->level + 1;
-    c->probe_extra_ord = -1;
+    c->probe_extra_fp = 0;
     return 0;
   }
   // ---- pass 2: slices of the newest level -> their part of level L+1 -> probe of level L+2
@@ -1590,7 +1580,7 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
             best_fp = c->h.viol_fp;
             c->probe_fp = pfp;
             c->probe_level = c->level + 1;
-            c->probe_extra_ord = meta_ord(k2);
+            c->probe_extra_fp = c->h.viol_fp;
           }
         }
       }
@@ -1625,7 +1615,7 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
   c->failed = 0;
   c->probe_fp = 0;
   c->probe_level = 0;
-  c->probe_extra_ord = -1;
+  c->probe_extra_fp = 0;
   int rc = phase_expand(c, nullptr, MODE_PROBE);
   if (rc) return rc;
   std::memset(info, 0, sizeof(*info));
@@ -1658,7 +1648,7 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
       if (found) {
         c->probe_fp = pfp;
         c->probe_level = c->level;
-        c->probe_extra_ord = meta_ord(key);
+        c->probe_extra_fp = c->h.viol_fp;
       }
     }
   }
@@ -1670,11 +1660,11 @@ int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t ca
   if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->probe_fp == 0) return fail(VSRMC_E_STATE, "no violation recorded by vsrmc_checker_probe");
   HIPCHK(hipSetDevice(c->opt.device));
-  std::vector<u32> ords;
-  int rc = walk_trace(c, c->probe_fp, c->probe_level, &ords);   // Init .. the deepest state of the path that is in the seen-set
+  std::vector<u64> fps;
+  int rc = walk_trace(c, c->probe_fp, c->probe_level, &fps);    // Init .. the deepest state of the path that is in the seen-set
   if (rc) return rc;
-  if (c->probe_extra_ord >= 0) ords.push_back((u32)c->probe_extra_ord);   // ... and the probed step beyond it
-  return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), (int32_t)ords.size(), words, cap_words, off, actions, cap_states, n_states);
+  if (c->probe_extra_fp) fps.push_back(c->probe_extra_fp);      // ... and the probed state beyond it
+  return vsrmc_model_replay_fps(&c->model, c->opt.device, fps.data(), (int32_t)fps.size(), words, cap_words, off, actions, cap_states, n_states);
 }
 
 int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
@@ -2189,9 +2179,10 @@ int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t ma
 }
 
 // ≙ the forward half of TLCTrace.getTrace: re-execute `nsteps` ordinals from Init on the GPU (k_replay)
-int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t* ords, int32_t nsteps, uint64_t* words,
+// re-execute a path from Init: by ordinals (fps == nullptr) or by the fingerprints of its states (fps[0 .. nsteps], fps[0] = Init)
+static int32_t replay_path(const vsrmc_model* m, int32_t device, const uint32_t* ords, const uint64_t* fps, int32_t nsteps, uint64_t* words,
                            uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
-  if (!m || !words || !off || !actions || !n_states || nsteps < 0 || (nsteps && !ords)) return fail(VSRMC_E_ARG, "bad argument");
+  if (!m || !words || !off || !actions || !n_states || nsteps < 0 || (nsteps && !ords && !fps)) return fail(VSRMC_E_ARG, "bad argument");
   int rc = check_device(device);
   if (rc) return rc;
   Model M = m->M;
@@ -2199,12 +2190,16 @@ int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t*
   const int level = nsteps + 1;
   if (cap_states < (u64)level + 1) return fail(VSRMC_E_ARG, "state buffers too small");
   u64 maxw = (u64)(M.fixed + M.max_bag + 8) * (u64)level;
-  u64 *d_w = nullptr, *d_o = nullptr, *d_m = nullptr;
+  u64 *d_w = nullptr, *d_o = nullptr, *d_m = nullptr, *d_fps = nullptr;
   u32* d_ords = nullptr;
   HIPCHK(hipMalloc((void**)&d_w, maxw * 8));
   HIPCHK(hipMalloc((void**)&d_o, ((u64)level + 1) * 8));
   HIPCHK(hipMalloc((void**)&d_m, (u64)std::max(nsteps, 1) * 32));
   HIPCHK(hipMalloc((void**)&d_ords, (u64)std::max(nsteps, 1) * 4));
+  if (fps) {
+    HIPCHK(hipMalloc((void**)&d_fps, (u64)level * 8));
+    HIPCHK(hipMemcpy(d_fps, fps, (u64)level * 8, hipMemcpyHostToDevice));
+  }
   std::vector<u64> wire, dev(512);
   init_record_wire(M, wire);
   int len = wire_to_device(M, wire.data(), dev.data());
@@ -2213,8 +2208,9 @@ int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t*
   for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
   HIPCHK(hipMemcpy(d_w, dev.data(), len * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(d_m, 0, (u64)std::max(nsteps, 1) * 32));
-  if (nsteps > 0) HIPCHK(hipMemcpy(d_ords, ords, (u64)nsteps * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL((M.model_id == 1 ? k_replay<1> : k_replay<0>), dim3(1), dim3(64), 0, 0, M, d_w, d_o, d_ords, nsteps, d_m);
+  if (nsteps > 0 && ords) HIPCHK(hipMemcpy(d_ords, ords, (u64)nsteps * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL((M.model_id == 1 ? k_replay<1> : k_replay<0>), dim3(1), dim3(64), 0, 0, M, d_w, d_o, d_ords, nsteps, d_m, d_fps,
+                     (u32*)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   std::vector<u64> hw(maxw), ho(level + 1), hm((size_t)std::max(nsteps, 1) * 4);
@@ -2222,6 +2218,7 @@ int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t*
   HIPCHK(hipMemcpy(hw.data(), d_w, maxw * 8, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(hm.data(), d_m, (u64)std::max(nsteps, 1) * 32, hipMemcpyDeviceToHost));
   (void)hipFree(d_w); (void)hipFree(d_o); (void)hipFree(d_m); (void)hipFree(d_ords);
+  if (d_fps) (void)hipFree(d_fps);
   u64 pos = 0;
   for (int t = 0; t < level; t++) {
     const u64* r = &hw[ho[t]];
@@ -2231,11 +2228,27 @@ int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t*
     device_to_wire(M, r, words + pos);
     pos += wl;
     actions[t] = t == 0 ? 0 : (int32_t)hm[4 * (t - 1)];
-    if (t > 0 && hm[4 * (t - 1) + 3]) return fail(VSRMC_E_STATE, "trace replay hit a disabled or failing step");
+    if (t > 0 && hm[4 * (t - 1) + 3])
+      return fail(VSRMC_E_STATE, fps ? "trace replay: a state of the path has no successor with the next fingerprint"
+                                     : "trace replay hit a disabled or failing step");
   }
   off[level] = pos;
   *n_states = (u64)level;
   return 0;
+}
+
+int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t* ords, int32_t nsteps, uint64_t* words,
+                           uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
+  if (nsteps && !ords) return fail(VSRMC_E_ARG, "bad argument");
+  return replay_path(m, device, ords, nullptr, nsteps, words, cap_words, off, actions, cap_states, n_states);
+}
+
+// ≙ the forward half of TLCTrace.getTrace for a path given by the fingerprints of its states (fps[0] = Init's, n_fps >= 1): what a
+// walk through the seen-set yields — at every step the successor with the next fingerprint is taken
+int32_t vsrmc_model_replay_fps(const vsrmc_model* m, int32_t device, const uint64_t* fps, int32_t n_fps, uint64_t* words,
+                               uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states) {
+  if (!fps || n_fps < 1) return fail(VSRMC_E_ARG, "bad argument");
+  return replay_path(m, device, nullptr, fps, n_fps - 1, words, cap_words, off, actions, cap_states, n_states);
 }
 
 int32_t vsrmc_checker_trace_fp(vsrmc_checker* c, int32_t level, uint64_t fp, uint64_t* words, uint64_t cap_words, uint64_t* off,
@@ -2244,10 +2257,10 @@ int32_t vsrmc_checker_trace_fp(vsrmc_checker* c, int32_t level, uint64_t fp, uin
   if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: walk the predecessor pointers with vsrmc_checker_lookup on every rank");
   if (level < 1 || level > c->level) return fail(VSRMC_E_ARG, "no such level");
   HIPCHK(hipSetDevice(c->opt.device));
-  std::vector<u32> ords;
-  int rc = walk_trace(c, fp, level, &ords);                    // through the seen-set, back to Init, on the device
+  std::vector<u64> fps;
+  int rc = walk_trace(c, fp, level, &fps);                     // through the seen-set, back to Init, on the device
   if (rc) return rc;
-  return vsrmc_model_replay(&c->model, c->opt.device, ords.data(), (int32_t)ords.size(), words, cap_words, off, actions, cap_states, n_states);
+  return vsrmc_model_replay_fps(&c->model, c->opt.device, fps.data(), (int32_t)fps.size(), words, cap_words, off, actions, cap_states, n_states);
 }
 
 int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uint64_t* words, uint64_t cap_words, uint64_t* off,

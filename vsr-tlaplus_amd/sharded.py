@@ -205,6 +205,7 @@ class ShardedChecker:
         """All ranks: compare the sizes of the new frontiers; move the surplus (tail of the index range) where it is missing."""
         e, x, me, w = self.e, self.x, self.rank, self.world
         valid, rng = e.count()
+        err = max(err, e.sticky_error() if hasattr(e, "sticky_error") else 0)
         both = x.allgather([valid, err])
         counts = [b[0] for b in both]
         self._raise_if(max(b[1] for b in both), "materialize")
@@ -240,6 +241,7 @@ class ShardedChecker:
             return self._step_replicated()
         e, x, me = self.e, self.x, self.rank
         cands, err = e.expand()
+        err = max(err, e.sticky_error() if hasattr(e, "sticky_error") else 0)   # e.g. a failed partition at the end of the replicated phase
         recv, gerr, cat = x.exchange(cands, err)                # 2 collectives: (count, err) pairs, then the buckets
         self._raise_if(gerr, "expand")
         verdict, err = e.claim(cat)
@@ -252,6 +254,7 @@ class ShardedChecker:
         err = max(err, e.materialize(vrecv))
         err = self._rebalance(err)                              # 1 all-gather (+ the moves, when the ranks drifted apart)
         info = e.commit()
+        err = max(err, e.sticky_error() if hasattr(e, "sticky_error") else 0)   # count / commit failures reach every rank here
         viol_fp = info["viol_fp"] if info["viol_mask"] else U64_MAX
         # one all-gather carries every per-level figure (a 64-bit fingerprint travels as two 32-bit halves: int64 tensors)
         rows = x.allgather([info["n_new"], info["generated"], info["deadlocks"], info["pending"], viol_fp >> 32,
@@ -293,21 +296,22 @@ class ShardedChecker:
         parts = self.x.allreduce([1 if hit is not None else 0, a >> 32, a & 0xFFFFFFFF, b >> 32, b & 0xFFFFFFFF], dist.ReduceOp.MAX)
         return ((parts[1] << 32) | parts[2], (parts[3] << 32) | parts[4]) if parts[0] else None
 
-    def trace_ordinals(self, level, fp):
+    def trace_fps(self, level, fp):
         """Walk the predecessor pointers — they live in the seen-set slots, i.e. on the owner of each state — from the level-`level`
-        state with fingerprint `fp` back to Init; every rank must call this.  Two small all-reduces per level.
-        meta = level(9) << 55 | auxkey(9) << 46 | ordinal(10) << 36 | parent fingerprint bits(35) << 1 | taken(1)."""
-        ords = []
+        state with fingerprint `fp` back to Init; every rank must call this.  -> the fingerprints of the path, Init first
+        (replay_fps re-executes it).  Two small all-reduces per level.
+        meta = level(9) << 55 | auxkey(9) << 46 | parent fingerprint bits(45) << 1 | taken(1)."""
+        fps = [fp]
         for l in range(level, 1, -1):
             hit = self._agree(self.e.lookup(fp, l, False))
             if hit is None or (hit[1] >> 55) != l:
                 raise ShardError("trace walk: no level-%d state with fingerprint %016x in any shard" % (l, fp))
-            ords.append((hit[1] >> 36) & 1023)
-            parent = self._agree(self.e.lookup((hit[1] >> 1) & ((1 << 35) - 1), l - 1, True))
+            parent = self._agree(self.e.lookup((hit[1] >> 1) & ((1 << 45) - 1), l - 1, True))
             if parent is None:
                 raise ShardError("trace walk: the parent of %016x is in no shard" % fp)
             fp = parent[0]
-        return ords[::-1]
+            fps.append(fp)
+        return fps[::-1]
 
 
 class HipShardEngine:
@@ -384,9 +388,15 @@ class HipShardEngine:
         return self._call(capi.load().vsrmc_shard_materialize(self._h, C.byref(self.io), C.c_void_p(self.verdict_in.data_ptr())))
 
     def count(self):
+        """-> (valid states, index range); a failure is remembered and rides on the next error code this rank contributes to a
+        collective (raising here would leave the other ranks blocked in their next all-gather)"""
         nv, nr = C.c_uint64(), C.c_uint64()
-        check(capi.load().vsrmc_shard_count(self._h, C.byref(nv), C.byref(nr)))
+        self._sticky = max(getattr(self, "_sticky", 0), self._call(capi.load().vsrmc_shard_count(self._h, C.byref(nv), C.byref(nr))))
         return nv.value, nr.value
+
+    def sticky_error(self):
+        """error code of an earlier phase that could not report it itself (count, commit, set_max_bag); 0 = none"""
+        return getattr(self, "_sticky", 0)
 
     def empty_streams(self):
         z = torch.zeros(0, dtype=torch.int64, device=self.dev)
@@ -413,7 +423,7 @@ class HipShardEngine:
 
     def commit(self):
         info = capi.LevelInfo()
-        check(capi.load().vsrmc_shard_commit(self._h, C.byref(info)))
+        self._sticky = max(getattr(self, "_sticky", 0), self._call(capi.load().vsrmc_shard_commit(self._h, C.byref(info))))
         d = info.as_dict()
         self.kernel_ms["expand"] += d["expand_ms"]
         self.kernel_ms["materialize"] += d["materialize_ms"]
@@ -434,11 +444,11 @@ class HipShardEngine:
 
     def partition(self):
         n = C.c_uint64()
-        check(capi.load().vsrmc_shard_partition(self._h, C.byref(n)))
+        self._sticky = max(getattr(self, "_sticky", 0), self._call(capi.load().vsrmc_shard_partition(self._h, C.byref(n))))
         return n.value
 
     def set_max_bag(self, max_bag):
-        check(capi.load().vsrmc_shard_set_max_bag(self._h, int(max_bag)))
+        self._sticky = max(getattr(self, "_sticky", 0), self._call(capi.load().vsrmc_shard_set_max_bag(self._h, int(max_bag))))
 
     def find_fp(self, fp):
         idx = C.c_uint64()
@@ -464,8 +474,23 @@ class HipShardEngine:
             self._h = None
 
 
+def replay_fps(model, fps, device=0):
+    """TLCTrace.getTrace, forward half: [(action name, wire record)] for a path given by the fingerprints of its states."""
+    from .checker import ACTION_NAMES
+    n = len(fps)
+    cap_w = (n + 2) * int(model.layout.max_record_words)
+    words = np.zeros(cap_w, dtype=np.uint64)
+    off = np.zeros(n + 3, dtype=np.uint64)
+    acts = np.zeros(n + 3, dtype=np.int32)
+    f = np.array(list(fps), dtype=np.uint64)
+    ns = C.c_uint64()
+    check(capi.load().vsrmc_model_replay_fps(model._h, device, C.c_void_p(f.ctypes.data), n, C.c_void_p(words.ctypes.data), cap_w,
+                                             C.c_void_p(off.ctypes.data), C.c_void_p(acts.ctypes.data), len(off), C.byref(ns)))
+    return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(ns.value)]
+
+
 def replay(model, ords, device=0):
-    """TLCTrace.getTrace, forward half: [(action name, wire record)] for a path of ordinals from Init."""
+    """[(action name, wire record)] for a path of ordinals from Init (simulation walks)."""
     from .checker import ACTION_NAMES
     n = len(ords)
     lay = model.layout

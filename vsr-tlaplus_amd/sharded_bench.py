@@ -67,9 +67,9 @@ def main(args, CONFIG, EXPECT):
             if d["n_new"] == 0 or sc.violation is not None:
                 break
         if sc.violation is not None:                          # counter-example reconstructed = found
-            ords = sc.trace_ordinals(sc.violation["level"], sc.violation["fp"])
+            fps = sc.trace_fps(sc.violation["level"], sc.violation["fp"])
             if rank == 0:
-                tr = sharded.replay(m, ords, device=local_rank)
+                tr = sharded.replay_fps(m, fps, device=local_rank)
                 assert len(tr) == sc.violation["level"]
         dt = time.perf_counter() - t0
         assert sc.distinct == EXPECT["distinct"] and sc.level == EXPECT["depth"], (sc.distinct, sc.level)

@@ -128,9 +128,9 @@ def main(argv=None):
     dt = time.time() - t0
     if code == 0 and sc.violation is not None:
         v = sc.violation
-        ords = sc.trace_ordinals(v["level"], v["fp"])                    # every rank takes part in the walk
+        path = sc.trace_fps(v["level"], v["fp"])                        # every rank takes part in the walk
         if rank == 0:
-            tr = sharded.replay(m, ords, device=local_rank)
+            tr = sharded.replay_fps(m, path, device=local_rank)
             fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64), device=local_rank)
             assert int(fps[0]) == v["fp"], "trace replay does not end in the violating state"
             for b, name in enumerate(INVARIANTS):
