@@ -135,7 +135,8 @@ def run_single(args):
             S["distinct"] += mc.distinct
             S["ttfv"].append(dt)
 
-    one_run(False, verify=True)                                                # untimed: the whole workload against the oracle fixture
+    if not args.no_verify:
+        one_run(False, verify=True)                                            # untimed: the whole workload against the oracle fixture
     for _ in range(args.warmup):
         one_run(False)
     torch.cuda.synchronize()
@@ -144,7 +145,49 @@ def run_single(args):
         one_run(True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    mc.close()                                                                 # the HBM goes to the config-3 leg
     return elapsed, S, m
+
+
+def config3_in_hbm():
+    """BASELINE configs[2] = the reference README's defect configuration (3 replicas, {v1,v2,v3}, limit 3; README:13-18), the part
+    that fits one GPU's HBM with both record buffers on the device: levels 1-20, 315 M distinct states (level 21 onwards needs the
+    host-resident buffer and the virtual / probe levels of `--workload config3`, which takes the same GPU to the depth-24 violation).
+    Untimed setup, one timed pass; every level the CPU oracle reached (tests/golden/oracle_levels_config3.json) is asserted."""
+    import vsr_tlaplus_amd as vt
+    path = os.path.join(ROOT, "tests", "golden", "oracle_levels_config3.json")
+    with open(path) as f:
+        g = json.load(f)
+    with open(os.path.join(ROOT, "tests", "golden", "config3_violation.json")) as f:
+        deep = json.load(f)["levels"]                                         # levels beyond the oracle's depth: the round-1 GPU run
+    m = vt.Model.from_constants(R=3, C_=1, n=3, L=3)
+    t0 = time.perf_counter()
+    mc = vt.ModelChecker(m, device=0, table_log2=30, frontier_words=int(7.6e9), frontier_states=int(1.75e8), pending_entries=1 << 15)
+    setup = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    kernel_ms, alg_bytes, gen = 0.0, 0.0, 0
+    cur_words = int(m.layout.fixed_words) + int(m.layout.permutations)
+    while mc.level < 20:
+        d = mc.step()
+        lv = d["level"]
+        if lv <= len(g["levels"]):
+            want = g["levels"][lv - 1]
+            assert (d["n_new"], d["generated"], d["deadlocks"], d["max_bag"]) == (want["new"], want["generated"], want["deadlocks"], want["max_bag"]), lv
+        else:
+            assert (d["n_new"], d["generated"]) == (deep[lv - 1]["n_new"], deep[lv - 1]["generated"]), lv
+        kernel_ms += d["expand_ms"]
+        alg_bytes += 8.0 * cur_words + 8.0 * d["generated"] + 8.0 * d["n_new"] + 8.0 * d["record_words"]
+        cur_words = d["record_words"]
+        gen += d["generated"]
+    dt = time.perf_counter() - t0
+    out = dict(workload="VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2,v3} StartViewOnTimerLimit=3 (BASELINE configs[2]), levels 1-20 "
+                        "(both record buffers in HBM)", levels=mc.level, distinct=mc.distinct, generated=gen, seconds=round(dt, 4),
+               states_per_s=round(mc.distinct / dt, 1), setup_s=round(setup, 2), oracle_pinned_levels=len(g["levels"]),
+               k_expand_ms=round(kernel_ms, 2), roofline_frac=round(alg_bytes / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+               pcie_bound=False, to_violation="depth 24 after 1.82e9 distinct states: `bench.py --workload config3` (level 22 host-resident: "
+                                              "PCIe-bound, 12.4 s in round 1)")
+    mc.close()
+    return out
 
 
 def run_config3(args):
@@ -191,6 +234,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed verification run (profiling: one run = 27 k_expand launches)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (levels 1-20 of the README defect configuration)")
     ap.add_argument("--workload", choices=["config2", "config3"], default="config2",
                     help="config2 (default) = BASELINE's 1-GPU configuration; config3 = the README defect config to its violation (one GPU, "
                          "host-resident level 22; minutes of setup, ~210 GB of host memory)")
@@ -213,7 +258,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 "
                                "(BASELINE configs[1] = shipped VSR.cfg), VIEW+SYMMETRY, to first violation: 28 levels, "
-                               "319228361 distinct states", "table_slots_log2": TABLE_LOG2, "trace_log": True},
+                               "319228361 distinct states", "table_slots_log2": TABLE_LOG2, "trace": "predecessor pointers in the seen-set, counter-example reconstructed in the timed region"},
         "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
         "generated_per_distinct": round(g, 3), "record_bytes": round(s_bytes, 1),
         "roofline": {"bound": "hbm", "kernel": "k_expand", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -223,13 +268,17 @@ def main():
                      "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3)}},
     }
     # HBM traffic of the same kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
-    tpath = os.path.join(ROOT, "profiles", "r01g_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01g_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             t = json.load(f)
         out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
         out["roofline"]["traffic_unit"] = "bytes per launch (PMC, %s)" % t["source"].split(" (")[0]
         out["roofline"]["alg_bytes_per_launch"] = round(S["alg_bytes"] / max(1, S["launches"]))
+    if not args.no_config3:
+        out["config3"] = config3_in_hbm()
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     print(json.dumps(out))
