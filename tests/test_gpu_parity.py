@@ -551,6 +551,33 @@ def test_seen_set_and_frontier_overflow_are_errors(vt):
     mc.close()
 
 
+@pytest.mark.parametrize("words_log2", [15, 16, 17, 18, 19])
+def test_small_record_buffers_fail_loudly_never_corrupt(vt, orc, words_log2):
+    """a tile's successors must fit the block's word chunk.  With record buffers far too small for the level the run
+    must end in ERR_FRONTIER_FULL (21) — every level that did complete equals the oracle's (no record was written into another
+    block's chunk or past the buffer)."""
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=20, frontier_words=1 << words_log2, frontier_states=1 << 15, pending_entries=1 << 15, keep_trace=False)
+    ob = orc.Bfs(orc.Params(3, 1, 2, 2))
+    done = 1
+    try:
+        for _ in range(11):
+            assert np.array_equal(mc.level_fps(), ob.level_fps(done))
+            d = mc.step()
+            assert d["n_new"] == ob.step() and d["generated"] == ob.info["generated"]
+            words, off = mc.frontier()                          # every record decodes and is what the oracle holds
+            ow, oo = ob.frontier()
+            assert sorted(_norm(orc, ob.P, words[int(off[i]): int(off[i + 1])]) for i in range(len(off) - 1)) == \
+                sorted(_norm(orc, ob.P, ow[int(oo[i]): int(oo[i + 1])]) for i in range(len(oo) - 1))
+            done += 1
+    except vt.VsrmcError as e:
+        assert e.code == -5 and "error 21" in e.message, e.message
+        assert done >= 5
+    else:
+        assert words_log2 >= 19
+    mc.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # checkpoint / recover (TLC: FPSet.beginChkpt/commitChkpt + StateQueue + TLCTrace checkpoints, `-recover`)
 # ---------------------------------------------------------------------------------------------------------------------
