@@ -216,6 +216,10 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info);
  * (viol_index = index in the newest level of the violator's parent resp. grandparent); vsrmc_checker_probe_trace gives the
  * counter-example.  The search cannot continue afterwards. */
 int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_level_info* probe);
+/* the same one level deeper: levels L+1 and L+2 virtual, level L+3 probed (level L is expanded three times, L+1 twice; scratch
+ * buffers of a quarter of the record buffers' size are allocated for the call).  A violation in a virtual level is reported in
+ * its info and ends the call; vsrmc_checker_probe_trace reconstructs the counter-example in every case. */
+int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_level_info* virt2, vsrmc_level_info* probe);
 int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
                                   uint64_t cap_states, uint64_t* n_states);
 

@@ -565,11 +565,10 @@ def test_small_record_buffers_fail_loudly_never_corrupt(vt, orc, words_log2):
             assert np.array_equal(mc.level_fps(), ob.level_fps(done))
             d = mc.step()
             assert d["n_new"] == ob.step() and d["generated"] == ob.info["generated"]
-            words, off = mc.frontier()                          # every record decodes and is what the oracle holds
-            ow, oo = ob.frontier()
-            assert sorted(_norm(orc, ob.P, words[int(off[i]): int(off[i + 1])]) for i in range(len(off) - 1)) == \
-                sorted(_norm(orc, ob.P, ow[int(oo[i]): int(oo[i + 1])]) for i in range(len(oo) - 1))
             done += 1
+            words, off = mc.frontier()                          # every stored record decodes and is a state of this level
+            got = sorted(orc.fingerprint(ob.P, words[int(off[i]): int(off[i + 1])])[0] for i in range(len(off) - 1))
+            assert got == [int(x) for x in ob.level_fps(done)]
     except vt.VsrmcError as e:
         assert e.code == -5 and "error 21" in e.message, e.message
         assert done >= 5
@@ -749,6 +748,79 @@ def test_probe2_virtual_level_plus_probe_level(vt, orc, oracle_levels):
     assert len(tr) == 28
     _check_walk_with_oracle(orc, P, tr, 1)
     mc.close()
+
+
+def test_probe3_two_virtual_levels_plus_probe_level(vt, orc, oracle_levels):
+    """Stop after level 25 of config 2.  probe3(): levels 26 and 27 as virtual levels (exact counts), level 28 probed over
+    regenerated sub-slices -> the golden violating fingerprint and a 28-state counter-example the oracle accepts.  Then the
+    stricter invariant (depth-19 violation) with buffers so small that every pass runs in many slices, stopping at each of the
+    three distances from the violation; and a violation-free space where every figure must equal the stepped run's."""
+    lv = oracle_levels["config2"]["levels"]
+    P = orc.Params(3, 1, 2, 2)
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=30, frontier_words=int(2.4e9), frontier_states=1 << 26, pending_entries=1 << 20)
+    while mc.level < 25:
+        assert mc.step()["viol_mask"] == 0
+    v1, v2, p = mc.probe3()
+    for v, k in ((v1, 25), (v2, 26)):
+        assert v["level"] == k + 1 and v["viol_mask"] == 0
+        assert (v["n_new"], v["generated"]) == (lv[k]["n_new"], lv[k]["generated"]), (k, v)
+    assert v2["distinct"] == sum(l["n_new"] for l in lv[:27])
+    assert p["level"] == 28 and p["viol_mask"] == 1 and p["viol_fp"] == _oracle_viol_fp(oracle_levels)
+    assert p["generated"] == lv[27]["generated"]
+    tr = mc.probe_trace()
+    assert len(tr) == 28
+    _check_walk_with_oracle(orc, P, tr, 1)
+    fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
+    assert int(fps[0]) == p["viol_fp"]
+    with pytest.raises(vt.VsrmcError):
+        mc.step()
+    mc.close()
+
+    P2 = orc.Params(3, 1, 2, 2, invariant_mask=2)
+    m2 = vt.Model.from_constants(R=3, C_=1, n=2, L=2, invariant_mask=2)
+    ref = vt.ModelChecker(m2, table_log2=26, frontier_words=1 << 28, frontier_states=1 << 23)
+    sizes = []
+    while ref.violation is None:
+        sizes.append(ref.step())
+    assert ref.level == 19
+    for stop in (16, 17, 18):
+        mc = vt.ModelChecker(m2, table_log2=26, frontier_words=1 << 25, frontier_states=1 << 20, pending_entries=1 << 16)
+        while mc.level < stop:
+            mc.step()
+        infos = mc.probe3()
+        for d in infos:
+            if d["level"] == 0:
+                continue
+            want = sizes[d["level"] - 1]
+            assert d["generated"] == want["generated"], (stop, d["level"])
+            if d["level"] < 19 and d is not infos[2]:
+                assert d["n_new"] == want["n_new"] and d["viol_mask"] == 0
+        hit = [d for d in infos if d["viol_mask"]]
+        assert len(hit) == 1 and hit[0]["level"] == 19 and hit[0]["viol_mask"] == 2 and hit[0]["viol_fp"] == ref.violation["fp"], (stop, infos)
+        tr = mc.probe_trace()
+        assert len(tr) == 19
+        _check_walk_with_oracle(orc, P2, tr, 2)
+        mc.close()
+    ref.close()
+
+    m1 = vt.Model.from_constants(R=2, C_=1, n=1, L=1)            # config 1: 76 states, depth 14, no violation
+    ref = vt.ModelChecker(m1, table_log2=12, frontier_words=1 << 14, frontier_states=1 << 10)
+    sizes = []
+    while ref.n_frontier:
+        sizes.append(ref.step())
+    ref.close()
+    for stop in range(1, 13):
+        mc = vt.ModelChecker(m1, table_log2=12, frontier_words=1 << 14, frontier_states=1 << 10)
+        while mc.level < stop:
+            mc.step()
+        infos = mc.probe3()
+        for d in infos:
+            want = sizes[d["level"] - 1] if d["level"] - 1 < len(sizes) else dict(generated=0, n_new=0)
+            assert d["viol_mask"] == 0 and d["generated"] == want["generated"], (stop, d)
+            if d is not infos[2]:
+                assert d["n_new"] == want["n_new"], (stop, d)
+        mc.close()
 
 
 def test_cli_probe2_and_probe_last(vt, tmp_path):

@@ -95,6 +95,7 @@ SYMBOLS = {
     "vsrmc_simulate": (C.c_int32, [V, C.c_int32, C.c_uint32, C.c_int32, C.c_uint64, C.c_double, C.POINTER(SimResult)]),
     "vsrmc_checker_probe": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_checker_probe2": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo)]),
+    "vsrmc_checker_probe3": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo), C.POINTER(LevelInfo)]),
     "vsrmc_checker_probe_trace": (C.c_int32, [V, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_save": (C.c_int32, [V, C.c_char_p]),
     "vsrmc_checker_status": (C.c_int32, [V, C.POINTER(LevelInfo)]),

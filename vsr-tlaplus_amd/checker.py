@@ -433,6 +433,19 @@ class ModelChecker:
                 self.violation = dict(level=d["level"], index=None, fp=d["viol_fp"], mask=d["viol_mask"], probed=True)
         return dv, dp
 
+    def probe3(self):
+        """Three levels beyond the newest one without storing any: level+1 and level+2 as virtual levels, level+3 as a probe over
+        regenerated sub-slices (level is expanded three times, level+1 twice).  -> (virtual dict, virtual dict, probe dict); a
+        violation in a virtual level ends the call early (the later dicts then have level 0)."""
+        v1, v2, p = capi.LevelInfo(), capi.LevelInfo(), capi.LevelInfo()
+        check(capi.load().vsrmc_checker_probe3(self._h, C.byref(v1), C.byref(v2), C.byref(p)))
+        out = [v1.as_dict(), v2.as_dict(), p.as_dict()]
+        for d in out:
+            d["ancestor_index"] = d.pop("viol_index")
+            if d["viol_mask"] and self.violation is None:
+                self.violation = dict(level=d["level"], index=None, fp=d["viol_fp"], mask=d["viol_mask"], probed=True)
+        return tuple(out)
+
     def probe_trace(self):
         """The counter-example of the violation probe() reported: [(action name, record)] from Init to the violator."""
         lay = self.model.layout

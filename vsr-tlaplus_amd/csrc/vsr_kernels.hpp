@@ -1067,6 +1067,14 @@ __global__ void k_table_init(Slot* table, u64 slots) {
   }
 }
 
+// clear the `taken` marks of one level's slots: a virtual level that was regenerated once (MODE_REGEN) can be regenerated again
+__global__ void k_table_clear_taken(Slot* table, u64 slots, int level) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (u64)gridDim.x * blockDim.x) {
+    const u64 m = table[i].meta;
+    if (table[i].fp != 0 && meta_level(m) == level && (m & META_TAKEN)) table[i].meta = m & ~META_TAKEN;
+  }
+}
+
 // ---- sharded seen-set: the owner's side of one level -------------------------------------------------------------
 // k_claim_batch: claim the received (fp, key) candidates in this rank's shard; rslot[i] = slot, or ~0 for a duplicate
 // of an earlier level.

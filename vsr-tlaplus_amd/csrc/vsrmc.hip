@@ -1411,8 +1411,15 @@ static int32_t step_local(vsrmc_checker* c, vsrmc_level_info* info) {
 namespace {
 // One single-pass launch over an arbitrary source (a slice of the newest level, or the partial next frontier a MODE_REGEN
 // slice just wrote), unsharded.  Resets the level counters, returns them in c->h.  Destination = the next-frontier buffers.
+struct PassDst {            // where a MODE_REGEN pass writes (records, refs, fingerprints); nullptr members = the next-frontier buffers
+  u64* words = nullptr;
+  u64 words_cap = 0;
+  u64* off = nullptr;
+  u64* fp = nullptr;
+  u64 cap = 0;
+};
 int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 n_parents, u64 p_offset, int level, int mode,
-                u64 src_max_bag) {
+                u64 src_max_bag, const PassDst* dst = nullptr) {
   const Model& M = c->model.M;
   std::memset(&c->h, 0, sizeof(c->h));
   c->h.viol_fp = ~(u64)0;
@@ -1424,17 +1431,21 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 ccap = fs.ccap;
     const size_t lds = fs.lds;
     const int nxt = c->cur ^ 1;
-    const u64 nx_cap = c->opt.frontier_states;
+    u64* const d_words = dst ? dst->words : c->words[nxt];
+    u64* const d_off = dst ? dst->off : c->off[nxt];
+    u64* const d_fp = dst ? dst->fp : c->lvl_fp;
+    const u64 d_wcap = dst ? dst->words_cap : c->words_cap(nxt);
+    const u64 nx_cap = dst ? dst->cap : c->opt.frontier_states;
     unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * fs.blocks_per_cu);
-    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
+    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), d_wcap / (4 * 16384))));
     const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(fs.stride + 5));   // see phase_expand
-    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, c->words_cap(nxt) / (4 * wmin)));
+    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, d_wcap / (4 * wmin)));
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
-    const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
+    const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
-                       c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp,
+                       d_words, d_wcap, d_off, nx_cap, d_fp,
                        ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0, mode, p_offset);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -1600,6 +1611,189 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   if (best_fp != ~(u64)0) {
     probe->viol_fp = best_fp;
     probe->viol_mask = (int32_t)mask2;
+  }
+  return 0;
+}
+
+// Three levels beyond the last materialised one: levels L+1 and L+2 become VIRTUAL levels, level L+3 is probed.
+//   pass 1: level L expanded, MODE_INSERT                                   -> level L+1 exists as seen-set entries
+//   pass 2: slices of L regenerated into the next buffers (MODE_REGEN), each slice's part of L+1 expanded, MODE_INSERT
+//                                                                           -> level L+2 exists as seen-set entries
+//           then the `taken` marks of level L+1 are cleared (k_table_clear_taken): the level is regenerated once more
+//   pass 3: slices of L regenerated again; sub-slices of each part of L+1 regenerated into a scratch buffer (MODE_REGEN of
+//           level L+2), each sub-slice's part of L+2 expanded, MODE_PROBE   -> invariants of level L+3
+// Cost: level L is expanded three times, level L+1 twice, level L+2 once; memory: the scratch buffers of two slices.  On the
+// README defect configuration this takes one MI355X from level 21 — the last level whose records fit the HBM
+// next to the seen-set — to the depth-24 violation without touching host memory.
+int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_level_info* virt2, vsrmc_level_info* probe) {
+  if (!c || !virt1 || !virt2 || !probe) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  if (c->level + 3 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
+  HIPCHK(hipSetDevice(c->opt.device));
+  std::memset(virt1, 0, sizeof(*virt1));
+  std::memset(virt2, 0, sizeof(*virt2));
+  std::memset(probe, 0, sizeof(*probe));
+  virt1->viol_fp = virt1->viol_index = virt2->viol_fp = virt2->viol_index = probe->viol_fp = probe->viol_index = ~(u64)0;
+  c->probe_fp = 0;
+  c->probe_level = 0;
+  c->probe_extra_fp = 0;
+  const Model& M = c->model.M;
+  const int L = c->level, nxt = c->cur ^ 1;
+  const u64 bagL = c->bag_known ? c->cur_max_bag : (u64)M.max_bag;
+  // ---- pass 1: virtual level L+1
+  double t0 = now_s();
+  c->expand_ms = 0;
+  int rc = expand_pass(c, c->words[c->cur], c->off[c->cur], c->n_frontier, 0, L + 1, MODE_INSERT, bagL);
+  c->failed = 1;                                               // the seen-set now holds levels that have no frontier: stepping on is impossible
+  c->failed_code = 0;
+  if (rc) return rc;
+  virt1->level = L + 1;
+  virt1->frontier = c->n_frontier;
+  virt1->generated = c->h.generated;
+  virt1->deadlocks = c->h.deadlocks;
+  virt1->n_new = c->h.n_new;
+  virt1->distinct = c->distinct + c->h.n_new;
+  virt1->total_generated = c->total_generated + c->h.generated;
+  virt1->probes = c->h.probes;
+  virt1->max_bag = c->h.max_bag;
+  virt1->expand_ms = c->expand_ms;
+  virt1->seconds = now_s() - t0;
+  const u64 gen1 = c->h.generated, bag1 = std::min<u64>(c->h.max_bag, (u64)M.max_bag);
+  if (c->h.viol_fp != ~(u64)0) {
+    virt1->viol_fp = c->h.viol_fp;
+    virt1->viol_mask = (int32_t)c->h.viol_mask;
+    c->probe_fp = c->h.viol_fp;
+    c->probe_level = L + 1;
+    return 0;
+  }
+  // slices of level L: a slice's part of level L+1 may fill a quarter of the next buffers (chunk slack included)
+  const u64 g1 = std::max<u64>(1, (gen1 + c->n_frontier - 1) / std::max<u64>(1, c->n_frontier));
+  u64 slice = std::min<u64>(c->opt.frontier_states / (4 * g1), c->words_cap(nxt) / (4 * g1 * (u64)c->lds_stride));
+  slice = std::max<u64>(128, slice & ~(u64)127);
+  // ---- pass 2: virtual level L+2
+  t0 = now_s();
+  c->expand_ms = 0;
+  u64 n2 = 0, gen2 = 0, dead2 = 0, probes2 = 0, bag2 = 0, viol2 = ~(u64)0, regen1 = 0;
+  u32 mask2 = 0;
+  for (u64 a = 0; a < c->n_frontier; a += slice) {
+    const u64 n = std::min<u64>(slice, c->n_frontier - a);
+    rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, L + 1, MODE_REGEN, bagL);
+    if (rc) return rc;
+    const u64 part = c->h.n_new;
+    regen1 += c->h.rec_words;
+    rc = expand_pass(c, c->words[nxt], c->off[nxt], part, 0, L + 2, MODE_INSERT, bag1);
+    if (rc) return rc;
+    n2 += c->h.n_new;
+    gen2 += c->h.generated;
+    dead2 += c->h.deadlocks;
+    probes2 += c->h.probes;
+    bag2 = std::max<u64>(bag2, c->h.max_bag);
+    if (c->h.viol_fp != ~(u64)0) {
+      mask2 |= c->h.viol_mask;
+      viol2 = std::min<u64>(viol2, c->h.viol_fp);
+    }
+  }
+  virt2->level = L + 2;
+  virt2->frontier = virt1->n_new;
+  virt2->generated = gen2;
+  virt2->deadlocks = dead2;
+  virt2->n_new = n2;
+  virt2->distinct = virt1->distinct + n2;
+  virt2->total_generated = virt1->total_generated + gen2;
+  virt2->probes = probes2;
+  virt2->max_bag = bag2;
+  virt2->record_words = regen1;
+  virt2->expand_ms = c->expand_ms;
+  virt2->seconds = now_s() - t0;
+  if (viol2 != ~(u64)0) {
+    virt2->viol_fp = viol2;
+    virt2->viol_mask = (int32_t)mask2;
+    c->probe_fp = viol2;
+    c->probe_level = L + 2;
+    return 0;
+  }
+  bag2 = std::min<u64>(bag2, (u64)M.max_bag);
+  hipLaunchKernelGGL(k_table_clear_taken, dim3(8192), dim3(256), 0, c->stream, c->table, c->tmask + 1, L + 1);
+  HIPCHK(hipGetLastError());
+  // ---- pass 3: probe of level L+3 over regenerated sub-slices of level L+2 (scratch buffers: a quarter of the next buffers' size)
+  t0 = now_s();
+  c->expand_ms = 0;
+  PassDst B;
+  B.words_cap = std::max<u64>((u64)1 << 22, c->words_cap(nxt) / 4);
+  B.cap = std::max<u64>((u64)1 << 16, c->opt.frontier_states / 4);
+  hipError_t e = hipMalloc((void**)&B.words, B.words_cap * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&B.off, (B.cap + 1) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&B.fp, B.cap * 8);
+  auto free_b = [&]() {
+    if (B.words) (void)hipFree(B.words);
+    if (B.off) (void)hipFree(B.off);
+    if (B.fp) (void)hipFree(B.fp);
+  };
+  if (e != hipSuccess) {
+    free_b();
+    return fail(VSRMC_E_HIP, std::string("hipMalloc of the probe3 scratch buffers: ") + hipGetErrorString(e));
+  }
+  const u64 g2 = std::max<u64>(1, (gen2 + virt1->n_new - 1) / std::max<u64>(1, virt1->n_new));
+  u64 sub = std::min<u64>(B.cap / (4 * g2), B.words_cap / (4 * g2 * (u64)c->lds_stride));
+  sub = std::max<u64>(128, sub & ~(u64)127);
+  u64 best_fp = ~(u64)0, gen3 = 0, dead3 = 0, probes3 = 0, seen_bad = 0, regen2 = 0;
+  u32 mask3 = 0;
+  for (u64 a = 0; a < c->n_frontier && !rc; a += slice) {
+    const u64 n = std::min<u64>(slice, c->n_frontier - a);
+    rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, L + 1, MODE_REGEN, bagL);
+    if (rc) break;
+    const u64 part = c->h.n_new;                               // index range of this slice's part of level L+1 (holes included)
+    for (u64 b = 0; b < part && !rc; b += sub) {
+      const u64 nb = std::min<u64>(sub, part - b);
+      rc = expand_pass(c, c->words[nxt], c->off[nxt] + b, nb, b, L + 2, MODE_REGEN, bag1, &B);
+      if (rc) break;
+      const u64 part2 = c->h.n_new;
+      regen2 += c->h.rec_words;
+      rc = expand_pass(c, B.words, B.off, part2, 0, L + 3, MODE_PROBE, bag2);
+      if (rc) break;
+      gen3 += c->h.generated;
+      dead3 += c->h.deadlocks;
+      probes3 += c->h.probes;
+      seen_bad += c->h.n_pending;
+      if (c->h.viol_fp != ~(u64)0) {
+        mask3 |= c->h.viol_mask;
+        if (c->h.viol_fp < best_fp) {
+          u64 k3 = ~(u64)0;
+          rc = min_violator(c, c->h.viol_fp, &k3);
+          if (rc) break;
+          if (k3 != ~(u64)0) {                                 // its parent: the level-(L+2) state with these fingerprint bits, in the seen-set
+            bool found = false;
+            u64 pfp = 0, pmeta = 0;
+            rc = table_lookup(c, meta_pfp(k3), L + 2, 1, &found, &pfp, &pmeta);
+            if (rc) break;
+            if (found) {
+              best_fp = c->h.viol_fp;
+              c->probe_fp = pfp;
+              c->probe_level = L + 2;
+              c->probe_extra_fp = c->h.viol_fp;
+            }
+          }
+        }
+      }
+    }
+  }
+  free_b();
+  if (rc) return rc;
+  probe->level = L + 3;
+  probe->frontier = n2;
+  probe->generated = gen3;
+  probe->deadlocks = dead3;
+  probe->probes = probes3;
+  probe->pending = seen_bad;
+  probe->record_words = regen2;
+  probe->distinct = virt2->distinct;
+  probe->total_generated = virt2->total_generated + gen3;
+  probe->expand_ms = c->expand_ms;
+  probe->seconds = now_s() - t0;
+  if (best_fp != ~(u64)0) {
+    probe->viol_fp = best_fp;
+    probe->viol_mask = (int32_t)mask3;
   }
   return 0;
 }
