@@ -764,8 +764,8 @@ def test_probe3_two_virtual_levels_plus_probe_level(vt, orc, oracle_levels):
     v1, v2, p = mc.probe3()
     for v, k in ((v1, 25), (v2, 26)):
         assert v["level"] == k + 1 and v["viol_mask"] == 0
-        assert (v["n_new"], v["generated"]) == (lv[k]["n_new"], lv[k]["generated"]), (k, v)
-    assert v2["distinct"] == sum(l["n_new"] for l in lv[:27])
+        assert (v["n_new"], v["generated"]) == (lv[k]["new"], lv[k]["generated"]), (k, v)
+    assert v2["distinct"] == sum(l["new"] for l in lv[:27])
     assert p["level"] == 28 and p["viol_mask"] == 1 and p["viol_fp"] == _oracle_viol_fp(oracle_levels)
     assert p["generated"] == lv[27]["generated"]
     tr = mc.probe_trace()
