@@ -149,25 +149,30 @@ def run_single(args):
     return elapsed, S, m
 
 
-def config3_in_hbm():
-    """BASELINE configs[2] = the reference README's defect configuration (3 replicas, {v1,v2,v3}, limit 3; README:13-18), the part
-    that fits one GPU's HBM with both record buffers on the device: levels 1-20, 315 M distinct states (level 21 onwards needs the
-    host-resident buffer and the virtual / probe levels of `--workload config3`, which takes the same GPU to the depth-24 violation).
-    Untimed setup, one timed pass; every level the CPU oracle reached (tests/golden/oracle_levels_config3.json) is asserted."""
+def config3_to_violation(dump_trace=None):
+    """BASELINE configs[2] = the reference README's defect configuration (3 replicas, {v1,v2,v3}, limit 3; README:13-18) on ONE GPU,
+    BFS to its first violation at depth 24 — everything in HBM: levels 1-21 are materialised (level 21: 261 M states, 91 GB of
+    records), level 22 is a VIRTUAL level (seen-set entries only, regenerated slice by slice), level 23 is streamed through a
+    scratch buffer (inserted, never kept), level 24 is PROBED (vsrmc_checker_probe3); the counter-example is reconstructed in the timed region.  Untimed setup (~245 GB of
+    device allocations), one timed pass.  Levels 1-19 are asserted against the CPU oracle's fixture
+    (tests/golden/oracle_levels_config3.json), deeper levels against tests/golden/config3_violation.json (GPU runs of two rounds,
+    two fingerprint functions, two level schemes: the oracle needs hours for them on the 16 host cores)."""
+    import numpy as np
     import vsr_tlaplus_amd as vt
-    path = os.path.join(ROOT, "tests", "golden", "oracle_levels_config3.json")
-    with open(path) as f:
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_config3.json")) as f:
         g = json.load(f)
     with open(os.path.join(ROOT, "tests", "golden", "config3_violation.json")) as f:
-        deep = json.load(f)["levels"]                                         # levels beyond the oracle's depth: the round-1 GPU run
+        fx = json.load(f)
+    deep = fx["levels"]
     m = vt.Model.from_constants(R=3, C_=1, n=3, L=3)
     t0 = time.perf_counter()
-    mc = vt.ModelChecker(m, device=0, table_log2=30, frontier_words=int(7.6e9), frontier_states=int(1.75e8), pending_entries=1 << 15)
+    mc = vt.ModelChecker(m, device=0, table_log2=32, frontier_words=int(12.8e9), frontier_words_b=int(7.0e9), frontier_states=int(2.85e8),
+                         pending_entries=1 << 16)
     setup = time.perf_counter() - t0
     t0 = time.perf_counter()
     kernel_ms, alg_bytes, gen = 0.0, 0.0, 0
     cur_words = int(m.layout.fixed_words) + int(m.layout.permutations)
-    while mc.level < 20:
+    while mc.level < 21:
         d = mc.step()
         lv = d["level"]
         if lv <= len(g["levels"]):
@@ -175,58 +180,50 @@ def config3_in_hbm():
             assert (d["n_new"], d["generated"], d["deadlocks"], d["max_bag"]) == (want["new"], want["generated"], want["deadlocks"], want["max_bag"]), lv
         else:
             assert (d["n_new"], d["generated"]) == (deep[lv - 1]["n_new"], deep[lv - 1]["generated"]), lv
+        assert d["viol_mask"] == 0
         kernel_ms += d["expand_ms"]
         alg_bytes += 8.0 * cur_words + 8.0 * d["generated"] + 8.0 * d["n_new"] + 8.0 * d["record_words"]
         cur_words = d["record_words"]
         gen += d["generated"]
+    t_mat = time.perf_counter() - t0
+    n_mat = mc.distinct
+    v1, v2, p = mc.probe3()
+    tr = mc.probe_trace()
     dt = time.perf_counter() - t0
-    out = dict(workload="VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2,v3} StartViewOnTimerLimit=3 (BASELINE configs[2]), levels 1-20 "
-                        "(both record buffers in HBM)", levels=mc.level, distinct=mc.distinct, generated=gen, seconds=round(dt, 4),
-               states_per_s=round(mc.distinct / dt, 1), setup_s=round(setup, 2), oracle_pinned_levels=len(g["levels"]),
-               k_expand_ms=round(kernel_ms, 2), roofline_frac=round(alg_bytes / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
-               pcie_bound=False, to_violation="depth 24 after 1.82e9 distinct states: `bench.py --workload config3` (level 22 host-resident: "
-                                              "PCIe-bound, 12.4 s in round 1)")
+    for v in (v1, v2):
+        assert (v["n_new"], v["generated"], v["viol_mask"]) == (deep[v["level"] - 1]["n_new"], deep[v["level"] - 1]["generated"], 0), v
+    assert p["level"] == 24 and p["viol_mask"] == 1 and len(tr) == 24 and p["generated"] == fx["probe"]["generated"]
+    assert fx.get("fp_version") != FP_VERSION or p["viol_fp"] == int(fx["viol_fp"], 16)
+    fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
+    assert int(fps[0]) == p["viol_fp"]                                   # the reconstructed path ends in the reported violator
+    same_trace = None                                                    # the counter-example is a function of the state space alone
+    if fx.get("fp_version") == FP_VERSION and fx.get("trace"):          # (min-merged keys): the same 24 states as the round's host-frontier run
+        same_trace = [(a, ["%016x" % int(w) for w in rec]) for a, rec in tr] == [(t["action"], t["words"]) for t in fx["trace"]]
+    if dump_trace:                                                       # refresh of tests/golden/config3_violation.json (tools/refresh_violation_fixtures.py)
+        with open(dump_trace, "w") as f:
+            f.write(json.dumps(dict(trace=[dict(action=a, words=["%016x" % int(w) for w in rec]) for a, rec in tr])) + "\n")
+    out = dict(workload="VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2,v3} StartViewOnTimerLimit=3 (BASELINE configs[2], README:13-18), "
+                        "VIEW+SYMMETRY, to the first violation at depth 24, all in HBM: levels 1-21 materialised, 22 virtual, 23 streamed, 24 probed",
+               time_to_first_violation_s=round(dt, 4), depth=24, distinct_through_level_23=v2["distinct"],
+               distinct_states_per_s=round(v2["distinct"] / dt, 1), generated=gen + v1["generated"] + v2["generated"] + p["generated"],
+               setup_s=round(setup, 2), oracle_pinned_levels=len(g["levels"]), pcie_bound=False, trace_equals_fixture=same_trace,
+               materialised=dict(levels=21, distinct=n_mat, seconds=round(t_mat, 4), states_per_s=round(n_mat / t_mat, 1),
+                                 k_expand_ms=round(kernel_ms, 2), roofline_frac=round(alg_bytes / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)),
+               probe3=dict(virtual_22_s=round(v1["seconds"], 4), virtual_23_s=round(v2["seconds"], 4), probe_24_s=round(p["seconds"], 4),
+                           k_expand_ms=round(v1["expand_ms"] + v2["expand_ms"] + p["expand_ms"], 2),
+                           slices=v2["pending"] >> 32, sub_slices=v2["pending"] & 0xFFFFFFFF, expansions=dict(level_21=2, level_22=1, level_23=1)))
     mc.close()
     return out
 
 
 def run_config3(args):
-    """--workload config3: the reference README's defect configuration (BASELINE configs[2]) on ONE GPU, BFS to its first violation.
-    Levels 2-22 are materialised (level 22: 164 GB of records in pinned host memory, read / written over PCIe), level 23 is a
-    virtual level, level 24 a probe level.  Needs ~210 GB of host memory and ~200 GB of HBM; not the default."""
-    import numpy as np
-    import vsr_tlaplus_amd as vt
-    with open(os.path.join(ROOT, "tests", "golden", "config3_violation.json")) as f:
-        fx = json.load(f)
-    m = vt.Model.from_constants(R=3, C_=1, n=3, L=3)
-    t_setup = time.perf_counter()
-    mc = vt.ModelChecker(m, device=0, table_log2=32, frontier_words=int(2 ** 33.65), frontier_words_b=int(2 ** 34.6),
-                         frontier_states=int(2 ** 29.05), pending_entries=1 << 20, host_frontier=2)
-    t_setup = time.perf_counter() - t_setup
-    t0 = time.perf_counter()
-    generated = 0
-    while mc.level < 22:
-        d = mc.step()
-        generated += d["generated"]
-        assert d["viol_mask"] == 0 and d["n_new"] == fx["levels"][d["level"] - 1]["n_new"]
-    v, p = mc.probe2()
-    tr = mc.probe_trace()
-    dt = time.perf_counter() - t0
-    assert v["n_new"] == fx["levels"][22]["n_new"] and p["viol_mask"] == 1 and len(tr) == 24
-    fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
-    assert int(fps[0]) == p["viol_fp"]                                   # the reconstructed path ends in the reported violator
-    if os.environ.get("VSR_BENCH_DUMP_TRACE"):                           # refresh of tests/golden/config3_violation.json (tools/refresh_violation_fixtures.py)
-        with open(os.environ["VSR_BENCH_DUMP_TRACE"], "w") as f:
-            f.write(json.dumps(dict(trace=[dict(action=a, words=["%016x" % int(w) for w in rec]) for a, rec in tr])) + "\n")
+    """--workload config3: only the README defect configuration (BASELINE configs[2]) to its first violation, as the bench line."""
+    c3 = config3_to_violation(os.environ.get("VSR_BENCH_DUMP_TRACE"))
+    dt = c3["time_to_first_violation_s"]
     print(json.dumps({
         "metric": "time-to-first-violation, VSR 3-replica README defect config (BFS, trace reconstructed)", "value": round(dt, 3), "unit": "s",
         "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": round(1e3 * dt, 1), "higher_is_better": False, "scaling": "strong",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2,v3} StartViewOnTimerLimit=3 (BASELINE configs[2], "
-                               "README:13-18), VIEW+SYMMETRY, to the first violation at depth 24: levels 2-22 materialised (level 22 in "
-                               "pinned host memory), level 23 virtual, level 24 probed"},
-        "distinct_states_through_level_23": v["distinct"], "distinct_states_per_s": round(v["distinct"] / dt, 1),
-        "generated": generated + v["generated"] + p["generated"], "setup_seconds": round(t_setup, 1)}))
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": {"workload": c3["workload"]}, "detail": c3}))
 
 
 def main():
@@ -237,10 +234,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed verification run (profiling: one run = 27 k_expand launches)")
-    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (levels 1-20 of the README defect configuration)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (the README defect configuration to its depth-24 violation; ~245 GB of HBM)")
     ap.add_argument("--workload", choices=["config2", "config3"], default="config2",
-                    help="config2 (default) = BASELINE's 1-GPU configuration; config3 = the README defect config to its violation (one GPU, "
-                         "host-resident level 22; minutes of setup, ~210 GB of host memory)")
+                    help="config2 (default) = BASELINE's 1-GPU configuration; config3 = only the README defect config to its violation")
     args = ap.parse_args()
     if args.workload == "config3":
         return run_config3(args)
@@ -280,7 +276,7 @@ def main():
         out["roofline"]["traffic_unit"] = "bytes per launch (PMC, %s)" % t["source"].split(" (")[0]
         out["roofline"]["alg_bytes_per_launch"] = round(S["alg_bytes"] / max(1, S["launches"]))
     if not args.no_config3:
-        out["config3"] = config3_in_hbm()
+        out["config3"] = config3_to_violation()
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     print(json.dumps(out))

@@ -216,10 +216,17 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info);
  * (viol_index = index in the newest level of the violator's parent resp. grandparent); vsrmc_checker_probe_trace gives the
  * counter-example.  The search cannot continue afterwards. */
 int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_level_info* probe);
-/* the same one level deeper: levels L+1 and L+2 virtual, level L+3 probed (level L is expanded three times, L+1 twice; scratch
- * buffers of a quarter of the record buffers' size are allocated for the call).  A violation in a virtual level is reported in
- * its info and ends the call; vsrmc_checker_probe_trace reconstructs the counter-example in every case. */
+/* the same one level deeper: level L+1 virtual, level L+2 streamed through scratch buffers (inserted into the seen-set, exact
+ * count, never kept), level L+3 probed.  Level L is expanded twice, L+1 and L+2 once; scratch buffers of a quarter of the record
+ * buffers' size are allocated for the call.  virt2->pending = (slices of level L) << 32 | sub-slices of level L+1.  A violation
+ * in level L+1 or L+2 is reported in that level's info (a violating level is still completed; nothing deeper is reported);
+ * vsrmc_checker_probe_trace reconstructs the counter-example in every case. */
 int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_level_info* virt2, vsrmc_level_info* probe);
+/* the (fingerprint, key) pairs of the violating successors the last vsrmc_checker_probe saw and did not find in this checker's
+ * seen-set (duplicates included; *n = their number, also when `pairs` is too small).  Sharded runs show them to their owners. */
+int32_t vsrmc_checker_probe_candidates(vsrmc_checker* c, uint64_t* pairs, uint64_t cap_pairs, uint64_t* n);
+/* seen[i] = 1 if fps[i] is in this checker's seen-set as a state of a level below `level` (host arrays) */
+int32_t vsrmc_checker_seen_batch(vsrmc_checker* c, const uint64_t* fps, uint64_t n, int32_t level, uint8_t* seen);
 int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
                                   uint64_t cap_states, uint64_t* n_states);
 

@@ -166,6 +166,40 @@ class FakeShardEngine:
         return dict(n_new=len(self.frontier), expand_ms=0.0, materialize_ms=0.0, generated=self.generated, deadlocks=self.deadlocks,
                     pending=len(self.local_pending), viol_fp=self.viol_fp, viol_mask=self.viol_mask, max_bag=0)
 
+    def probe(self):
+        """the local part of the newest level, nothing stored: violating successors that are not in THIS rank's seen-set"""
+        gen = dead = mask = 0
+        bad = []
+        for pidx, rec in enumerate(self.frontier):
+            if rec is None:
+                continue
+            succ = orc.successors(self.P, rec)
+            gen += len(succ)
+            dead += 0 if succ else 1
+            for k, s in enumerate(succ):
+                if s["inv"] and s["fp"] not in self.seen:
+                    bad.append((s["fp"], self._key(self.level + 1, s["auxkey"], self.fps[pidx], k)))
+                    mask |= s["inv"]
+        return dict(generated=gen, deadlocks=dead, viol_mask=mask), np.array(bad, dtype=np.uint64).reshape(-1, 2), 0
+
+    def seen_before(self, fps, level):
+        return np.array([int(f) in self.seen and (self.seen[int(f)] >> 55) < level for f in fps], dtype=bool)
+
+    def save(self, path):
+        import pickle
+        with open(path, "wb") as f:
+            pickle.dump(dict(seen=self.seen, frontier=self.frontier, fps=self.fps, level=self.level, total=self.total), f)
+        return 0
+
+    @classmethod
+    def load(cls, path, params, rank, world, owner_of):
+        import pickle
+        self = cls(params, rank, world, owner_of)
+        with open(path, "rb") as f:
+            d = pickle.load(f)
+        self.seen, self.frontier, self.fps, self.level, self.total = d["seen"], d["frontier"], d["fps"], d["level"], d["total"]
+        return self
+
     def lookup(self, key, level, by_low_bits):
         """one step of a trace walk through this rank's part of the seen-set -> (fingerprint, meta) or None"""
         if not by_low_bits:

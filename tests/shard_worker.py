@@ -19,26 +19,52 @@ def main():
     dist.init_process_group("gloo")           # CPU test: gloo; on the one-GPU box both ranks share device 0 over gloo
     rank, world = dist.get_rank(), dist.get_world_size()
     from vsr_tlaplus_amd import sharded
+    # optional legs (environment): SHARD_INV_MASK = the invariants checked; SHARD_CHECKPOINT_AT = k: after level k the run is
+    # checkpointed, every engine is thrown away and the run continues from the files; SHARD_PROBE_AT = k: level k is probed
+    # (ShardedChecker.probe) instead of stepped into
+    inv_mask = int(os.environ.get("SHARD_INV_MASK", "1"))
+    chk_at, probe_at = int(os.environ.get("SHARD_CHECKPOINT_AT", "0")), int(os.environ.get("SHARD_PROBE_AT", "0"))
     if engine_kind == "fake":
         from fake_shard_engine import FakeShardEngine
         from oracle import orc
-        eng = FakeShardEngine(orc.Params(R, C_, n, L), rank, world, sharded.owner_of)
+        P = orc.Params(R, C_, n, L, invariant_mask=inv_mask)
+
+        def make_engine(recover=None):
+            return FakeShardEngine.load(recover, P, rank, world, sharded.owner_of) if recover else FakeShardEngine(P, rank, world, sharded.owner_of)
     else:
         import vsr_tlaplus_amd as vt
-        m = vt.Model.from_constants(R=R, C_=C_, n=n, L=L)
-        eng = sharded.HipShardEngine(m, rank, world, device=0, table_log2=20, frontier_words=1 << 22, frontier_states=1 << 17,
-                                     pending_entries=1 << 19, cand_cap=1 << 18, rec_cap=1 << 17, rec_words_cap=1 << 22,
-                                     exact_ties=engine_kind == "hip-exact", filter_log2=16)
+        m = vt.Model.from_constants(R=R, C_=C_, n=n, L=L, invariant_mask=inv_mask)
+
+        def make_engine(recover=None):
+            return sharded.HipShardEngine(m, rank, world, device=0, table_log2=20, frontier_words=1 << 22, frontier_states=1 << 17,
+                                          pending_entries=1 << 19, cand_cap=1 << 18, rec_cap=1 << 17, rec_words_cap=1 << 22,
+                                          exact_ties=engine_kind == "hip-exact", filter_log2=16, recover=recover)
+    eng = make_engine()
     sc = sharded.ShardedChecker(eng, sharded.Exchanger(), replicate_below=replicate_below)
     # "replicated": the level's states are on every rank (the ranks explored it on their own), else each state is on one rank
     levels = [dict(level=1, n_new=sc.distinct, generated=0, deadlocks=0, replicated=sc.replicated,
                    fps=["%016x" % int(f) for f in eng.level_fps()])]
+    restored = False
     while sc.level < max_depth:
+        if chk_at and sc.level == chk_at and not restored:
+            sc.save(out + ".chk")
+            if hasattr(eng, "close"):
+                eng.close()
+            x = sc.x
+            del sc, eng
+            sc = sharded.ShardedChecker.restore(out + ".chk", make_engine, x)
+            eng = sc.e
+            restored = True
         d = sc.step()
         if d["n_new"] == 0:
             break
         levels.append(dict(level=d["level"], n_new=d["n_new"], generated=d["generated"], deadlocks=d["deadlocks"],
                            replicated=sc.replicated, fps=["%016x" % int(f) for f in eng.level_fps()]))
+    probe = None
+    if probe_at and sc.level == probe_at - 1:
+        probe = sc.probe()
+        probe["viol_fp"] = "%016x" % probe["viol_fp"] if probe["viol_fp"] is not None else None
+        probe["fps"] = ["%016x" % f for f in sc.probe_trace_fps()] if probe["viol_fp"] else []
     # trace of the last state of the deepest non-empty local level (every rank takes part in every walk)
     walks = []
     for r in range(world):
@@ -52,7 +78,7 @@ def main():
             walks.append(dict(rank=r, level=sc.level, fp="%016x" % fp, fps=["%016x" % f for f in sc.trace_fps(sc.level, fp)]))
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks,
-                       bytes_sent=sc.x.bytes_sent, moved=sc.moved), f)
+                       bytes_sent=sc.x.bytes_sent, moved=sc.moved, probe=probe, restored=restored), f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -780,19 +780,20 @@ def test_probe3_two_virtual_levels_plus_probe_level(vt, orc, oracle_levels):
     P2 = orc.Params(3, 1, 2, 2, invariant_mask=2)
     m2 = vt.Model.from_constants(R=3, C_=1, n=2, L=2, invariant_mask=2)
     ref = vt.ModelChecker(m2, table_log2=26, frontier_words=1 << 28, frontier_states=1 << 23)
-    sizes = []
+    sizes = {}
     while ref.violation is None:
-        sizes.append(ref.step())
+        d = ref.step()
+        sizes[d["level"]] = d
     assert ref.level == 19
     for stop in (16, 17, 18):
-        mc = vt.ModelChecker(m2, table_log2=26, frontier_words=1 << 25, frontier_states=1 << 20, pending_entries=1 << 16)
+        mc = vt.ModelChecker(m2, table_log2=26, frontier_words=1 << 27, frontier_states=1 << 22, pending_entries=1 << 16)
         while mc.level < stop:
             mc.step()
         infos = mc.probe3()
         for d in infos:
             if d["level"] == 0:
                 continue
-            want = sizes[d["level"] - 1]
+            want = sizes[d["level"]]
             assert d["generated"] == want["generated"], (stop, d["level"])
             if d["level"] < 19 and d is not infos[2]:
                 assert d["n_new"] == want["n_new"] and d["viol_mask"] == 0
@@ -805,19 +806,22 @@ def test_probe3_two_virtual_levels_plus_probe_level(vt, orc, oracle_levels):
     ref.close()
 
     m1 = vt.Model.from_constants(R=2, C_=1, n=1, L=1)            # config 1: 76 states, depth 14, no violation
-    ref = vt.ModelChecker(m1, table_log2=12, frontier_words=1 << 14, frontier_states=1 << 10)
-    sizes = []
+    ref = vt.ModelChecker(m1, table_log2=12, frontier_words=1 << 20, frontier_states=1 << 14)
+    sizes = {}
     while ref.n_frontier:
-        sizes.append(ref.step())
+        d = ref.step()
+        sizes[d["level"] if d["n_new"] else d["level"] + 1] = d    # an empty level is not committed: the level number stays
     ref.close()
+    with pytest.raises(vt.VsrmcError):                            # smaller than one index chunk: refused, not overrun
+        vt.ModelChecker(m1, table_log2=12, frontier_words=1 << 14, frontier_states=1 << 10)
     for stop in range(1, 13):
-        mc = vt.ModelChecker(m1, table_log2=12, frontier_words=1 << 14, frontier_states=1 << 10)
+        mc = vt.ModelChecker(m1, table_log2=12, frontier_words=1 << 20, frontier_states=1 << 14)
         while mc.level < stop:
             mc.step()
         infos = mc.probe3()
         for d in infos:
-            want = sizes[d["level"] - 1] if d["level"] - 1 < len(sizes) else dict(generated=0, n_new=0)
-            assert d["viol_mask"] == 0 and d["generated"] == want["generated"], (stop, d)
+            want = sizes.get(d["level"], dict(generated=0, n_new=0))
+            assert d["viol_mask"] == 0 and d["generated"] == want["generated"], (stop, d["level"], d["generated"], sorted(sizes))
             if d is not infos[2]:
                 assert d["n_new"] == want["n_new"], (stop, d)
         mc.close()
@@ -833,6 +837,10 @@ def test_cli_probe2_and_probe_last(vt, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Virtual(9):" in r.stdout and "Probe(10):" in r.stdout and "No violation up to level 10" in r.stdout
+    r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01", "-probe3At", "9"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert all(x in r.stdout for x in ("Virtual(9):", "Virtual(10):", "Probe(11):", "No violation up to level 11")), r.stdout
 
 
 def test_exists_on_majority_fails_at_depth_19_on_the_shipped_constants(vt, orc):

@@ -1067,14 +1067,6 @@ __global__ void k_table_init(Slot* table, u64 slots) {
   }
 }
 
-// clear the `taken` marks of one level's slots: a virtual level that was regenerated once (MODE_REGEN) can be regenerated again
-__global__ void k_table_clear_taken(Slot* table, u64 slots, int level) {
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (u64)gridDim.x * blockDim.x) {
-    const u64 m = table[i].meta;
-    if (table[i].fp != 0 && meta_level(m) == level && (m & META_TAKEN)) table[i].meta = m & ~META_TAKEN;
-  }
-}
-
 // ---- sharded seen-set: the owner's side of one level -------------------------------------------------------------
 // k_claim_batch: claim the received (fp, key) candidates in this rank's shard; rslot[i] = slot, or ~0 for a duplicate
 // of an earlier level.
@@ -1302,6 +1294,16 @@ __global__ void k_table_lookup(const Slot* table, u64 tmask, u64 key, int level,
   out[0] = slot != ~(u64)0 ? 1 : 0;
   out[1] = slot != ~(u64)0 ? table[slot].fp : 0;
   out[2] = slot != ~(u64)0 ? table[slot].meta : 0;
+}
+
+// flags[i] = 1 if fingerprint fps[i] is a state of a level below `level` (a streamed probe collects violating successors while the
+// level above them is still being inserted: the ones that turn out to be states of that level — same VIEW fingerprint, i.e. the
+// same state for the search, whatever the invariant says about this copy's aux variables — are dropped afterwards)
+__global__ void k_table_seen(const Slot* table, u64 tmask, const u64* __restrict__ fps, u64 n, int level, u64* flags) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 slot = find_exact(table, tmask, fps[i]);
+  flags[i] = (slot != ~(u64)0 && meta_level(table[slot].meta) < level) ? 1 : 0;
 }
 
 // k_select: indices of the frontier records in which at least one instance of an action of `action_mask` (bit a = action id a)

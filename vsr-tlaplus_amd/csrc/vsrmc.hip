@@ -1124,7 +1124,10 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
       o->pending_entries < 4 * (uint64_t)VSR_CAND_CAP)
     return fail(VSRMC_E_ARG, "bad options");
   if (o->world < 1 || o->world > 8 || o->rank < 0 || o->rank >= o->world) return fail(VSRMC_E_ARG, "bad rank / world (1..8 ranks)");
-    if (o->frontier_states > ((uint64_t)1 << 40)) return fail(VSRMC_E_ARG, "frontier_states > 2^40");   // origin word: parent index | ordinal << 40
+  if (o->frontier_states > ((uint64_t)1 << 40)) return fail(VSRMC_E_ARG, "frontier_states > 2^40");   // origin word: parent index | ordinal << 40
+  // a block reserves frontier indices in chunks of at least VSR_CAND_CAP (one tile's successors) and clears the unused tail of its
+  // chunk: a frontier smaller than one chunk would be written past its end
+  if (o->frontier_states < (uint64_t)VSR_CAND_CAP) return fail(VSRMC_E_ARG, "frontier_states must be at least 2048 (one index chunk)");
   int rc = check_device(o->device);
   if (rc) return rc;
   vsrmc_checker* c = new vsrmc_checker();
@@ -1615,16 +1618,21 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   return 0;
 }
 
-// Three levels beyond the last materialised one: levels L+1 and L+2 become VIRTUAL levels, level L+3 is probed.
-//   pass 1: level L expanded, MODE_INSERT                                   -> level L+1 exists as seen-set entries
-//   pass 2: slices of L regenerated into the next buffers (MODE_REGEN), each slice's part of L+1 expanded, MODE_INSERT
-//                                                                           -> level L+2 exists as seen-set entries
-//           then the `taken` marks of level L+1 are cleared (k_table_clear_taken): the level is regenerated once more
-//   pass 3: slices of L regenerated again; sub-slices of each part of L+1 regenerated into a scratch buffer (MODE_REGEN of
-//           level L+2), each sub-slice's part of L+2 expanded, MODE_PROBE   -> invariants of level L+3
-// Cost: level L is expanded three times, level L+1 twice, level L+2 once; memory: the scratch buffers of two slices.  On the
-// README defect configuration this takes one MI355X from level 21 — the last level whose records fit the HBM
-// next to the seen-set — to the depth-24 violation without touching host memory.
+// Three levels beyond the last materialised one: level L+1 is a VIRTUAL level, level L+2 is streamed through a scratch buffer
+// (inserted into the seen-set, never kept), level L+3 is probed.
+//   pass 1: level L expanded, MODE_INSERT                      -> level L+1 exists as seen-set entries (exact count, final keys)
+//   pass 2: for each slice of L:      MODE_REGEN into the next buffers            = that slice's part of level L+1
+//             for each sub-slice:     MODE_NORMAL into the scratch buffers        = new level-(L+2) states, inserted + written
+//                                     MODE_PROBE over the scratch buffers         = invariants of their successors (level L+3)
+// Level L+1 must be complete in the seen-set before the first level-(L+2) state is inserted (else a state of L+1 met first
+// as a successor of L+1 would be filed one level too deep).  Level L+2 is NOT complete while level L+3 is probed, and that
+// matters: the invariants read aux variables that are outside the VIEW (VSR.tla:102-104), so a successor with the fingerprint
+// of a level-(L+2) state that is not inserted yet can look violating although the search never visits it (TLC drops it as
+// seen).  The probe passes therefore only COLLECT violating successors (fingerprint, key); when level L+2 is complete the
+// ones that are states of a level < L+3 are dropped (k_table_seen) and the smallest remaining fingerprint is the violation.
+// Cost: level L is expanded twice, levels L+1 and L+2 once.  Slice sizes adapt to the fill of the buffers (first slice: worst-case sizing).  On the README
+// defect configuration this takes one MI355X from level 21 — the last level whose records fit the HBM next
+// to the seen-set — to the depth-24 violation without touching host memory.
 int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_level_info* virt2, vsrmc_level_info* probe) {
   if (!c || !virt1 || !virt2 || !probe) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
@@ -1667,33 +1675,117 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
     c->probe_level = L + 1;
     return 0;
   }
-  // slices of level L: a slice's part of level L+1 may fill a quarter of the next buffers (chunk slack included)
-  const u64 g1 = std::max<u64>(1, (gen1 + c->n_frontier - 1) / std::max<u64>(1, c->n_frontier));
-  u64 slice = std::min<u64>(c->opt.frontier_states / (4 * g1), c->words_cap(nxt) / (4 * g1 * (u64)c->lds_stride));
-  slice = std::max<u64>(128, slice & ~(u64)127);
-  // ---- pass 2: virtual level L+2
+  // ---- pass 2
   t0 = now_s();
   c->expand_ms = 0;
-  u64 n2 = 0, gen2 = 0, dead2 = 0, probes2 = 0, bag2 = 0, viol2 = ~(u64)0, regen1 = 0;
-  u32 mask2 = 0;
-  for (u64 a = 0; a < c->n_frontier; a += slice) {
+  struct Scratch {
+    PassDst d;
+    ~Scratch() {
+      if (d.words) (void)hipFree(d.words);
+      if (d.off) (void)hipFree(d.off);
+      if (d.fp) (void)hipFree(d.fp);
+    }
+  } scratch;
+  PassDst& B = scratch.d;                                      // scratch buffers: a quarter of the next buffers' size
+  B.words_cap = std::max<u64>((u64)1 << 22, c->words_cap(nxt) / 4);
+  B.cap = std::max<u64>((u64)1 << 16, c->opt.frontier_states / 4);
+  hipError_t e = hipMalloc((void**)&B.words, B.words_cap * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&B.off, (B.cap + 1) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&B.fp, B.cap * 8);
+  if (e != hipSuccess) return fail(VSRMC_E_HIP, std::string("hipMalloc of the probe3 scratch buffers: ") + hipGetErrorString(e));
+  // Slice sizes.  A target buffer loses up to a quarter to the blocks' unfinished chunks; states and words of a slice are
+  // budgeted at a third of it (1.5x headroom over the expectation).
+  //  * slices of level L: MODE_REGEN writes a state where its min-key parent sits — keys order by the parent's fingerprint,
+  //    so the new states spread evenly over the parents: (level-(L+1) states per valid parent, known exactly from pass 1) x
+  //    (average record of level L + 2 words);
+  //  * sub-slices of level L+1: MODE_NORMAL is first come, first served — early sub-slices find more new states per parent than
+  //    late ones, and the index range they come from is dense at its start (the holes of unfinished chunks sit at its end):
+  //    the first sub-slice is sized for the worst case (every generated successor new, of the largest size), later ones by
+  //    the largest per-position yield seen so far.
+  const u64 g1 = std::max<u64>(1, (gen1 + c->n_frontier - 1) / std::max<u64>(1, c->n_frontier));
+  auto worst_size = [&](u64 cap_n, u64 cap_w) {
+    const u64 sz = std::min<u64>(cap_n / (4 * g1), cap_w / (4 * g1 * (u64)c->lds_stride));
+    return std::max<u64>(128, sz & ~(u64)127);
+  };
+  auto sized = [&](u64 cap_n, u64 cap_w, double per_n, double per_w) {
+    const double sz = std::min((double)cap_n / (3.0 * std::max(per_n, 1e-3)), (double)cap_w / (3.0 * std::max(per_w, 1e-3)));
+    return std::max<u64>(128, (u64)std::min(sz, 1e15) & ~(u64)127);
+  };
+  const double nbar1 = (double)virt1->n_new / (double)std::max<u64>(1, c->n_valid);
+  const double wbar1 = (double)c->cur_w / (double)std::max<u64>(1, c->n_valid) + 2.0;
+  const u64 slice = std::max<u64>(worst_size(c->opt.frontier_states, c->words_cap(nxt)),
+                                  sized(c->opt.frontier_states, c->words_cap(nxt), nbar1, nbar1 * wbar1));
+  u64 sub = worst_size(B.cap, B.words_cap);
+  double yield_n = 0, yield_w = 0;
+  u64 n2 = 0, gen2 = 0, dead2 = 0, probes2 = 0, bag2 = 0, viol2 = ~(u64)0, words2 = 0, n_slices = 0, n_subs = 0;
+  u64 gen3 = 0, dead3 = 0, probes3 = 0;
+  std::vector<u64> bad;                                        // (fingerprint, key) of the violating successors the probe passes saw
+  u32 mask2 = 0, mask3 = 0;
+  double ms2 = 0, ms3 = 0;
+  for (u64 a = 0; a < c->n_frontier && !rc;) {
     const u64 n = std::min<u64>(slice, c->n_frontier - a);
+    c->expand_ms = 0;
     rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, L + 1, MODE_REGEN, bagL);
-    if (rc) return rc;
-    const u64 part = c->h.n_new;
-    regen1 += c->h.rec_words;
-    rc = expand_pass(c, c->words[nxt], c->off[nxt], part, 0, L + 2, MODE_INSERT, bag1);
-    if (rc) return rc;
-    n2 += c->h.n_new;
-    gen2 += c->h.generated;
-    dead2 += c->h.deadlocks;
-    probes2 += c->h.probes;
-    bag2 = std::max<u64>(bag2, c->h.max_bag);
-    if (c->h.viol_fp != ~(u64)0) {
-      mask2 |= c->h.viol_mask;
-      viol2 = std::min<u64>(viol2, c->h.viol_fp);
+    if (rc) break;
+    ms2 += c->expand_ms;
+    a += n;
+    n_slices++;
+    const u64 part = c->h.n_new;                               // index range of this slice's part of level L+1 (holes included)
+    for (u64 b = 0; b < part && !rc;) {
+      const u64 nb = std::min<u64>(sub, part - b);
+      c->expand_ms = 0;
+      rc = expand_pass(c, c->words[nxt], c->off[nxt] + b, nb, b, L + 2, MODE_NORMAL, bag1, &B);
+      if (rc) break;
+      ms2 += c->expand_ms;
+      b += nb;
+      n_subs++;
+      const u64 part2 = c->h.n_new;
+      gen2 += c->h.generated;
+      dead2 += c->h.deadlocks;
+      probes2 += c->h.probes;
+      words2 += c->h.rec_words;
+      bag2 = std::max<u64>(bag2, c->h.max_bag);
+      if (c->h.ties) {
+        rc = fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables (SURVEY F2)");
+        break;
+      }
+      if (c->h.viol_fp != ~(u64)0) {
+        mask2 |= c->h.viol_mask;
+        viol2 = std::min<u64>(viol2, c->h.viol_fp);
+      }
+      if (part2) {
+        u64 cnt = 0;
+        HIPCHK(hipMemcpyAsync(c->d_find, &cnt, 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_count_valid, dim3(1024), dim3(256), 0, c->stream, B.off, part2, c->d_find);
+        HIPCHK(hipMemcpyAsync(&cnt, c->d_find, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        n2 += cnt;
+        yield_n = std::max(yield_n, (double)cnt / (double)nb);
+        yield_w = std::max(yield_w, (double)c->h.rec_words / (double)nb);
+        sub = std::max<u64>(worst_size(B.cap, B.words_cap), sized(B.cap, B.words_cap, yield_n, yield_w));
+      }
+      if (viol2 != ~(u64)0 || part2 == 0) continue;            // a violation one level up: level L+2 is completed, nothing deeper is probed
+      c->expand_ms = 0;
+      rc = expand_pass(c, B.words, B.off, part2, 0, L + 3, MODE_PROBE, std::min<u64>(c->h.max_bag, (u64)M.max_bag));
+      if (rc) break;
+      ms3 += c->expand_ms;
+      gen3 += c->h.generated;
+      dead3 += c->h.deadlocks;
+      probes3 += c->h.probes;
+      if (c->h.n_pending) {
+        mask3 |= c->h.viol_mask;
+        if (c->h.n_pending > c->opt.pending_entries || bad.size() / 2 + c->h.n_pending > ((u64)1 << 24)) {
+          rc = fail(VSRMC_E_REP, "more violating successors in the probed level than the pending list holds (pending_entries)");
+          break;
+        }
+        const size_t at = bad.size();
+        bad.resize(at + 2 * c->h.n_pending);
+        HIPCHK(hipMemcpy(bad.data() + at, c->pending, 16 * c->h.n_pending, hipMemcpyDeviceToHost));
+      }
     }
   }
+  if (rc) return rc;
+  const double dt2 = now_s() - t0;
   virt2->level = L + 2;
   virt2->frontier = virt1->n_new;
   virt2->generated = gen2;
@@ -1703,97 +1795,65 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
   virt2->total_generated = virt1->total_generated + gen2;
   virt2->probes = probes2;
   virt2->max_bag = bag2;
-  virt2->record_words = regen1;
-  virt2->expand_ms = c->expand_ms;
-  virt2->seconds = now_s() - t0;
+  virt2->record_words = words2;
+  virt2->pending = n_slices << 32 | n_subs;                    // (slices of level L) << 32 | sub-slices of level L+1
+  virt2->expand_ms = ms2;
+  virt2->seconds = dt2 * (ms2 / std::max(1e-9, ms2 + ms3));   // the two levels share the pass: split by kernel time
   if (viol2 != ~(u64)0) {
     virt2->viol_fp = viol2;
     virt2->viol_mask = (int32_t)mask2;
     c->probe_fp = viol2;
     c->probe_level = L + 2;
+    c->probe_extra_fp = 0;
     return 0;
   }
-  bag2 = std::min<u64>(bag2, (u64)M.max_bag);
-  hipLaunchKernelGGL(k_table_clear_taken, dim3(8192), dim3(256), 0, c->stream, c->table, c->tmask + 1, L + 1);
-  HIPCHK(hipGetLastError());
-  // ---- pass 3: probe of level L+3 over regenerated sub-slices of level L+2 (scratch buffers: a quarter of the next buffers' size)
-  t0 = now_s();
-  c->expand_ms = 0;
-  PassDst B;
-  B.words_cap = std::max<u64>((u64)1 << 22, c->words_cap(nxt) / 4);
-  B.cap = std::max<u64>((u64)1 << 16, c->opt.frontier_states / 4);
-  hipError_t e = hipMalloc((void**)&B.words, B.words_cap * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&B.off, (B.cap + 1) * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&B.fp, B.cap * 8);
-  auto free_b = [&]() {
-    if (B.words) (void)hipFree(B.words);
-    if (B.off) (void)hipFree(B.off);
-    if (B.fp) (void)hipFree(B.fp);
-  };
-  if (e != hipSuccess) {
-    free_b();
-    return fail(VSRMC_E_HIP, std::string("hipMalloc of the probe3 scratch buffers: ") + hipGetErrorString(e));
-  }
-  const u64 g2 = std::max<u64>(1, (gen2 + virt1->n_new - 1) / std::max<u64>(1, virt1->n_new));
-  u64 sub = std::min<u64>(B.cap / (4 * g2), B.words_cap / (4 * g2 * (u64)c->lds_stride));
-  sub = std::max<u64>(128, sub & ~(u64)127);
-  u64 best_fp = ~(u64)0, gen3 = 0, dead3 = 0, probes3 = 0, seen_bad = 0, regen2 = 0;
-  u32 mask3 = 0;
-  for (u64 a = 0; a < c->n_frontier && !rc; a += slice) {
-    const u64 n = std::min<u64>(slice, c->n_frontier - a);
-    rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, L + 1, MODE_REGEN, bagL);
-    if (rc) break;
-    const u64 part = c->h.n_new;                               // index range of this slice's part of level L+1 (holes included)
-    for (u64 b = 0; b < part && !rc; b += sub) {
-      const u64 nb = std::min<u64>(sub, part - b);
-      rc = expand_pass(c, c->words[nxt], c->off[nxt] + b, nb, b, L + 2, MODE_REGEN, bag1, &B);
-      if (rc) break;
-      const u64 part2 = c->h.n_new;
-      regen2 += c->h.rec_words;
-      rc = expand_pass(c, B.words, B.off, part2, 0, L + 3, MODE_PROBE, bag2);
-      if (rc) break;
-      gen3 += c->h.generated;
-      dead3 += c->h.deadlocks;
-      probes3 += c->h.probes;
-      seen_bad += c->h.n_pending;
-      if (c->h.viol_fp != ~(u64)0) {
-        mask3 |= c->h.viol_mask;
-        if (c->h.viol_fp < best_fp) {
-          u64 k3 = ~(u64)0;
-          rc = min_violator(c, c->h.viol_fp, &k3);
-          if (rc) break;
-          if (k3 != ~(u64)0) {                                 // its parent: the level-(L+2) state with these fingerprint bits, in the seen-set
-            bool found = false;
-            u64 pfp = 0, pmeta = 0;
-            rc = table_lookup(c, meta_pfp(k3), L + 2, 1, &found, &pfp, &pmeta);
-            if (rc) break;
-            if (found) {
-              best_fp = c->h.viol_fp;
-              c->probe_fp = pfp;
-              c->probe_level = L + 2;
-              c->probe_extra_fp = c->h.viol_fp;
-            }
-          }
-        }
-      }
-    }
-  }
-  free_b();
-  if (rc) return rc;
   probe->level = L + 3;
   probe->frontier = n2;
   probe->generated = gen3;
   probe->deadlocks = dead3;
   probe->probes = probes3;
-  probe->pending = seen_bad;
-  probe->record_words = regen2;
   probe->distinct = virt2->distinct;
   probe->total_generated = virt2->total_generated + gen3;
-  probe->expand_ms = c->expand_ms;
-  probe->seconds = now_s() - t0;
-  if (best_fp != ~(u64)0) {
-    probe->viol_fp = best_fp;
-    probe->viol_mask = (int32_t)mask3;
+  probe->expand_ms = ms3;
+  probe->seconds = dt2 - virt2->seconds;
+  // level L+2 is complete now: which of the collected successors are states of level L+3?
+  const u64 nbad = bad.size() / 2;
+  if (nbad) {
+    std::vector<std::pair<u64, u64>> pairs(nbad);
+    for (u64 i = 0; i < nbad; i++) pairs[i] = std::make_pair(bad[2 * i], bad[2 * i + 1]);
+    std::sort(pairs.begin(), pairs.end());                     // by fingerprint, then key
+    std::vector<u64> fps, flags;
+    for (u64 i = 0; i < nbad; i++)
+      if (i == 0 || pairs[i].first != pairs[i - 1].first) fps.push_back(pairs[i].first);
+    flags.assign(fps.size(), 0);
+    std::vector<uint8_t> seen8(fps.size(), 0);
+    rc = vsrmc_checker_seen_batch(c, fps.data(), (u64)fps.size(), L + 3, seen8.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < fps.size(); i++) flags[i] = seen8[i];
+    u64 first = ~(u64)0, k3 = ~(u64)0;
+    size_t g = 0;                                              // group index = index into fps
+    for (u64 i = 0; i < nbad; i++) {
+      if (i && pairs[i].first != pairs[i - 1].first) g++;
+      if (flags[g]) continue;
+      probe->pending++;                                        // violating successors seen, duplicates included
+      if (first == ~(u64)0) {
+        first = pairs[i].first;                                // smallest fingerprint; of its entries the smallest key
+        k3 = pairs[i].second;
+      }
+    }
+    if (first != ~(u64)0) {
+      bool found = false;
+      u64 pfp = 0, pmeta = 0;                                  // its parent: the level-(L+2) state with these fingerprint bits, in the seen-set
+      rc = table_lookup(c, meta_pfp(k3), L + 2, 1, &found, &pfp, &pmeta);
+      if (rc) return rc;
+      probe->viol_fp = first;
+      probe->viol_mask = (int32_t)mask3;
+      if (found) {
+        c->probe_fp = pfp;
+        c->probe_level = L + 2;
+        c->probe_extra_fp = first;
+      }
+    }
   }
   return 0;
 }
@@ -1804,7 +1864,9 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
 // counter-example reconstructed (vsrmc_checker_probe_trace).  Also valid right after a step that failed with "frontier full".
 int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
   if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
-  if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
+  // sharded: the rank probes its part of the newest level against ITS part of the seen-set; the violating successors it could
+  // not find there (vsrmc_checker_probe_candidates) still have to be shown to their owners (sharded.py: ShardedChecker.probe)
+  if (c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need a single-pass checker");
   if (c->failed && c->failed_code != ERR_FRONTIER_FULL) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   c->failed = 0;
   c->probe_fp = 0;
@@ -1834,7 +1896,7 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
     u64 key = ~(u64)0;
     rc = min_violator(c, c->h.viol_fp, &key);
     if (rc) return rc;
-    if (key != ~(u64)0) {                                       // its parent: the newest level's state with these fingerprint bits
+    if (key != ~(u64)0 && c->opt.world <= 1) {                  // its parent: the newest level's state with these fingerprint bits
       bool found = false;
       u64 pfp = 0, pmeta = 0;
       rc = table_lookup(c, meta_pfp(key), c->level, 1, &found, &pfp, &pmeta);
@@ -1846,6 +1908,37 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
       }
     }
   }
+  return 0;
+}
+
+int32_t vsrmc_checker_probe_candidates(vsrmc_checker* c, uint64_t* pairs, uint64_t cap_pairs, uint64_t* n) {
+  if (!c || !n) return fail(VSRMC_E_ARG, "NULL argument");
+  *n = c->h.n_pending;
+  if (c->h.n_pending > c->opt.pending_entries) return fail(VSRMC_E_REP, "more violating successors than the pending list holds (pending_entries)");
+  if (c->h.n_pending == 0) return 0;
+  if (!pairs || cap_pairs < c->h.n_pending) return fail(VSRMC_E_ARG, "buffer too small");
+  HIPCHK(hipSetDevice(c->opt.device));
+  HIPCHK(hipMemcpy(pairs, c->pending, 16 * c->h.n_pending, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int32_t vsrmc_checker_seen_batch(vsrmc_checker* c, const uint64_t* fps, uint64_t n, int32_t level, uint8_t* seen) {
+  if (!c || (n && (!fps || !seen))) return fail(VSRMC_E_ARG, "NULL argument");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(c->opt.device));
+  u64* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 16 * n));
+  std::vector<u64> flags(n, 0);
+  hipError_t e = hipMemcpy(d, fps, 8 * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_table_seen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, c->tmask, d, (u64)n, (int)level, d + n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(flags.data(), d + n, 8 * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(VSRMC_E_HIP, std::string("vsrmc_checker_seen_batch: ") + hipGetErrorString(e));
+  for (u64 i = 0; i < n; i++) seen[i] = flags[i] ? 1 : 0;
   return 0;
 }
 
@@ -2079,7 +2172,7 @@ namespace {
 struct ChkHeader {
   char magic[8];                 // "VSRMCCK2" (1 = the format with a separate trace log and index-based meta words)
   int32_t consts[8];             // R, C, n, L, symmetry, inv_mask, assume_commit, np
-  int32_t level, cur_unused;
+  int32_t level, shard;          // shard: 0 = unsharded, else world << 16 | rank (each rank writes and reads its own file)
   u64 n_frontier, n_valid, cur_w, distinct, total_generated, n_levels, table_entries, trace_entries;
 };
 bool dev_to_file(FILE* f, const void* d_ptr, u64 bytes, std::vector<char>& buf) {
@@ -2103,7 +2196,7 @@ bool file_to_dev(FILE* f, void* d_ptr, u64 bytes, std::vector<char>& buf) {
 int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   if (!c || !path) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
-  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "checkpoints of sharded checkers are not supported");
+  if (c->opt.world > 1 && c->opt.exact_ties) return fail(VSRMC_E_STATE, "checkpoints of sharded exact-mode checkers are not supported");
   HIPCHK(hipSetDevice(c->opt.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   const Model& M = c->model.M;
@@ -2116,6 +2209,7 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   const int32_t consts[8] = {M.R, M.C, M.n, M.L, c->model.symmetry, M.inv_mask, M.assume_commit, M.np};
   std::memcpy(h.consts, consts, sizeof(consts));
   h.level = c->level;
+  h.shard = c->opt.world > 1 ? (c->opt.world << 16 | c->opt.rank) : 0;
   h.n_frontier = c->n_frontier;
   h.n_valid = c->n_valid;
   h.cur_w = c->cur_w;
@@ -2162,7 +2256,7 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
 
 int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const char* path, vsrmc_checker** out) {
   if (!m || !o || !path || !out) return fail(VSRMC_E_ARG, "NULL argument");
-  if (o->world > 1) return fail(VSRMC_E_STATE, "checkpoints of sharded checkers are not supported");
+  if (o->world > 1 && o->exact_ties) return fail(VSRMC_E_STATE, "checkpoints of sharded exact-mode checkers are not supported");
   FILE* f = std::fopen(path, "rb");
   if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + path);
   ChkHeader h;
@@ -2178,6 +2272,10 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
   if (std::memcmp(h.consts, consts, sizeof(consts)) != 0) {
     std::fclose(f);
     return fail(VSRMC_E_CFG, "the checkpoint was written for different model constants");
+  }
+  if (h.shard != (o->world > 1 ? (o->world << 16 | o->rank) : 0)) {   // the seen-set is partitioned by owner_of(fp, world)
+    std::fclose(f);
+    return fail(VSRMC_E_CFG, "the checkpoint was written by another rank or for another world size");
   }
   const int buf_of_level = (h.level - 1) & 1;                   // level L lives in record buffer (L - 1) mod 2, also after recovery
   const u64 cap_of_buf = (buf_of_level == 1 && o->frontier_words_b) ? o->frontier_words_b : o->frontier_words;

@@ -37,6 +37,8 @@ static void usage() {
       "  -hostFrontierMask M   the same per buffer: bit 0 = first buffer (levels 1, 3, ..), bit 1 = second (levels 2, 4, ..)\n"
       "  -probe2At N       when level N-1 is complete: level N as a VIRTUAL level (seen-set entries and invariants only) and level N+1\n"
       "                    as a PROBE level (nothing stored) — two levels beyond the last frontier that fits; the search ends there\n"
+      "  -probe3At N       the same with TWO virtual levels (N, N+1) and level N+2 probed: three levels beyond the last stored one\n"
+      "                    (level N-1 is expanded three times, level N twice; scratch buffers of a quarter of -frontierGiB)\n"
       "  -probeLast        when the next level does not fit the frontier buffers, still check its states' invariants without\n"
       "                    storing them (finds a violation one level beyond memory; the search ends there)\n"
       "  -dump FILE        write every distinct state in the text form of `tlc2.TLC -dump` (State k: + /\\ var = value conjuncts), level by\n"
@@ -81,7 +83,7 @@ int main(int argc, char** argv) {
   unsigned sim_walkers = 1u << 17;
   unsigned long long sim_seed = 1;
   double sim_seconds = 60.0;
-  int max_depth = 1 << 30, device = 0, table_log2 = 28, probe2_at = 0, host_mask = 0;
+  int max_depth = 1 << 30, device = 0, table_log2 = 28, probe2_at = 0, probe3_at = 0, host_mask = 0;
   double frontier_gib = 8.0, frontier_b_gib = 0.0;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -99,6 +101,7 @@ int main(int argc, char** argv) {
     else if (a == "-hostFrontier") host_frontier = true;
     else if (a == "-probeLast") probe_last = true;
     else if (a == "-probe2At" && i + 1 < argc) probe2_at = std::atoi(argv[++i]);
+    else if (a == "-probe3At" && i + 1 < argc) probe3_at = std::atoi(argv[++i]);
     else if (a == "-hostFrontierMask" && i + 1 < argc) host_mask = std::atoi(argv[++i]);
     else if (a == "-validateTrace" && i + 1 < argc) trace_file = argv[++i];
     else if (a == "-checkpoint" && i + 1 < argc) chk_file = argv[++i];
@@ -273,31 +276,32 @@ int main(int argc, char** argv) {
   uint64_t viol_level = 0, viol_index = 0;
   int depth = info.level;
   while (depth < max_depth) {
-    if (probe2_at > 0 && depth + 1 == probe2_at) {
-      vsrmc_level_info vi, pi;
-      rc = vsrmc_checker_probe2(c, &vi, &pi);
+    if ((probe2_at > 0 && depth + 1 == probe2_at) || (probe3_at > 0 && depth + 1 == probe3_at)) {
+      const int nv = probe3_at > 0 && depth + 1 == probe3_at ? 2 : 1;        // virtual levels before the probed one
+      vsrmc_level_info li[3];
+      rc = nv == 2 ? vsrmc_checker_probe3(c, &li[0], &li[1], &li[2]) : vsrmc_checker_probe2(c, &li[0], &li[1]);
       if (rc != 0) break;
       double dtp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      std::printf("Virtual(%d): %llu states generated, %llu distinct states found, %llu states in the level (not stored). (%.2f s)\n", vi.level,
-                  (unsigned long long)vi.total_generated, (unsigned long long)vi.distinct, (unsigned long long)vi.n_new, dtp);
-      info.total_generated = vi.total_generated;
-      info.distinct = vi.distinct;
-      info.n_new = vi.n_new;
-      depth = vi.level;
-      if (vi.viol_mask) {
-        probed_violation = true;
-        info.viol_mask = vi.viol_mask;
-        viol_level = (uint64_t)vi.level;
-      } else {
-        std::printf("Probe(%d): %llu states generated from %llu states, %llu violating successors seen. (%.2f s)\n", pi.level,
-                    (unsigned long long)pi.generated, (unsigned long long)pi.frontier, (unsigned long long)pi.pending, dtp);
-        info.total_generated = pi.total_generated;
-        if (pi.viol_mask) {
-          probed_violation = true;
-          info.viol_mask = pi.viol_mask;
-          viol_level = (uint64_t)pi.level;
+      for (int k = 0; k <= nv && !probed_violation; k++) {
+        const vsrmc_level_info& x = li[k];
+        if (x.level == 0) break;
+        if (k < nv) {
+          std::printf("Virtual(%d): %llu states generated, %llu distinct states found, %llu states in the level (not stored). (%.2f s)\n", x.level,
+                      (unsigned long long)x.total_generated, (unsigned long long)x.distinct, (unsigned long long)x.n_new, dtp);
+          info.distinct = x.distinct;
+          info.n_new = x.n_new;
         } else {
-          std::printf("No violation up to level %d; the search is incomplete beyond it.\n", pi.level);
+          std::printf("Probe(%d): %llu states generated from %llu states, %llu violating successors seen. (%.2f s)\n", x.level,
+                      (unsigned long long)x.generated, (unsigned long long)x.frontier, (unsigned long long)x.pending, dtp);
+        }
+        info.total_generated = x.total_generated;
+        depth = x.level;
+        if (x.viol_mask) {
+          probed_violation = true;
+          info.viol_mask = x.viol_mask;
+          viol_level = (uint64_t)x.level;
+        } else if (k == nv) {
+          std::printf("No violation up to level %d; the search is incomplete beyond it.\n", x.level);
         }
       }
       break;

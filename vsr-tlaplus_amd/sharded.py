@@ -13,6 +13,8 @@ drives any engine that implements the phase methods; `HipShardEngine` is the pro
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -289,6 +291,87 @@ class ShardedChecker:
             if self.violation is not None and stop_on_violation:
                 return "violation"
 
+    def probe(self):
+        """One level beyond the newest one without storing it (the level that no longer fits the ranks' buffers): every rank
+        expands its part of the newest level in probe mode and keeps the violating successors it cannot find in its own part
+        of the seen-set; those go to their owners (one all-to-all), which drop the ones they know — a successor with the VIEW
+        fingerprint of an earlier state is that state for the search, whatever its aux variables say — and the smallest
+        remaining fingerprint is the violation (smallest key among its copies -> its parent).  Every rank must call this.
+        -> dict(level, generated, deadlocks, viol_fp or None, viol_mask, candidates)"""
+        e, x, me, w = self.e, self.x, self.rank, self.world
+        L = self.level
+        info, pairs, err = e.probe()
+        keep = pairs
+        if not self.replicated:                                 # replicated phase: every rank holds the whole seen-set
+            own = np.array([owner_of(int(f), w) for f in pairs[:, 0]], dtype=np.int64) if len(pairs) else np.zeros(0, dtype=np.int64)
+            dev = getattr(e, "dev", None)
+            send = [torch.from_numpy(pairs[own == p].view(np.int64).copy()).reshape(-1, 2) for p in range(w)]
+            if dev is not None:
+                send = [t.to(dev) for t in send]
+            recv, gerr, cat = x.exchange(send, err)
+            self._raise_if(gerr, "probe")
+            got = cat.cpu().numpy().view(np.uint64).reshape(-1, 2)
+            keep = got[~e.seen_before(got[:, 0], L + 1)] if len(got) else got
+        elif err:
+            self._raise_if(err, "probe")
+        best = min(((int(f), int(k)) for f, k in keep), default=(U64_MAX, U64_MAX))
+        rows = x.allgather([info["generated"], info["deadlocks"], best[0] >> 32, best[0] & 0xFFFFFFFF, best[1] >> 32, best[1] & 0xFFFFFFFF,
+                            info["viol_mask"], len(keep)])
+        div = w if self.replicated else 1                       # replicated: every rank probed the same level
+        gbest = min(((r[2] << 32) | r[3], (r[4] << 32) | r[5]) for r in rows)
+        out = dict(level=L + 1, generated=sum(r[0] for r in rows) // div, deadlocks=sum(r[1] for r in rows) // div, viol_fp=None, viol_mask=0,
+                   candidates=sum(r[7] for r in rows) // div)
+        if gbest[0] != U64_MAX:
+            mask = 0
+            for r in rows:
+                mask |= r[6]
+            parent = self._agree(e.lookup((gbest[1] >> 1) & ((1 << 45) - 1), L, True))
+            if parent is None:
+                raise ShardError("probe: the parent of the violating successor %016x is in no shard" % gbest[0])
+            out.update(viol_fp=gbest[0], viol_mask=mask)
+            if self.violation is None:
+                self.violation = dict(level=L + 1, fp=gbest[0], mask=mask, probed=True, parent_fp=parent[0])
+        return out
+
+    def probe_trace_fps(self):
+        """fingerprints of the counter-example probe() found, Init first (collective, like trace_fps)"""
+        v = self.violation
+        if not v or not v.get("probed"):
+            raise ShardError("no violation recorded by probe()")
+        return self.trace_fps(v["level"] - 1, v["parent_fp"]) + [v["fp"]]
+
+    def save(self, prefix):
+        """Checkpoint between two levels (TLC: FPSet + StateQueue checkpoint, per worker): every rank writes its shard to
+        <prefix>.rank<r>of<w>, rank 0 the loop's own state to <prefix>.json.  Collective; -> None, raises on any rank's failure."""
+        import json
+        err = self.e.save("%s.rank%dof%d" % (prefix, self.rank, self.world))
+        if self.rank == 0 and not err:
+            tmp = prefix + ".json.tmp"
+            with open(tmp, "w") as f:
+                json.dump(dict(world=self.world, level=self.level, distinct=self.distinct, n_frontier=self.n_frontier,
+                               replicated=self.replicated, replicate_below=self.replicate_below, moved=self.moved), f)
+            os.replace(tmp, prefix + ".json")
+        rows = self.x.allgather([err])
+        self._raise_if(max(r[0] for r in rows), "checkpoint")
+
+    @classmethod
+    def restore(cls, prefix, make_engine, exchanger, balance_tol=1.25):
+        """Continue the run save() wrote: make_engine(path of this rank's shard file) -> engine.  Same world size."""
+        import json
+        with open(prefix + ".json") as f:
+            d = json.load(f)
+        if d["world"] != exchanger.world:
+            raise ShardError("the checkpoint was written by %d ranks, this run has %d" % (d["world"], exchanger.world))
+        self = cls.__new__(cls)
+        self.e = make_engine("%s.rank%dof%d" % (prefix, exchanger.rank, exchanger.world))
+        self.x = exchanger
+        self.rank, self.world = exchanger.rank, exchanger.world
+        self.level, self.distinct, self.n_frontier = d["level"], d["distinct"], d["n_frontier"]
+        self.violation, self.levels = None, []
+        self.balance_tol, self.moved = balance_tol, d["moved"]
+        self.replicated, self.replicate_below = d["replicated"], d["replicate_below"]
+        return self
+
     def _agree(self, hit):
         """hit = (a, b) 64-bit values on the rank(s) that found something, None elsewhere -> the pair on every rank (or None).
         64-bit values cross ranks as 32-bit halves (signed int64 all-reduce); ranks that hold the same state hold the same pair."""
@@ -319,9 +402,9 @@ class HipShardEngine:
 
     def __init__(self, model, rank, world, device=0, table_log2=26, frontier_words=1 << 27, frontier_states=1 << 22,
                  pending_entries=1 << 23, cand_cap=1 << 22, rec_cap=1 << 21, rec_words_cap=1 << 26, keep_trace=True,
-                 trace_entries=0, exact_ties=False, filter_log2=0):
+                 trace_entries=0, exact_ties=False, filter_log2=0, recover=None):
         """cand_cap: (fp, key) candidates per peer and level; rec_cap / rec_words_cap: records / words one rebalancing move
-        to one peer may carry."""
+        to one peer may carry.  recover: this rank's checkpoint file (save()), written by the same rank of the same world."""
         self.model, self.rank, self.world, self.device = model, rank, world, device
         o = capi.Options()
         capi.load().vsrmc_options_default(C.byref(o))
@@ -330,7 +413,10 @@ class HipShardEngine:
         o.keep_trace, o.trace_entries, o.rank, o.world = int(keep_trace), trace_entries, rank, world
         o.exact_ties, o.filter_log2 = int(exact_ties), filter_log2
         self._h = C.c_void_p()
-        check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))
+        if recover is None:
+            check(capi.load().vsrmc_checker_create(model._h, C.byref(o), C.byref(self._h)))
+        else:
+            check(capi.load().vsrmc_checker_load(model._h, C.byref(o), os.fsencode(recover), C.byref(self._h)))
         dev = torch.device("cuda", device)
         self.dev = dev
         self.cand_cap, self.rec_cap, self.rec_words_cap = cand_cap, rec_cap, rec_words_cap
@@ -362,6 +448,34 @@ class HipShardEngine:
 
     def reset(self):
         check(capi.load().vsrmc_checker_reset(self._h))
+
+    def save(self, path):
+        """this rank's shard (its part of the seen-set and of the newest level) between two levels -> error code"""
+        return self._call(capi.load().vsrmc_checker_save(self._h, os.fsencode(path)))
+
+    def probe(self):
+        """the local part of the newest level expanded without storing anything -> (dict(generated, deadlocks, viol_mask),
+        uint64 array (n, 2) of the violating successors' (fingerprint, key) that are not in THIS rank's seen-set, err)"""
+        info = capi.LevelInfo()
+        err = self._call(capi.load().vsrmc_checker_probe(self._h, C.byref(info)))
+        if err:
+            return dict(generated=0, deadlocks=0, viol_mask=0), np.zeros((0, 2), dtype=np.uint64), err
+        n = C.c_uint64()
+        err = self._call(capi.load().vsrmc_checker_probe_candidates(self._h, None, 0, C.byref(n)))
+        pairs = np.zeros((max(1, n.value), 2), dtype=np.uint64)
+        if not err and n.value:
+            err = self._call(capi.load().vsrmc_checker_probe_candidates(self._h, C.c_void_p(pairs.ctypes.data), n.value, C.byref(n)))
+        d = info.as_dict()
+        self.kernel_ms["expand"] += d["expand_ms"]
+        return dict(generated=d["generated"], deadlocks=d["deadlocks"], viol_mask=d["viol_mask"]), pairs[: n.value if not err else 0], err
+
+    def seen_before(self, fps, level):
+        """which of these fingerprints are states of a level < `level` in this rank's seen-set -> bool array"""
+        f = np.ascontiguousarray(fps, dtype=np.uint64)
+        out = np.zeros(max(1, len(f)), dtype=np.uint8)
+        if len(f):
+            check(capi.load().vsrmc_checker_seen_batch(self._h, C.c_void_p(f.ctypes.data), len(f), int(level), C.c_void_p(out.ctypes.data)))
+        return out[: len(f)].astype(bool)
 
     def expand(self):
         counts = (C.c_uint64 * 8)()
