@@ -223,7 +223,7 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
  * vsrmc_checker_probe_trace reconstructs the counter-example in every case. */
 int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_level_info* virt2, vsrmc_level_info* probe);
 /* the (fingerprint, key) pairs of the violating successors the last vsrmc_checker_probe saw and did not find in this checker's
- * seen-set (duplicates included; *n = their number, also when `pairs` is too small).  Sharded runs show them to their owners. */
+ * seen-set (duplicates included; *n = their number; pairs == NULL asks for the number only).  Sharded runs show them to their owners. */
 int32_t vsrmc_checker_probe_candidates(vsrmc_checker* c, uint64_t* pairs, uint64_t cap_pairs, uint64_t* n);
 /* seen[i] = 1 if fps[i] is in this checker's seen-set as a state of a level below `level` (host arrays) */
 int32_t vsrmc_checker_seen_batch(vsrmc_checker* c, const uint64_t* fps, uint64_t n, int32_t level, uint8_t* seen);

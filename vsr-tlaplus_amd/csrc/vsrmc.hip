@@ -1915,8 +1915,8 @@ int32_t vsrmc_checker_probe_candidates(vsrmc_checker* c, uint64_t* pairs, uint64
   if (!c || !n) return fail(VSRMC_E_ARG, "NULL argument");
   *n = c->h.n_pending;
   if (c->h.n_pending > c->opt.pending_entries) return fail(VSRMC_E_REP, "more violating successors than the pending list holds (pending_entries)");
-  if (c->h.n_pending == 0) return 0;
-  if (!pairs || cap_pairs < c->h.n_pending) return fail(VSRMC_E_ARG, "buffer too small");
+  if (c->h.n_pending == 0 || !pairs) return 0;                 // pairs == NULL: only the number is asked for
+  if (cap_pairs < c->h.n_pending) return fail(VSRMC_E_ARG, "buffer too small");
   HIPCHK(hipSetDevice(c->opt.device));
   HIPCHK(hipMemcpy(pairs, c->pending, 16 * c->h.n_pending, hipMemcpyDeviceToHost));
   return 0;
