@@ -206,6 +206,19 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
                         "-backend", "gloo", "-tableLog2", "20", "-frontierGiB", "0.05", "-replicateBelow", "8"], capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_PORT="29672"))
     assert "76 distinct states found" in r.stdout and "[sharded]" in r.stdout and "2 rank(s)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    # checkpoint after every level to depth 10, then a second run recovers it and probes level 19 of (3,1,{v1,v2},1) with the stricter
+    # invariant: violated there (109 878 states up to level 18), 19-state counter-example
+    d3 = tmp_path / "c3"
+    d3.mkdir()
+    cfg3 = _cfg(d3, L=1, extra="AcknowledgedWritesExistOnMajority")
+    chk = str(d3 / "chk")
+    r = run(cfg3, "-replicateBelow", "100", "-maxDepth", "10", "-checkpoint", chk, "-checkpointMinutes", "0")
+    assert "Checkpointing of run %s completed (level 10)." % chk in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert os.path.exists(chk + ".json") and os.path.exists(chk + ".rank1of2")
+    r = run(cfg3, "-recover", chk, "-probeAt", "19")
+    assert "Recovered from checkpoint" in r.stdout and "Probe(19):" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Error: Invariant AcknowledgedWritesExistOnMajority is violated." in r.stdout
+    assert "State 19: <" in r.stdout and "State 20: <" not in r.stdout and "109878 distinct states found" in r.stdout, r.stdout[-1500:]
     # the shipped VSR.cfg constants: the run ends in the depth-28 violation of AcknowledgedWriteNotLost (319 M states)
     d2 = tmp_path / "c2"
     d2.mkdir()

@@ -14,6 +14,11 @@ TLC's exit code (0 = no error, 12 = safety violation, 11 = deadlock, 1 = failure
   -replicateBelow K   levels with fewer than K new states are explored by every rank on its own (default 2^20; 0 = never)
   -exactTies          two-kernel levels that arbitrate same-level VIEW ties like the oracle (default: single-pass levels)
   -backend nccl|gloo  (default nccl)                                   -json    one JSON object per level
+  -checkpoint PREFIX  checkpoint between levels, at most every -checkpointMinutes M (default 30; 0 = after every level): every
+                      rank writes its shard to PREFIX.rank<r>of<N>, rank 0 the loop state to PREFIX.json
+  -recover PREFIX     continue the run a checkpoint stopped at (same constants, same number of ranks)
+  -probeAt N          level N is PROBED instead of explored: its states' invariants are checked, nothing is stored (one level beyond
+                      what the ranks' buffers hold); the search ends there
 """
 import json
 import os
@@ -30,7 +35,8 @@ INVARIANTS = ["AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"]
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     opt = dict(cfg=None, tla=None, max_depth=1 << 30, table_log2=26, frontier_gib=2.0, replicate_below=1 << 20, exact=False,
-               backend="nccl", json=False, no_tla=False, check_deadlock=False)
+               backend="nccl", json=False, no_tla=False, check_deadlock=False, checkpoint=None, checkpoint_minutes=30.0, recover=None,
+               probe_at=0)
     i = 0
     while i < len(argv):
         a = argv[i]
@@ -47,6 +53,14 @@ def main(argv=None):
             opt["replicate_below"] = int(val); i += 1
         elif a == "-backend" and val:
             opt["backend"] = val; i += 1
+        elif a == "-checkpoint" and val:
+            opt["checkpoint"] = val; i += 1
+        elif a == "-checkpointMinutes" and val:
+            opt["checkpoint_minutes"] = float(val); i += 1
+        elif a == "-recover" and val:
+            opt["recover"] = val; i += 1
+        elif a == "-probeAt" and val:
+            opt["probe_at"] = int(val); i += 1
         elif a == "-exactTies":
             opt["exact"] = True
         elif a == "-json":
@@ -88,23 +102,40 @@ def main(argv=None):
     lay = m.layout
     words = int(opt["frontier_gib"] * (1 << 30) / 8)
     states = max(1 << 12, words // 24)
-    eng = sharded.HipShardEngine(
-        m, rank, world, device=local_rank, table_log2=opt["table_log2"], frontier_words=words, frontier_states=states,
-        pending_entries=max(1 << 16, 3 * states if opt["exact"] else 0), cand_cap=int(1.5 * states / world) + (1 << 16),
-        rec_cap=max(1 << 12, states // 8), rec_words_cap=max(1 << 16, words // 8), keep_trace=True,
-        # one entry per state the rank ends up holding, plus the unused tails of the index chunks its resident blocks leave behind
-        # per level (<= 4 blocks per CU x 8192 indices), for some thirty large levels
-        trace_entries=(1 << opt["table_log2"]) // 2 + 32 * 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count * 8192,
-        exact_ties=opt["exact"])
-    sc = sharded.ShardedChecker(eng, sharded.Exchanger(), replicate_below=opt["replicate_below"])
+    def make_engine(recover=None):
+        return sharded.HipShardEngine(
+            m, rank, world, device=local_rank, table_log2=opt["table_log2"], frontier_words=words, frontier_states=states,
+            pending_entries=max(1 << 16, 3 * states if opt["exact"] else 0), cand_cap=int(1.5 * states / world) + (1 << 16),
+            rec_cap=max(1 << 12, states // 8), rec_words_cap=max(1 << 16, words // 8), exact_ties=opt["exact"], recover=recover)
+
+    try:
+        if opt["recover"]:
+            sc = sharded.ShardedChecker.restore(opt["recover"], make_engine, sharded.Exchanger())
+        else:
+            sc = sharded.ShardedChecker(make_engine(), sharded.Exchanger(), replicate_below=opt["replicate_below"])
+    except (sharded.ShardError, vt.VsrmcError, OSError) as e:
+        say("Error: %s" % e)
+        return 1
     say("vsrmc: VSR.tla lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), invariant "
         "mask %d; %d rank(s), backend %s" % (lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
                                              lay.permutations, lay.invariant_mask, world, opt["backend"]))
-    say("Finished computing initial states: 1 distinct state generated.")
-    t0 = time.time()
-    total_generated, code, last, deadlocked = 0, 0, dict(n_new=1), False
+    if opt["recover"]:
+        say("Recovered from checkpoint %s: level %d, %d distinct states found, %d states left on queue."
+            % (opt["recover"], sc.level, sc.distinct, sc.n_frontier))
+    else:
+        say("Finished computing initial states: 1 distinct state generated.")
+    t0 = t_chk = time.time()
+    total_generated, code, last, deadlocked, probed = 0, 0, dict(n_new=1), False, None
     try:
         while sc.level < opt["max_depth"]:
+            if opt["probe_at"] and sc.level + 1 == opt["probe_at"]:
+                probed = sc.probe()
+                total_generated += probed["generated"]
+                say("Probe(%d): %d states generated, %d violating successors kept by their owners. (%.2f s)"
+                    % (probed["level"], probed["generated"], probed["candidates"], time.time() - t0))
+                if sc.violation is None:
+                    say("No violation up to level %d; the search is incomplete beyond it." % probed["level"])
+                break
             d = sc.step()
             last = d
             total_generated += d["generated"]
@@ -122,19 +153,29 @@ def main(argv=None):
                 break
             if d["n_new"] == 0:
                 break
+            if opt["checkpoint"]:
+                # rank 0's clock decides for everybody (a checkpoint is a collective)
+                due = 1 if time.time() - t_chk >= 60.0 * opt["checkpoint_minutes"] else 0
+                if sc.x.allreduce([due if rank == 0 else 0], dist.ReduceOp.MAX)[0]:
+                    sc.save(opt["checkpoint"])
+                    say("Checkpointing of run %s completed (level %d)." % (opt["checkpoint"], sc.level))
+                    t_chk = time.time()
     except (sharded.ShardError, vt.VsrmcError) as e:
         say("Error: %s" % e)
         code = 1
     dt = time.time() - t0
     if code == 0 and sc.violation is not None:
         v = sc.violation
-        path = sc.trace_fps(v["level"], v["fp"])                        # every rank takes part in the walk
+        path = sc.probe_trace_fps() if v.get("probed") else sc.trace_fps(v["level"], v["fp"])    # every rank takes part in the walk
         if rank == 0:
             tr = sharded.replay_fps(m, path, device=local_rank)
             fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64), device=local_rank)
             assert int(fps[0]) == v["fp"], "trace replay does not end in the violating state"
+            mask = int(v["mask"])
+            if v.get("probed"):     # the probe's mask is the union over every violating successor the ranks saw: ask the path's last state
+                mask = m.check_trace([rec for _, rec in tr], device=local_rank)["inv_mask_last"]
             for b, name in enumerate(INVARIANTS):
-                if (int(v["mask"]) >> b) & 1:
+                if (mask >> b) & 1:
                     print("Error: Invariant %s is violated." % name)
             print("Error: The behavior up to this point is:")
             for t, (action, rec) in enumerate(tr):
