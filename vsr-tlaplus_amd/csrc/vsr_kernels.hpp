@@ -92,6 +92,16 @@ __host__ __device__ __forceinline__ int owner_of(u64 fp, int world) { return (in
 enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #define VSR_TILE_MAX 128     // frontier records staged per block iteration: 64 or 128 (kernel parameter `tile`)
 #define VSR_BLOCK 256
+// per-phase shader clocks of k_expand (vsrmc_level_info.phase_cycles; tools/run_bfs.py prints the breakdown): every read is an
+// s_memtime that waits for the wave's outstanding LDS / scalar loads.  -DVSR_PHASE_CLOCKS=0 builds without them.
+#ifndef VSR_PHASE_CLOCKS
+#define VSR_PHASE_CLOCKS 1
+#endif
+#if VSR_PHASE_CLOCKS
+#define VSR_CLK() __builtin_readcyclecounter()
+#else
+#define VSR_CLK() ((u64)0)
+#endif
 #define VSR_CAND_CAP 2048    // enabled instances per tile the LDS work list can hold
 
 __device__ __forceinline__ void raise_error(LevelCtl* ctl, int code, u64 info) {
@@ -331,7 +341,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   for (u64 tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
     const u64 p_base = tile_i * (u64)tile;
     const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
-    const u64 t_0 = __builtin_readcyclecounter();
+    const u64 t_0 = VSR_CLK();
     if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; }
     if (tid < tile) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
@@ -381,7 +391,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       s_pfp[tid] = pf;
     }
 
-    const u64 t_1 = __builtin_readcyclecounter();
+    const u64 t_1 = VSR_CLK();
     // ---- enumerate enabled instances, slot-major: item = slot * 64 + record, so the 64 lanes of a wave evaluate the same
     // slot kind for 64 different records (LDS columns are conflict-free: odd record stride).  Work list entry =
     // action id << 17 | record << 11 | ordinal; per-action counters feed the counting sort below.
@@ -460,7 +470,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       s_ncand = acc > ccap ? ccap : acc;
       if (fused) s_wneed = s_ncand * (u32)(M.fixed + (int)s_maxbag + 5);   // upper bound of the successors' total length
     }
-    const u64 t_2 = __builtin_readcyclecounter();
+    const u64 t_2 = VSR_CLK();
     __syncthreads();
     const u32 ncand = s_ncand;
     for (u32 c = tid; c < ccap; c += VSR_BLOCK) {
@@ -471,7 +481,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     }
     __syncthreads();
 
-    const u64 t_3 = __builtin_readcyclecounter();
+    const u64 t_3 = VSR_CLK();
     if (fused && (mode == MODE_NORMAL || mode == MODE_REGEN)) {
       // ---- reserve room for this tile's successors (upper bounds: ncand states, s_wneed words) in the block's chunks
       if (s_ich_used + ncand > ichunk) {                        // block-uniform
@@ -532,7 +542,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
       const u64* rec = s_rec + p * stride;
       Delta D;
-      const u64 a_0 = __builtin_readcyclecounter();
+      const u64 a_0 = VSR_CLK();
       if (!Ops::template gen_<false>(M, rec, ord, D) || D.action != (int)(code >> 18)) {
         raise_error(ctl, ERR_INTERNAL, ((p_base + (u64)p) << 16) | (u64)ord);
         continue;
@@ -541,14 +551,14 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         raise_error(ctl, D.err, ((p_base + (u64)p) << 16) | (u64)ord);
         continue;
       }
-      const u64 a_1 = __builtin_readcyclecounter();
+      const u64 a_1 = VSR_CLK();
       u64 Hc[6];
       Ops::hash_child_(M, rec, D, Hc);
       u64 fp;
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
       const u64 key = meta_make(level, ak, s_pfp[p]);
-      const u64 a_2 = __builtin_readcyclecounter();
+      const u64 a_2 = VSR_CLK();
       if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
       if (!fused && world > 1) {                                // sharded seen-set, exact scheme: route to the owner of fp
         const int owner = owner_of(fp, world);
@@ -629,7 +639,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           my_words++;                                           // counts states in this mode
           do_write = false;
         }
-        const u64 a_3 = __builtin_readcyclecounter();
+        const u64 a_3 = VSR_CLK();
         if (tid == 0) s_acc[12] += a_3 - a_2;
         if (do_write) {                                         // new state (or: possibly new, the owner decides): write it out
           const int plen = (int)(s_ref[p] & 255);
@@ -702,7 +712,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
         // same-level duplicate with a different canonical auxkey = the tie the single-pass scheme cannot arbitrate
         if (prev_meta != META_EMPTY && meta_level(prev_meta) == level && meta_auxkey(prev_meta) != meta_auxkey(key)) atomicAdd(&s_acc[8], 1ull);
-        if (tid == 0) s_acc[13] += __builtin_readcyclecounter() - a_3;
+        if (tid == 0) s_acc[13] += VSR_CLK() - a_3;
         continue;
       }
       bool found_old, full;
@@ -723,7 +733,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         pending[3 * i + 2] = origin_make(p_offset + p_base + (u64)p, ord);
       }
     }
-    const u64 t_4 = __builtin_readcyclecounter();
+    const u64 t_4 = VSR_CLK();
     // wave-level reduction of the per-lane statistics (probes; fused: words written, largest bag)
     for (int o = 32; o > 0; o >>= 1) {
       my_probes += __shfl_down(my_probes, o);
@@ -748,7 +758,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
       s_acc[0] += s_ncand;
       s_acc[1] += s_dead;
-      const u64 t_5 = __builtin_readcyclecounter();
+      const u64 t_5 = VSR_CLK();
       s_acc[3] += t_1 - t_0;
       s_acc[4] += t_2 - t_1;
       s_acc[5] += t_3 - t_2;
