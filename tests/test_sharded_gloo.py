@@ -245,23 +245,33 @@ def test_bench_sharded_leg_at_full_scale(world):
 
 
 @pytest.mark.gpu
-def test_reset_clears_the_sent_filter():
+def test_reset_clears_the_sent_filter(tmp_path):
     """the sent-filter of a sharded single-pass checker (announced (fingerprint, auxkey) tags, any level) must not survive
-    vsrmc_checker_reset: a second run announces exactly what the first one did"""
-    import vsr_tlaplus_amd as vt
-    from vsr_tlaplus_amd import sharded
-    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
-    eng = sharded.HipShardEngine(m, 0, 2, device=0, table_log2=20, frontier_words=1 << 22, frontier_states=1 << 17,
-                                 pending_entries=1 << 19, cand_cap=1 << 18, rec_cap=1 << 17, rec_words_cap=1 << 22, filter_log2=16)
-    runs = []
-    for _ in range(2):
-        for _ in range(7):
-            eng.local_step()                                # replicated phase: levels 2-8 on this rank alone
-        eng.partition()
-        cands, err = eng.expand()                           # rank 0 of 2: what it would announce to rank 1 for level 9
-        assert err == 0
-        # 0 = unused entry of a block's chunk; the filter is a lossy cache, so a tag can be announced twice: compare the SETS
-        runs.append(sorted(set(int(x) for x in cands[1][:, 0].cpu().numpy().view(np.uint64) if x)))
-        eng.reset()
-    assert len(runs[0]) > 100 and runs[0] == runs[1]
-    eng.close()
+    vsrmc_checker_reset: a second run announces exactly what the first one did.  (Own process: torch has to be loaded before
+    libvsrmc.so — both bind libamdhip64.so.7 — and this pytest process has used the library already.)"""
+    script = tmp_path / "sent_filter.py"
+    script.write_text("""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from vsr_tlaplus_amd import sharded
+import vsr_tlaplus_amd as vt
+m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+eng = sharded.HipShardEngine(m, 0, 2, device=0, table_log2=20, frontier_words=1 << 22, frontier_states=1 << 17,
+                             pending_entries=1 << 19, cand_cap=1 << 18, rec_cap=1 << 17, rec_words_cap=1 << 22, filter_log2=16)
+runs = []
+for _ in range(2):
+    for _ in range(7):
+        eng.local_step()                                # replicated phase: levels 2-8 on this rank alone
+    eng.partition()
+    cands, err = eng.expand()                           # rank 0 of 2: what it would announce to rank 1 for level 9
+    assert err == 0
+    # 0 = unused entry of a block's chunk; the filter is a lossy cache, so a tag can be announced twice: compare the SETS
+    runs.append(sorted(set(int(x) for x in cands[1][:, 0].cpu().numpy().view(np.uint64) if x)))
+    eng.reset()
+assert len(runs[0]) > 100 and runs[0] == runs[1], (len(runs[0]), len(runs[1]))
+eng.close()
+print("OK", len(runs[0]))
+""" % ROOT)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

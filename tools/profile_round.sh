@@ -1,7 +1,8 @@
 #!/bin/bash
 # The round's measurement set, run on the GPU box through gpurun:  tools/profile_round.sh r02
 # -> gpurun_out/<tag>_bench.json (driver-style bench line), <tag>_kernel_stats.md (rocprofv3 --kernel-trace --stats),
-#    <tag>_pmc_fetch.md / _pmc_write.md (separate --pmc passes), <tag>_sq_counters_{a,b}.md.  Copy what is to be judged into profiles/.
+#    <tag>_pmc_fetch.md / _pmc_write.md (separate --pmc passes), <tag>_sq_counters_{a,b}.md, <tag>_config3_bench.json,
+#    <tag>_config3_kernel_stats.md.  Copy what is to be judged into profiles/.
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
@@ -19,6 +20,13 @@ one() {   # name, rocprofv3 flags...
   rm -rf $OUT/prof_$name
   head -8 $OUT/${TAG}_$name.md
 }
+# the README defect configuration to its depth-24 violation (levels 1-21 stored, 22 virtual, 23 streamed, 24 probed), alone and traced
+python $R/bench.py --workload config3 > $OUT/${TAG}_config3_bench.json 2> $OUT/${TAG}_config3_bench.err
+tail -c 400 $OUT/${TAG}_config3_bench.json
+PROF_SAVE=$PROF
+PROF="python $R/bench.py --workload config3"
+one config3_kernel_stats --kernel-trace --stats
+PROF=$PROF_SAVE
 one kernel_stats --kernel-trace --stats
 one pmc_fetch --kernel-trace --pmc FETCH_SIZE
 one pmc_write --kernel-trace --pmc WRITE_SIZE

@@ -406,6 +406,12 @@ class HipShardEngine:
         """cand_cap: (fp, key) candidates per peer and level; rec_cap / rec_words_cap: records / words one rebalancing move
         to one peer may carry.  recover: this rank's checkpoint file (save()), written by the same rank of the same world."""
         self.model, self.rank, self.world, self.device = model, rank, world, device
+        if not torch.cuda.is_available():
+            # libvsrmc.so and torch both bind libamdhip64.so.7 (ROCm's resp. torch's bundled copy); the first one loaded serves the
+            # whole process, and torch cannot enumerate devices on ROCm's copy: `import torch` (or this module) before the first
+            # vsrmc call in a process that needs both
+            raise ShardError("torch sees no GPU (no device, or libvsrmc.so was loaded before torch in this process: import "
+                             "vsr_tlaplus_amd.sharded / torch first)")
         o = capi.Options()
         capi.load().vsrmc_options_default(C.byref(o))
         o.device, o.table_log2 = device, table_log2
