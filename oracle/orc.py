@@ -17,8 +17,9 @@ BIN_MT = os.path.join(HERE, "build", "vsr_oracle_mt")
 
 def build(force=False):
     srcs = [os.path.join(HERE, f) for f in ("vsr_oracle.cpp", "vsr_oracle_bfs.cpp", "vsr_oracle_mt.cpp", "vsr_oracle.hpp", "Makefile",
-                                            "vrst_oracle.cpp", "vrst_oracle.hpp")]
-    outs = (LIB, BIN, BIN_MT, os.path.join(HERE, "build", "liborc2.so"), os.path.join(HERE, "build", "vrst_oracle_mt"))
+                                            "vrst_oracle.cpp", "vrst_oracle.hpp", "vras_oracle.cpp", "vras_oracle.hpp")]
+    outs = (LIB, BIN, BIN_MT, os.path.join(HERE, "build", "liborc2.so"), os.path.join(HERE, "build", "vrst_oracle_mt"),
+            os.path.join(HERE, "build", "liborc3.so"), os.path.join(HERE, "build", "vras_oracle_mt"))
     stale = force or not all(os.path.exists(o) for o in outs) or any(
         os.path.getmtime(s) > min(os.path.getmtime(o) for o in outs) for s in srcs)
     if stale:

@@ -1,0 +1,84 @@
+"""Third model ("then 04-application-state"): /root/reference/vsr-revisited/paper/analysis/04-application-state/
+VR_APP_STATE.{tla,cfg}.
+Two independent CPU readings — the C++ oracle (oracle/vras_oracle.cpp) and the Python restatement (oracle/pyoracle3.py) — must
+agree on whole small state spaces: level sizes, generated counts, per-state successor multisets (action, record), invariant
+verdicts, and fingerprint = VIEW identity (no collisions, no false splits).  Expected outcome of the model: no violation."""
+import numpy as np
+import pytest
+
+from oracle import orc3 as orc2, pyoracle3 as po
+
+
+def _cpp_levels(P, max_depth):
+    b = orc2.Bfs(P)
+    out = [dict(new=1, generated=0)]
+    while b.info["depth"] < max_depth:
+        nn = b.step()
+        if nn == 0:
+            break
+        assert b.info["viol_mask"] == 0 and b.info["ties"] == 0
+        out.append(dict(new=nn, generated=b.info["generated"]))
+    total = b.info["distinct"]
+    b.close()
+    return out, total
+
+
+@pytest.mark.parametrize("R,vals,L,depth", [(2, ("a",), 1, 99), (2, ("a", "b"), 1, 99), (2, ("a", "b"), 2, 14), (3, ("a",), 1, 11), (3, ("a", "b"), 2, 7)])
+def test_level_counts_agree(R, vals, L, depth):
+    M = po.Model(R, vals, L)
+    levels, gen, viol = po.bfs(M, max_depth=depth)
+    assert viol is None                                     # VR_APP_STATE.cfg: the invariants hold
+    cpp, total = _cpp_levels(orc2.Params(R, len(vals), L), depth)
+    assert [l["new"] for l in cpp] == [len(l) for l in levels]
+    assert [l["generated"] for l in cpp] == gen
+    if depth == 99:
+        assert total == sum(len(l) for l in levels)
+
+
+def test_successor_sets_agree_on_every_state_of_a_small_space():
+    M = po.Model(2, ("a", "b"), 2)
+    P = orc2.Params(2, 2, 2)
+    levels, _, _ = po.bfs(M, max_depth=16)
+    fp_of_view = {}
+    acts = set()
+    for lvl in levels:
+        for s in lvl[::3]:
+            w = np.array(po.pack(M, s), dtype=np.uint64)
+            succ = orc2.successors(P, w)
+            cs = sorted((orc2.ACTIONS[x["action"]], tuple(po.normalise(M, [int(v) for v in x["words"]])), x["inv"]) for x in succ)
+            ps = sorted((n, tuple(po.normalise(M, po.pack(M, t))), po.invariant_mask(M, t)) for n, t in po.successors(M, s))
+            assert cs == ps
+            acts.update(a for a, _, _ in cs)
+            assert orc2.invariants(P, w) == po.invariant_mask(M, s) == 0
+            fp, _ = orc2.fingerprint(P, w)
+            assert fp_of_view.setdefault(po.view_of(s), fp) == fp
+    assert len(set(fp_of_view.values())) == len(fp_of_view) == sum(len(l[::3]) for l in levels)
+    assert {"TimerSendSVC", "SendDVC", "SendSV", "ReceiveSV", "ReceiveClientRequest", "ReceivePrepareMsg", "PrimaryExecuteOp", "ReceiveMatchingDVC"} <= acts
+
+
+def test_state_transfer_actions_of_the_third_model():
+    """states of (3, {a,b}, 2) in which SendGetState / ReceiveGetState / ReceiveNewState fire (harvested by the C++ oracle's BFS):
+    the Python restatement produces the same successors"""
+    M = po.Model(3, ("a", "b"), 2)
+    P = orc2.Params(3, 2, 2)
+    b = orc2.Bfs(P)
+    seen = {13: 0, 14: 0, 15: 0}
+    while b.info["depth"] < 15 and min(seen.values()) < 3:
+        assert b.step() > 0
+        if b.info["depth"] < 9:
+            continue
+        words, off = b.frontier()
+        for i in range(0, len(off) - 1, 13):
+            rec = words[int(off[i]): int(off[i + 1])]
+            succ = orc2.successors(P, rec)
+            hit = [x["action"] for x in succ if x["action"] in seen]
+            if not hit or all(seen[a] >= 12 for a in hit):
+                continue
+            for a in hit:
+                seen[a] += 1
+            s = po.unpack(M, [int(x) for x in rec])
+            cs = sorted((orc2.ACTIONS[x["action"]], tuple(po.normalise(M, [int(v) for v in x["words"]]))) for x in succ)
+            ps = sorted((n, tuple(po.normalise(M, po.pack(M, t)))) for n, t in po.successors(M, s))
+            assert cs == ps
+    b.close()
+    assert min(seen.values()) >= 3, seen
