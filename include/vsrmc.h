@@ -62,6 +62,11 @@ int32_t vsrmc_model_from_constants(int32_t replica_count, int32_t client_count, 
  * SHA-256 of the .tla (or, without a .tla, by the cfg's constants); every other entry point takes either model. */
 int32_t vsrmc_model2_from_constants(int32_t replica_count, int32_t value_count, int32_t start_view_on_timer_limit,
                                     int32_t no_progress_change_limit, int32_t symmetry, int32_t invariant_mask, vsrmc_model** out);
+/* The third model ("then 04-application-state"): analysis/04-application-state/VR_APP_STATE.tla under the constants
+ * of VR_APP_STATE.cfg:4-7 (ReplicaCount <= 3).  invariant_mask as above plus 16 NoAppStateDivergence (the shipped cfg checks
+ * 2 + 4 + 8 + 16 = 30).  Without a .tla, vsrmc_model_load takes an analysis cfg that lists NoAppStateDivergence for this model. */
+int32_t vsrmc_model3_from_constants(int32_t replica_count, int32_t value_count, int32_t start_view_on_timer_limit,
+                                    int32_t no_progress_change_limit, int32_t symmetry, int32_t invariant_mask, vsrmc_model** out);
 int32_t vsrmc_model_info(const vsrmc_model* m, vsrmc_layout* out);
 /* Init (VSR.tla:323-348) in wire layout */
 int32_t vsrmc_model_init_state(const vsrmc_model* m, uint64_t* rec, int32_t cap_words, int32_t* n_words);

@@ -1,0 +1,111 @@
+"""Third model (VR_APP_STATE), host side (no GPU): the cfg loader tells VR_APP_STATE.cfg from its neighbour's, refuses what is not
+lowered, Init equals the oracle's, and the printer's output parses back to the Python restatement's value."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG = """\\* SPECIFICATION
+CONSTANTS
+    ReplicaCount = %(R)d
+    Values = {%(vals)s}
+    StartViewOnTimerLimit = %(L)d
+    NoProgressChangeLimit = %(npl)d
+    Normal = Normal
+    ViewChange = ViewChange
+    StateTransfer = StateTransfer
+    PrepareMsg = PrepareMsg
+    PrepareOkMsg = PrepareOkMsg
+    StartViewChangeMsg = StartViewChangeMsg
+    DoViewChangeMsg = DoViewChangeMsg
+    StartViewMsg = StartViewMsg
+    GetStateMsg = GetStateMsg
+    NewStateMsg = NewStateMsg
+    Nil = Nil
+    AnyDest = AnyDest
+
+SPECIFICATION %(spec)s \\* Use when not doing liveness checking
+
+VIEW view
+%(extra)s
+INVARIANT
+AcknowledgedWritesExistOnMajority
+NoLogDivergence
+NoAppStateDivergence
+CommitNumberNeverHigherThanOpNumber
+"""
+
+
+@pytest.fixture(scope="module")
+def vt():
+    import __graft_entry__
+    __graft_entry__.build()
+    import vsr_tlaplus_amd as vt
+    return vt
+
+
+def _cfg(tmp_path, R=3, vals="a, b", L=2, npl=0, spec="Spec", extra=""):
+    p = tmp_path / ("m3_%d_%d_%d_%s.cfg" % (R, L, npl, spec))
+    p.write_text(CFG % dict(R=R, vals=vals, L=L, npl=npl, spec=spec, extra=extra))
+    return str(p)
+
+
+def test_loader_reads_the_third_models_cfg(vt, tmp_path):
+    lay = vt.Model.load(_cfg(tmp_path)).layout                     # no .tla: the constants + NoAppStateDivergence identify the module
+    assert (lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit) == (3, 0, 2, 2)
+    assert (lay.symmetry, lay.permutations, lay.invariant_mask, lay.words_per_replica, lay.fixed_words) == (0, 1, 30, 2, 7)
+    ref = "/root/reference/vsr-revisited/paper/analysis"
+    if os.path.exists(ref):                                         # the shipped files themselves, module SHA-256-pinned
+        m = vt.Model.load(ref + "/04-application-state/VR_APP_STATE.cfg", ref + "/04-application-state/VR_APP_STATE.tla")
+        lay = m.layout
+        assert (lay.replica_count, lay.value_count, lay.start_view_on_timer_limit, lay.invariant_mask, lay.words_per_replica) == (3, 2, 2, 30, 2)
+        assert "a :> " not in m.format_state(m.init_state()) and "rep_app_state |-> <<<<>>, <<>>, <<>>>>" in m.format_state(m.init_state())
+        # the neighbour's .tla with this cfg: NoAppStateDivergence is not an invariant of that module
+        with pytest.raises(vt.VsrmcError):
+            vt.Model.load(ref + "/04-application-state/VR_APP_STATE.cfg", ref + "/03-state-transfer/VR_STATE_TRANSFER.tla")
+        # this .tla with the neighbour's cfg: the same constants, three of the four invariants
+        lay = vt.Model.load(ref + "/03-state-transfer/VR_STATE_TRANSFER.cfg", ref + "/04-application-state/VR_APP_STATE.tla").layout
+        assert (lay.invariant_mask, lay.words_per_replica) == (14, 2)
+
+
+def test_loader_refuses_what_is_not_lowered(vt, tmp_path):
+    for kw in (dict(npl=1), dict(spec="LivenessSpec"), dict(extra="SYMMETRY symmValues"), dict(extra="PROPERTY ConvergenceToView"), dict(R=4)):
+        with pytest.raises(vt.VsrmcError):
+            vt.Model.load(_cfg(tmp_path, **kw))
+    with pytest.raises(vt.VsrmcError):
+        vt.Model.third_model(no_progress_limit=2)
+
+
+def test_init_and_printer_against_the_restatements(vt):
+    from oracle import orc3 as orc2, pyoracle3 as po, tlcvalue
+    for R, n, L in ((3, 2, 2), (2, 1, 1), (3, 3, 3)):
+        m = vt.Model.third_model(R=R, n=n, L=L)
+        P = orc2.Params(R, n, L)
+        assert np.array_equal(m.init_state(), orc2.init_record(P))
+    # states of a small BFS of the Python restatement, printed by the product and parsed back with the test-side TLC value parser
+    M = po.Model(3, ("a", "b"), 2)
+    m = vt.Model.third_model(R=3, n=2, L=2)
+    levels, _, _ = po.bfs(M, max_depth=8)
+    empty = lambda x: {} if x == () else x                          # noqa: E731
+
+    def seq_logs(msgs):
+        out = {}
+        for mm, c in (msgs.items() if isinstance(msgs, dict) else []):
+            d = dict(mm)
+            if d.get("type") == "NewStateMsg" and d["log"] and not isinstance(d["log"][0][0], int):
+                d["log"] = tuple((d["first_op"] + i, e) for i, e in enumerate(d["log"]))
+            out[tuple(sorted(d.items()))] = c
+        return out
+    n = 0
+    for lvl in levels:
+        for s in lvl[::7]:
+            val = dict(tlcvalue.parse_value(m.format_state(np.array(po.pack(M, s), dtype=np.uint64))))
+            for k in po.VIEW_VARS + ["aux_svc", "aux_client_acked", "aux_restart"]:
+                a, b = (seq_logs(val[k]), seq_logs(s[k])) if k == "messages" else (val[k], s[k])
+                if k == "replicas":
+                    b = frozenset(b)
+                assert po.canon(empty(a)) == po.canon(empty(b)), k
+            n += 1
+    assert n > 50

@@ -30,15 +30,15 @@ def main():
     ap.add_argument("--max-depth", type=int, default=0)
     ap.add_argument("--max-seconds", type=float, default=0)
     ap.add_argument("--count-only-from", type=int, default=0)
-    ap.add_argument("--inv-mask", type=int, default=0, help="default: the shipped cfg's invariants (model 1: 1, model 2: 14)")
-    ap.add_argument("--model", type=int, default=1, help="1 = VSR.tla (vsr_oracle_mt), 2 = analysis/03-state-transfer/VR_STATE_TRANSFER.tla (vrst_oracle_mt)")
+    ap.add_argument("--inv-mask", type=int, default=0, help="default: the shipped cfg's invariants (model 1: 1, model 2: 14, model 3: 30)")
+    ap.add_argument("--model", type=int, default=1, help="1 = VSR.tla (vsr_oracle_mt), 2 = analysis/03-state-transfer/VR_STATE_TRANSFER.tla (vrst_oracle_mt), 3 = analysis/04-application-state/VR_APP_STATE.tla (vras_oracle_mt)")
     ap.add_argument("--no-symmetry", action="store_true")
     ap.add_argument("--label", default="")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
-    exe = os.path.join(ROOT, "oracle", "build", "vsr_oracle_mt" if a.model == 1 else "vrst_oracle_mt")
-    a.inv_mask = a.inv_mask or (1 if a.model == 1 else 14)
+    exe = os.path.join(ROOT, "oracle", "build", {1: "vsr_oracle_mt", 2: "vrst_oracle_mt", 3: "vras_oracle_mt"}[a.model])
+    a.inv_mask = a.inv_mask or {1: 1, 2: 14, 3: 30}[a.model]
     cmd = [exe, str(a.R), str(a.C), str(a.n), str(a.L), "--inv-mask", str(a.inv_mask)]
     if a.threads:
         cmd += ["--threads", str(a.threads)]
@@ -58,8 +58,9 @@ def main():
         killed (timeout) still leaves every completed level behind"""
         out = dict(
             source="CPU oracle: oracle/%s (multi-threaded driver over oracle/%s) — " % (
-                       ("vsr_oracle_mt", "vsr_oracle.cpp, the restatement of VSR.tla") if a.model == 1 else
-                       ("vrst_oracle_mt", "vrst_oracle.cpp, the restatement of VR_STATE_TRANSFER.tla")) +
+                       {1: ("vsr_oracle_mt", "vsr_oracle.cpp, the restatement of VSR.tla"),
+                        2: ("vrst_oracle_mt", "vrst_oracle.cpp, the restatement of VR_STATE_TRANSFER.tla"),
+                        3: ("vras_oracle_mt", "vras_oracle.cpp, the restatement of VR_APP_STATE.tla")}[a.model]) +
                    "`%s`, %s threads on %s (%d logical CPUs), %.1f s; written by tools/make_oracle_levels.py"
                    % (" ".join([os.path.basename(exe)] + cmd[1:]), summary.get("threads", a.threads or "all"), platform.processor() or platform.machine(),
                       os.cpu_count() or 0, time.time() - t0),

@@ -54,6 +54,7 @@ SYMBOLS = {
     "vsrmc_model_load": (C.c_int32, [C.c_char_p, C.c_char_p, C.POINTER(V)]),
     "vsrmc_model_from_constants": (C.c_int32, [C.c_int32] * 8 + [C.POINTER(V)]),
     "vsrmc_model2_from_constants": (C.c_int32, [C.c_int32] * 6 + [C.POINTER(V)]),
+    "vsrmc_model3_from_constants": (C.c_int32, [C.c_int32] * 6 + [C.POINTER(V)]),
     "vsrmc_model_info": (C.c_int32, [V, C.POINTER(Layout)]),
     "vsrmc_model_init_state": (C.c_int32, [V, V, C.c_int32, C.POINTER(C.c_int32)]),
     "vsrmc_model_format_state": (C.c_int32, [V, V, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),

@@ -59,6 +59,14 @@ class Model:
         check(capi.load().vsrmc_model2_from_constants(R, n, L, no_progress_limit, int(symmetry), invariant_mask, C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def third_model(cls, R=3, n=2, L=2, no_progress_limit=0, symmetry=False, invariant_mask=30):
+        """analysis/04-application-state/VR_APP_STATE.tla under the constants of its cfg (the shipped one: 3, {a,b}, 2, 0; INVARIANT
+        AcknowledgedWritesExistOnMajority, NoLogDivergence, NoAppStateDivergence, CommitNumberNeverHigherThanOpNumber = mask 30)."""
+        h = C.c_void_p()
+        check(capi.load().vsrmc_model3_from_constants(R, n, L, no_progress_limit, int(symmetry), invariant_mask, C.byref(h)))
+        return cls(h)
+
     def init_state(self):
         out = np.zeros(256, dtype=np.uint64)
         n = C.c_int32()

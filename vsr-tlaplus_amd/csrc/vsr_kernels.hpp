@@ -15,11 +15,12 @@
 
 #include "vsr_actions.hpp"
 #include "vrst_actions.hpp"
+#include "vras_actions.hpp"
 
 namespace vsr {
 
 // The model a kernel instantiation checks: 0 = VSR.tla (vsr_actions.hpp), 1 = analysis/03-state-transfer/VR_STATE_TRANSFER.tla
-// (vrst_actions.hpp).  Everything above the action table — staging, enumeration, sort, seen-set, frontier, trace — is shared.
+// (vrst_actions.hpp), 2 = analysis/04-application-state/VR_APP_STATE.tla (vras_actions.hpp).  Everything above the action table — staging, enumeration, sort, seen-set, frontier, trace — is shared.
 template <int MODEL>
 struct ModelOps;
 template <>
@@ -57,6 +58,25 @@ struct ModelOps<1> {
   static VSR_HD void hash_full_(const Model& M, PTR rec, u64* H) { vrst::hash_full(M, rec, H); }
   template <typename PTR>
   static VSR_HD int invariants(const Model& M, PTR rec, const Delta& D) { return vrst::check_invariants_child(M, rec, D); }
+};
+
+template <>
+struct ModelOps<2> {   // analysis/04-application-state/VR_APP_STATE.tla (vras_actions.hpp)
+  template <bool GUARD_ONLY, typename PTR>
+  static VSR_HD bool gen_(const Model& M, PTR rec, int ord, Delta& D) { return vras::gen<GUARD_ONLY>(M, rec, ord, D); }
+  template <typename PTR>
+  static VSR_HD u32 guard_pre(const Model& M, PTR rec, u64, const u64*, int slot, int* kind0, int) {
+    return vras::guard_slot(M, rec, slot, kind0);
+  }
+  template <typename PTR>
+  static VSR_HD u32 guard(const Model& M, PTR rec, int slot, int* kind0) { return vras::guard_slot(M, rec, slot, kind0); }
+  static VSR_HD int other_kind(int kind0) { return kind0; }       // bits 1.. of a slot: the same action taken by another replica (AnyDest)
+  template <typename PTR>
+  static VSR_HD void hash_child_(const Model& M, PTR rec, const Delta& D, u64* Hc) { vras::hash_child(M, rec, D, Hc); }
+  template <typename PTR>
+  static VSR_HD void hash_full_(const Model& M, PTR rec, u64* H) { vras::hash_full(M, rec, H); }
+  template <typename PTR>
+  static VSR_HD int invariants(const Model& M, PTR rec, const Delta& D) { return vras::check_invariants_child(M, rec, D); }
 };
 
 struct Slot {       // one seen-set slot: 16 bytes, fp == 0 means empty
@@ -256,8 +276,8 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
       M.m0 = 4 * SR + SR * SC * SN;
       if (Marg.np == 1) M.np = 1;                              // symmetry off: block-uniform, still cheap
       else M.np = SN == 1 ? 1 : SN == 2 ? 2 : 6;
-    } else {                                                   // the second model: one word per replica, no clients, no symmetry
-      M.wpr = 1;
+    } else {                                                   // the second / third model: one / two words per replica, no clients, no symmetry
+      M.wpr = MODEL == 1 ? 1 : 2;
       M.m0 = 4 * SR + SR * SN;
       M.np = 1;
     }

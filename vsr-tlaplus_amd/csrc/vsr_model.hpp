@@ -57,7 +57,7 @@ enum {
 };
 
 struct Model {
-  int model_id;          // 0 = VSR.tla, 1 = analysis/03-state-transfer/VR_STATE_TRANSFER.tla (vrst_actions.hpp)
+  int model_id;          // 0 = VSR.tla, 1 = analysis/03-state-transfer/VR_STATE_TRANSFER.tla (vrst_actions.hpp), 2 = analysis/04-application-state/VR_APP_STATE.tla (vras_actions.hpp)
   int R, C, n, L;        // ReplicaCount, ClientCount, Cardinality(Values), StartViewOnTimerLimit
   int wpr;               // words per replica block
   int h0;                // index of H[0]

@@ -17,6 +17,7 @@
 #include "../../include/vsrmc.h"
 #include "vsr_format.hpp"
 #include "vrst_format.hpp"
+#include "vras_format.hpp"
 #include "vsr_parse.hpp"
 #include "vsr_kernels.hpp"
 
@@ -88,6 +89,8 @@ std::string sha256_hex(const std::string& data) {
 const char* const VSR_TLA_SHA256 = "f37efb7b055316624c885e2805550097fa609864b1b7a782279c189f8e2dbf22";
 // ... and of the second one: /root/reference/vsr-revisited/paper/analysis/03-state-transfer/VR_STATE_TRANSFER.tla (948 lines)
 const char* const VRST_TLA_SHA256 = "e716e3e04a9f9284d9e2df039271a37d4974c1d32d19dbe54a8da5de46331eee";
+// /root/reference/vsr-revisited/paper/analysis/04-application-state/VR_APP_STATE.tla (the third model, vras_actions.hpp)
+const char* const VRAS_TLA_SHA256 = "6ef22989c86c9d5bb9c9c9829a09e9ee0e035c75e7b894c0bc6dbeba1f476bb6";
 
 }  // namespace
 
@@ -166,6 +169,34 @@ int build_model2(int R, int n, int L, int no_progress_limit, int symmetry, int i
   return 0;
 }
 
+// The third model (VR_APP_STATE.tla): two words per replica (state + received DoViewChange set), no clients, no symmetry
+// (vras_actions.hpp); ReplicaCount <= 3: the received-DoViewChange word holds three 17-bit slots
+int build_model3(int R, int n, int L, int no_progress_limit, int symmetry, int inv_mask, vsrmc_model* out) {
+  if (R < 2 || R > 3 || n < 1 || n > 3 || L < 0 || L > 6)
+    return fail(VSRMC_E_CFG, "model constants outside the supported bounds (ReplicaCount 2..3, |Values| 1..3, StartViewOnTimerLimit 0..6)");
+  if (no_progress_limit != 0)
+    return fail(VSRMC_E_CFG, "NoProgressChangeLimit > 0 is not supported: NoProgressChange (VR_APP_STATE.tla:797-807) is not lowered");
+  if (symmetry)
+    return fail(VSRMC_E_CFG, "SYMMETRY is not lowered for VR_APP_STATE.tla (VR_APP_STATE.cfg:26-28 keeps it commented out)");
+  Model& M = out->M;
+  std::memset(&M, 0, sizeof(M));
+  M.model_id = 2;
+  M.R = R; M.C = 0; M.n = n; M.L = L;
+  M.wpr = 2;
+  M.h0 = 1 + 2 * R;
+  M.np = 1;
+  M.pitab[0] = 0x24u;                                            // the identity
+  M.fixed = M.h0 + 1;
+  M.inv_mask = inv_mask;
+  M.max_bag = 63 - M.fixed;
+  M.m0 = 4 * R + R * n;
+  for (int v = 1; v <= 7; v++) M.primtab |= (u32)(1 + ((v - 1) % R)) << (3 * v);   // Primary(v), VR_APP_STATE.tla:238-239
+  out->symmetry = 0;
+  out->value_names.clear();
+  for (int v = 0; v < n; v++) out->value_names.push_back(std::string(1, (char)('a' + v)));   // VR_APP_STATE.cfg:5 Values = {a, b}
+  return 0;
+}
+
 std::string strip(const std::string& s) {
   size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
   return a == std::string::npos ? "" : s.substr(a, b - a + 1);
@@ -192,6 +223,10 @@ void init_record_wire(const Model& M, std::vector<u64>& rec) {   // Init, VSR.tl
     for (int r = 1; r <= M.R; r++) rec[r] = a_set_lnv(a_set_view(a_set_status(0, vrst::ST2_NORMAL), 1), 1);   // view 1, last normal view 1
     return;
   }
+  if (M.model_id == 2) {                                         // Init, VR_APP_STATE.tla:292-315 (rep_app_state, rep_recv_dvc empty)
+    for (int r = 1; r <= M.R; r++) rec[vras::c_ia(r)] = a_set_lnv(a_set_view(a_set_status(0, vrst::ST2_NORMAL), 1), 1);
+    return;
+  }
   for (int r = 1; r <= M.R; r++) {
     u64 A = 0;
     A = a_set_status(A, ST_NORMAL);        // rep_status = Normal            :328
@@ -204,6 +239,7 @@ void init_record_wire(const Model& M, std::vector<u64>& rec) {   // Init, VSR.tl
 // view hashes of a device-layout record on the host (pure arithmetic, the same functions the kernels run)
 void hash_full_host(const Model& M, const u64* rec, u64* H) {
   if (M.model_id == 1) vrst::hash_full(M, rec, H);
+  else if (M.model_id == 2) vras::hash_full(M, rec, H);
   else hash_full(M, rec, H);
 }
 
@@ -239,11 +275,21 @@ int32_t vsrmc_model2_from_constants(int32_t R, int32_t n, int32_t L, int32_t no_
   return 0;
 }
 
+int32_t vsrmc_model3_from_constants(int32_t R, int32_t n, int32_t L, int32_t no_progress_limit, int32_t symmetry, int32_t inv_mask,
+                                    vsrmc_model** out) {
+  if (!out) return fail(VSRMC_E_ARG, "out is NULL");
+  vsrmc_model* m = new vsrmc_model();
+  int rc = build_model3(R, n, L, no_progress_limit, symmetry, inv_mask, m);
+  if (rc) { delete m; return rc; }
+  *out = m;
+  return 0;
+}
+
 // The TLC cfg grammar as used by VSR.cfg:1-39: CONSTANTS (name = int | name = {mv, ...} | name = mv), INIT, NEXT,
 // VIEW, SYMMETRY, INVARIANT[S] (multi-line list), CHECK_DEADLOCK, `\*` comments.  SPECIFICATION / PROPERTY are refused.
 int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model** out) {
   if (!cfg_path || !out) return fail(VSRMC_E_ARG, "cfg_path / out is NULL");
-  int module = -1;                                               // 0 = VSR.tla, 1 = VR_STATE_TRANSFER.tla, -1 = decided by the cfg
+  int module = -1;                                               // 0 = VSR.tla, 1 = VR_STATE_TRANSFER.tla, 2 = VR_APP_STATE.tla, -1 = decided by the cfg
   if (tla_path) {
     module = 0;
     std::ifstream f(tla_path, std::ios::binary);
@@ -252,9 +298,10 @@ int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model
     ss << f.rdbuf();
     std::string dig = sha256_hex(ss.str());
     if (dig == VRST_TLA_SHA256) module = 1;
+    else if (dig == VRAS_TLA_SHA256) module = 2;
     else if (dig != VSR_TLA_SHA256)
       return fail(VSRMC_E_CFG, std::string(tla_path) + ": sha256 " + dig + " is neither the VSR.tla (" + VSR_TLA_SHA256 +
-                                   ") nor the VR_STATE_TRANSFER.tla (" + VRST_TLA_SHA256 +
+                                   "), the VR_STATE_TRANSFER.tla (" + VRST_TLA_SHA256 + ") nor the VR_APP_STATE.tla (" + VRAS_TLA_SHA256 +
                                    ") this build lowers; refusing to check a module the action table was not derived from");
   }
   std::ifstream f(cfg_path);
@@ -316,8 +363,13 @@ int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model
     *v = (int)x;
     return true;
   };
-  if (module < 0) module = consts.count("NoProgressChangeLimit") ? 1 : 0;   // no module given: the cfg's constants tell them apart
-  if (module == 1) {  // ---- VR_STATE_TRANSFER.cfg
+  // no module given: the cfg's constants tell VSR.cfg from the analysis cfgs; of those two only VR_APP_STATE has NoAppStateDivergence
+  if (module < 0) {
+    module = consts.count("NoProgressChangeLimit") ? 1 : 0;
+    for (const std::string& iv : invariants)
+      if (module == 1 && iv == "NoAppStateDivergence") module = 2;
+  }
+  if (module == 1 || module == 2) {  // ---- VR_STATE_TRANSFER.cfg / VR_APP_STATE.cfg (the same constants and sections)
     int R2, L2, npl;
     if (!need_int("ReplicaCount", &R2) || !need_int("StartViewOnTimerLimit", &L2) || !need_int("NoProgressChangeLimit", &npl))
       return fail(VSRMC_E_CFG, std::string(cfg_path) + ": CONSTANTS must bind ReplicaCount, StartViewOnTimerLimit, "
@@ -352,11 +404,13 @@ int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model
       else if (iv == "AcknowledgedWritesExistOnMajority") mask2 |= 2;   // :818-824
       else if (iv == "NoLogDivergence") mask2 |= 4;                     // :806-811
       else if (iv == "CommitNumberNeverHigherThanOpNumber") mask2 |= 8; // :845-847
+      else if (iv == "NoAppStateDivergence" && module == 2) mask2 |= 16;   // VR_APP_STATE.tla:852-858
       else if (iv == "TestInv") mask2 |= 0;                             // :849 (TRUE)
       else return fail(VSRMC_E_CFG, std::string(cfg_path) + ": unknown INVARIANT " + iv);
     }
     vsrmc_model* m2 = new vsrmc_model();
-    int rc2 = build_model2(R2, (int)values2.size(), L2, npl, symmetry.empty() ? 0 : 1, mask2, m2);
+    int rc2 = module == 2 ? build_model3(R2, (int)values2.size(), L2, npl, symmetry.empty() ? 0 : 1, mask2, m2)
+                          : build_model2(R2, (int)values2.size(), L2, npl, symmetry.empty() ? 0 : 1, mask2, m2);
     if (rc2) { delete m2; return rc2; }
     m2->value_names = values2;
     m2->check_deadlock = check_deadlock;
@@ -439,7 +493,9 @@ int32_t vsrmc_model_init_state(const vsrmc_model* m, uint64_t* rec, int32_t cap,
 
 int32_t vsrmc_model_format_state(const vsrmc_model* m, const uint64_t* rec, char* buf, int64_t cap, int64_t* n) {
   if (!m || !rec || !n) return fail(VSRMC_E_ARG, "NULL argument");
-  std::string s = m->M.model_id == 1 ? vrst::format_state_tlc(m->M, m->value_names, rec) : format_state_tlc(m->M, m->value_names, rec);
+  std::string s = m->M.model_id == 1   ? vrst::format_state_tlc(m->M, m->value_names, rec)
+                  : m->M.model_id == 2 ? vras::format_state_tlc(m->M, m->value_names, rec)
+                                       : format_state_tlc(m->M, m->value_names, rec);
   *n = (int64_t)s.size() + 1;
   if (buf && cap >= *n) std::memcpy(buf, s.c_str(), s.size() + 1);
   else if (buf && cap > 0) return fail(VSRMC_E_ARG, "buffer too small");
@@ -588,7 +644,7 @@ int upload_records(const Model& M, const u64* words, const u64* off, u64 n, u64*
   HIPCHK(hipMalloc((void**)d_off, (n + 1) * 8));
   HIPCHK(hipMemcpy(*d_words, dev.data(), dev.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(*d_off, doff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL((M.model_id == 1 ? k_hash_records<1> : k_hash_records<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, *d_words, *d_off, n);
+  hipLaunchKernelGGL((M.model_id == 1 ? k_hash_records<1> : M.model_id == 2 ? k_hash_records<2> : k_hash_records<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, *d_words, *d_off, n);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -615,7 +671,7 @@ int32_t vsrmc_expand_batch(const vsrmc_model* m, int32_t device, const uint64_t*
   HIPCHK(hipMalloc((void**)&d_om, std::max<u64>(out_cap, 1) * 64));
   HIPCHK(hipMalloc((void**)&d_cnt, 32));
   HIPCHK(hipMemset(d_cnt, 0, 32));
-  hipLaunchKernelGGL((M.model_id == 1 ? k_successors<1> : k_successors<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, d_words, d_off, n, d_ow, dev_words_cap,
+  hipLaunchKernelGGL((M.model_id == 1 ? k_successors<1> : M.model_id == 2 ? k_successors<2> : k_successors<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, M, d_words, d_off, n, d_ow, dev_words_cap,
                      d_om, out_cap, d_cnt);
   HIPCHK(hipGetLastError());
   u64 cnt[4];
@@ -894,6 +950,7 @@ extern "C" int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t
   typedef void (*SimKernel)(Model, const u64*, int, u64*, int, u32*, u16*, u64*, u32, int, int, SimCtl*);
   SimKernel sim_kernel = k_simulate<0>;
   if (M.model_id == 1) sim_kernel = k_simulate<1000>;
+  if (M.model_id == 2) sim_kernel = k_simulate<2000>;
   else
   switch (M.R * 100 + M.C * 10 + M.n) {                        // the same per-configuration instantiations as k_expand
     case 312: sim_kernel = k_simulate<312>; break;
@@ -981,6 +1038,7 @@ typedef void (*ExpandKernel)(Model, const u64*, const u64*, u64, int, int, Slot*
 // instantiation with the model constants folded in; anything else runs the generic one.
 ExpandKernel exact_kernel_for(const Model& M) {               // two-kernel levels: k_expand<false, SPEC>
   if (M.model_id == 1) return k_expand<false, 1000>;
+  if (M.model_id == 2) return k_expand<false, 2000>;
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 211: return k_expand<false, 211>;
     case 312: return k_expand<false, 312>;
@@ -993,6 +1051,7 @@ typedef void (*MaterializeKernel)(Model, const u64*, const u64*, const u64*, u64
                                   const uint8_t*, u64*, u64*, int, u32, u32, int, const u64*);
 MaterializeKernel materialize_kernel_for(const Model& M) {
   if (M.model_id == 1) return k_materialize<1000>;
+  if (M.model_id == 2) return k_materialize<2000>;
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 211: return k_materialize<211>;
     case 312: return k_materialize<312>;
@@ -1003,6 +1062,7 @@ MaterializeKernel materialize_kernel_for(const Model& M) {
 }
 ExpandKernel plain_kernel_for(const Model& M) {               // unsharded ordinary levels: modes and sharding compiled out
   if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true> : nullptr;   // the shipped VR_STATE_TRANSFER.cfg
+  if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302, true> : nullptr;   // the shipped VR_APP_STATE.cfg
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 312: return k_expand<true, 312, true>;
     case 313: return k_expand<true, 313, true>;
@@ -1012,6 +1072,7 @@ ExpandKernel plain_kernel_for(const Model& M) {               // unsharded ordin
 }
 ExpandKernel fused_kernel_for(const Model& M) {
   if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302> : k_expand<true, 1000>;
+  if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302> : k_expand<true, 2000>;
   switch (M.R * 100 + M.C * 10 + M.n) {
     case 211: return k_expand<true, 211>;
     case 212: return k_expand<true, 212>;
@@ -2440,7 +2501,7 @@ int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t ma
     (void)hipFree(d_idx);
     return fail(VSRMC_E_HIP, "hipMalloc failed");
   }
-  hipLaunchKernelGGL((M.model_id == 1 ? k_select<1> : k_select<0>), dim3((unsigned)((c->n_frontier + 255) / 256)), dim3(256), 0, c->stream, M, c->words[c->cur], c->off[c->cur],
+  hipLaunchKernelGGL((M.model_id == 1 ? k_select<1> : M.model_id == 2 ? k_select<2> : k_select<0>), dim3((unsigned)((c->n_frontier + 255) / 256)), dim3(256), 0, c->stream, M, c->words[c->cur], c->off[c->cur],
                      c->n_frontier, action_mask, d_idx, max_states, d_cnt);
   u64 cnt = 0;
   bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
@@ -2501,7 +2562,7 @@ static int32_t replay_path(const vsrmc_model* m, int32_t device, const uint32_t*
   HIPCHK(hipMemcpy(d_w, dev.data(), len * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(d_m, 0, (u64)std::max(nsteps, 1) * 32));
   if (nsteps > 0 && ords) HIPCHK(hipMemcpy(d_ords, ords, (u64)nsteps * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL((M.model_id == 1 ? k_replay<1> : k_replay<0>), dim3(1), dim3(64), 0, 0, M, d_w, d_o, d_ords, nsteps, d_m, d_fps,
+  hipLaunchKernelGGL((M.model_id == 1 ? k_replay<1> : M.model_id == 2 ? k_replay<2> : k_replay<0>), dim3(1), dim3(64), 0, 0, M, d_w, d_o, d_ords, nsteps, d_m, d_fps,
                      (u32*)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
