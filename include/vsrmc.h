@@ -49,7 +49,8 @@ typedef struct vsrmc_layout {
   int32_t permutations;          /* |Permutations(Values)| hashed per state */
   int32_t max_bag;               /* largest message bag a record may hold */
   int32_t max_record_words;      /* wire layout upper bound */
-  int32_t reserved[3];
+  int32_t module;                /* 0 = VSR.tla, 1 = VR_STATE_TRANSFER.tla, 2 = VR_APP_STATE.tla */
+  int32_t reserved[2];
 } vsrmc_layout;
 
 int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model** out);

@@ -144,3 +144,21 @@ def test_model3_simulation_and_printer(vt, orc2):
                 "rep_app_state", "rep_recv_dvc", "rep_rec_number", "rep_rec_recv", "aux_restart"):
         assert ("\n%s |-> " % var) in txt
     assert "rep_last_normal_view |-> <<1, 1, 1>>" in txt and "rep_status |-> <<Normal, Normal, Normal>>" in txt
+
+
+def test_model3_cli(vt, orc2, tmp_path):
+    """vsrmc -config <VR_APP_STATE.cfg> (no .tla: recognised by its constants and NoAppStateDivergence) to depth 12: TLC-style
+    progress lines, the oracle's distinct-state count, no error"""
+    import os
+    import subprocess
+    from test_model3_host_cpu import _cfg
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    r = subprocess.run([cli, "-config", _cfg(tmp_path), "-maxDepth", "12", "-tableLog2", "22", "-frontierGiB", "0.5"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ob = orc2.Bfs(orc2.Params(3, 2, 2))
+    while ob.info["depth"] < 12:
+        ob.step()
+    assert "VR_APP_STATE.tla lowered" in r.stdout and "invariant mask 30" in r.stdout
+    assert "%d distinct states found" % ob.info["distinct"] in r.stdout, r.stdout[-1500:]
+    ob.close()

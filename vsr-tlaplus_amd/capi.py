@@ -12,7 +12,7 @@ class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "replica_count", "client_count", "value_count", "start_view_on_timer_limit", "symmetry", "invariant_mask",
         "assume_commit_number", "check_deadlock", "words_per_replica", "fixed_words", "permutations", "max_bag",
-        "max_record_words")] + [("reserved", C.c_int32 * 3)]
+        "max_record_words", "module")] + [("reserved", C.c_int32 * 2)]
 
 
 class Options(C.Structure):

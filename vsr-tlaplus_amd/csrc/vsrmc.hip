@@ -478,6 +478,7 @@ int32_t vsrmc_model_info(const vsrmc_model* m, vsrmc_layout* out) {
   out->check_deadlock = m->check_deadlock;
   out->words_per_replica = M.wpr; out->fixed_words = M.h0; out->permutations = M.np; out->max_bag = M.max_bag;
   out->max_record_words = 256;   // wire-layout upper bound (8-bit length); BFS records are bounded by max_bag
+  out->module = M.model_id;
   return 0;
 }
 

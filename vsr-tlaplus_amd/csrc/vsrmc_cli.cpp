@@ -16,6 +16,10 @@
 
 #include "../../include/vsrmc.h"
 
+// invariant_mask bits (include/vsrmc.h): 0-1 in all three models, 2-3 in VSR.tla (NoLogDivergence only) and the analysis models, 4 only in VR_APP_STATE
+static const char* const INVARIANT_NAMES[5] = {"AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority", "NoLogDivergence",
+                                               "CommitNumberNeverHigherThanOpNumber", "NoAppStateDivergence"};
+
 static void usage() {
   std::printf(
       "usage: vsrmc -config <file.cfg> <spec.tla> [options]\n"
@@ -162,8 +166,8 @@ int main(int argc, char** argv) {
       code = 1;
     } else {
       std::printf("The trace is a behaviour of the model.\n");
-      const char* names[2] = {"AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"};
-      for (int b = 0; b < 2; b++)
+      const char* const* names = INVARIANT_NAMES;
+      for (int b = 0; b < 5; b++)
         if (inv & (1 << b)) { std::printf("Its last state violates invariant %s.\n", names[b]); code = 12; }
     }
     vsrmc_model_destroy(m);
@@ -178,8 +182,8 @@ int main(int argc, char** argv) {
     std::printf("Running Random Simulation with seed %llu: %u walkers on the GPU, depth %d.\n", sim_seed, sim_walkers, sim_depth);
     int code = 0;
     if (r.found == 1) {
-      const char* names[2] = {"AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"};
-      for (int b = 0; b < 2; b++)
+      const char* const* names = INVARIANT_NAMES;
+      for (int b = 0; b < 5; b++)
         if (r.viol_mask & (1 << b)) std::printf("Error: Invariant %s is violated.\n", names[b]);
       std::printf("Error: The behavior up to this point is:\n");
       uint64_t cap_w = (uint64_t)(r.viol_steps + 3) * 256, n_states = 0;
@@ -224,8 +228,9 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "Error: %s\n", vsrmc_last_error());
     return 1;
   }
-  std::printf("vsrmc: VSR.tla lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), "
-              "invariant mask %d\n", lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
+  static const char* const MODULES[3] = {"VSR.tla", "VR_STATE_TRANSFER.tla", "VR_APP_STATE.tla"};
+  std::printf("vsrmc: %s lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), "
+              "invariant mask %d\n", MODULES[lay.module >= 0 && lay.module < 3 ? lay.module : 0], lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
               lay.permutations, lay.invariant_mask);
   auto t0 = std::chrono::steady_clock::now();
   auto t_chk = t0;
@@ -353,8 +358,8 @@ int main(int argc, char** argv) {
     std::printf("Error: %s\n", vsrmc_last_error());
     exit_code = rc == VSRMC_E_EVAL ? 12 : 1;
   } else if (violated || probed_violation) {
-    const char* names[2] = {"AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"};
-    for (int b = 0; b < 2; b++)
+    const char* const* names = INVARIANT_NAMES;
+    for (int b = 0; b < 5; b++)
       if (info.viol_mask & (1 << b)) std::printf("Error: Invariant %s is violated.\n", names[b]);
     std::printf("Error: The behavior up to this point is:\n");
     uint64_t cap_w = (viol_level + 2) * (uint64_t)lay.max_record_words, n_states = 0;

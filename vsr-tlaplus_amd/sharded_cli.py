@@ -29,7 +29,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-INVARIANTS = ["AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority"]
+INVARIANTS = ["AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority", "NoLogDivergence", "CommitNumberNeverHigherThanOpNumber",
+              "NoAppStateDivergence"]            # invariant_mask bits (include/vsrmc.h)
 
 
 def main(argv=None):
@@ -116,8 +117,8 @@ def main(argv=None):
     except (sharded.ShardError, vt.VsrmcError, OSError) as e:
         say("Error: %s" % e)
         return 1
-    say("vsrmc: VSR.tla lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), invariant "
-        "mask %d; %d rank(s), backend %s" % (lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
+    say("vsrmc: %s lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), invariant "
+        "mask %d; %d rank(s), backend %s" % (["VSR.tla", "VR_STATE_TRANSFER.tla", "VR_APP_STATE.tla"][lay.module], lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit,
                                              lay.permutations, lay.invariant_mask, world, opt["backend"]))
     if opt["recover"]:
         say("Recovered from checkpoint %s: level %d, %d distinct states found, %d states left on queue."
