@@ -358,7 +358,18 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   if (tid < 8) s_cstate[tid] = (CS_NONE << 24) | cchunk;
   __syncthreads();
 
-  for (u64 tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+  // blockIdx -> tiles.  Default: tile = blockIdx + k * gridDim (consecutive tiles on consecutive blocks, i.e. round-robin over the 8
+  // XCDs).  -DVSR_XCD_CONTIG (experiment): every XCD (blockIdx mod 8) walks its own contiguous eighth of the frontier.
+  u64 t_first = blockIdx.x, t_step = gridDim.x, t_end = ntiles;
+#ifdef VSR_XCD_CONTIG
+  if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
+    const u64 xcd = blockIdx.x & 7, per_xcd = (ntiles + 7) / 8;
+    t_first = xcd * per_xcd + (blockIdx.x >> 3);
+    t_step = gridDim.x >> 3;
+    t_end = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+  }
+#endif
+  for (u64 tile_i = t_first; tile_i < t_end; tile_i += t_step) {
     const u64 p_base = tile_i * (u64)tile;
     const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
     const u64 t_0 = VSR_CLK();
