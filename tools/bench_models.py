@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Throughput of the second and third model on one GPU: the shipped cfgs (3 replicas, two values, limit 2) through the depth their oracle
+fixtures reach (tests/golden/oracle_levels_model{2,3}.json), every level asserted against the fixture.  One JSON line per model.
+    python tools/bench_models.py [--runs 3]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=3)
+    a = ap.parse_args()
+    import numpy as np
+    import vsr_tlaplus_amd as vt
+    for label, make in (("model2", vt.Model.second_model), ("model3", vt.Model.third_model)):
+        with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_%s.json" % label)) as f:
+            g = json.load(f)
+        p = g["params"]
+        m = make(R=p["R"], n=p["n"], L=p["L"], invariant_mask=p["inv_mask"])
+        biggest = max(lv["new"] for lv in g["levels"])
+        mc = vt.ModelChecker(m, table_log2=max(20, int(np.ceil(np.log2(2.5 * g["distinct"])))),
+                             frontier_words=int(biggest * (m.layout.fixed_words + 1 + g["max_bag"]) * 1.1) + (1 << 29),
+                             frontier_states=int(biggest * 1.3) + (1 << 24), pending_entries=1 << 15)
+        best = None
+        for _ in range(a.runs + 1):                              # the first run warms up
+            mc.reset()
+            t0 = time.perf_counter()
+            kms = 0.0
+            for lv in g["levels"][1:]:
+                d = mc.step()
+                assert (d["n_new"], d["generated"], d["viol_mask"]) == (lv["new"], lv["generated"], 0), lv["level"]
+                kms += d["expand_ms"]
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, kms)
+        print(json.dumps(dict(model=g["label"], levels=len(g["levels"]), distinct=mc.distinct, generated=g["generated"], seconds=round(best[0], 4),
+                              distinct_states_per_s=round(mc.distinct / best[0], 1), k_expand_ms=round(best[1], 2))))
+        mc.close()
+
+
+if __name__ == "__main__":
+    main()
