@@ -104,6 +104,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
   // enumerate, sort, apply, tail; fused apply loop of thread 0: [5..7] gen, hash, probe (+ act_generated[0] = successor write);
   // k_materialize (two-kernel levels) adds its lane-0 clocks to [5..7]: fetch + stage, gen + patch, allocate + write
   u64 phase_cycles[8];
+  u64 tile_cursor;         // k_expand: the next frontier tile no block has taken yet
 };
 
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
@@ -358,25 +359,29 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   if (tid < 8) s_cstate[tid] = (CS_NONE << 24) | cchunk;
   __syncthreads();
 
-  // blockIdx -> tiles.  Default: tile = blockIdx + k * gridDim (consecutive tiles on consecutive blocks, i.e. round-robin over the 8
-  // XCDs).  -DVSR_XCD_CONTIG (experiment): every XCD (blockIdx mod 8) walks its own contiguous eighth of the frontier.
-  u64 t_first = blockIdx.x, t_step = gridDim.x, t_end = ntiles;
-#ifdef VSR_XCD_CONTIG
-  if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
-    const u64 xcd = blockIdx.x & 7, per_xcd = (ntiles + 7) / 8;
-    t_first = xcd * per_xcd + (blockIdx.x >> 3);
-    t_step = gridDim.x >> 3;
-    t_end = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
-  }
-#endif
-  for (u64 tile_i = t_first; tile_i < t_end; tile_i += t_step) {
-    const u64 p_base = tile_i * (u64)tile;
-    const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
+  // blockIdx -> tiles: the persistent blocks draw tiles from an atomic counter (ctl->tile_cursor, zeroed by the host with the other
+  // level counters).  Tile costs are uneven and correlated along the frontier (successors per record, bag sizes), so the static
+  // mapping tile = blockIdx + k * gridDim left blocks idle at the end of every launch: 203.8 -> 177.6 ms per run of the benchmark
+  // workload.  Thread 0 draws one tile ahead, so the atomic's latency hides behind the current tile.  The order in
+  // which tiles are taken changes the order of the records in the next frontier, nothing else: counts, fingerprint sets and the
+  // min-merged predecessor keys do not depend on it.
+  __shared__ u64 s_tile_cur;
+  u64 my_next = 0;
+  if (tid == 0) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+  for (;;) {
+    if (tid == 0) {
+      s_tile_cur = my_next;
+      if (my_next < ntiles) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+    }
     const u64 t_0 = VSR_CLK();
     if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; }
     if (tid < tile) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
     __syncthreads();
+    const u64 tile_i = s_tile_cur;
+    if (tile_i >= ntiles) break;
+    const u64 p_base = tile_i * (u64)tile;
+    const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
 
     // ---- stage the tile.  Frontier refs are (word offset << 8 | length): one coalesced load of 64 refs, then 16 lanes per
     // record / 16 records per pass, all 16 loads of a thread issued before the first LDS store (one HBM latency per tile)
