@@ -354,7 +354,10 @@ def test_trace_reconstruction_is_a_valid_shortest_path(vt, orc):
             nxt = _norm(orc, P, tr[t + 1][1])
             hits = [s for s in orc.successors(P, tr[t][1]) if _norm(orc, P, s["words"]) == nxt]
             assert len(hits) >= 1 and orc.ACTIONS[hits[0]["action"]] == tr[t + 1][0]
-        assert _norm(orc, P, tr[-1][1]) == _norm(orc, P, words[int(off[k]): int(off[k + 1])])
+        # the path ends in THE state (VIEW + SYMMETRY identity = canonical fingerprint); which value-permuted representative of it the
+        # frontier holds depends on which candidate claimed the slot first, the replayed one on the min-merged keys
+        lf, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
+        assert int(lf[0]) == int(ffp[k]) and orc.fingerprint(P, tr[-1][1])[0] == int(ffp[k])
         assert int(ffp[k]) in set(int(x) for x in fps)
     mc.close()
 
