@@ -105,6 +105,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
   // k_materialize (two-kernel levels) adds its lane-0 clocks to [5..7]: fetch + stage, gen + patch, allocate + write
   u64 phase_cycles[8];
   u64 tile_cursor;         // k_expand: the next frontier tile no block has taken yet
+  u64 n_written;           // fused mode: records written to the next frontier (unsharded: = new states; sharded: incl. speculative ones)
 };
 
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
@@ -789,6 +790,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       if (fused) {
         s_ich_used += s_tile_icur;
         s_wch_used += s_tile_wcur;
+        s_acc[14] += s_tile_icur;
       } else {
         s_chunk_used += s_tile_cursor;
       }
@@ -828,6 +830,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
       if (tid == 0) {
         if (s_acc[8]) atomicAdd((unsigned long long*)&ctl->ties, s_acc[8]);
+        if (s_acc[14]) atomicAdd((unsigned long long*)&ctl->n_written, s_acc[14]);
         if (s_acc[9]) atomicAdd((unsigned long long*)(mode == MODE_INSERT ? &ctl->n_new : &ctl->rec_words), s_acc[9]);
         if (s_maxbag_out) atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)s_maxbag_out);
       }

@@ -1404,7 +1404,9 @@ int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
   info->materialize_ms = c->materialize_ms;
   // nx_n is an index RANGE: waves allocate indices in chunks and publish unused ones as invalid refs (0)
   u64 n_new = 0;
-  if (c->nx_n > 0) {
+  if (c->nx_n > 0 && c->opt.world == 1 && !c->opt.exact_ties) {
+    n_new = h.n_written;                                         // single-pass, unsharded: every record written is a new state
+  } else if (c->nx_n > 0) {
     u64 zero = 0;
     HIPCHK(hipMemcpyAsync(c->d_find, &zero, 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_count_valid, dim3(1024), dim3(256), 0, c->stream, c->off[c->cur ^ 1], c->nx_n, c->d_find);
@@ -1816,11 +1818,7 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
         viol2 = std::min<u64>(viol2, c->h.viol_fp);
       }
       if (part2) {
-        u64 cnt = 0;
-        HIPCHK(hipMemcpyAsync(c->d_find, &cnt, 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_count_valid, dim3(1024), dim3(256), 0, c->stream, B.off, part2, c->d_find);
-        HIPCHK(hipMemcpyAsync(&cnt, c->d_find, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        const u64 cnt = c->h.n_written;                          // records written = new level-(L+2) states of this sub-slice
         n2 += cnt;
         yield_n = std::max(yield_n, (double)cnt / (double)nb);
         yield_w = std::max(yield_w, (double)c->h.rec_words / (double)nb);
