@@ -213,7 +213,10 @@ void vsrmc_checker_destroy(vsrmc_checker* c);
  * not a state of an earlier level, nothing is inserted or written, so the level costs no frontier memory; the search cannot
  * continue afterwards.  Finds a violation one level beyond what memory can hold.  Also valid right after a step that failed
  * with "frontier full".  info: level (the probed one), generated, viol_fp / viol_mask, viol_index = index of the violator's
- * PARENT in the newest level, pending = violating successors seen.  vsrmc_checker_probe_trace: Init .. violator. */
+ * PARENT in the newest level, pending = violating successors seen.  vsrmc_checker_probe_trace: Init .. violator.
+ * On a sharded checker (world > 1) the call probes this rank's part of the newest level against this rank's part of the seen-set and
+ * resolves nothing: a violating successor owned by another rank may be a state that rank has seen, so the candidates
+ * (vsrmc_checker_probe_candidates) must be shown to their owners (vsrmc_checker_seen_batch there) — sharded.py: ShardedChecker.probe. */
 int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info);
 /* Two levels beyond the last materialised one: level L+1 becomes a VIRTUAL level (fingerprints claimed, invariants checked, exact
  * count, no records), then the newest level is expanded a second time in slices — the successors that won their slot are written
