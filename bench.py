@@ -154,9 +154,9 @@ def config3_to_violation(dump_trace=None):
     BFS to its first violation at depth 24 — everything in HBM: levels 1-21 are materialised (level 21: 261 M states, 91 GB of
     records), level 22 is a VIRTUAL level (seen-set entries only, regenerated slice by slice), level 23 is streamed through a
     scratch buffer (inserted, never kept), level 24 is PROBED (vsrmc_checker_probe3); the counter-example is reconstructed in the timed region.  Untimed setup (~245 GB of
-    device allocations), one timed pass.  Levels 1-19 are asserted against the CPU oracle's fixture
-    (tests/golden/oracle_levels_config3.json), deeper levels against tests/golden/config3_violation.json (GPU runs of two rounds,
-    two fingerprint functions, two level schemes: the oracle needs hours for them on the 16 host cores)."""
+    device allocations), one timed pass.  Levels 1-21 — every level that is stored — are asserted against the CPU
+    oracle's fixture (tests/golden/oracle_levels_config3.json), the virtual / streamed levels 22-23 against
+    tests/golden/config3_violation.json (GPU runs of two rounds, two fingerprint functions, three level schemes)."""
     import numpy as np
     import vsr_tlaplus_amd as vt
     with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_config3.json")) as f:
