@@ -187,3 +187,39 @@ def test_cli_dump_is_readable_and_complete(vt, tmp_path):
             break
         level += 1
     assert sorted(int(x) for x in fps) == sorted(want) and len(set(want)) == 76
+
+
+@pytest.mark.gpu
+def test_diff_tlc_dump_tool(vt, tmp_path):
+    """tools/diff_tlc_dump.py on a stand-in for `tlc2.TLC -dump`: this checker's own dump of (2, {v1,v2}, 1) — 163 states under
+    VIEW + SYMMETRY — with the states shuffled and the two values swapped in every second one (TLC keeps whichever representative it
+    meets first): the sets are equal.  With one state removed the tool names it; with a state of another configuration added, too."""
+    import random
+    import re
+    import sys
+    from test_host_cpu import _cfg
+    cfg = _cfg(tmp_path, R=2, vals="v1, v2", L=1)
+    out = tmp_path / "states.dump"
+    r = subprocess.run([os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc"), "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.05",
+                        "-dump", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "163 states dumped" in r.stdout, r.stdout + r.stderr
+    blocks = [b for b in re.split(r"(?m)^State \d+:\n", out.read_text()) if b.strip()]
+    assert len(blocks) == 163
+    swap = lambda t: re.sub(r"\bv([12])\b", lambda mm: "v2" if mm.group(1) == "1" else "v1", t)   # noqa: E731
+    blocks = [swap(b) if k % 2 else b for k, b in enumerate(blocks)]
+    random.Random(5).shuffle(blocks)
+    tool = [sys.executable, os.path.join(ROOT, "tools", "diff_tlc_dump.py"), "-config", cfg, "--table-log2", "16", "--frontier-gib", "0.05"]
+
+    def run(bl, *extra):
+        f = tmp_path / "tlc.dump"
+        f.write_text("".join("State %d:\n%s" % (k + 1, b) for k, b in enumerate(bl)))
+        return subprocess.run(tool + [str(f)] + list(extra), capture_output=True, text=True, timeout=300)
+    r = run(blocks)
+    assert r.returncode == 0 and "163 distinct under VIEW + SYMMETRY" in r.stdout and "The two sets of states are equal." in r.stdout, r.stdout + r.stderr
+    r = run(blocks[:-1])
+    assert r.returncode == 1 and "only in the GPU BFS: 1" in r.stdout and "reached by:" in r.stdout, r.stdout + r.stderr
+    assert run(blocks[:-1], "--subset-ok").returncode == 0
+    alien = blocks[0].replace("aux_svc = 0", "aux_svc = 0").replace("rep_view_number = <<1, 1>>", "rep_view_number = <<3, 3>>")
+    if alien != blocks[0]:
+        r = run(blocks + [alien])
+        assert r.returncode == 1 and "only in the TLC dump: 1" in r.stdout, r.stdout + r.stderr
