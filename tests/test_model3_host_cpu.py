@@ -87,7 +87,7 @@ def test_init_and_printer_against_the_restatements(vt):
     # states of a small BFS of the Python restatement, printed by the product and parsed back with the test-side TLC value parser
     M = po.Model(3, ("a", "b"), 2)
     m = vt.Model.third_model(R=3, n=2, L=2)
-    levels, _, _ = po.bfs(M, max_depth=8)
+    levels, _, _ = po.bfs(M, max_depth=7)
     empty = lambda x: {} if x == () else x                          # noqa: E731
 
     def seq_logs(msgs):
