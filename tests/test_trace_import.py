@@ -223,3 +223,25 @@ def test_diff_tlc_dump_tool(vt, tmp_path):
     if alien != blocks[0]:
         r = run(blocks + [alien])
         assert r.returncode == 1 and "only in the TLC dump: 1" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_dump_trace_tla_round_trip(vt, tmp_path):
+    """vsrmc -dumpTrace tla FILE writes the counter-example in the form of the reference's golden file (a TLA+ trace expression with
+    _TEAction records); -validateTrace reads it back, re-walks it on the GPU and confirms the violation; the test-side TLC value parser
+    reads the same file."""
+    from oracle import tlcvalue
+    from test_host_cpu import _cfg
+    cfg = _cfg(tmp_path, L=1, extra="AcknowledgedWritesExistOnMajority")          # (3,1,{v1,v2},1): violated at depth 19
+    out = tmp_path / "cex.tla.txt"
+    cli = os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc")
+    r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "20", "-frontierGiB", "0.1", "-dumpTrace", "tla", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 12 and "The counter-example was written to" in r.stdout, r.stdout[-2000:] + r.stderr
+    text = out.read_text()
+    assert text.startswith("<<\n[\n _TEAction |-> [\n   position |-> 1,\n   name |-> \"Initial predicate\",") and text.rstrip().endswith(">>")
+    states = tlcvalue.parse_value(text)
+    assert len(states) == 19 and [dict(dict(s)["_TEAction"])["position"] for s in states] == list(range(1, 20))
+    r2 = subprocess.run([cli, "-config", cfg, "-noTLA", "-validateTrace", str(out)], capture_output=True, text=True, timeout=300)
+    assert "19 states read" in r2.stdout and "The trace is a behaviour of the model." in r2.stdout, r2.stdout + r2.stderr
+    assert "Its last state violates invariant AcknowledgedWritesExistOnMajority." in r2.stdout

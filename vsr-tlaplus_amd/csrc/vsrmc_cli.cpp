@@ -45,6 +45,8 @@ static void usage() {
       "                    (level N-1 is expanded three times, level N twice; scratch buffers of a quarter of -frontierGiB)\n"
       "  -probeLast        when the next level does not fit the frontier buffers, still check its states' invariants without\n"
       "                    storing them (finds a violation one level beyond memory; the search ends there)\n"
+      "  -dumpTrace tla FILE   write the counter-example as a TLA+ trace expression (TLC's -dumpTrace tla; the form of the reference's\n"
+      "                    state_transfer_violation_trace.txt); -validateTrace reads it back\n"
       "  -dump FILE        write every distinct state in the text form of `tlc2.TLC -dump` (State k: + /\\ var = value conjuncts), level by\n"
       "                    level; for cross-checking small configurations against a real TLC run (refused beyond -dumpMax states, 1e6)\n"
       "  -checkpoint FILE  write a checkpoint between levels, at most every -checkpointMinutes M (default 30; 0 = after every level)\n"
@@ -76,10 +78,33 @@ static int exec_sharded(int argc, char** argv, int gpus_at) {
   return 1;
 }
 
+// -dumpTrace tla FILE: the counter-example as a TLA+ trace expression — the form of the reference's state_transfer_violation_trace.txt
+// (a sequence of records, each with TLC's _TEAction field in front of the variables); source locations are not tracked by the
+// lowering, so `location` says so for every step.  The product's reader (-validateTrace) takes the file back.
+static bool write_trace_expression(const std::string& path, const vsrmc_model* m, const std::vector<uint64_t>& words,
+                                   const std::vector<uint64_t>& off, const std::vector<int32_t>& acts, uint64_t n_states) {
+  FILE* f = std::fopen(path.c_str(), "w");
+  if (!f) return false;
+  std::fprintf(f, "<<\n");
+  for (uint64_t t = 0; t < n_states; t++) {
+    int64_t need = 0;
+    vsrmc_model_format_state(m, &words[off[t]], nullptr, 0, &need);
+    std::string buf((size_t)need, '\0');
+    vsrmc_model_format_state(m, &words[off[t]], &buf[0], need, &need);
+    while (!buf.empty() && buf.back() == '\0') buf.pop_back();
+    const size_t first_nl = buf.find('\n');                     // "[\nvar |-> value,\n...\n]": splice the _TEAction field after the bracket
+    std::fprintf(f, "[\n _TEAction |-> [\n   position |-> %llu,\n   name |-> \"%s\",\n   location |-> \"Unknown location\"\n ],\n%s%s\n",
+                 (unsigned long long)(t + 1), vsrmc_action_name(acts[t]), first_nl == std::string::npos ? "" : buf.c_str() + first_nl + 1,
+                 t + 1 < n_states ? "," : "");
+  }
+  std::fprintf(f, ">>\n");
+  return std::fclose(f) == 0;
+}
+
 int main(int argc, char** argv) {
   for (int i = 1; i + 1 < argc; i++)
     if (std::string(argv[i]) == "-gpus" && std::atoi(argv[i + 1]) > 1) return exec_sharded(argc, argv, i);
-  std::string cfg, tla, trace_file, chk_file, recover_file, dump_file;
+  std::string cfg, tla, trace_file, chk_file, recover_file, dump_file, dump_trace_file;
   unsigned long long dump_max = 1000000ull, dumped = 0;
   double chk_minutes = 30.0;
   bool check_deadlock = false, no_tla = false, json = false, simulate = false, host_frontier = false, probe_last = false;
@@ -112,6 +137,7 @@ int main(int argc, char** argv) {
     else if (a == "-checkpointMinutes" && i + 1 < argc) chk_minutes = std::atof(argv[++i]);
     else if (a == "-recover" && i + 1 < argc) recover_file = argv[++i];
     else if (a == "-dump" && i + 1 < argc) dump_file = argv[++i];
+    else if (a == "-dumpTrace" && i + 2 < argc && std::string(argv[i + 1]) == "tla") { dump_trace_file = argv[i + 2]; i += 2; }
     else if (a == "-dumpMax" && i + 1 < argc) dump_max = std::strtoull(argv[++i], nullptr, 10);
     else if (a == "-simulate") simulate = true;
     else if (a == "-depth" && i + 1 < argc) sim_depth = std::atoi(argv[++i]);
@@ -377,6 +403,12 @@ int main(int argc, char** argv) {
         std::string buf((size_t)need, '\0');
         vsrmc_model_format_state(m, &words[off[t]], &buf[0], need, &need);
         std::printf("State %llu: <%s>\n%s\n\n", (unsigned long long)(t + 1), vsrmc_action_name(acts[t]), buf.c_str());
+      }
+      if (!dump_trace_file.empty()) {
+        if (write_trace_expression(dump_trace_file, m, words, off, acts, n_states))
+          std::printf("The counter-example was written to %s (TLA+ trace expression).\n", dump_trace_file.c_str());
+        else
+          std::printf("Warning: cannot write %s\n", dump_trace_file.c_str());
       }
       exit_code = 12;   // TLC's exit code for a safety violation
     }
