@@ -854,6 +854,9 @@ def test_cli_probe2_and_probe_last(vt, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert all(x in r.stdout for x in ("Virtual(9):", "Virtual(10):", "Probe(11):", "No violation up to level 11")), r.stdout
+    r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01", "-coverage"], capture_output=True, text=True, timeout=120)
+    cov = dict(l.strip().split(": ") for l in r.stdout.split("The coverage statistics")[1].splitlines()[1:16])
+    assert r.returncode == 0 and sum(int(v) for v in cov.values()) == 99 and int(cov["TimerSendSVC"]) > 0 and "ExecuteOp" in cov, r.stdout
 
 
 def test_exists_on_majority_fails_at_depth_19_on_the_shipped_constants(vt, orc):

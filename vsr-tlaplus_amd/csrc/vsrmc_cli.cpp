@@ -45,6 +45,7 @@ static void usage() {
       "                    (level N-1 is expanded three times, level N twice; scratch buffers of a quarter of -frontierGiB)\n"
       "  -probeLast        when the next level does not fit the frontier buffers, still check its states' invariants without\n"
       "                    storing them (finds a violation one level beyond memory; the search ends there)\n"
+      "  -coverage         print the successors generated per action of Next at the end (TLC's -coverage, totals only)\n"
       "  -dumpTrace tla FILE   write the counter-example as a TLA+ trace expression (TLC's -dumpTrace tla; the form of the reference's\n"
       "                    state_transfer_violation_trace.txt); -validateTrace reads it back\n"
       "  -dump FILE        write every distinct state in the text form of `tlc2.TLC -dump` (State k: + /\\ var = value conjuncts), level by\n"
@@ -107,7 +108,7 @@ int main(int argc, char** argv) {
   std::string cfg, tla, trace_file, chk_file, recover_file, dump_file, dump_trace_file;
   unsigned long long dump_max = 1000000ull, dumped = 0;
   double chk_minutes = 30.0;
-  bool check_deadlock = false, no_tla = false, json = false, simulate = false, host_frontier = false, probe_last = false;
+  bool check_deadlock = false, no_tla = false, json = false, simulate = false, host_frontier = false, probe_last = false, coverage = false;
   int sim_depth = 100;
   unsigned sim_walkers = 1u << 17;
   unsigned long long sim_seed = 1;
@@ -145,6 +146,7 @@ int main(int argc, char** argv) {
     else if (a == "-seed" && i + 1 < argc) sim_seed = std::strtoull(argv[++i], nullptr, 10);
     else if (a == "-maxSeconds" && i + 1 < argc) sim_seconds = std::atof(argv[++i]);
     else if (a == "-json") json = true;
+    else if (a == "-coverage") coverage = true;
     else if (a == "-workers" && i + 1 < argc) ++i;   // accepted for command-line compatibility; the GPU is the worker pool
     else if (!a.empty() && a[0] != '-') tla = a;
     else { std::fprintf(stderr, "vsrmc: unknown option %s\n", a.c_str()); usage(); return 2; }
@@ -304,6 +306,7 @@ int main(int argc, char** argv) {
   };
   if (dump && recover_file.empty() && !dump_level(1)) return 1;
   bool violated = false, deadlocked = false, probed_violation = false;
+  unsigned long long cov[16] = {0};
   uint64_t viol_level = 0, viol_index = 0;
   int depth = info.level;
   while (depth < max_depth) {
@@ -358,6 +361,7 @@ int main(int argc, char** argv) {
       break;
     }
     if (rc != 0) break;
+    for (int a2 = 1; a2 < 16; a2++) cov[a2] += info.act_generated[a2];
     if (info.n_new) depth = info.level;
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (json)
@@ -417,6 +421,10 @@ int main(int argc, char** argv) {
     exit_code = 11;
   } else if (info.n_new == 0) {
     std::printf("Model checking completed. No error has been found.\n");
+  }
+  if (coverage) {   // ≙ tlc2.TLC -coverage, per action of Next: successors generated in the stored levels (probed / virtual levels not included)
+    std::printf("The coverage statistics (successors generated per action):\n");
+    for (int a2 = 1; a2 < 16; a2++) std::printf("  %s: %llu\n", vsrmc_action_name(a2), (unsigned long long)cov[a2]);
   }
   {  // TLC prints the same estimate: every generated state that was judged "seen" could be a 64-bit fingerprint collision
     const double n = (double)info.distinct, g = (double)info.total_generated;
