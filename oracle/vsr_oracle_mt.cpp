@@ -206,7 +206,7 @@ int main(int argc, char** argv) {
         for (size_t a = 0; a < frontier[p].n(); a += csz) chunks.push_back(Chunk{(u32)p, (u32)a, (u32)std::min(csz, frontier[p].n() - a)});
     }
     std::atomic<size_t> cursor{0};
-    std::atomic<int> abort_flag{0};
+    std::atomic<int> abort_flag{0};                              // 1 = a worker raised an error, 2 = --max-seconds passed inside the level
     run_threads([&](int t) {
       Worker& w = workers[t];
       w.out.reset();
@@ -222,6 +222,10 @@ int main(int argc, char** argv) {
         for (;;) {
           const size_t ci = cursor.fetch_add(1, std::memory_order_relaxed);
           if (ci >= chunks.size() || abort_flag.load(std::memory_order_relaxed)) break;
+          if (t == 0 && (ci & 63) == 0 && now_s() - t0 > max_seconds) {   // the bound also ends a level in progress (it is discarded)
+            abort_flag.store(2);
+            break;
+          }
           const Chunk c = chunks[ci];
           const Piece& pc = frontier[c.piece];
           for (u32 k = c.first; k < c.first + c.count; k++) {
@@ -287,6 +291,7 @@ int main(int argc, char** argv) {
     for (Worker& w : workers)
       if (w.error_code) { error = w.error; failed = true; }
     if (failed) { why = "error"; break; }
+    if (abort_flag.load() == 2) { why = "max-seconds"; break; }
     // ---- same-level VIEW ties: the smallest canonical auxkey keeps the slot (sequential; never observed)
     u64 ties = 0;
     for (Worker& w : workers)
