@@ -162,3 +162,34 @@ def test_model3_cli(vt, orc2, tmp_path):
     assert "VR_APP_STATE.tla lowered" in r.stdout and "invariant mask 30" in r.stdout
     assert "%d distinct states found" % ob.info["distinct"] in r.stdout, r.stdout[-1500:]
     ob.close()
+
+
+def test_model3_validate_trace_cli(vt, tmp_path):
+    """a 15-state behaviour of VR_APP_STATE (GPU successors, an arbitrary but fixed choice per step), printed as a TLA+ trace
+    expression by the product's printer, is read back and re-walked by `vsrmc -validateTrace`; with one state damaged it is refused
+    at that state"""
+    import os
+    import subprocess
+    from test_model3_host_cpu import _cfg
+    m = vt.Model.third_model(R=3, n=2, L=2)
+    rec = m.init_state()
+    path = [("Initial predicate", rec)]
+    from vsr_tlaplus_amd.checker import ACTION_NAMES
+    for t in range(14):
+        succ = m.get_next_states(rec, np.array([0, len(rec)], dtype=np.uint64))
+        assert succ
+        s = succ[(5 * t + 3) % len(succ)]
+        rec = s["words"]
+        path.append((ACTION_NAMES[s["action"]], rec))
+    body = ",\n".join("[\n _TEAction |-> [\n   position |-> %d,\n   name |-> \"%s\",\n   location |-> \"Unknown location\"\n ],\n%s"
+                       % (k + 1, a, m.format_state(r).split("\n", 1)[1]) for k, (a, r) in enumerate(path))
+    f = tmp_path / "m3.trace"
+    f.write_text("<<\n" + body + "\n>>\n")
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    r = subprocess.run([cli, "-config", _cfg(tmp_path), "-validateTrace", str(f)], capture_output=True, text=True, timeout=300)
+    assert "15 states read" in r.stdout and "The trace is a behaviour of the model." in r.stdout, r.stdout + r.stderr
+    bad = f.read_text().replace("rep_view_number |-> <<", "rep_view_number |-> <<7, ", 1)
+    bad = bad.replace("<<7, 1, 1, 1>>", "<<7, 1, 1>>", 1)
+    f.write_text(bad)
+    r = subprocess.run([cli, "-config", _cfg(tmp_path), "-validateTrace", str(f)], capture_output=True, text=True, timeout=300)
+    assert "The trace is a behaviour of the model." not in r.stdout, r.stdout

@@ -109,3 +109,35 @@ def test_init_and_printer_against_the_restatements(vt):
                 assert po.canon(empty(a)) == po.canon(empty(b)), k
             n += 1
     assert n > 50
+
+
+def test_reader_takes_the_printer_back(vt):
+    """format_state -> parse_states is the identity on records (the product's TLC reader knows this model's variables and message
+    records: what -validateTrace and tools/diff_tlc_dump.py need), in all three text forms: one state record, a trace expression with
+    _TEAction fields, console "State k:" blocks; malformed text is refused with the variable's name."""
+    from oracle import pyoracle3 as po
+    M = po.Model(3, ("a", "b"), 2)
+    m = vt.Model.third_model(R=3, n=2, L=2)
+    levels, _, _ = po.bfs(M, max_depth=8)
+    recs = [np.array(po.pack(M, s), dtype=np.uint64) for lvl in levels for s in lvl[::5]]
+    assert len(recs) > 150
+    norm = lambda w: po.normalise(M, [int(x) for x in w])          # noqa: E731
+    texts = [m.format_state(r) for r in recs]
+    for r, t in zip(recs, texts):
+        back = m.parse_states(t)
+        assert len(back) == 1 and norm(back[0][1]) == norm(r)
+    sample = list(range(0, len(recs), 9))
+    expr = "<<\n" + ",\n".join("[\n _TEAction |-> [\n   position |-> %d,\n   name |-> \"SendSV\",\n   location |-> \"Unknown location\"\n ],\n%s"
+                                  % (k + 1, texts[i].split("\n", 1)[1]) for k, i in enumerate(sample)) + "\n>>\n"
+    back = m.parse_states(expr)
+    assert [a for a, _ in back] == ["SendSV"] * len(sample) and [norm(w) for _, w in back] == [norm(recs[i]) for i in sample]
+    console = ""
+    for k, i in enumerate(sample):
+        lines = [l.rstrip(",") for l in texts[i].splitlines()[1:-1]]
+        console += "State %d: <SendDVC line 1, col 1 to line 2, col 2 of module X>\n" % (k + 1) + "\n".join("/\\ " + l.replace(" |-> ", " = ", 1) for l in lines) + "\n\n"
+    back = m.parse_states(console)
+    assert [a for a, _ in back] == ["SendDVC"] * len(sample) and [norm(w) for _, w in back] == [norm(recs[i]) for i in sample]
+    for bad in (texts[3].replace("rep_status |-> <<", "rep_status |-> <<Recovering, ", 1), texts[3].replace("aux_svc |-> ", "aux_svc |-> 9", 1),
+                texts[3].replace("rep_view_number", "rep_view_numbr")):
+        with pytest.raises(vt.VsrmcError):
+            m.parse_states(bad)

@@ -8,7 +8,7 @@ Reads TLC's -dump file (State k: + /\\ var = value conjuncts) with the product's
 canonical VIEW + SYMMETRY fingerprint of every dumped state on the GPU (vsrmc_fingerprint_batch) — TLC and this checker may keep
 different value-permuted representatives of a state, the fingerprint does not care —, runs the GPU BFS on the same configuration and
 compares the two SETS of states.  Exit code 0: the sets are equal (or, with --subset-ok, every TLC state was found here: a TLC run
-that stopped at a violation dumps only part of its last level).  Needs a GPU; VSR.tla only (the reader knows its variables)."""
+that stopped at a violation dumps only part of its last level).  Needs a GPU; any of the three modules the build lowers."""
 import argparse
 import os
 import sys

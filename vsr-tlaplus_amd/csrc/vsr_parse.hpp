@@ -35,6 +35,10 @@ struct TVal {
   }
 };
 
+// encoder of the two analysis models' states (vras_parse.hpp)
+inline bool encode_state_analysis_models(const Model& M, const std::vector<std::string>& vals, const TVal& st, std::vector<u64>* out,
+                                         std::string* err);
+
 class TlcParser {
  public:
   explicit TlcParser(const std::string& text) : t_(text) {}
@@ -420,11 +424,19 @@ inline bool parse_states_tlc(const Model& M, const std::vector<std::string>& val
                              std::vector<ParsedState>* out, std::string* err) {
   out->clear();
   auto encode_one = [&](const TVal& st, const std::string& action) {
-    StateEncoder enc(M, vals);
     ParsedState ps;
-    if (!enc.encode(st, &ps.rec)) {
-      *err = "state " + std::to_string(out->size() + 1) + ": " + enc.error;
-      return false;
+    if (M.model_id != 0) {                                       // VR_STATE_TRANSFER / VR_APP_STATE: their own record layouts
+      std::string e2;
+      if (!encode_state_analysis_models(M, vals, st, &ps.rec, &e2)) {
+        *err = "state " + std::to_string(out->size() + 1) + ": " + e2;
+        return false;
+      }
+    } else {
+      StateEncoder enc(M, vals);
+      if (!enc.encode(st, &ps.rec)) {
+        *err = "state " + std::to_string(out->size() + 1) + ": " + enc.error;
+        return false;
+      }
     }
     ps.action = action;
     if (const TVal* te = st.field("_TEAction"))

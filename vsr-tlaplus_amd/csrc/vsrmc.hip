@@ -19,6 +19,7 @@
 #include "vrst_format.hpp"
 #include "vras_format.hpp"
 #include "vsr_parse.hpp"
+#include "vras_parse.hpp"
 #include "vsr_kernels.hpp"
 
 using namespace vsr;
