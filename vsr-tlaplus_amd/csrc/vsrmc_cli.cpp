@@ -29,7 +29,8 @@ static void usage() {
       "  -device D         HIP device ordinal (default 0)\n"
       "  -gpus N           N > 1: run the sharded checker on N GPUs of this node (re-executes as\n"
       "                    python3 -m torch.distributed.run ... -m vsr_tlaplus_amd.sharded_cli with the other arguments;\n"
-      "                    -tableLog2 / -frontierGiB are then PER RANK; see that module for -replicateBelow, -backend, -exactTies)\n"
+      "                    -tableLog2 / -frontierGiB are then PER RANK; see that module for -replicateBelow, -backend, -exactTies,\n"
+      "                    -checkpoint PREFIX / -recover PREFIX (one file per rank), -probeAt N)\n"
       "  -tableLog2 N      seen-set slots = 2^N x 16 B (default 28)\n"
       "  -frontierGiB G    size of each of the two frontier buffers (default 8); -frontierBGiB G: the second one (levels 2, 4, ..)\n"
       "  -simulate         random walks instead of BFS (TLC -simulate): -depth N (default 100) -walkers N (131072) -seed S -maxSeconds T\n"
