@@ -115,7 +115,7 @@ def test_model3_successors_state_by_state(vt, orc2):
 
 
 def test_model3_whole_workload_against_the_oracle(vt, oracle_levels):
-    """the shipped VR_APP_STATE.cfg as deep as the CPU oracle went (tests/golden/oracle_levels_model3.json: 21 levels, 142 M states)"""
+    """the shipped VR_APP_STATE.cfg as deep as the CPU oracle went (tests/golden/oracle_levels_model3.json: 22 levels, 224 M states)"""
     g = oracle_levels["model3"]
     p = g["params"]
     m = vt.Model.third_model(R=p["R"], n=p["n"], L=p["L"], invariant_mask=p["inv_mask"])
