@@ -25,6 +25,7 @@ class StateEncoder2 {
     for (int r = 1; r <= M.R; r++) rec[(size_t)aidx(r)] = a_set_lnv(a_set_view(a_set_status(0, vrst::ST2_NORMAL), 1), 1);   // Init
     u64 hdr = 0;
     std::vector<u64> bag;
+    int app_len[6] = {-1, -1, -1, -1, -1, -1};                        // Len(rep_app_state[r]) as read, -1 = the text does not give it
     static const char* const ORDER[] = {"rep_view_number", "rep_status", "rep_op_number", "rep_commit_number", "rep_last_normal_view",
                                         "rep_sent_dvc", "rep_sent_sv", "rep_peer_op_number", "rep_log", "rep_app_state", "rep_recv_dvc",
                                         "rep_rec_number", "rep_rec_recv", "no_progress", "no_progress_ctr", "aux_svc", "aux_client_acked",
@@ -108,6 +109,7 @@ class StateEncoder2 {
               if (!entry(e.items[i], &vi)) return false;
               A = a_set(A, 34 + 2 * (int)i, 2, vi);
             }
+            app_len[r] = (int)e.items.size();
           } else if (n == "rep_recv_dvc") {
             if (e.kind != TVal::SET) return fail("rep_recv_dvc: a set of DoViewChange records expected");
             u64& B = rec[(size_t)aidx(r) + 1];
@@ -122,6 +124,11 @@ class StateEncoder2 {
           }
         }
       }
+    }
+    for (int r = 1; r <= M.R; r++) {                            // what the packed record relies on (vrst_ / vras_actions.hpp)
+      const u64 A = rec[(size_t)aidx(r)];
+      if (app_len[r] >= 0 && app_len[r] != a_commit(A)) return fail("Len(rep_app_state[r]) differs from rep_commit_number[r]");
+      if (a_op(A) != vrst::blog_len(vrst::b_log(A))) return fail("rep_op_number[r] differs from Len(rep_log[r])");
     }
     if ((int)bag.size() > 255) return fail("more than 255 distinct messages");
     std::sort(bag.begin(), bag.end());
