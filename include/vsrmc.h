@@ -162,6 +162,8 @@ typedef struct vsrmc_level_info {
   double materialize_ms;         /* HIP-event time of k_materialize */
   uint64_t act_generated[16];    /* generated successors per action id */
   uint64_t phase_cycles[8];      /* k_expand shader clocks summed over blocks: stage, enumerate, sort, apply, tail */
+  uint64_t fp_xor, fp_sum;       /* vsrmc_checker_probe2 / _probe3, the levels that are never stored: xor / sum (mod 2^64) of the level's
+                                  * fingerprints (a stored level: vsrmc_checker_level_checksum) */
 } vsrmc_level_info;
 
 void vsrmc_options_default(vsrmc_options* o);

@@ -185,6 +185,9 @@ class FakeShardEngine:
     def seen_before(self, fps, level):
         return np.array([int(f) in self.seen and (self.seen[int(f)] >> 55) < level for f in fps], dtype=bool)
 
+    def loaded_level(self):
+        return self.level
+
     def save(self, path):
         import pickle
         with open(path, "wb") as f:

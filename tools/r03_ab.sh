@@ -1,0 +1,21 @@
+#!/bin/bash
+# round-3 A/B runs on the GPU box: tools/r03_ab.sh "<lib name>[:ENV=VAL,...]" ...  -> per variant k_expand ms per run (bench.py's timed
+# runs assert the 28 level sizes and the violating fingerprint of config 2 against the oracle fixture), two rounds each
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+for round in 1 2; do
+for spec in "$@"; do
+  name=${spec%%:*}; envs=""
+  if [[ "$spec" == *:* ]]; then envs=$(echo "${spec#*:}" | tr ',' ' '); fi
+  env $envs VSRMC_LIB=$PWD/vsr-tlaplus_amd/ab/libvsrmc_$name.so python bench.py --no-verify --no-config3 --no-cpu-baseline --steps 5 --warmup 1 \
+    2> gpurun_out/ab_$name.err | python -c "
+import sys, json
+l = sys.stdin.readline()
+try:
+    d = json.loads(l)
+    print('$spec', 'round $round', 'k_expand ms/run', d['roofline']['kernel_ms_per_step']['k_expand'], 'ms_per_step', d['ms_per_step'], 'value %.4g' % d['value'])
+except Exception as e:
+    print('$spec', 'FAILED', l[:200])"
+  tail -2 gpurun_out/ab_$name.err | cut -c1-300
+done
+done

@@ -27,7 +27,8 @@ class LevelInfo(C.Structure):
                 ("deadlocks", C.c_uint64), ("pending", C.c_uint64), ("probes", C.c_uint64), ("words_new", C.c_uint64), ("record_words", C.c_uint64),
                 ("max_bag", C.c_uint64), ("viol_fp", C.c_uint64), ("viol_index", C.c_uint64), ("viol_mask", C.c_int32),
                 ("reserved0", C.c_int32), ("seconds", C.c_double), ("expand_ms", C.c_double),
-                ("materialize_ms", C.c_double), ("act_generated", C.c_uint64 * 16), ("phase_cycles", C.c_uint64 * 8)]
+                ("materialize_ms", C.c_double), ("act_generated", C.c_uint64 * 16), ("phase_cycles", C.c_uint64 * 8),
+                ("fp_xor", C.c_uint64), ("fp_sum", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("act_generated", "reserved0", "phase_cycles")}

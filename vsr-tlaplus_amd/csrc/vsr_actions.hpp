@@ -88,12 +88,16 @@ VSR_HD void bag_send_at(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, co
   D.pj[SLOT] = -1;
   D.pold[SLOT] = 0;
   D.pnew[SLOT] = m_set_count(key, 1);
-  for (int j = 0; j < nmsg; j++) {
-    u64 w = bag[j];
-    if ((w & KEYMASK) == key) {
+  // four bag words per trip: the loads are independent, so a trip costs one LDS latency instead of four (keys are unique in a bag:
+  // at most one entry matches; 0 is no key)
+  for (int j0 = 0; j0 < nmsg; j0 += 4) {
+    const u64 w0 = bag[j0], w1 = j0 + 1 < nmsg ? bag[j0 + 1] : 0, w2 = j0 + 2 < nmsg ? bag[j0 + 2] : 0, w3 = j0 + 3 < nmsg ? bag[j0 + 3] : 0;
+    const bool h0 = (w0 & KEYMASK) == key, h1 = (w1 & KEYMASK) == key, h2 = (w2 & KEYMASK) == key, h3 = (w3 & KEYMASK) == key;
+    if (h0 | h1 | h2 | h3) {
+      const u64 w = h0 ? w0 : h1 ? w1 : h2 ? w2 : w3;
       int c = m_count(w) + 1;
       if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
-      D.pj[SLOT] = j;
+      D.pj[SLOT] = j0 + (h0 ? 0 : h1 ? 1 : h2 ? 2 : 3);
       D.pold[SLOT] = w;
       D.pnew[SLOT] = m_set_count(w, c);
       return;
@@ -115,19 +119,31 @@ VSR_HD void bag_broadcast(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, 
       D.pnew[d] = m_set_count(m_set_dest(key, d), 1);
     }
   const u64 nodest = ~((u64)7 << 6);
-  for (int j = 0; j < nmsg; j++) {
-    u64 w = bag[j];
-    if (((w ^ key) & KEYMASK & nodest) != 0) continue;         // same record up to dest
-    const int d = m_dest(w);
-    int c = m_count(w) + 1;
-    if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
+  for (int j0 = 0; j0 < nmsg; j0 += 4) {                         // four independent loads per trip (see bag_send_at)
+    u64 wq[4];
+    wq[0] = bag[j0];
+    wq[1] = j0 + 1 < nmsg ? bag[j0 + 1] : 0;
+    wq[2] = j0 + 2 < nmsg ? bag[j0 + 2] : 0;
+    wq[3] = j0 + 3 < nmsg ? bag[j0 + 3] : 0;
+    bool any = false;
 #pragma unroll
-    for (int q = 1; q <= 5; q++)
-      if (q == d && ((D.used >> q) & 1)) {
-        D.pj[q] = j;
-        D.pold[q] = w;
-        D.pnew[q] = m_set_count(w, c);
-      }
+    for (int u = 0; u < 4; u++) any |= ((wq[u] ^ key) & KEYMASK & nodest) == 0;
+    if (!any) continue;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const u64 w = wq[u];
+      if (((w ^ key) & KEYMASK & nodest) != 0) continue;       // same record up to dest
+      const int d = m_dest(w);
+      int c = m_count(w) + 1;
+      if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
+#pragma unroll
+      for (int q = 1; q <= 5; q++)
+        if (q == d && ((D.used >> q) & 1)) {
+          D.pj[q] = j0 + u;
+          D.pold[q] = w;
+          D.pnew[q] = m_set_count(w, c);
+        }
+    }
   }
   // a copy whose key is the entry this action just discarded (slot 0) stacks on that patch instead
   if (D.used & 1) {
@@ -143,8 +159,10 @@ VSR_HD void bag_broadcast(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, 
 }
 template <typename PTR>
 VSR_HD bool bag_has_key(PTR bag, int nmsg, u64 key) {          // key \in DOMAIN messages (any count)
-  for (int j = 0; j < nmsg; j++)
-    if ((bag[j] & KEYMASK) == key) return true;
+  for (int j0 = 0; j0 < nmsg; j0 += 4) {
+    const u64 w0 = bag[j0], w1 = j0 + 1 < nmsg ? bag[j0 + 1] : 0, w2 = j0 + 2 < nmsg ? bag[j0 + 2] : 0, w3 = j0 + 3 < nmsg ? bag[j0 + 3] : 0;
+    if (((w0 & KEYMASK) == key) | ((w1 & KEYMASK) == key) | ((w2 & KEYMASK) == key) | ((w3 & KEYMASK) == key)) return true;
+  }
   return false;
 }
 
@@ -571,6 +589,51 @@ VSR_HD u32 guard_slot_pre(const Model& M, PTR rec, u64 hdr, const u64* Areg, int
       if (d != r && !bag_has_key(rec + M.fixed, hdr_nmsg(hdr), m_make(T_GETSTATE, mview, d, r, tr, 0, 0, 0, 0))) mask |= 1u << d;
   }
   return mask;
+}
+
+// ---- two-stage enumeration (k_expand, VSR.tla model): a cheap superset test per bag entry, the exact guard only on the survivors --
+// prefilter_lut(A, r): bit (type + 8 * view_number) is set iff a message of that type and view addressed to replica r COULD be
+// received (or, a Prepare, could start a SendGetState) in the state A of r — every conjunct of guard_slot_pre that only looks at
+// (type, view_number) and r's status / view / primary-ness, none of those that compare op numbers.  The low six bits of a bag
+// word ARE type | view << 3, so the test is one shift.  A superset of "guard_slot_pre(...) != 0" by construction: each row
+// below is the guard's own condition with the op-number conjunct dropped.
+VSR_HD u64 prefilter_lut(const Model& M, u64 A, int r) {
+  const int view = a_view(A), st = a_status(A);
+  const bool prim = primary_of(M, view) == r;
+  const u64 COL = 0x0101010101010101ULL;
+  const u64 ge = ~(u64)0 << (8 * view), eq = (u64)0xFF << (8 * view), gt = ge & ~eq;
+  u64 lut = ((COL << T_SVC) & (gt | (st == ST_VIEWCHANGE ? eq : (u64)0)))                     // VSR.tla:605 / :628-630
+            | (((COL << T_DVC) | (COL << T_SV)) & ge);                                          // :680 / :699 / :776
+  if (st == ST_NORMAL) {
+    lut |= eq & ((COL << T_PREPARE) | (COL << T_GETSTATE) | (COL << T_NEWSTATE)                // :408-409, :529-530, :554-555
+                 | (prim ? (COL << T_PREPAREOK) : (u64)0));                                     // :440-442
+    if (!prim) lut |= gt & (COL << T_PREPARE);                                                  // SendGetState :498-502
+  }
+  return lut;
+}
+// the replica-bound instances of replica r as a bit mask: bit 0 TimerSendSVC(r), 1 SendDVC(r), 2 SendSV(r), 3 ExecuteOp(r),
+// 4 + (c-1)*n + v ReceiveClientRequest(r, c, v) — the same guards as the slot < m0 half of guard_slot_pre
+template <typename PTR>
+VSR_HD u32 rep_slots_mask(const Model& M, PTR rec, u64 hdr, u64 A, int r) {
+  PTR pb = rec + 1 + (r - 1) * M.wpr;
+  const bool prim = primary_of(M, a_view(A)) == r;
+  const int st = a_status(A);
+  u32 m = (hdr_aux_svc(hdr) < M.L && !prim) ? 1u : 0u;                                          // VSR.tla:579-581
+  if (st == ST_VIEWCHANGE) {
+    if (!a_sent_dvc(A) && __builtin_popcount(a_svcmask(A)) >= M.R / 2) m |= 2u;                 // :650-652
+    if (!a_sent_sv(A) && blk_dvc_count(M, pb) >= M.R / 2 + 1) m |= 4u;                          // :737-739
+  } else if (st == ST_NORMAL && prim) {
+    if (a_commit(A) < a_op(A)) {                                                                // :464-467
+      int q = 0;
+      for (int p = 1; p <= M.R; p++) q += a_peer(A, p) >= a_commit(A) + 1 ? 1 : 0;
+      if (q >= M.R / 2) m |= 8u;
+    }
+    for (int c = 1; c <= M.C; c++)                                                              // :368-371
+      if (ct_exec(a_ctrow(A, c)))
+        for (int v = 0; v < M.n; v++)
+          if (hdr_acked(hdr, v) == 0) m |= 16u << ((c - 1) * M.n + v);
+  }
+  return m;
 }
 
 template <typename PTR>

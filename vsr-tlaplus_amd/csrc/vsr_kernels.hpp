@@ -106,6 +106,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
   u64 phase_cycles[8];
   u64 tile_cursor;         // k_expand: the next frontier tile no block has taken yet
   u64 n_written;           // fused mode: records written to the next frontier (unsharded: = new states; sharded: incl. speculative ones)
+  u64 fp_xor, fp_sum;      // MODE_INSERT (virtual level): xor / sum of the fingerprints this pass inserted = the level's checksums (no lvl_fp array exists)
 };
 
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
@@ -125,6 +126,37 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #define VSR_CLK() ((u64)0)
 #endif
 #define VSR_CAND_CAP 2048    // enabled instances per tile the LDS work list can hold
+// two-stage enumeration of the enabled instances in k_expand (VSR.tla model): 0 = the full guard for every (record, slot) pair
+#ifndef VSR_ENUM2
+#define VSR_ENUM2 1
+#endif
+// Block barriers of k_expand.  __syncthreads() is "s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier": every barrier also waits until the
+// wave's outstanding GLOBAL stores have been acknowledged — after the apply phase that is the drain of ~28 scattered stores per
+// new state.  Nothing in k_expand hands data from wave to wave through global memory inside a launch (the waves of a block talk
+// through LDS, blocks through atomics), so the barriers only have to order LDS: wait for the wave's LDS operations, then s_barrier.
+// The stores keep draining underneath the next tile's staging loads.
+#ifndef VSR_RELAXED_SYNC
+#define VSR_RELAXED_SYNC 0
+#endif
+#if VSR_RELAXED_SYNC
+#define VSR_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define VSR_SYNC() __syncthreads()
+#endif
+// seen-set probes read the home slot (16 B) first and the rest of its 64-byte line only when that slot holds another fingerprint
+#ifndef VSR_HOME_FIRST
+#define VSR_HOME_FIRST 1
+#endif
+// successor write: parent words copied eight per trip (four LDS reads in flight) instead of two
+#ifndef VSR_COPY8
+#define VSR_COPY8 0
+#endif
+#ifndef VSR_DIAG_DBLPROBE
+#define VSR_DIAG_DBLPROBE 0
+#endif
+#ifndef VSR_DIAG_DBLWRITE
+#define VSR_DIAG_DBLWRITE 0
+#endif
 
 __device__ __forceinline__ void raise_error(LevelCtl* ctl, int code, u64 info) {
   if (atomicCAS(&ctl->err, 0u, (u32)code) == 0u) ctl->err_info = info;
@@ -159,6 +191,23 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32
   Probe r;
   r.slot = 0; r.meta = META_EMPTY; r.claimed = false; r.reload = false; r.full = false;
   u64 i = fp & mask;
+#if VSR_HOME_FIRST
+  {
+    const u64x2 sk = *(const u64x2*)&table[i];
+    (*nprobe)++;
+    u64 cur = sk.x;
+    if (cur == 0) {
+      cur = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
+      if (cur == 0) { r.slot = i; r.claimed = true; return r; }
+      if (cur == fp) { r.slot = i; r.reload = true; return r; }
+    } else if (cur == fp) {
+      r.slot = i;
+      r.meta = sk.y;
+      return r;
+    }
+    i = (i + 1) & mask;
+  }
+#endif
   for (u32 lines = 0; lines < 2048; lines++) {
     const u64 lb = i & ~(u64)3;
     const u64x2* lp = (const u64x2*)&table[lb];
@@ -297,8 +346,12 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
 // in the constants, still specific to the model): the constants of the model
 // become compile-time constants of this instantiation (every device function below is inlined), so loops over replicas,
 // clients, values and permutations unroll without predicates and strides fold into addresses.
-template <bool FUSED, int SPEC = 0, bool PLAIN = false>
-__global__ void __launch_bounds__(VSR_BLOCK, FUSED ? (SPEC ? 4 : 2) : 3)
+// BLK = threads per block: 256 (four waves share a tile of 64 or 128 records, block barriers between the phases) or 64 — one wave per
+// block with a tile of 16 records of its own: the same phases, but a barrier of a one-wave workgroup costs nothing, no wave waits
+// for the slowest wave of its tile, and the 16 waves of a CU drift apart so that their memory and issue phases interleave.
+template <bool FUSED, int SPEC = 0, bool PLAIN = false, int BLK = VSR_BLOCK>
+// (hipcc turns the second bound into waves per SIMD as blocks * max(1, threads / 256): 4 = 128 VGPRs for either block size)
+__global__ void __launch_bounds__(BLK, FUSED ? (SPEC ? 4 : 2) : 3)
 k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world_arg, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
@@ -327,10 +380,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
   u32* s_cand2 = s_cand + ccap;                        // the same, sorted by action
-  __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out, s_skip;
-  __shared__ u32 s_alive[VSR_TILE_MAX];
-  __shared__ u64 s_ref[VSR_TILE_MAX];
-  __shared__ u64 s_pfp[VSR_TILE_MAX];                          // canonical fingerprint of every staged record (the parent part of its successors' keys)
+  __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv;
+  constexpr int TILE_MAX = BLK == VSR_BLOCK ? VSR_TILE_MAX : BLK / 2;
+  __shared__ u32 s_alive[TILE_MAX];
+  __shared__ u64 s_ref[TILE_MAX];
+  __shared__ u64 s_pfp[TILE_MAX];                          // canonical fingerprint of every staged record (the parent part of its successors' keys)
   __shared__ u32 s_kcount[16], s_kbase[16];
   __shared__ int s_slotinfo[64];                               // decode of the replica-bound slots (m0 <= 50), see slot_info()
   // per-block accumulators (flushed once at the end: no hot global counters inside the tile loop)
@@ -349,7 +403,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
 
   const int tid = threadIdx.x, lane = tid & 63;
   const u64 ntiles = (n_parents + tile - 1) / tile;
-  const int tshift = tile == 128 ? 7 : 6;
+  const int tshift = 31 - __clz(tile);                           // tile is a power of two
   if (tid < 32) s_acc[tid] = 0;
   if (tid == 0) s_maxbag_out = 0;
   if (tid < 64) s_slotinfo[tid] = (SPEC / 1000 == 0 && tid < M.m0) ? slot_info(M, tid) : 0;
@@ -358,7 +412,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     s_ich_base = 0; s_ich_used = ichunk; s_wch_base = 0; s_wch_used = wchunk;
   }
   if (tid < 8) s_cstate[tid] = (CS_NONE << 24) | cchunk;
-  __syncthreads();
+  VSR_SYNC();
 
   // blockIdx -> tiles: the persistent blocks draw tiles from an atomic counter (ctl->tile_cursor, zeroed by the host with the other
   // level counters).  Tile costs are uneven and correlated along the frontier (successors per record, bag sizes), so the static
@@ -375,10 +429,10 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       if (my_next < ntiles) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
     }
     const u64 t_0 = VSR_CLK();
-    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; }
+    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; s_nsurv = 0; }
     if (tid < tile) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
-    __syncthreads();
+    VSR_SYNC();
     const u64 tile_i = s_tile_cur;
     if (tile_i >= ntiles) break;
     const u64 p_base = tile_i * (u64)tile;
@@ -392,13 +446,14 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
       if ((int)(ref & 255) > stride) raise_error(ctl, ERR_INTERNAL, (p_base + (u64)tid) << 16);   // LDS slots sized for shorter records
     }
-    __syncthreads();
-    for (int half = 0; half < tile; half += 64)
+    VSR_SYNC();
+    constexpr int SG = BLK / 16;                                 // records staged per pass (16 lanes each)
+    for (int half = 0; half < tile; half += 4 * SG)
       for (int wbase = 0; wbase < stride; wbase += 64) {      // records longer than 64 words (R >= 4): a second window
         u64 v[4][4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const int p = half + (tid >> 4) + 16 * q;
+          const int p = half + (tid >> 4) + SG * q;
           const u64 ref = p < np_tile ? s_ref[p] : 0;
           const u64 off = ref >> 8;
           const int len = (int)(ref & 255) < stride ? (int)(ref & 255) : stride;
@@ -410,7 +465,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const int p = half + (tid >> 4) + 16 * q;
+          const int p = half + (tid >> 4) + SG * q;
           const int len = p < np_tile ? ((int)(s_ref[p] & 255) < stride ? (int)(s_ref[p] & 255) : stride) : 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -419,7 +474,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           }
         }
       }
-    __syncthreads();
+    VSR_SYNC();
     if (tid < np_tile && s_ref[tid] != 0) {                     // the parent's own fingerprint, from the view hashes it carries
       const u64* r0 = s_rec + tid * stride;
       u64 pf;
@@ -452,19 +507,97 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       // in a register, no atomics, no cross-lane traffic inside the slot loop; the entries beyond 256*PRIV are a shared
       // overflow area (atomic cursor) for the rare thread that finds more.  Unused entries hold ~0; the counting sort below
       // skips them.
-      const u32 PRIV = (ccap - 256u) / VSR_BLOCK;               // 5 at ccap 1536, 7 at 2048
-      const u32 shared0 = PRIV * VSR_BLOCK;
-      for (u32 k = tid; k < ccap; k += VSR_BLOCK) s_cand[k] = ~0u;
-      __syncthreads();
+      const u32 PRIV = (ccap - (u32)BLK) / BLK;               // 5 at ccap 1536, 7 at 2048
+      const u32 shared0 = PRIV * BLK;
+      for (u32 k = tid; k < ccap; k += BLK) s_cand[k] = ~0u;
+      VSR_SYNC();
       u32 nmine = 0;
       bool alive = false;
+#if VSR_ENUM2
+      if constexpr (SPEC / 1000 == 0) {
+        // Two-stage enumeration.  Evaluating the full guard for every (record, slot) pair was more than half of the kernel's
+        // instructions although 1 pair in 20 is enabled.  Stage 1, per bag entry: delivery count > 0 and one bit of a 64-bit table
+        // per replica (prefilter_lut: the guard's (type, view) conjuncts) — the survivors, (record, entry) pairs, are compacted
+        // into a list with one ballot and one LDS atomic per wave.  Stage 2: the exact guard on the list, dense.  The replica-bound
+        // instances of a record are evaluated as one bit mask per replica by the record's threads (thread g takes replicas g+1, g+1+G, ..).
+        auto emit = [&](int kind, int p, int ord) {
+          atomicAdd(&s_kcount[kind], 1u);
+          u32 idx;
+          if (nmine < PRIV) idx = (u32)tid * PRIV + nmine;
+          else idx = shared0 + atomicAdd(&s_ncand, 1u);
+          nmine++;
+          if (idx < ccap) s_cand[idx] = ((u32)kind << 18) | ((u32)p << 11) | (u32)ord;
+          else s_ncand = 0x40000000u;                             // overflow marker (work list too small)
+          s_alive[p] = 1;
+        };
+        const int G = BLK >> tshift, g = tid >> tshift;     // threads per record, this thread's rank among them
+        u64 lut[6] = {0, 0, 0, 0, 0, 0};
+        if (mine_valid) {
+#pragma unroll
+          for (int r = 1; r <= 5; r++)
+            if (r <= M.R) lut[r] = prefilter_lut(M, Areg[r], r);
+          for (int r = g + 1; r <= M.R; r += G) {
+            u32 m = rep_slots_mask(M, rec_mine, hdr_mine, areg_of(Areg, r), r);
+            while (m) {
+              const int b = __ffs((int)m) - 1;
+              m &= m - 1;
+              const int kind = b == 0 ? A_TimerSendSVC : b == 1 ? A_SendDVC : b == 2 ? A_SendSV : b == 3 ? A_ExecuteOp : A_ReceiveClientRequest;
+              emit(kind, p_mine, b < 4 ? b * M.R + (r - 1) : 4 * M.R + (r - 1) * M.C * M.n + (b - 4));
+            }
+          }
+        }
+        u16* s_surv = (u16*)s_cand2;                              // 2 * ccap entries of (record << 8 | bag index); s_cand2 is free until the sort
+        const int nmsg_mine = mine_valid ? hdr_nmsg(hdr_mine) : 0;
+        const int maxbag = (int)s_maxbag;
+        const int jbatch = (int)((2u * ccap) >> tshift);          // bag entries per batch: even if every pair survives the list holds them
+        for (int j0 = 0; j0 < maxbag; j0 += jbatch) {
+          const int j1 = j0 + jbatch < maxbag ? j0 + jbatch : maxbag;
+          for (int jj = j0; jj < j1; jj += G) {                   // block-uniform trip count (the ballot below wants every lane)
+            const int j = jj + g;
+            bool pass = false;
+            if (j < j1 && j < nmsg_mine) {
+              const u64 w = rec_mine[M.fixed + j];
+              const int r = m_dest(w);
+              const u64 l = r == 1 ? lut[1] : r == 2 ? lut[2] : r == 3 ? lut[3] : r == 4 ? lut[4] : lut[5];
+              pass = m_count(w) != 0 && ((l >> (w & 63)) & 1);
+            }
+            const u64 bal = __ballot(pass);
+            if (bal) {
+              u32 base = 0;
+              if (lane == 0) base = atomicAdd(&s_nsurv, (u32)__popcll(bal));
+              base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+              if (pass) s_surv[base + (u32)__popcll(bal & (((u64)1 << lane) - 1))] = (u16)((p_mine << 8) | j);
+            }
+          }
+          VSR_SYNC();
+          const u32 nsurv = s_nsurv;
+          for (u32 i = tid; i < nsurv; i += BLK) {
+            const int p = s_surv[i] >> 8, j = s_surv[i] & 255;
+            int kind0 = 0;
+            u32 mask = Ops::guard(M, s_rec + p * stride, M.m0 + j, &kind0);
+            const int ordbase = M.m0 + j * (M.R + 1);
+            while (mask) {
+              const int k = __ffs((int)mask) - 1;
+              mask &= mask - 1;
+              emit(k == 0 ? kind0 : Ops::other_kind(kind0), p, ordbase + k);
+            }
+          }
+          if (j1 < maxbag) {                                      // another batch: the list is reused
+            VSR_SYNC();
+            if (tid == 0) s_nsurv = 0;
+            VSR_SYNC();
+          }
+        }
+      } else
+#endif
+      {
       // four independent guard evaluations per trip
-      for (int item0 = tid; item0 < nitems; item0 += 4 * VSR_BLOCK) {
+      for (int item0 = tid; item0 < nitems; item0 += 4 * BLK) {
         u32 masks[4];
         int kinds[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int item = item0 + u * VSR_BLOCK;
+          const int item = item0 + u * BLK;
           const int slot = item >> tshift;
           masks[u] = 0;
           kinds[u] = 0;
@@ -474,7 +607,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         for (int u = 0; u < 4; u++) {
           u32 mask = masks[u];
           if (!mask) continue;
-          const int slot = (item0 + u * VSR_BLOCK) >> tshift;
+          const int slot = (item0 + u * BLK) >> tshift;
           const int ordbase = slot < M.m0 ? slot : M.m0 + (slot - M.m0) * (M.R + 1);
           alive = true;
           while (mask) {
@@ -492,8 +625,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
       }
       if (alive) s_alive[p_mine] = 1;
+      }
     }
-    __syncthreads();
+    VSR_SYNC();
     if (tid < np_tile && s_alive[tid] == 0 && s_ref[tid] != 0) atomicAdd(&s_dead, 1u);   // ref 0 = unused index (see k_materialize)
     // ---- counting sort of the work list by action id: the lanes of a wave then run the same action (no divergence between
     // the 15 action bodies, only inside one)
@@ -508,15 +642,15 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       if (fused) s_wneed = s_ncand * (u32)(M.fixed + (int)s_maxbag + 5);   // upper bound of the successors' total length
     }
     const u64 t_2 = VSR_CLK();
-    __syncthreads();
+    VSR_SYNC();
     const u32 ncand = s_ncand;
-    for (u32 c = tid; c < ccap; c += VSR_BLOCK) {
+    for (u32 c = tid; c < ccap; c += BLK) {
       const u32 code = s_cand[c];
       if (code == ~0u) continue;
       const u32 pos = atomicAdd(&s_kbase[code >> 18], 1u);
       if (pos < ccap) s_cand2[pos] = code;
     }
-    __syncthreads();
+    VSR_SYNC();
 
     const u64 t_3 = VSR_CLK();
     if (fused && (mode == MODE_NORMAL || mode == MODE_REGEN)) {
@@ -524,21 +658,21 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       if (s_ich_used + ncand > ichunk) {                        // block-uniform
         const u32 used = s_ich_used;
         const u64 base = s_ich_base;
-        for (u32 k = used + tid; k < ichunk; k += VSR_BLOCK) {  // unused indices of the old chunk: invalid refs
+        for (u32 k = used + tid; k < ichunk; k += BLK) {  // unused indices of the old chunk: invalid refs
           nx_off[base + k] = 0;
           lvl_fp[base + k] = 0;
         }
-        __syncthreads();
+        VSR_SYNC();
         if (tid == 0) {
           u64 nb = atomicAdd((unsigned long long*)&ctl->n_new, (unsigned long long)ichunk);
           if (nb + ichunk > nx_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
           s_ich_base = nb;
           s_ich_used = 0;
         }
-        __syncthreads();
+        VSR_SYNC();
       }
       if (s_wch_used + s_wneed > wchunk) {                      // records do not straddle chunks: the remainder is skipped
-        __syncthreads();
+        VSR_SYNC();
         if (tid == 0) {
           u64 nb = atomicAdd((unsigned long long*)&ctl->words_new, (unsigned long long)wchunk);
           if (nb + wchunk > nx_words_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
@@ -548,7 +682,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           s_wch_base = nb;
           s_wch_used = 0;
         }
-        __syncthreads();
+        VSR_SYNC();
       }
       if (tid == 0) { s_tile_ibase = s_ich_used; s_tile_wbase = s_wch_used; s_tile_icur = 0; s_tile_wcur = 0; }
     } else
@@ -556,8 +690,8 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     if (!fused && s_chunk_used + ncand > pchunk) {          // block-uniform
       const u32 used = s_chunk_used;
       const u64 base = s_chunk_base;
-      for (u32 k = used + tid; k < pchunk && used < pchunk; k += VSR_BLOCK) pending[3 * (base + k) + 1] = ~(u64)0;
-      __syncthreads();
+      for (u32 k = used + tid; k < pchunk && used < pchunk; k += BLK) pending[3 * (base + k) + 1] = ~(u64)0;
+      VSR_SYNC();
       if (tid == 0) {
         u64 nb = atomicAdd((unsigned long long*)&ctl->n_pending, (unsigned long long)pchunk);
         if (nb + pchunk > pending_cap) {
@@ -567,14 +701,15 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         s_chunk_base = nb;
         s_chunk_used = 0;
       }
-      __syncthreads();
+      VSR_SYNC();
     }
     if (tid == 0) { s_tile_base = s_chunk_used; s_tile_cursor = 0; }
-    __syncthreads();
+    VSR_SYNC();
     // ---- apply + fingerprint + seen-set claim: one lane per enabled instance
     u32 my_probes = 0, my_maxbag = 0, my_words = 0;
+    u64 my_fx = 0, my_fs = 0;                                   // virtual level: checksums of the fingerprints this lane inserted
     const u32 ncand_apply = s_skip ? 0u : ncand;                // s_skip: the tile was refused (see the word-chunk reservation)
-    for (u32 c = tid; c < ncand_apply; c += VSR_BLOCK) {
+    for (u32 c = tid; c < ncand_apply; c += BLK) {
       const u32 code = s_cand2[c];
       const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
       const u64* rec = s_rec + p * stride;
@@ -595,6 +730,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
       const u64 key = meta_make(level, ak, s_pfp[p]);
+#if VSR_DIAG_DBLPROBE     // diagnostic build: one more random seen-set line per successor (marginal cost of a probe)
+      { u64 m_ = 0; if (probe_lookup(table, tmask, fp * 0x9E3779B97F4A7C15ull + 1, &m_, &my_probes)) my_maxbag += (u32)(m_ & 1); }
+#endif
       const u64 a_2 = VSR_CLK();
       if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
       if (!fused && world > 1) {                                // sharded seen-set, exact scheme: route to the owner of fp
@@ -674,6 +812,8 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           }
           my_maxbag = my_maxbag > (u32)hdr_nmsg(D.hdr) ? my_maxbag : (u32)hdr_nmsg(D.hdr);
           my_words++;                                           // counts states in this mode
+          my_fx ^= fp;
+          my_fs += fp;
           do_write = false;
         }
         const u64 a_3 = VSR_CLK();
@@ -689,6 +829,17 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           // parent from LDS, 16 bytes per store (records are 8-byte aligned), then the patches on top (same lane: ordered)
           typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
           int k = 0;
+#if VSR_COPY8
+          for (; k + 7 < plen; k += 8) {
+            u64x2_a8 a2, b2, c2, d2;
+            a2.x = rec[k]; a2.y = rec[k + 1]; b2.x = rec[k + 2]; b2.y = rec[k + 3];
+            c2.x = rec[k + 4]; c2.y = rec[k + 5]; d2.x = rec[k + 6]; d2.y = rec[k + 7];
+            *(u64x2_a8*)(out + k) = a2;
+            *(u64x2_a8*)(out + k + 2) = b2;
+            *(u64x2_a8*)(out + k + 4) = c2;
+            *(u64x2_a8*)(out + k + 6) = d2;
+          }
+#endif
           for (; k + 1 < plen; k += 2) {
             u64x2_a8 v2;
             v2.x = rec[k];
@@ -696,6 +847,17 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             *(u64x2_a8*)(out + k) = v2;
           }
           if (k < plen) out[k] = rec[k];
+#if VSR_DIAG_DBLWRITE     // diagnostic build: the parent copy is stored a second time, half a buffer away (marginal cost of the successor write)
+          {
+            u64* out2 = nx_words + ((dst + (nx_words_cap >> 1)) % (nx_words_cap - 256));
+            for (int k2 = 0; k2 + 1 < plen; k2 += 2) {
+              u64x2_a8 v2;
+              v2.x = rec[k2];
+              v2.y = rec[k2 + 1];
+              *(u64x2_a8*)(out2 + k2) = v2;
+            }
+          }
+#endif
           out[0] = D.hdr;
           u64* ob = out + 1 + (D.r - 1) * M.wpr;
           ob[0] = D.rep[0];
@@ -744,7 +906,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             const u64 e = (u64)owner * cand_cap + i;
             cand_send[2 * e] = fp;
             cand_send[2 * e + 1] = key;
-            cand_idx[e] = idx | ((u64)bad << 62);
+            cand_idx[e] = idx | ((u64)bad << 56);                   // invariant mask: 8 bits (the analysis models use bits up to 16)
           }
         }
         // same-level duplicate with a different canonical auxkey = the tie the single-pass scheme cannot arbitrate
@@ -780,12 +942,22 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         my_maxbag = t > my_maxbag ? t : my_maxbag;
       }
     }
+    if (!PLAIN && mode == MODE_INSERT) {
+      for (int o = 32; o > 0; o >>= 1) {
+        my_fx ^= __shfl_down(my_fx, o);
+        my_fs += __shfl_down(my_fs, o);
+      }
+      if (lane == 0 && (my_fx | my_fs)) {
+        atomicXor((unsigned long long*)&ctl->fp_xor, (unsigned long long)my_fx);
+        atomicAdd((unsigned long long*)&ctl->fp_sum, (unsigned long long)my_fs);
+      }
+    }
     if (lane == 0 && my_probes) atomicAdd(&s_acc[2], (unsigned long long)my_probes);
     if (fused && lane == 0 && my_words) {
       atomicAdd(&s_acc[9], (unsigned long long)my_words);
       atomicMax(&s_maxbag_out, my_maxbag);
     }
-    __syncthreads();
+    VSR_SYNC();
     if (tid == 0) {
       if (fused) {
         s_ich_used += s_tile_icur;
@@ -804,25 +976,25 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       s_acc[7] += t_5 - t_4;
     }
     if (tid < 16) s_acc[16 + tid] += s_kcount[tid];
-    __syncthreads();
+    VSR_SYNC();
   }
   // ---- block epilogue: invalidate the unused tail of the chunk, flush the accumulators
   {
     if (fused) {
       const u32 used = s_ich_used;
       const u64 base = s_ich_base;
-      for (u32 k = used + tid; k < ichunk; k += VSR_BLOCK) {
+      for (u32 k = used + tid; k < ichunk; k += BLK) {
         nx_off[base + k] = 0;
         lvl_fp[base + k] = 0;
       }
       if (world > 1) {
-        __syncthreads();
+        VSR_SYNC();
         for (int o = 0; o < world; o++) {
           const u64 st = s_cstate[o];
           const u64 base = st >> 24;
           const u32 used = (u32)(st & 0xFFFFFFull) < cchunk ? (u32)(st & 0xFFFFFFull) : cchunk;
           if (base == CS_NONE) continue;
-          for (u32 k = used + tid; k < cchunk; k += VSR_BLOCK) {
+          for (u32 k = used + tid; k < cchunk; k += BLK) {
             cand_send[2 * ((u64)o * cand_cap + base + k)] = 0;  // fingerprint 0 = no candidate
             cand_send[2 * ((u64)o * cand_cap + base + k) + 1] = ~(u64)0;
           }
@@ -837,7 +1009,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     } else {
       const u32 used = s_chunk_used;
       const u64 base = s_chunk_base;
-      for (u32 k = used + tid; k < pchunk; k += VSR_BLOCK) pending[3 * (base + k) + 1] = ~(u64)0;
+      for (u32 k = used + tid; k < pchunk; k += BLK) pending[3 * (base + k) + 1] = ~(u64)0;
     }
     if (tid == 0) {
       if (s_acc[0]) atomicAdd((unsigned long long*)&ctl->generated, s_acc[0]);
@@ -1164,7 +1336,7 @@ __global__ void k_claim_batch_fused(Slot* table, u64 tmask, const u64* __restric
   if ((threadIdx.x & 63) == 0 && np) atomicAdd((unsigned long long*)&ctl->probes, (unsigned long long)np);
 }
 // k_apply_verdict: the generator's side of the single-pass sharded level — candidate i of the bucket sent to one owner was
-// written speculatively at state index cand_idx[i] (bits 62..63: violated-invariant mask); losers are withdrawn (invalid
+// written speculatively at state index cand_idx[i] (bits 56..63: violated-invariant mask); losers are withdrawn (invalid
 // ref, exactly like an unused index), winners that violate an invariant are reported now.
 __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __restrict__ cand_idx, const uint8_t* __restrict__ verdict,
                                 u64 n, u64* nx_off, u64* lvl_fp, LevelCtl* ctl) {
@@ -1173,9 +1345,9 @@ __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __re
   const u64 fp = entries[2 * i];
   if (fp == 0) return;
   const u64 e = cand_idx[i];
-  const u64 idx = e & (((u64)1 << 62) - 1);
+  const u64 idx = e & (((u64)1 << 56) - 1);
   if (verdict[i]) {
-    const u32 bad = (u32)(e >> 62);
+    const u32 bad = (u32)(e >> 56);
     if (bad) {
       atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
       atomicOr(&ctl->viol_mask, bad);

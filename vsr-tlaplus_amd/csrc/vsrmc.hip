@@ -22,6 +22,12 @@
 #include "vras_parse.hpp"
 #include "vsr_kernels.hpp"
 
+// threads per block of the ordinary-level kernel (k_expand<.., PLAIN, BLK>): 64 = one wave per block with its own 16-record tiles
+#define VSRMC_FP_VERSION 2          // fingerprint function of this build; checkpoints of another version are refused
+#ifndef VSRMC_DEFAULT_BLK
+#define VSRMC_DEFAULT_BLK 256
+#endif
+
 using namespace vsr;
 
 namespace {
@@ -1023,6 +1029,7 @@ struct vsrmc_checker {
   // the single-pass kernel of this model (a specialised instantiation when there is one) and its launch shape
   void* fused_kernel = nullptr;
   void* plain_kernel = nullptr;          // the same without modes / sharding, when the configuration has one (ordinary unsharded levels)
+  int plain_blk = VSR_BLOCK;             // threads per block of plain_kernel: 256, or 64 = one wave per block with a 16-record tile of its own
   u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
   bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
   // vsrmc_checker_probe / _probe2: where the reported violator's counter-example is walked from — the fingerprint of the deepest
@@ -1062,7 +1069,16 @@ MaterializeKernel materialize_kernel_for(const Model& M) {
     default: return k_materialize<0>;
   }
 }
-ExpandKernel plain_kernel_for(const Model& M) {               // unsharded ordinary levels: modes and sharding compiled out
+ExpandKernel plain_kernel_for(const Model& M, int blk) {      // unsharded ordinary levels: modes and sharding compiled out
+  if (blk == 64) {                                             // one wave per block, 16-record tiles (vsr_kernels.hpp, BLK)
+    if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true, 64> : nullptr;
+    if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302, true, 64> : nullptr;
+    switch (M.R * 100 + M.C * 10 + M.n) {
+      case 312: return k_expand<true, 312, true, 64>;
+      case 313: return k_expand<true, 313, true, 64>;
+      default: return nullptr;
+    }
+  }
   if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true> : nullptr;   // the shipped VR_STATE_TRANSFER.cfg
   if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302, true> : nullptr;   // the shipped VR_APP_STATE.cfg
   switch (M.R * 100 + M.C * 10 + M.n) {
@@ -1092,22 +1108,32 @@ ExpandKernel fused_kernel_for(const Model& M) {
 // worst case, so deep levels of small bags leave room for more resident blocks.  64-record tiles when that gives at least
 // three blocks per CU (registers and LDS, asked from the runtime), else 128-record tiles (R <= 3) at two.
 struct FusedShape {
+  int blk;
   int tile;
   u32 ccap;
   int stride;
   size_t lds;
   unsigned blocks_per_cu;
 };
-FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source) {
+FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = false) {
   const Model& M = c->model.M;
   FusedShape f;
   f.stride = (int)std::min<u64>((u64)c->lds_stride, (u64)((M.fixed + (int)std::min<u64>(max_bag_of_source, 255)) | 1));
+  const void* kernel = (plain && c->plain_kernel) ? c->plain_kernel : c->fused_kernel;
+  const int blk = (plain && c->plain_kernel) ? c->plain_blk : VSR_BLOCK;
   auto occupancy = [&](int tile, u32 ccap, size_t* lds) {
     *lds = (size_t)tile * f.stride * 8 + 2 * (size_t)ccap * 4;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c->fused_kernel, VSR_BLOCK, *lds) != hipSuccess) nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, blk, *lds) != hipSuccess) nb = 0;
     return nb;
   };
+  f.blk = blk;
+  if (blk == 64) {                                              // one wave, 16 records, 24 (R <= 3) or 32 work-list entries per record
+    f.tile = 16;
+    f.ccap = M.R <= 3 ? 384u : 512u;
+    f.blocks_per_cu = (unsigned)std::max(1, std::min(occupancy(16, f.ccap, &f.lds), 16));
+    return f;
+  }
   size_t lds64 = 0, lds128 = 0;
   const u32 ccap64 = M.R <= 3 ? 1536u : (u32)VSR_CAND_CAP;      // work-list entries per tile (24 resp. 32 per record)
   const int occ64 = occupancy(64, ccap64, &lds64);
@@ -1117,6 +1143,8 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source) {
   } else {
     f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, 4));
   }
+  if (const char* e = std::getenv("VSRMC_MAX_BPC"))            // diagnostic: fewer resident blocks per CU (occupancy sweeps)
+    f.blocks_per_cu = (unsigned)std::max(1, std::min<int>((int)f.blocks_per_cu, std::atoi(e)));
   return f;
 }
 
@@ -1228,7 +1256,13 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
   c->fused_kernel = (void*)fused_kernel_for(M);
-  c->plain_kernel = (void*)plain_kernel_for(M);
+  {
+    // VSRMC_BLK=256 selects the four-wave blocks (64-record tiles, block barriers) for A/B runs; default: one wave per block
+    const char* e = std::getenv("VSRMC_BLK");
+    const int want = e ? std::atoi(e) : VSRMC_DEFAULT_BLK;
+    c->plain_blk = (want == 64 && plain_kernel_for(M, 64)) ? 64 : VSR_BLOCK;
+    c->plain_kernel = (void*)plain_kernel_for(M, c->plain_blk);
+  }
   rc = checker_seed(c);
   if (rc) { vsrmc_checker_destroy(c); return rc; }
   *out = c;
@@ -1271,7 +1305,9 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
     const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
     // sharded: records arrive from other ranks (rebalancing), the local maximum says nothing -> the format's capacity
-    const FusedShape fs = fused_shape(c, c->bag_known ? c->cur_max_bag : (u64)M.max_bag);
+    const bool use_plain = fused && !io && mode == MODE_NORMAL && c->plain_kernel;
+    const FusedShape fs = fused_shape(c, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, use_plain);
+    const int cdiv = VSR_BLOCK / fs.blk;                         // one-wave blocks: four times the blocks, a quarter of the chunk sizes
     const int tile = fused ? fs.tile : (M.R <= 3 ? 128 : 64);
     const int stride = fused ? fs.stride : c->lds_stride;
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
@@ -1299,19 +1335,19 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
       // persistent blocks (2 resident per CU: 225 VGPRs, 79 KB LDS): every block leaves one partly used index chunk and
       // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
       grid = (unsigned)std::min<u64>((u64)ntiles, (u64)c->num_cus * fs.blocks_per_cu);
-      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
+      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP / cdiv), c->words_cap(nxt) / (4 * 16384))));
       // a tile's successors (at most ccap records of at most stride + 5 words each) must fit one word chunk, and every block
       // may leave one partly used chunk behind: fewer blocks if the buffer is too small for that
       // (a buffer too small even for one such chunk keeps going with what it has: the kernel refuses a tile that does not fit
       // its chunk with ERR_FRONTIER_FULL instead of writing past it)
       const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(stride + 5));
       grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, c->words_cap(nxt) / (4 * wmin)));
-      ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
-      wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
+      ichunk = (u32)std::max<u64>(VSR_CAND_CAP / cdiv, std::min<u64>(8192 / cdiv, nx_cap / (4 * (u64)grid)));
+      wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144 / cdiv, c->words_cap(nxt) / (4 * (u64)grid)));
     }
     if (fused)
-      hipLaunchKernelGGL((ExpandKernel)((!io && mode == MODE_NORMAL && c->plain_kernel) ? c->plain_kernel : c->fused_kernel), dim3(grid),
-                         dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+      hipLaunchKernelGGL((ExpandKernel)(use_plain ? c->plain_kernel : c->fused_kernel), dim3(grid),
+                         dim3(use_plain ? fs.blk : VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, ichunk,
@@ -1610,6 +1646,8 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   virt->total_generated = c->total_generated + c->h.generated;
   virt->probes = c->h.probes;
   virt->max_bag = c->h.max_bag;
+  virt->fp_xor = c->h.fp_xor;
+  virt->fp_sum = c->h.fp_sum;
   virt->expand_ms = c->expand_ms;
   virt->seconds = now_s() - t0;
   const u64 gen1 = c->h.generated, virt_max_bag = c->h.max_bag;
@@ -1730,6 +1768,8 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
   virt1->total_generated = c->total_generated + c->h.generated;
   virt1->probes = c->h.probes;
   virt1->max_bag = c->h.max_bag;
+  virt1->fp_xor = c->h.fp_xor;
+  virt1->fp_sum = c->h.fp_sum;
   virt1->expand_ms = c->expand_ms;
   virt1->seconds = now_s() - t0;
   const u64 gen1 = c->h.generated, bag1 = std::min<u64>(c->h.max_bag, (u64)M.max_bag);
@@ -1783,7 +1823,10 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
   u64 sub = worst_size(B.cap, B.words_cap);
   double yield_n = 0, yield_w = 0;
   u64 n2 = 0, gen2 = 0, dead2 = 0, probes2 = 0, bag2 = 0, viol2 = ~(u64)0, words2 = 0, n_slices = 0, n_subs = 0;
-  u64 gen3 = 0, dead3 = 0, probes3 = 0;
+  u64 gen3 = 0, dead3 = 0, probes3 = 0, fx2 = 0, fs2 = 0;
+  u64* d_sum = nullptr;
+  if (hipMalloc((void**)&d_sum, 24) != hipSuccess) return fail(VSRMC_E_HIP, "hipMalloc");
+  struct FreeSum { u64* p; ~FreeSum() { (void)hipFree(p); } } free_sum{d_sum};
   std::vector<u64> bad;                                        // (fingerprint, key) of the violating successors the probe passes saw
   u32 mask2 = 0, mask3 = 0;
   double ms2 = 0, ms3 = 0;
@@ -1819,6 +1862,15 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
         viol2 = std::min<u64>(viol2, c->h.viol_fp);
       }
       if (part2) {
+        {   // checksums of the streamed level: the sub-slice's fingerprints sit in the scratch buffer until it is reused
+          u64 hsum[3] = {0, 0, 0};
+          if (hipMemsetAsync(d_sum, 0, 24, c->stream) != hipSuccess) { rc = fail(VSRMC_E_HIP, "probe3: hipMemsetAsync"); break; }
+          hipLaunchKernelGGL(k_level_checksum, dim3(1024), dim3(256), 0, c->stream, B.fp, part2, d_sum);
+          if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hsum, d_sum, 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+              hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(VSRMC_E_HIP, "probe3: k_level_checksum"); break; }
+          fx2 ^= hsum[0];
+          fs2 += hsum[1];
+        }
         const u64 cnt = c->h.n_written;                          // records written = new level-(L+2) states of this sub-slice
         n2 += cnt;
         yield_n = std::max(yield_n, (double)cnt / (double)nb);
@@ -1856,6 +1908,8 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
   virt2->total_generated = virt1->total_generated + gen2;
   virt2->probes = probes2;
   virt2->max_bag = bag2;
+  virt2->fp_xor = fx2;
+  virt2->fp_sum = fs2;
   virt2->record_words = words2;
   virt2->pending = n_slices << 32 | n_subs;                    // (slices of level L) << 32 | sub-slices of level L+1
   virt2->expand_ms = ms2;
@@ -2231,8 +2285,9 @@ int32_t vsrmc_shard_commit(vsrmc_checker* c, vsrmc_level_info* info) {
 // ---- checkpoint / recover ≙ TLC's checkpoints (ModelChecker.checkpoint: FPSet.beginChkpt/commitChkpt, StateQueue, TLCTrace) ----
 namespace {
 struct ChkHeader {
-  char magic[8];                 // "VSRMCCK2" (1 = the format with a separate trace log and index-based meta words)
-  int32_t consts[8];             // R, C, n, L, symmetry, inv_mask, assume_commit, np
+  char magic[8];                 // "VSRMCCK3" (1 = the format with a separate trace log and index-based meta words; 2 = without the module in the header)
+  int32_t consts[12];            // R, C, n, L, symmetry, inv_mask, assume_commit, np, module (model_id), words per replica, fixed words,
+                                 // version of the fingerprint function: records and fingerprints mean nothing under another layout or hash
   int32_t level, shard;          // shard: 0 = unsharded, else world << 16 | rank (each rank writes and reads its own file)
   u64 n_frontier, n_valid, cur_w, distinct, total_generated, n_levels, table_entries, trace_entries;
 };
@@ -2266,8 +2321,8 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   if (!f) return fail(VSRMC_E_CFG, "cannot write " + tmp);
   ChkHeader h;
   std::memset(&h, 0, sizeof(h));
-  std::memcpy(h.magic, "VSRMCCK2", 8);
-  const int32_t consts[8] = {M.R, M.C, M.n, M.L, c->model.symmetry, M.inv_mask, M.assume_commit, M.np};
+  std::memcpy(h.magic, "VSRMCCK3", 8);
+  const int32_t consts[12] = {M.R, M.C, M.n, M.L, c->model.symmetry, M.inv_mask, M.assume_commit, M.np, M.model_id, M.wpr, M.fixed, VSRMC_FP_VERSION};
   std::memcpy(h.consts, consts, sizeof(consts));
   h.level = c->level;
   h.shard = c->opt.world > 1 ? (c->opt.world << 16 | c->opt.rank) : 0;
@@ -2321,7 +2376,7 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
   FILE* f = std::fopen(path, "rb");
   if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + path);
   ChkHeader h;
-  bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VSRMCCK2", 8) == 0;
+  bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VSRMCCK3", 8) == 0;
   // header invariants (a truncated or foreign file must not become an inconsistent checker)
   if (ok) ok = h.level >= 1 && h.level < 511 && (u64)h.level == h.n_levels && h.n_valid <= h.n_frontier && h.trace_entries == 0;
   if (!ok) {
@@ -2329,10 +2384,10 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
     return fail(VSRMC_E_CFG, std::string(path) + " is not a (consistent) vsrmc checkpoint");
   }
   const Model& M = m->M;
-  const int32_t consts[8] = {M.R, M.C, M.n, M.L, m->symmetry, M.inv_mask, M.assume_commit, M.np};
+  const int32_t consts[12] = {M.R, M.C, M.n, M.L, m->symmetry, M.inv_mask, M.assume_commit, M.np, M.model_id, M.wpr, M.fixed, VSRMC_FP_VERSION};
   if (std::memcmp(h.consts, consts, sizeof(consts)) != 0) {
     std::fclose(f);
-    return fail(VSRMC_E_CFG, "the checkpoint was written for different model constants");
+    return fail(VSRMC_E_CFG, "the checkpoint was written for another module, other model constants or another fingerprint function");
   }
   if (h.shard != (o->world > 1 ? (o->world << 16 | o->rank) : 0)) {   // the seen-set is partitioned by owner_of(fp, world)
     std::fclose(f);

@@ -342,21 +342,43 @@ class ShardedChecker:
 
     def save(self, prefix):
         """Checkpoint between two levels (TLC: FPSet + StateQueue checkpoint, per worker): every rank writes its shard to
-        <prefix>.rank<r>of<w>, rank 0 the loop's own state to <prefix>.json.  Collective; -> None, raises on any rank's failure."""
+        <prefix>.rank<r>of<w>, rank 0 the loop's own state to <prefix>.json.  Collective; -> None, raises on any rank's failure.
+        Two phases, so that a failure on one rank cannot leave shards of different levels under one <prefix>.json: (1) every rank
+        writes its shard under a level-tagged name and the error codes are gathered — on any failure the tagged files are removed
+        and the previous checkpoint stays whole; (2) every rank renames its shard into place, the renames are gathered, and only
+        then rank 0 replaces <prefix>.json.  A crash inside phase 2 leaves new shards under the old json: restore() compares the
+        level every engine loaded with the json's and refuses."""
         import json
-        err = self.e.save("%s.rank%dof%d" % (prefix, self.rank, self.world))
-        if self.rank == 0 and not err:
+        final = "%s.rank%dof%d" % (prefix, self.rank, self.world)
+        tagged = "%s.L%d" % (final, self.level)
+        err = self.e.save(tagged)
+        worst = max(r[0] for r in self.x.allgather([err]))
+        if worst:
+            try:
+                os.remove(tagged)
+            except OSError:
+                pass
+            self._raise_if(worst, "checkpoint")
+        try:
+            os.replace(tagged, final)
+            err = 0
+        except OSError:
+            err = 1
+        if max(r[0] for r in self.x.allgather([err])):
+            raise ShardError("checkpoint: a rank could not move its shard into place; %s.json still names the previous checkpoint, "
+                             "whose shards may be gone" % prefix)
+        if self.rank == 0:
             tmp = prefix + ".json.tmp"
             with open(tmp, "w") as f:
                 json.dump(dict(world=self.world, level=self.level, distinct=self.distinct, n_frontier=self.n_frontier,
                                replicated=self.replicated, replicate_below=self.replicate_below, moved=self.moved), f)
             os.replace(tmp, prefix + ".json")
-        rows = self.x.allgather([err])
-        self._raise_if(max(r[0] for r in rows), "checkpoint")
+        self.x.barrier()
 
     @classmethod
     def restore(cls, prefix, make_engine, exchanger, balance_tol=1.25):
-        """Continue the run save() wrote: make_engine(path of this rank's shard file) -> engine.  Same world size."""
+        """Continue the run save() wrote: make_engine(path of this rank's shard file) -> engine.  Same world size.  Every engine
+        must have loaded the level <prefix>.json names (a crash inside save() can leave newer shards under an older json)."""
         import json
         with open(prefix + ".json") as f:
             d = json.load(f)
@@ -366,6 +388,9 @@ class ShardedChecker:
         self.e = make_engine("%s.rank%dof%d" % (prefix, exchanger.rank, exchanger.world))
         self.x = exchanger
         self.rank, self.world = exchanger.rank, exchanger.world
+        levels = [r[0] for r in self.x.allgather([int(self.e.loaded_level())])]
+        if any(l != d["level"] for l in levels):
+            raise ShardError("the shards under %s hold levels %s, %s.json names level %d: not one checkpoint" % (prefix, levels, prefix, d["level"]))
         self.level, self.distinct, self.n_frontier = d["level"], d["distinct"], d["n_frontier"]
         self.violation, self.levels = None, []
         self.balance_tol, self.moved = balance_tol, d["moved"]
@@ -454,6 +479,12 @@ class HipShardEngine:
 
     def reset(self):
         check(capi.load().vsrmc_checker_reset(self._h))
+
+    def loaded_level(self):
+        """the BFS level of the engine's newest frontier (after a recovery: the level the shard file held)"""
+        info = capi.LevelInfo()
+        check(capi.load().vsrmc_checker_status(self._h, C.byref(info)))
+        return int(info.level)
 
     def save(self, path):
         """this rank's shard (its part of the seen-set and of the newest level) between two levels -> error code"""
