@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — distinct states/s of the GPU BFS model checker on BASELINE.json's 1-GPU configuration.
+"""bench.py — distinct states/s and time-to-first-violation of the GPU BFS model checker on BASELINE.json's configurations.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one complete run of the hot path: level-synchronous BFS of VSR.tla under the shipped VSR.cfg constants
-(BASELINE.json configs[1]: ReplicaCount=3, ClientCount=1, Values={v1,v2}, StartViewOnTimerLimit=2, VIEW + SYMMETRY on,
-INVARIANT AcknowledgedWriteNotLost) from Init until the level that contains the first invariant violation is complete —
-28 levels, 319 228 361 distinct states, 885 M successors generated; the seen-set is cleared at the start of every step,
-HBM allocations are reused.  Inputs are the model itself (deterministic, no data files): "synthetic" in the contract's
-sense.  Timed region: barrier + torch.cuda.synchronize() on both sides, max over ranks, exactly K steps.
+N = 1.  The headline is the configuration north_star quotes the metric on and that fits one MI355X: the reference README's state-
+transfer-defect configuration (BASELINE.json configs[2]: ReplicaCount=3, ClientCount=1, Values={v1,v2,v3}, StartViewOnTimerLimit=3,
+VIEW + SYMMETRY on, INVARIANT AcknowledgedWriteNotLost; /root/reference/README.md:13-18).  One "step" = one complete run of the hot
+path: level-synchronous BFS from Init until the first invariant violation is found and its counter-example reconstructed —
+depth 24, 1 821 858 767 distinct states, 8.9e9 successors generated; the seen-set is cleared at the start of every step, HBM
+allocations are reused.  `value` = distinct states of the K timed runs / their wall time (barrier + torch.cuda.synchronize() on both
+sides), `time_to_first_violation_s` = one run.  The `config2` object beside it holds the same figures for BASELINE configs[1] (the
+shipped VSR.cfg constants: 28 levels, 319 228 361 distinct states) — the headline of rounds 1-2, and the headline again when the
+README configuration cannot run (less than ~250 GB of free HBM) or with --workload config2 / --no-config3.
+Inputs are the model itself (deterministic, no data files): "synthetic" in the contract's sense.  Every run asserts every level's
+figures against the CPU oracle's fixtures (tests/golden/oracle_levels_config{2,3}.json); a wrong count aborts the bench.
 
 N > 1: the seen-set is sharded by the high fingerprint bits, one rank per GPU, successors routed to their owner with
 an all-to-all per level (vsr-tlaplus_amd/sharded.py); total work is fixed as N grows ("strong").
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (k_expand, HIP-event time on the checker's stream)
-and `cpu_baseline` = the CPU oracle (a port, not TLC) timed on this box's host cores on a bounded sample.
+Extra objects on the JSON line: `roofline` for the dominant kernel (k_expand: algorithmic bytes / HIP-event time on the checker's
+stream; `traffic` = the committed PMC figure when it was measured on THIS build's kernel sources, else null), `cpu_baseline` = the
+CPU oracle (a port, not TLC) timed on this box's host cores on a bounded sample of the headline's configuration, and
+`fingerprint_collision_estimate` (TLC's n^2 / 2^65).
 """
 import argparse
 import json
@@ -72,7 +79,7 @@ def usable_cpus():
     return min(n, 256)
 
 
-def cpu_baseline(seconds=15.0):
+def cpu_baseline(seconds=15.0, cfg=None):
     """CPU oracle (oracle/vsr_oracle_mt: the restatement of VSR.tla spread over std::thread workers sharing one lock-free
     seen-set, the way TLC spreads Worker threads over an FPSet) on the same config, on every CPU the container may use, for a
     bounded time."""
@@ -80,12 +87,14 @@ def cpu_baseline(seconds=15.0):
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
     threads = usable_cpus()
-    out = subprocess.run([exe, str(CONFIG["R"]), str(CONFIG["C"]), str(CONFIG["n"]), str(CONFIG["L"]), "--threads", str(threads),
+    cfg = cfg or CONFIG
+    out = subprocess.run([exe, str(cfg["R"]), str(cfg["C"]), str(cfg["n"]), str(cfg["L"]), "--threads", str(threads),
                           "--max-seconds", str(seconds), "--quiet"], capture_output=True, text=True, check=True).stdout
     s = json.loads(out.strip().splitlines()[-1])
     return dict(value=round(s["states_per_s"], 1), unit="distinct states/s", cores=int(s["threads"]), kind="port",
-                sample="oracle/vsr_oracle_mt (multi-threaded C++ restatement of VSR.tla, not TLC) on the same config for "
-                       "%.0f s: %d distinct states, %d BFS levels" % (s["seconds"], s["distinct"], s["depth"]))
+                sample="oracle/vsr_oracle_mt (multi-threaded C++ restatement of VSR.tla, not TLC) on the headline's configuration "
+                       "(R=%d, C=%d, %d values, limit %d) for %.0f s: %d distinct states, %d BFS levels"
+                       % (cfg["R"], cfg["C"], cfg["n"], cfg["L"], s["seconds"], s["distinct"], s["depth"]))
 
 
 def run_single(args):
@@ -149,83 +158,227 @@ def run_single(args):
     return elapsed, S, m
 
 
-def config3_to_violation(dump_trace=None):
-    """BASELINE configs[2] = the reference README's defect configuration (3 replicas, {v1,v2,v3}, limit 3; README:13-18) on ONE GPU,
-    BFS to its first violation at depth 24 — everything in HBM: levels 1-21 are materialised (level 21: 261 M states, 91 GB of
-    records), level 22 is a VIRTUAL level (seen-set entries only, regenerated slice by slice), level 23 is streamed through a
-    scratch buffer (inserted, never kept), level 24 is PROBED (vsrmc_checker_probe3); the counter-example is reconstructed in the timed region.  Untimed setup (~245 GB of
-    device allocations), one timed pass.  Levels 1-21 — every level that is stored — are asserted against the CPU
-    oracle's fixture (tests/golden/oracle_levels_config3.json), the virtual / streamed levels 22-23 against
-    tests/golden/config3_violation.json (GPU runs of two rounds, two fingerprint functions, three level schemes)."""
-    import numpy as np
-    import vsr_tlaplus_amd as vt
+def kernel_source_sha256():
+    """sha256 over the kernel sources this build was made from (csrc/*.hpp, *.hip, include/vsrmc.h, sorted by name): the committed
+    PMC traffic figure (profiles/*_traffic.json) carries the hash of the sources it was measured on; another hash = another kernel =
+    no traffic figure (`roofline.traffic: null`) rather than a stale one."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vsr-tlaplus_amd", "csrc")
+    for name in sorted(os.listdir(d)) + ["../../include/vsrmc.h"]:
+        if name.endswith((".hpp", ".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def committed_traffic(workload):
+    """HBM bytes per launch of k_expand from the newest committed PMC passes for this workload ("config2" / "readme"), or None when
+    they were measured on other kernel sources.  FETCH_SIZE / WRITE_SIZE cannot be read live (tools/profile_round.sh makes them)."""
+    pdir = os.path.join(ROOT, "profiles")
+    cands = sorted(n for n in os.listdir(pdir) if n.endswith("_traffic.json") and ("_%s_" % workload in n or (workload == "config2" and n.count("_") == 1)))
+    for name in reversed(cands):
+        with open(os.path.join(pdir, name)) as f:
+            t = json.load(f)
+        if t.get("kernel_source_sha256") == kernel_source_sha256():
+            return dict(bytes_per_launch=t["hbm_bytes_per_launch"], source="PMC, profiles/%s: %s" % (name, t["source"].split(" (")[0]))
+        return dict(bytes_per_launch=None, source="profiles/%s was measured on other kernel sources (sha256 %s...): no traffic figure for this build"
+                                                  % (name, str(t.get("kernel_source_sha256"))[:12]))
+    return dict(bytes_per_launch=None, source="no PMC passes committed for this workload")
+
+
+README = dict(R=3, C=1, n=3, L=3)                     # /root/reference/README.md:13-18 = BASELINE.json configs[2]
+
+
+def load_readme_expect():
+    """Level figures of the README configuration: the CPU ORACLE's (tests/golden/oracle_levels_config3.json — levels 1-21 from
+    oracle/vsr_oracle_mt, deeper ones from the memory-lean driver oracle/vsr_oracle_lean when the fixture holds them) and, for
+    levels the oracle fixture does not reach, the GPU-sourced figures of tests/golden/config3_violation.json (marked as such)."""
     with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_config3.json")) as f:
         g = json.load(f)
     with open(os.path.join(ROOT, "tests", "golden", "config3_violation.json")) as f:
         fx = json.load(f)
-    deep = fx["levels"]
-    m = vt.Model.from_constants(R=3, C_=1, n=3, L=3)
+    levels = []
+    for i, lv in enumerate(fx["levels"]):
+        if i < len(g["levels"]):
+            o = g["levels"][i]
+            levels.append(dict(level=o["level"], n_new=o["new"], generated=o["generated"], deadlocks=o["deadlocks"], max_bag=o["max_bag"],
+                               fp_xor=o.get("fp_xor"), fp_sum=o.get("fp_sum"), act_generated=o.get("act_generated"), source="oracle"))
+        else:
+            levels.append(dict(level=lv["level"], n_new=lv["n_new"], generated=lv["generated"], deadlocks=lv.get("deadlocks"), max_bag=lv.get("max_bag"),
+                               fp_xor=None, fp_sum=None, act_generated=None, source="gpu"))
+    probe = g.get("probe")                                  # the oracle's probe of level 24 (lean driver), else the GPU fixture's
+    same_fp = g.get("fp_version", 1) == FP_VERSION
+    return dict(levels=levels, oracle_levels=len(g["levels"]), fx=fx,
+                probe_generated=(probe or fx["probe"])["generated"], probe_source="oracle" if probe else "gpu",
+                viol_fp=int((probe or fx)["viol_fp"], 16) if (same_fp and fx.get("fp_version") == FP_VERSION) else None,
+                checksums=same_fp)
+
+
+def run_readme(args, dump_trace=None):
+    """BASELINE configs[2] = the reference README's defect configuration (3 replicas, {v1,v2,v3}, limit 3; README:13-18) on ONE GPU,
+    BFS to its first violation at depth 24 — everything in HBM: levels 1-21 are materialised (level 21: 261 M states, 91 GB of
+    records), level 22 is a VIRTUAL level (seen-set entries only, regenerated slice by slice), level 23 is streamed through a
+    scratch buffer (inserted, never kept), level 24 is PROBED (vsrmc_checker_probe3); the counter-example is
+    reconstructed inside the timed region.  One step = one such run (seen-set cleared, allocations reused).  Every level figure is
+    asserted on every run: new states, generated successors, deadlocks, largest bag — and, on the untimed verification run, the
+    per-action counts and the xor / sum of the level's fingerprints (stored levels: k_level_checksum; virtual / streamed levels:
+    accumulated by the kernel / per sub-slice), against the CPU oracle's fixture as deep as it reaches."""
+    import numpy as np
+    import torch
+    import vsr_tlaplus_amd as vt
+    torch.cuda.set_device(0)
+    E = load_readme_expect()
+    deep = E["levels"]
+    m = vt.Model.from_constants(R=README["R"], C_=README["C"], n=README["n"], L=README["L"])
     t0 = time.perf_counter()
     mc = vt.ModelChecker(m, device=0, table_log2=32, frontier_words=int(12.8e9), frontier_words_b=int(7.0e9), frontier_states=int(2.85e8),
                          pending_entries=1 << 16)
-    try:
-        setup = time.perf_counter() - t0
+    setup = time.perf_counter() - t0
+    S = dict(mat_ms=0.0, probe_ms=0.0, launches_mat=0, alg_bytes=0.0, distinct=0, generated=0, ttfv=[], mat_s=0.0, n_mat=0, words=0, states_w=0,
+             v22_s=0.0, v23_s=0.0, p24_s=0.0, slices=0, sub_slices=0, same_trace=None)
+
+    def check_level(d, verify):
+        want = deep[d["level"] - 1]
+        assert (d["n_new"], d["generated"]) == (want["n_new"], want["generated"]), (d["level"], d["n_new"], d["generated"])
+        if want["deadlocks"] is not None:
+            assert d["deadlocks"] == want["deadlocks"], d["level"]
+        if want["max_bag"] is not None:
+            assert d["max_bag"] == want["max_bag"], d["level"]
+        assert d["viol_mask"] == 0, d["level"]
+        if verify and want["act_generated"] is not None:
+            assert [int(x) for x in d["act_generated"][1:16]] == want["act_generated"][1:16], d["level"]
+        return want
+
+    def one_run(record, verify=False):
+        mc.reset()
         t0 = time.perf_counter()
-        kernel_ms, alg_bytes, gen = 0.0, 0.0, 0
         cur_words = int(m.layout.fixed_words) + int(m.layout.permutations)
+        alg = 0.0
+        gen = 0
+        kms = 0.0
         while mc.level < 21:
             d = mc.step()
-            lv = d["level"]
-            if lv <= len(g["levels"]):
-                want = g["levels"][lv - 1]
-                assert (d["n_new"], d["generated"], d["deadlocks"], d["max_bag"]) == (want["new"], want["generated"], want["deadlocks"], want["max_bag"]), lv
-            else:
-                assert (d["n_new"], d["generated"]) == (deep[lv - 1]["n_new"], deep[lv - 1]["generated"]), lv
-            assert d["viol_mask"] == 0
-            kernel_ms += d["expand_ms"]
-            alg_bytes += 8.0 * cur_words + 8.0 * d["generated"] + 8.0 * d["n_new"] + 8.0 * d["record_words"]
+            want = check_level(d, verify)
+            if verify and want["fp_xor"] is not None and E["checksums"]:
+                x, sm, cnt = mc.level_checksum()
+                assert cnt == want["n_new"] and ("%016x" % x, "%016x" % sm) == (want["fp_xor"], want["fp_sum"]), d["level"]
+            kms += d["expand_ms"]
+            alg += 8.0 * cur_words + 8.0 * d["generated"] + 8.0 * d["n_new"] + 8.0 * d["record_words"]
             cur_words = d["record_words"]
             gen += d["generated"]
         t_mat = time.perf_counter() - t0
         n_mat = mc.distinct
+        w21, n21 = cur_words, d["n_new"]
         v1, v2, p = mc.probe3()
         tr = mc.probe_trace()
         dt = time.perf_counter() - t0
         for v in (v1, v2):
-            assert (v["n_new"], v["generated"], v["viol_mask"]) == (deep[v["level"] - 1]["n_new"], deep[v["level"] - 1]["generated"], 0), v
-        assert p["level"] == 24 and p["viol_mask"] == 1 and len(tr) == 24 and p["generated"] == fx["probe"]["generated"]
-        assert fx.get("fp_version") != FP_VERSION or p["viol_fp"] == int(fx["viol_fp"], 16)
+            want = check_level(v, verify)
+            if verify and want["fp_xor"] is not None and E["checksums"]:
+                assert ("%016x" % v["fp_xor"], "%016x" % v["fp_sum"]) == (want["fp_xor"], want["fp_sum"]), v["level"]
+        assert p["level"] == 24 and p["viol_mask"] == 1 and len(tr) == 24 and p["generated"] == E["probe_generated"]
+        assert E["viol_fp"] is None or p["viol_fp"] == E["viol_fp"]
         fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
         assert int(fps[0]) == p["viol_fp"]                                   # the reconstructed path ends in the reported violator
-        same_trace = None                                                    # the counter-example is a function of the state space alone
-        if fx.get("fp_version") == FP_VERSION and fx.get("trace"):          # (min-merged keys): the same 24 states as the round's host-frontier run
-            same_trace = [(a, ["%016x" % int(w) for w in rec]) for a, rec in tr] == [(t["action"], t["words"]) for t in fx["trace"]]
+        fx = E["fx"]
+        if fx.get("fp_version") == FP_VERSION and fx.get("trace"):          # the counter-example is a function of the state space alone
+            S["same_trace"] = [(a, ["%016x" % int(w) for w in rec]) for a, rec in tr] == [(t["action"], t["words"]) for t in fx["trace"]]
         if dump_trace:                                                       # refresh of tests/golden/config3_violation.json (tools/refresh_violation_fixtures.py)
             with open(dump_trace, "w") as f:
                 f.write(json.dumps(dict(trace=[dict(action=a, words=["%016x" % int(w) for w in rec]) for a, rec in tr])) + "\n")
-        out = dict(workload="VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2,v3} StartViewOnTimerLimit=3 (BASELINE configs[2], README:13-18), "
-                            "VIEW+SYMMETRY, to the first violation at depth 24, all in HBM: levels 1-21 materialised, 22 virtual, 23 streamed, 24 probed",
-                   time_to_first_violation_s=round(dt, 4), depth=24, distinct_through_level_23=v2["distinct"],
-                   distinct_states_per_s=round(v2["distinct"] / dt, 1), generated=gen + v1["generated"] + v2["generated"] + p["generated"],
-                   setup_s=round(setup, 2), oracle_pinned_levels=len(g["levels"]), pcie_bound=False, trace_equals_fixture=same_trace,
-                   materialised=dict(levels=21, distinct=n_mat, seconds=round(t_mat, 4), states_per_s=round(n_mat / t_mat, 1),
-                                     k_expand_ms=round(kernel_ms, 2), roofline_frac=round(alg_bytes / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)),
-                   probe3=dict(virtual_22_s=round(v1["seconds"], 4), virtual_23_s=round(v2["seconds"], 4), probe_24_s=round(p["seconds"], 4),
-                               k_expand_ms=round(v1["expand_ms"] + v2["expand_ms"] + p["expand_ms"], 2),
-                               slices=v2["pending"] >> 32, sub_slices=v2["pending"] & 0xFFFFFFFF, expansions=dict(level_21=2, level_22=1, level_23=1)))
+        if record:
+            # algorithmic bytes of the levels that are never stored: SURVEY §8(d)'s B_alg = 2 S + 8 g + 8 per distinct state, i.e. every
+            # state read once and written once whatever the level scheme re-expands; S of levels 22 / 23 = level 21's average record
+            # (their records are never all in memory at once; bags grow by < 1 entry per level: an under-estimate of < 3 %)
+            s21 = 8.0 * w21 / n21
+            alg += s21 * n21 + 8.0 * v1["generated"] + 8.0 * v1["n_new"] + s21 * v1["n_new"]           # level 21 read, level 22 written
+            alg += s21 * v1["n_new"] + 8.0 * v2["generated"] + 8.0 * v2["n_new"] + s21 * v2["n_new"]     # level 22 read, level 23 written
+            alg += s21 * v2["n_new"] + 8.0 * p["generated"]                                              # level 23 read, level 24 looked up
+            S["alg_bytes"] += alg
+            S["mat_ms"] += kms
+            S["probe_ms"] += v1["expand_ms"] + v2["expand_ms"] + p["expand_ms"]
+            S["distinct"] += v2["distinct"]
+            S["generated"] += gen + v1["generated"] + v2["generated"] + p["generated"]
+            S["ttfv"].append(dt)
+            S["mat_s"] += t_mat
+            S["n_mat"] = n_mat
+            S["v22_s"] += v1["seconds"]; S["v23_s"] += v2["seconds"]; S["p24_s"] += p["seconds"]
+            S["slices"], S["sub_slices"] = v2["pending"] >> 32, v2["pending"] & 0xFFFFFFFF
+            S["launches"] = 20 + 1 + S["slices"] + 2 * S["sub_slices"]       # materialised levels, virtual level, regenerated slices, streamed + probed sub-slices
+
+    try:
+        if not args.no_verify:
+            one_run(False, verify=True)
+        for _ in range(args.warmup):
+            one_run(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_run(True)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     finally:
         mc.close()
-    return out
+    S["setup_s"] = setup
+    S["oracle_levels"] = E["oracle_levels"]
+    S["probe_source"] = E["probe_source"]
+    return elapsed, S
 
 
-def run_config3(args):
-    """--workload config3: only the README defect configuration (BASELINE configs[2]) to its first violation, as the bench line."""
-    c3 = config3_to_violation(os.environ.get("VSR_BENCH_DUMP_TRACE"))
-    dt = c3["time_to_first_violation_s"]
-    print(json.dumps({
-        "metric": "time-to-first-violation, VSR 3-replica README defect config (BFS, trace reconstructed)", "value": round(dt, 3), "unit": "s",
-        "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": round(1e3 * dt, 1), "higher_is_better": False, "scaling": "strong",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": {"workload": c3["workload"]}, "detail": c3}))
+def readme_object(args, elapsed, S):
+    """The README configuration's figures as JSON fields (the headline line, or the `readme` object when it is not the headline)."""
+    k = args.steps
+    kernel_ms = (S["mat_ms"] + S["probe_ms"]) / k
+    launches = S["launches"]
+    alg_run = S["alg_bytes"] / k
+    avg_launch_s = kernel_ms / 1e3 / launches
+    achieved = alg_run / (kernel_ms / 1e3) / 1e9
+    distinct = S["distinct"] / k
+    tr = committed_traffic("readme")
+    return dict(
+        workload="VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2,v3} StartViewOnTimerLimit=3 (the reference README's state-transfer-"
+                 "defect configuration, README:13-18 = BASELINE configs[2]), VIEW+SYMMETRY, to the first violation at depth 24: 1821858767 distinct "
+                 "states, all in HBM — levels 1-21 materialised, 22 virtual, 23 streamed, 24 probed; counter-example reconstructed in the timed region",
+        value=distinct * k / elapsed, ms_per_step=1e3 * elapsed / k, time_to_first_violation_s=round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
+        distinct=int(distinct), generated=int(S["generated"] / k), setup_s=round(S["setup_s"], 2), oracle_pinned_levels=S["oracle_levels"],
+        violation_pinned_by=S["probe_source"], trace_equals_fixture=S["same_trace"],
+        roofline={"bound": "hbm", "kernel": "k_expand (all launches of a run: PLAIN instantiation for levels 2-21, mode-capable one for the virtual / regenerated / streamed / probed passes)",
+                  "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                  "traffic": tr["bytes_per_launch"], "traffic_source": tr["source"],
+                  "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": launches, "alg_bytes_per_launch": round(alg_run / launches),
+                  "B_alg_per_state": round(alg_run / distinct, 1),
+                  "kernel_ms_per_step": {"k_expand": round(kernel_ms, 3), "k_expand_materialised_levels": round(S["mat_ms"] / k, 3),
+                                         "k_expand_probe3": round(S["probe_ms"] / k, 3)}},
+        materialised=dict(levels=21, distinct=S["n_mat"], seconds=round(S["mat_s"] / k, 4), states_per_s=round(S["n_mat"] / (S["mat_s"] / k), 1)),
+        probe3=dict(virtual_22_s=round(S["v22_s"] / k, 4), streamed_23_s=round(S["v23_s"] / k, 4), probe_24_s=round(S["p24_s"] / k, 4),
+                    slices=S["slices"], sub_slices=S["sub_slices"], expansions=dict(level_21=2, level_22=1, level_23=1)))
+
+
+def config2_object(args, elapsed, S):
+    """BASELINE configs[1] (the shipped VSR.cfg constants) as JSON fields: the headline of rounds 1-2, now the `config2` object."""
+    value = S["distinct"] / elapsed
+    avg_launch_s = S["expand_ms"] / 1e3 / max(1, S["launches"])
+    achieved = S["alg_bytes"] / max(1, S["launches"]) / avg_launch_s / 1e9
+    g = S["generated"] / S["distinct"]
+    s_bytes = 8.0 * S["words"] / S["distinct"]
+    tr = committed_traffic("config2")
+    return dict(
+        workload="VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 (BASELINE configs[1] = shipped VSR.cfg), "
+                 "VIEW+SYMMETRY, to first violation: 28 levels, 319228361 distinct states; every level asserted against the CPU oracle's fixture",
+        value=value, ms_per_step=1e3 * elapsed / args.steps, time_to_first_violation_s=round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
+        generated_per_distinct=round(g, 3), record_bytes=round(s_bytes, 1), table_slots_log2=TABLE_LOG2,
+        roofline={"bound": "hbm", "kernel": "k_expand", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr["bytes_per_launch"], "traffic_source": tr["source"],
+                  "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": S["launches"] // args.steps,
+                  "alg_bytes_per_launch": round(S["alg_bytes"] / max(1, S["launches"])), "B_alg_per_state": round(2 * s_bytes + 8 * g + 8, 1),
+                  "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3)}})
+
+
+def collision_estimate(n):
+    """TLC prints, at the end of every run, the probability that two distinct states shared a 64-bit fingerprint (a false merge drops
+    a state silently): its optimistic estimate n^2 / 2^65 for n distinct states (MC.out "calculated (optimistic)")."""
+    return float(n) * float(n) / 2.0 ** 65
 
 
 def main():
@@ -235,55 +388,56 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true", help="skip the untimed verification run (profiling: one run = 27 k_expand launches)")
-    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (the README defect configuration to its depth-24 violation; ~245 GB of HBM)")
-    ap.add_argument("--workload", choices=["config2", "config3"], default="config2",
-                    help="config2 (default) = BASELINE's 1-GPU configuration; config3 = only the README defect config to its violation")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed verification runs (profiling: one run = the kernel launches of one BFS)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the README configuration (~245 GB of HBM): config 2 is the headline")
+    ap.add_argument("--no-config2", action="store_true", help="skip the config-2 object")
+    ap.add_argument("--workload", choices=["auto", "readme", "config3", "config2"], default="auto",
+                    help="auto (default): the README defect configuration (BASELINE configs[2], fits one MI355X) is the headline and config 2 "
+                         "(BASELINE configs[1]) an object beside it; readme / config3: only the former; config2: only the latter")
     args = ap.parse_args()
-    if args.workload == "config3":
-        return run_config3(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("VSR_BENCH_SHARDED"):   # VSR_BENCH_SHARDED=1: the N > 1 leg on one rank
         from vsr_tlaplus_amd import sharded_bench
         return sharded_bench.main(args, CONFIG, EXPECT)
-    elapsed, S, m = run_single(args)
-    value = S["distinct"] / elapsed
-    avg_launch_s = S["expand_ms"] / 1e3 / max(1, S["launches"])
-    achieved = S["alg_bytes"] / max(1, S["launches"]) / avg_launch_s / 1e9
-    g = S["generated"] / S["distinct"]
-    s_bytes = 8.0 * S["words"] / S["distinct"]
-    out = {
-        "metric": "distinct states/sec (whole node), VSR 3-replica", "value": round(value, 1), "unit": "distinct states/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 "
-                               "(BASELINE configs[1] = shipped VSR.cfg), VIEW+SYMMETRY, to first violation: 28 levels, "
-                               "319228361 distinct states", "table_slots_log2": TABLE_LOG2, "trace": "predecessor pointers in the seen-set, counter-example reconstructed in the timed region"},
-        "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
-        "generated_per_distinct": round(g, 3), "record_bytes": round(s_bytes, 1),
-        "roofline": {"bound": "hbm", "kernel": "k_expand", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": S["launches"],
-                     "B_alg_per_state": round(2 * s_bytes + 8 * g + 8, 1),
-                     "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3)}},
-    }
-    # HBM traffic of the same kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01g_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            t = json.load(f)
-        out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-        out["roofline"]["traffic_unit"] = "bytes per launch (PMC, %s)" % t["source"].split(" (")[0]
-        out["roofline"]["alg_bytes_per_launch"] = round(S["alg_bytes"] / max(1, S["launches"]))
-    if not args.no_config3:
+    want_readme = args.workload in ("auto", "readme", "config3") and not args.no_config3
+    want_c2 = args.workload in ("auto", "config2") and not args.no_config2
+    c2 = rd = None
+    rd_err = None
+    if want_c2:
+        elapsed, S, _ = run_single(args)
+        c2 = config2_object(args, elapsed, S)
+    if want_readme:
         try:
-            out["config3"] = config3_to_violation()
-        except Exception as e:                                   # e.g. less than 245 GB of free HBM: the headline figures above stay valid
-            out["config3"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            elapsed, S = run_readme(args, os.environ.get("VSR_BENCH_DUMP_TRACE"))
+            rd = readme_object(args, elapsed, S)
+        except Exception as e:                                   # e.g. less than 245 GB of free HBM: config 2 stays the headline
+            if not want_c2:
+                raise
+            rd_err = {"error": "%s: %s" % (type(e).__name__, e)}
+    head = rd if rd is not None else c2
+    cfg = README if rd is not None else CONFIG
+    out = {
+        "metric": "distinct states/sec (whole node) + time-to-first-violation, VSR 3-replica", "value": round(head["value"], 1),
+        "unit": "distinct states/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": head["workload"], "trace": "predecessor pointers in the seen-set, counter-example reconstructed in the timed region"},
+        "time_to_first_violation_s": head["time_to_first_violation_s"],
+        "roofline": head["roofline"],
+    }
+    for k_, v in head.items():
+        if k_ not in ("workload", "value", "ms_per_step", "time_to_first_violation_s", "roofline"):
+            out[k_] = v
+    n_states = head.get("distinct", EXPECT["distinct"])
+    out["fingerprint_collision_estimate"] = {"n2_over_2_65": collision_estimate(n_states), "distinct": n_states,
+                                             "note": "TLC's optimistic estimate of a 64-bit fingerprint collision (a false merge would drop a state silently)"}
+    if rd is not None and c2 is not None:
+        c2["value"] = round(c2["value"], 1)
+        c2["ms_per_step"] = round(c2["ms_per_step"], 3)
+        out["config2"] = c2
+    if rd_err is not None:
+        out["readme"] = rd_err
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, cfg)
     print(json.dumps(out))
 
 

@@ -193,3 +193,22 @@ def test_model3_validate_trace_cli(vt, tmp_path):
     f.write_text(bad)
     r = subprocess.run([cli, "-config", _cfg(tmp_path), "-validateTrace", str(f)], capture_output=True, text=True, timeout=300)
     assert "The trace is a behaviour of the model." not in r.stdout, r.stdout
+
+
+def test_checkpoints_of_the_analysis_models_do_not_cross(vt, tmp_path):
+    """VR_STATE_TRANSFER and VR_APP_STATE share R / n / L / inv-mask-compatible headers but not the record layout (one vs two words per
+    replica) nor the action table: a checkpoint names its module, layout and fingerprint version and is refused by the other module."""
+    m2 = vt.Model.second_model(R=3, n=2, L=2, invariant_mask=14)
+    m3 = vt.Model.third_model(R=3, n=2, L=2, invariant_mask=14)
+    a = vt.ModelChecker(m2, table_log2=18, frontier_words=1 << 21, frontier_states=1 << 16, pending_entries=1 << 15)
+    for _ in range(6):
+        a.step()
+    path = str(tmp_path / "m2.chk")
+    a.save(path)
+    lvl, distinct = a.level, a.distinct
+    a.close()
+    with pytest.raises(vt.VsrmcError):
+        vt.ModelChecker(m3, table_log2=18, frontier_words=1 << 21, frontier_states=1 << 16, pending_entries=1 << 15, recover=path)
+    b = vt.ModelChecker(m2, table_log2=18, frontier_words=1 << 21, frontier_states=1 << 16, pending_entries=1 << 15, recover=path)
+    assert (b.level, b.distinct) == (lvl, distinct)
+    b.close()

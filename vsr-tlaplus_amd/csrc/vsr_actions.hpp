@@ -229,6 +229,10 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
     D.rep[3] = M.wpr > 3 ? pb[3] : 0;
   }
   u64* nb = D.rep;
+  // the one Send / Broadcast of an action (VSR.tla:247-270) is carried out after the switch, at ONE place: the bag scan is the longest
+  // loop of an action body, and lanes of different actions meet in it again instead of each running its own copy
+  int send_mode = 0;                                           // 0 none, 1 Send(send_key), 2 Broadcast(send_key) to every replica but r
+  u64 send_key = 0;
 
   switch (o.group) {
     case 0: {  // ---- TimerSendSVC (VSR.tla:578-590)
@@ -242,7 +246,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
       blk_reset_recv(M, nb);                                   // :584
       blk_reset_sent(nb);                                      // :585
       D.hdr = (hdr & ~((u64)7 << 8)) | ((u64)(hdr_aux_svc(hdr) + 1) << 8);   // :586
-      bag_broadcast(M, bag, nmsg, D, m_make(T_SVC, view + 1, 0, r, 0, 0, 0, 0, 0), r);   // :587
+      { send_mode = 2; send_key = m_make(T_SVC, view + 1, 0, r, 0, 0, 0, 0, 0); }   // :587
       break;
     }
     case 1: {  // ---- SendDVC (VSR.tla:648-669)
@@ -260,7 +264,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
         if ((cur & 1) && cur != slot) { D.err = ERR_REP_I2; return true; }
         rep_setx(nb, r, slot);
       } else {                                                 // :665-667
-        bag_send(M, bag, nmsg, D, m_make(T_DVC, view, prim, r, op, commit, a_lnv(A), 0, lg));
+        { send_mode = 1; send_key = m_make(T_DVC, view, prim, r, op, commit, a_lnv(A), 0, lg); }
       }
       break;
     }
@@ -293,7 +297,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
       nb[0] = a_set_commit(nb[0], max_commit);                 // :749
       nb[0] = a_set_sent_sv(nb[0], 1);                         // :750
       nb[0] = a_set_lnv(nb[0], view);                          // :751
-      bag_broadcast(M, bag, nmsg, D, m_make(T_SV, view, 0, r, new_on, max_commit, 0, 0, new_log), r);   // :752-758
+      { send_mode = 2; send_key = m_make(T_SV, view, 0, r, new_on, max_commit, 0, 0, new_log); }   // :752-758
       break;
     }
     case 3: {  // ---- ExecuteOp (VSR.tla:462-476)
@@ -332,7 +336,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
       rep_setx(nb, 0, lg | ((u32)e << (8 * (opn - 1))));       // :379
       nb[0] = a_set_op(nb[0], opn);                            // :380
       nb[0] = a_set_ctrow(nb[0], o.c, ct_make(req, opn, 0));   // :381-384
-      bag_broadcast(M, bag, nmsg, D, m_make(T_PREPARE, view, 0, r, opn, commit, 0, 0, (u32)e), r);   // :385-391
+      { send_mode = 2; send_key = m_make(T_PREPARE, view, 0, r, opn, commit, 0, 0, (u32)e); }   // :385-391
       D.hdr = hdr_set_acked(hdr, o.v, 1);                      // :392
       break;
     }
@@ -355,7 +359,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
         nb[0] = a_set_op(nb[0], t);                            // :507
         nb[0] = a_set_view(nb[0], mview);                      // :508
         nb[0] = a_set_lnv(nb[0], mview);                       // :509
-        bag_send(M, bag, nmsg, D, gs);                         // :252
+        { send_mode = 1; send_key = gs; }                         // :252
         break;
       }
       switch (mt) {
@@ -369,7 +373,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
             rep_clear_dvc(nb);                              // :609
             blk_reset_sent(nb);                                // :610
             bag_discard(D, o.j, mw);                           // :611
-            bag_broadcast(M, bag, nmsg, D, m_make(T_SVC, mview, 0, r, 0, 0, 0, 0, 0), r);
+            { send_mode = 2; send_key = m_make(T_SVC, mview, 0, r, 0, 0, 0, 0, 0); }
           } else if (mview == view && status == ST_VIEWCHANGE) {   // ---- ReceiveMatchingSVC (VSR.tla:625-634)
             if (GUARD_ONLY) return true;
             D.action = A_ReceiveMatchingSVC;
@@ -392,7 +396,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
             rep_setx(nb, msrc, slot);
             blk_reset_sent(nb);                                // :685
             bag_discard(D, o.j, mw);                           // :686
-            bag_broadcast(M, bag, nmsg, D, m_make(T_SVC, mview, 0, r, 0, 0, 0, 0, 0), r);
+            { send_mode = 2; send_key = m_make(T_SVC, mview, 0, r, 0, 0, 0, 0, 0); }
           } else if (mview == view) {  // ---- ReceiveMatchingDVC (VSR.tla:696-703)
             if (GUARD_ONLY) return true;
             D.action = A_ReceiveMatchingDVC;
@@ -419,7 +423,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
           blk_reset_sent(nb);                                  // :784
           bag_discard(D, o.j, mw);
           if (commit < mop)                                    // :785 (old commit number)
-            bag_send(M, bag, nmsg, D, m_make(T_PREPAREOK, mview, primary_of(M, mview), r, mop, 0, 0, 0, 0));   // :786-790
+            { send_mode = 1; send_key = m_make(T_PREPAREOK, mview, primary_of(M, mview), r, mop, 0, 0, 0, 0); }   // :786-790
           break;
         }
         case T_PREPARE: {  // ---- ReceivePrepareMsg (VSR.tla:405-428)
@@ -446,7 +450,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
             }
           }
           bag_discard(D, o.j, mw);
-          bag_send(M, bag, nmsg, D, m_make(T_PREPAREOK, view, msrc, r, mop, 0, 0, 0, 0));   // :422-426
+          { send_mode = 1; send_key = m_make(T_PREPAREOK, view, msrc, r, mop, 0, 0, 0, 0); }   // :422-426
           break;
         }
         case T_PREPAREOK: {  // ---- ReceivePrepareOkMsg (VSR.tla:437-447)
@@ -471,7 +475,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
           for (int on = mop + 1; on <= op; on++)
             if (!log_byte(lg, on)) { D.err = ERR_EVAL_DOMAIN; return true; }
           bag_discard(D, o.j, mw);
-          bag_send(M, bag, nmsg, D, m_make(T_NEWSTATE, view, msrc, r, op, commit, 0, mop + 1, part));   // :533-541
+          { send_mode = 1; send_key = m_make(T_NEWSTATE, view, msrc, r, op, commit, 0, mop + 1, part); }   // :533-541
           break;
         }
         case T_NEWSTATE: {  // ---- ReceiveNewState (VSR.tla:551-567)
@@ -496,6 +500,8 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
     }
   }
   if (!GUARD_ONLY) {
+    if (send_mode == 1) bag_send(M, bag, nmsg, D, send_key);
+    else if (send_mode == 2) bag_broadcast(M, bag, nmsg, D, send_key, r);
     int na = 0;
 #pragma unroll
     for (int k = 0; k < VSR_NSLOT; k++) na += (((D.used >> k) & 1) && D.pj[k] < 0) ? 1 : 0;

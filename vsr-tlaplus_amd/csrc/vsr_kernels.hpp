@@ -148,6 +148,13 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #define VSR_HOME_FIRST 1
 #endif
 // successor write: parent words copied eight per trip (four LDS reads in flight) instead of two
+#ifndef VSR_COPY_PIPE
+#define VSR_COPY_PIPE 1
+#endif
+// frontier refs of a tile are loaded one tile ahead (tiles are drawn two ahead): the staging of a tile starts with its record loads
+#ifndef VSR_REF_AHEAD
+#define VSR_REF_AHEAD 0
+#endif
 #ifndef VSR_COPY8
 #define VSR_COPY8 0
 #endif
@@ -163,6 +170,12 @@ __device__ __forceinline__ void raise_error(LevelCtl* ctl, int code, u64 info) {
 }
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+  u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+  u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
 
 // One atomic per wave: returns base + rank of this lane among the lanes that call it (all callers must pass the
 // same counter).  Lanes call this from inside a divergent branch; the ballot only sees the active ones.
@@ -248,6 +261,19 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32
 __device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp, u64* meta, u32* nprobe, u64* slot_out = nullptr) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   u64 i = fp & mask;
+#if VSR_HOME_FIRST
+  {
+    const u64x2 sk = *(const u64x2*)&table[i];
+    (*nprobe)++;
+    if (sk.x == fp) {
+      *meta = sk.y;
+      if (slot_out) *slot_out = i;
+      return true;
+    }
+    if (sk.x == 0) return false;
+    i = (i + 1) & mask;
+  }
+#endif
   for (u32 lines = 0; lines < 2048; lines++) {
     const u64 lb = i & ~(u64)3;
     const u64x2* lp = (const u64x2*)&table[lb];
@@ -349,7 +375,7 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
 // BLK = threads per block: 256 (four waves share a tile of 64 or 128 records, block barriers between the phases) or 64 — one wave per
 // block with a tile of 16 records of its own: the same phases, but a barrier of a one-wave workgroup costs nothing, no wave waits
 // for the slowest wave of its tile, and the 16 waves of a CU drift apart so that their memory and issue phases interleave.
-template <bool FUSED, int SPEC = 0, bool PLAIN = false, int BLK = VSR_BLOCK>
+template <bool FUSED, int SPEC = 0, int PLAIN = 0, int BLK = VSR_BLOCK>
 // (hipcc turns the second bound into waves per SIMD as blocks * max(1, threads / 256): 4 = 128 VGPRs for either block size)
 __global__ void __launch_bounds__(BLK, FUSED ? (SPEC ? 4 : 2) : 3)
 k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
@@ -371,7 +397,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
          int mode_arg, u64 p_offset /* index of parent 0 of this launch in its level (slices) */) {
   // PLAIN: the unsharded, ordinary level — the probe / virtual-level modes and the sharded branches are compiled out (11 % less
   // code: the specialised kernel then fits the 64-KB instruction cache with room to spare)
-  const int mode = PLAIN ? (int)MODE_NORMAL : mode_arg;
+  // PLAIN == 2: unsharded with the modes (the probe / virtual / regenerated / streamed passes of vsrmc_checker_probe*): only the
+  // sharded branches are compiled out — the mode-capable kernel of the README configuration then fits the 64-KB instruction cache
+  const int mode = PLAIN == 1 ? (int)MODE_NORMAL : mode_arg;
   const int world = PLAIN ? 1 : world_arg;
   Model M = Marg;
   specialise<SPEC>(M, Marg);
@@ -423,11 +451,36 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   __shared__ u64 s_tile_cur;
   u64 my_next = 0;
   if (tid == 0) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+#if VSR_REF_AHEAD
+  // wave 0 keeps a two-deep queue: my_next = the tile of the coming trip (its refs already loaded into ref_pref), my_next2 = the
+  // tile after it (drawn, its refs are loaded during the coming trip).  Lane 0 draws, the wave shares the index by readfirstlane.
+  u64 my_next2 = 0, ref_pref = 0;
+  if (tid < 64) {
+    my_next = readlane64(my_next, 0);
+    if (tid < tile && my_next < ntiles && my_next * (u64)tile + tid < n_parents) ref_pref = fr_off[my_next * (u64)tile + tid];
+    if (tid == 0 && my_next < ntiles) my_next2 = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+  }
+#endif
   for (;;) {
+#if VSR_REF_AHEAD
+    u64 ref_now = 0;
+    if (tid < 64) {
+      if (tid == 0) s_tile_cur = my_next;
+      ref_now = ref_pref;
+      const u64 done = my_next;
+      my_next = readlane64(my_next2, 0);                          // waits for the draw issued one trip ago
+      ref_pref = 0;
+      if (done < ntiles) {
+        if (tid < tile && my_next < ntiles && my_next * (u64)tile + tid < n_parents) ref_pref = fr_off[my_next * (u64)tile + tid];
+        if (tid == 0 && my_next < ntiles) my_next2 = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+      }
+    }
+#else
     if (tid == 0) {
       s_tile_cur = my_next;
       if (my_next < ntiles) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
     }
+#endif
     const u64 t_0 = VSR_CLK();
     if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; s_nsurv = 0; }
     if (tid < tile) s_alive[tid] = 0;
@@ -441,7 +494,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     // ---- stage the tile.  Frontier refs are (word offset << 8 | length): one coalesced load of 64 refs, then 16 lanes per
     // record / 16 records per pass, all 16 loads of a thread issued before the first LDS store (one HBM latency per tile)
     if (tid < np_tile) {
+#if VSR_REF_AHEAD
+      const u64 ref = tile <= 64 ? ref_now : fr_off[p_base + tid];   // 128-record tiles (two waves of refs) load them here
+#else
       const u64 ref = fr_off[p_base + tid];
+#endif
       s_ref[tid] = ref;
       if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
       if ((int)(ref & 255) > stride) raise_error(ctl, ERR_INTERNAL, (p_base + (u64)tid) << 16);   // LDS slots sized for shorter records
@@ -752,28 +809,15 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           continue;
         }
       }
-      if (fused && mode == MODE_PROBE) {
-        u64 m = META_EMPTY;
-        const bool seen = probe_lookup(table, tmask, fp, &m, &my_probes) && meta_level(m) < level;
-        if (!seen) {
-          const int bad = Ops::invariants(M, rec, D);
-          if (bad) {
-            const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
-            if (i < pending_cap) {
-              pending[2 * i] = fp;
-              pending[2 * i + 1] = key;
-            }
-            atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
-            atomicOr(&ctl->viol_mask, (u32)bad);
-          }
-        }
-        continue;
-      }
       if (fused) {
-        bool do_write, remote = false;
+        bool do_write = false, remote = false, check = false;
         u64 prev_meta = META_EMPTY;
         const int owner = world > 1 ? owner_of(fp, world) : rank;
-        if (owner != rank) {
+        if (mode == MODE_PROBE) {                               // probe level: looked up, not inserted; unseen successors are checked
+          u64 m = META_EMPTY;
+          check = !(probe_lookup(table, tmask, fp, &m, &my_probes) && meta_level(m) < level);
+          if (!check) continue;
+        } else if (owner != rank) {
           // sent-filter: a direct-mapped, lossy set of (fingerprint, auxkey) tags this rank has announced before (any level).
           // A hit = an exact repeat, dropped; a miss (or an evicted tag) only costs a redundant announcement.  Plain 8-byte
           // loads / stores: a lost update has the same effect as an eviction.
@@ -799,8 +843,21 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           }
           do_write = claimed;
         }
+        // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
+        const int bad = (check || do_write) ? Ops::invariants(M, rec, D) : 0;
+        if (mode == MODE_PROBE) {
+          if (bad) {
+            const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
+            if (i < pending_cap) {
+              pending[2 * i] = fp;
+              pending[2 * i + 1] = key;
+            }
+            atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
+            atomicOr(&ctl->viol_mask, (u32)bad);
+          }
+          continue;
+        }
         if (do_write && mode == MODE_INSERT) {                  // virtual level: the state is counted and checked, not stored
-          const int bad = Ops::invariants(M, rec, D);
           if (bad) {
             const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
             if (i < pending_cap) {
@@ -829,6 +886,22 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           // parent from LDS, 16 bytes per store (records are 8-byte aligned), then the patches on top (same lane: ordered)
           typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
           int k = 0;
+#if VSR_COPY_PIPE     // the next pair of words is read from LDS before the current pair is stored: one LDS latency per two trips
+          if (plen >= 2) {
+            u64x2_a8 cur;
+            cur.x = rec[0];
+            cur.y = rec[1];
+            for (; k + 3 < plen; k += 2) {
+              u64x2_a8 nxt;
+              nxt.x = rec[k + 2];
+              nxt.y = rec[k + 3];
+              *(u64x2_a8*)(out + k) = cur;
+              cur = nxt;
+            }
+            *(u64x2_a8*)(out + k) = cur;
+            k += 2;
+          }
+#endif
 #if VSR_COPY8
           for (; k + 7 < plen; k += 8) {
             u64x2_a8 a2, b2, c2, d2;
@@ -876,7 +949,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             }
           nx_off[idx] = (dst << 8) | (u64)clen;
           lvl_fp[idx] = fp;
-          const int bad = Ops::invariants(M, rec, D);
           if (bad && !remote) {
             atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
             atomicOr(&ctl->viol_mask, (u32)bad);
@@ -906,7 +978,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             const u64 e = (u64)owner * cand_cap + i;
             cand_send[2 * e] = fp;
             cand_send[2 * e + 1] = key;
-            cand_idx[e] = idx | ((u64)bad << 56);                   // invariant mask: 8 bits (the analysis models use bits up to 16)
+            cand_idx[e] = cand_pack(idx, (u32)bad);
           }
         }
         // same-level duplicate with a different canonical auxkey = the tie the single-pass scheme cannot arbitrate
@@ -942,7 +1014,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         my_maxbag = t > my_maxbag ? t : my_maxbag;
       }
     }
-    if (!PLAIN && mode == MODE_INSERT) {
+    if (PLAIN != 1 && mode == MODE_INSERT) {
       for (int o = 32; o > 0; o >>= 1) {
         my_fx ^= __shfl_down(my_fx, o);
         my_fs += __shfl_down(my_fs, o);
@@ -1050,11 +1122,6 @@ __device__ __forceinline__ void write_child_serial(const Model& M, const u64* re
 #define VSR_MAT_BLOCK 64
 #define VSR_MAT_GROUP 16
 
-__device__ __forceinline__ u64 readlane64(u64 v, int l) {
-  u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
-  u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
-  return ((u64)hi << 32) | lo;
-}
 __device__ __forceinline__ void lds_wave_sync() {   // orders this wave's LDS writes before its later LDS reads (other lanes)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -1345,9 +1412,9 @@ __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __re
   const u64 fp = entries[2 * i];
   if (fp == 0) return;
   const u64 e = cand_idx[i];
-  const u64 idx = e & (((u64)1 << 56) - 1);
+  const u64 idx = cand_index(e);
   if (verdict[i]) {
-    const u32 bad = (u32)(e >> 56);
+    const u32 bad = cand_bad(e);
     if (bad) {
       atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
       atomicOr(&ctl->viol_mask, bad);

@@ -269,6 +269,15 @@ VSR_HD u64 meta_make(int level, u32 auxkey, u64 parent_fp) {
 VSR_HD int meta_level(u64 m) { return (int)(m >> 55); }
 VSR_HD int meta_auxkey(u64 m) { return (int)((m >> 46) & 511); }
 VSR_HD u64 meta_pfp(u64 m) { return (m >> 1) & PFP_MASK; }
+// sharded single-pass levels: what the generator keeps beside a successor it announced to a remote owner — the state index it wrote
+// the record to speculatively, and the mask of invariants the successor violates (5 bits today: VR_APP_STATE's NoAppStateDivergence
+// is bit 4; round 2 kept 2 bits and lost the masks 4, 8 and 16 of the analysis models)
+constexpr u64 cand_pack(u64 idx, u32 bad) { return idx | ((u64)bad << 56); }
+constexpr u64 cand_index(u64 e) { return e & (((u64)1 << 56) - 1); }
+constexpr u32 cand_bad(u64 e) { return (u32)(e >> 56); }
+static_assert(cand_bad(cand_pack(((u64)1 << 56) - 1, 31)) == 31 && cand_index(cand_pack(((u64)1 << 56) - 1, 31)) == ((u64)1 << 56) - 1 &&
+              cand_bad(cand_pack(12345, 16)) == 16 && cand_bad(cand_pack(12345, 4)) == 4 && cand_bad(cand_pack(12345, 6)) == 6,
+              "every invariant bit of every model survives the candidate entry");
 // what the generator keeps beside a candidate of the schemes that materialise after the level: parent index | ordinal << 40
 VSR_HD u64 origin_make(u64 pidx, int ord) { return pidx | ((u64)ord << 40); }
 VSR_HD u64 origin_pidx(u64 o) { return o & (((u64)1 << 40) - 1); }

@@ -1029,6 +1029,7 @@ struct vsrmc_checker {
   // the single-pass kernel of this model (a specialised instantiation when there is one) and its launch shape
   void* fused_kernel = nullptr;
   void* plain_kernel = nullptr;          // the same without modes / sharding, when the configuration has one (ordinary unsharded levels)
+  void* modes_kernel = nullptr;          // the same without sharding (expand_pass: the passes of vsrmc_checker_probe / _probe2 / _probe3), or null
   int plain_blk = VSR_BLOCK;             // threads per block of plain_kernel: 256, or 64 = one wave per block with a 16-record tile of its own
   u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
   bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
@@ -1085,6 +1086,15 @@ ExpandKernel plain_kernel_for(const Model& M, int blk) {      // unsharded ordin
     case 312: return k_expand<true, 312, true>;
     case 313: return k_expand<true, 313, true>;
     case 512: return k_expand<true, 512, true>;
+    default: return nullptr;
+  }
+}
+ExpandKernel modes_kernel_for(const Model& M) {               // unsharded passes with a mode (probe / virtual / regenerated / streamed levels)
+  if (M.model_id != 0) return nullptr;
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 312: return k_expand<true, 312, 2>;
+    case 313: return k_expand<true, 313, 2>;
+    case 512: return k_expand<true, 512, 2>;
     default: return nullptr;
   }
 }
@@ -1256,6 +1266,7 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
     return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
   c->fused_kernel = (void*)fused_kernel_for(M);
+  c->modes_kernel = (void*)modes_kernel_for(M);
   {
     // VSRMC_BLK=256 selects the four-wave blocks (64-record tiles, block barriers) for A/B runs; default: one wave per block
     const char* e = std::getenv("VSRMC_BLK");
@@ -1547,7 +1558,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
     const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
+    hipLaunchKernelGGL((ExpandKernel)(c->modes_kernel ? c->modes_kernel : c->fused_kernel), dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
                        ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0, mode, p_offset);
