@@ -17,7 +17,7 @@ Inputs are the model itself (deterministic, no data files): "synthetic" in the c
 figures against the CPU oracle's fixtures (tests/golden/oracle_levels_config{2,3}.json); a wrong count aborts the bench.
 
 N > 1: the seen-set is sharded by the high fingerprint bits, one rank per GPU, successors routed to their owner with
-an all-to-all per level (vsr-tlaplus_amd/sharded.py); total work is fixed as N grows ("strong").
+an all-to-all per level (vsr_tlaplus_amd/sharded.py); total work is fixed as N grows ("strong").
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (k_expand: algorithmic bytes / HIP-event time on the checker's
 stream; `traffic` = the committed PMC figure when it was measured on THIS build's kernel sources, else null), `cpu_baseline` = the
@@ -164,7 +164,7 @@ def kernel_source_sha256():
     no traffic figure (`roofline.traffic: null`) rather than a stale one."""
     import hashlib
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "vsr-tlaplus_amd", "csrc")
+    d = os.path.join(ROOT, "vsr_tlaplus_amd", "csrc")
     for name in sorted(os.listdir(d)) + ["../../include/vsrmc.h"]:
         if name.endswith((".hpp", ".hip", ".h")):
             with open(os.path.join(d, name), "rb") as f:

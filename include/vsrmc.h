@@ -284,7 +284,7 @@ int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t n_walkers,
                        double max_seconds, vsrmc_sim_result* out);
 
 /* ---- sharded seen-set (≙ tlc2.tool.fp.MultiFPSet across GPUs): the phases of one BFS level -----------------------
- * world ranks, one per GPU; owner(fp) = ((fp >> 40) & 0xFFFFFF) % world.  The caller (vsr-tlaplus_amd/sharded.py over
+ * world ranks, one per GPU; owner(fp) = ((fp >> 40) & 0xFFFFFF) % world.  The caller (vsr_tlaplus_amd/sharded.py over
  * torch.distributed / RCCL) owns the exchange buffers and moves them between ranks; every pointer is a device pointer.
  *   1. vsrmc_shard_expand       expand the local frontier; local-owner candidates are claimed at once, the others are
  *                               bucketed per owner as (fp, key) pairs in io->cand_send; returns the bucket sizes

@@ -5,6 +5,10 @@ package tlc2.tool.fp;
 
 import java.io.IOException;
 import java.rmi.RemoteException;
+import java.util.ArrayDeque;
+import java.util.concurrent.atomic.AtomicBoolean;
+import java.util.concurrent.locks.Condition;
+import java.util.concurrent.locks.ReentrantLock;
 
 import tlc2.util.BitVector;
 import tlc2.util.LongVec;
@@ -38,21 +42,72 @@ public class GpuFPSet extends FPSet {
         return this;
     }
 
-    // TLC's workers call put/contains one fingerprint at a time; each call is a batch of one under the monitor.
-    // (The intended use is putBlock/containsBlock, or replacing the whole loop — INTEGRATION.md §2.)
-    @Override
-    public synchronized boolean put(long fp) throws IOException {
-        byte[] out = new byte[1];
-        if (putBlock0(handle, new long[] {fp}, out) != 0) throw new IOException(lastError0());
-        return out[0] != 0;
+    // TLC's workers call put / contains one fingerprint at a time, from every worker thread.  One JNI call plus two PCIe copies per
+    // fingerprint would cost more than TLC's own FPSet, so the calls are COMBINED: a caller files its request in a queue; whoever finds
+    // no flush in progress becomes the leader, takes everything queued so far (up to BATCH requests of all threads), makes ONE native
+    // call for the batch outside the lock, hands the answers back and wakes the others.  Two threads that put the same new fingerprint
+    // in one batch get one "new" and one "present" (k_fpset_put claims a slot with one compare-and-swap), as with any FPSet.
+    private static final class Req {
+        final long fp;
+        final boolean isPut;
+        boolean done, present;
+        IOException error;
+        Req(long fp, boolean isPut) { this.fp = fp; this.isPut = isPut; }
+    }
+
+    private final ReentrantLock lock = new ReentrantLock();
+    private final Condition flushed = lock.newCondition();
+    private final ArrayDeque<Req> queue = new ArrayDeque<Req>();
+    private boolean flushing = false;
+
+    private boolean combined(long fp, boolean isPut) throws IOException {
+        final Req r = new Req(fp, isPut);
+        lock.lock();
+        try {
+            queue.add(r);
+            while (!r.done) {
+                if (flushing) {
+                    flushed.awaitUninterruptibly();
+                    continue;
+                }
+                flushing = true;                                  // this thread leads one flush: the oldest request decides the operation
+                final boolean op = queue.peek().isPut;
+                final ArrayDeque<Req> batch = new ArrayDeque<Req>();
+                while (!queue.isEmpty() && batch.size() < BATCH && queue.peek().isPut == op) batch.add(queue.poll());
+                lock.unlock();
+                final int m = batch.size();
+                final long[] fps = new long[m];
+                final byte[] out = new byte[m];
+                int i = 0;
+                for (Req q : batch) fps[i++] = q.fp;
+                IOException err = null;
+                try {
+                    final int rc = op ? putBlock0(handle, fps, out) : containsBlock0(handle, fps, out);
+                    if (rc != 0) err = new IOException(lastError0());
+                } finally {
+                    lock.lock();
+                }
+                i = 0;
+                for (Req q : batch) {
+                    q.present = out[i++] != 0;
+                    q.error = err;
+                    q.done = true;
+                }
+                flushing = false;
+                flushed.signalAll();
+            }
+        } finally {
+            lock.unlock();
+        }
+        if (r.error != null) throw r.error;
+        return r.present;
     }
 
     @Override
-    public synchronized boolean contains(long fp) throws IOException {
-        byte[] out = new byte[1];
-        if (containsBlock0(handle, new long[] {fp}, out) != 0) throw new IOException(lastError0());
-        return out[0] != 0;
-    }
+    public boolean put(long fp) throws IOException { return combined(fp, true); }
+
+    @Override
+    public boolean contains(long fp) throws IOException { return combined(fp, false); }
 
     @Override
     public synchronized BitVector putBlock(LongVec fpv) throws IOException {
@@ -96,13 +151,18 @@ public class GpuFPSet extends FPSet {
     // TLC checkpoints periodically by default (every 30 minutes): these hooks must not abort a long run.  The set lives in HBM
     // and this shim does not persist it — begin / commit are no-ops (a `-recover` of such a checkpoint finds an empty set and is
     // refused below); the native checker's own checkpoint (vsrmc_checker_save / _load) is the supported way to stop and resume.
-    @Override public void beginChkpt() { }
+    private static final AtomicBoolean warned = new AtomicBoolean(false);
+    @Override public void beginChkpt() {
+        if (warned.compareAndSet(false, true))
+            System.err.println("GpuFPSet: TLC checkpoints do NOT contain the fingerprint set (it lives in HBM and is not written out); "
+                               + "a -recover of this run will be refused.  Use the native checker's -checkpoint / -recover instead.");
+    }
     @Override public void commitChkpt() { }
     @Override public void recover() throws IOException {
         throw new IOException("GpuFPSet does not persist fingerprints across TLC checkpoints; resume with the native checker's -recover");
     }
     @Override public void beginChkpt(String filename) { beginChkpt(); }
     @Override public void commitChkpt(String filename) { commitChkpt(); }
-    @Override public void recover(String filename) { recover(); }
+    @Override public void recover(String filename) throws IOException { recover(); }
     @Override public void recoverFP(long fp) throws IOException { put(fp); }
 }

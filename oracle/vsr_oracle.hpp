@@ -7,7 +7,7 @@
 // i.e. what TLC (tlc2.tool.Worker / Tool.getNextStates / TLCState.fingerPrint / FPSet) computes for
 // this one model.  It works on *unpacked* structs (records, sorted sets, a sorted bag) and full
 // recomputation everywhere, so that it shares no algorithmic code with the HIP path it checks
-// (vsr-tlaplus_amd/csrc/*), which works on the packed record with incremental hashing.
+// (vsr_tlaplus_amd/csrc/*), which works on the packed record with incremental hashing.
 //
 // PARITY STATUS: "parity unpinned" against TLC itself — TLC (Java) is not in /root/reference, no JVM
 // exists in this image, and the reference pins no TLC version, fingerprints or state counts

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: a CPU stand-in for one rank's shard engine, built on the CPU oracle, implementing the phase protocol
-of vsr-tlaplus_amd/sharded.py (expand / claim / materialize / append / commit).  It lets the world_size-2 gloo test exercise
+of vsr_tlaplus_amd/sharded.py (expand / claim / materialize / append / commit).  It lets the world_size-2 gloo test exercise
 the orchestrator + exchange protocol without a GPU.  Never imported by product code."""
 import numpy as np
 import torch

@@ -401,7 +401,7 @@ def test_cli_runs_config1_to_completion(vt, tmp_path):
     import os
     import subprocess
     from test_host_cpu import _cfg
-    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr_tlaplus_amd", "vsrmc")
     cfg = _cfg(tmp_path, R=2, vals="v1", L=1)
     r = subprocess.run([cli, "-config", cfg, "VSR.tla", "-noTLA", "-deadlock", "-tableLog2", "16", "-frontierGiB", "0.01"],
                        capture_output=True, text=True, timeout=120)
@@ -480,7 +480,7 @@ def test_cli_simulate_finds_the_readme_defect(vt, tmp_path):
     import os
     import subprocess
     from test_host_cpu import _cfg
-    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr_tlaplus_amd", "vsrmc")
     cfg = _cfg(tmp_path, R=3, vals="v1, v2, v3", L=3)                              # README:13-18
     r = subprocess.run([cli, "-config", cfg, "VSR.tla", "-noTLA", "-simulate", "-depth", "60", "-seed", "2", "-maxSeconds", "40"],
                        capture_output=True, text=True, timeout=120)
@@ -648,7 +648,7 @@ def test_cli_checkpoint_and_recover(vt, tmp_path):
     import os
     import subprocess
     from test_host_cpu import _cfg
-    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr_tlaplus_amd", "vsrmc")
     cfg = _cfg(tmp_path, R=2, vals="v1", L=1)
     chk = str(tmp_path / "c1.chk")
     r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01", "-maxDepth", "8", "-checkpoint", chk,
@@ -844,7 +844,7 @@ def test_cli_probe2_and_probe_last(vt, tmp_path):
     """vsrmc -probe2At / -probeLast / -hostFrontierMask on config 1 (76 states, depth 14, no violation) and on a cfg that violates."""
     import subprocess
     from test_host_cpu import _cfg
-    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr_tlaplus_amd", "vsrmc")
     cfg = _cfg(tmp_path, R=2, vals="v1", L=1)
     r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01", "-probe2At", "9", "-hostFrontierMask", "1"],
                        capture_output=True, text=True, timeout=120)

@@ -98,7 +98,7 @@ def test_no_gpu_means_loud_failure_not_fallback(vt):
 
 
 def test_product_sources_never_touch_the_oracle():
-    pkg = os.path.join(ROOT, "vsr-tlaplus_amd")
+    pkg = os.path.join(ROOT, "vsr_tlaplus_amd")
     for dp, _, fs in os.walk(pkg):
         for f in fs:
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".java", ".c")):
@@ -231,7 +231,7 @@ def test_config2_counterexample_is_a_behaviour(golden_counts):
 
 
 def test_cli_help_and_cfg_errors(vt, tmp_path):
-    cli = os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc")
+    cli = os.path.join(ROOT, "vsr_tlaplus_amd", "vsrmc")
     if not os.path.exists(cli):
         pytest.skip("CLI not built")
     r = subprocess.run([cli, "--help"], capture_output=True, text=True)

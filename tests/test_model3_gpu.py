@@ -152,7 +152,7 @@ def test_model3_cli(vt, orc2, tmp_path):
     import os
     import subprocess
     from test_model3_host_cpu import _cfg
-    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr_tlaplus_amd", "vsrmc")
     r = subprocess.run([cli, "-config", _cfg(tmp_path), "-maxDepth", "12", "-tableLog2", "22", "-frontierGiB", "0.5"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -185,7 +185,7 @@ def test_model3_validate_trace_cli(vt, tmp_path):
                        % (k + 1, a, m.format_state(r).split("\n", 1)[1]) for k, (a, r) in enumerate(path))
     f = tmp_path / "m3.trace"
     f.write_text("<<\n" + body + "\n>>\n")
-    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-tlaplus_amd", "vsrmc")
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr_tlaplus_amd", "vsrmc")
     r = subprocess.run([cli, "-config", _cfg(tmp_path), "-validateTrace", str(f)], capture_output=True, text=True, timeout=300)
     assert "15 states read" in r.stdout and "The trace is a behaviour of the model." in r.stdout, r.stdout + r.stderr
     bad = f.read_text().replace("rep_view_number |-> <<", "rep_view_number |-> <<7, ", 1)

@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 (and 3) gloo runs of the sharded level loop (vsr-tlaplus_amd/sharded.py) over a
+"""The N>1 path on CPU: world_size-2 (and 3) gloo runs of the sharded level loop (vsr_tlaplus_amd/sharded.py) over a
 CPU stand-in engine built on the oracle; the union of the shards' per-level fingerprint sets must equal the
 single-process oracle BFS, for any world size.  (`-m gpu` has the same test over the HIP engine.)"""
 import json
@@ -188,7 +188,7 @@ def test_sharded_hip_checkpoint_and_probe_level(tmp_path, world, rb):
 
 @pytest.mark.gpu
 def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
-    """`vsrmc` on N ranks (vsr-tlaplus_amd/sharded_cli.py): config 1 to completion, and the shipped cfg to its violation
+    """`vsrmc` on N ranks (vsr_tlaplus_amd/sharded_cli.py): config 1 to completion, and the shipped cfg to its violation
     with the counter-example printed in TLC's syntax."""
     from test_host_cpu import _cfg
 
@@ -202,7 +202,7 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
     assert "Model checking completed. No error has been found." in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert "76 distinct states found" in r.stdout and "search is 14" in r.stdout and "[sharded]" in r.stdout
     # the same through `vsrmc -gpus 2` (the C++ front end re-executes itself under torch.distributed.run)
-    r = subprocess.run([os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc"), "-config", _cfg(tmp_path, R=2, vals="v1", L=1), "-noTLA", "-gpus", "2",
+    r = subprocess.run([os.path.join(ROOT, "vsr_tlaplus_amd", "vsrmc"), "-config", _cfg(tmp_path, R=2, vals="v1", L=1), "-noTLA", "-gpus", "2",
                         "-backend", "gloo", "-tableLog2", "20", "-frontierGiB", "0.05", "-replicateBelow", "8"], capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_PORT="29672"))
     assert "76 distinct states found" in r.stdout and "[sharded]" in r.stdout and "2 rank(s)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -1,4 +1,4 @@
-"""TLC state / trace import (vsr-tlaplus_amd/csrc/vsr_parse.hpp behind vsrmc_model_parse_states).
+"""TLC state / trace import (vsr_tlaplus_amd/csrc/vsr_parse.hpp behind vsrmc_model_parse_states).
 
 CPU part: the reader is the inverse of the printer, and the printer is pinned line by line to the reference's
 state_transfer_violation_trace.txt (test_host_cpu.py), so reading back the printed golden states must give the golden
@@ -149,7 +149,7 @@ def test_cli_validate_trace(vt, golden_trace, tmp_path):
     cfg = _cfg(tmp_path, R=3, vals="v1, v2, v3", L=3)                              # README:13-18
     tf = tmp_path / "trace.txt"
     tf.write_text(_trace_expression(m, golden_trace["states"]))
-    r = subprocess.run([os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc"), "-config", str(cfg), "-noTLA", "-validateTrace", str(tf)],
+    r = subprocess.run([os.path.join(ROOT, "vsr_tlaplus_amd", "vsrmc"), "-config", str(cfg), "-noTLA", "-validateTrace", str(tf)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 12, r.stdout + r.stderr
     assert "24 states read" in r.stdout and "The trace is a behaviour of the model." in r.stdout
@@ -166,7 +166,7 @@ def test_cli_dump_is_readable_and_complete(vt, tmp_path):
     from test_host_cpu import _cfg
     cfg = _cfg(tmp_path, R=2, vals="v1", L=1)
     out = tmp_path / "states.dump"
-    r = subprocess.run([os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc"), "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01",
+    r = subprocess.run([os.path.join(ROOT, "vsr_tlaplus_amd", "vsrmc"), "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01",
                         "-dump", str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "76 states dumped" in r.stdout, r.stdout + r.stderr
     text = out.read_text()
@@ -200,7 +200,7 @@ def test_diff_tlc_dump_tool(vt, tmp_path):
     from test_host_cpu import _cfg
     cfg = _cfg(tmp_path, R=2, vals="v1, v2", L=1)
     out = tmp_path / "states.dump"
-    r = subprocess.run([os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc"), "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.05",
+    r = subprocess.run([os.path.join(ROOT, "vsr_tlaplus_amd", "vsrmc"), "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.05",
                         "-dump", str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "163 states dumped" in r.stdout, r.stdout + r.stderr
     blocks = [b for b in re.split(r"(?m)^State \d+:\n", out.read_text()) if b.strip()]
@@ -234,7 +234,7 @@ def test_cli_dump_trace_tla_round_trip(vt, tmp_path):
     from test_host_cpu import _cfg
     cfg = _cfg(tmp_path, L=1, extra="AcknowledgedWritesExistOnMajority")          # (3,1,{v1,v2},1): violated at depth 19
     out = tmp_path / "cex.tla.txt"
-    cli = os.path.join(ROOT, "vsr-tlaplus_amd", "vsrmc")
+    cli = os.path.join(ROOT, "vsr_tlaplus_amd", "vsrmc")
     r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "20", "-frontierGiB", "0.1", "-dumpTrace", "tla", str(out)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 12 and "The counter-example was written to" in r.stdout, r.stdout[-2000:] + r.stderr

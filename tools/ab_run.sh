@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for round in 1 2; do
 for name in "$@"; do
-  VSRMC_LIB=$PWD/vsr-tlaplus_amd/ab/libvsrmc_$name.so python bench.py --no-verify --no-config3 --no-cpu-baseline --steps 5 --warmup 1 \
+  VSRMC_LIB=$PWD/vsr_tlaplus_amd/ab/libvsrmc_$name.so python bench.py --no-verify --no-config3 --no-cpu-baseline --steps 5 --warmup 1 \
     2> gpurun_out/ab_$name.err | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())

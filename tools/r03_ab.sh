@@ -7,7 +7,7 @@ for round in 1 2; do
 for spec in "$@"; do
   name=${spec%%:*}; envs=""
   if [[ "$spec" == *:* ]]; then envs=$(echo "${spec#*:}" | tr ',' ' '); fi
-  env $envs VSRMC_LIB=$PWD/vsr-tlaplus_amd/ab/libvsrmc_$name.so python bench.py --no-verify --no-config3 --no-cpu-baseline --steps 5 --warmup 1 \
+  env $envs VSRMC_LIB=$PWD/vsr_tlaplus_amd/ab/libvsrmc_$name.so python bench.py --no-verify --no-config3 --no-cpu-baseline --steps 5 --warmup 1 \
     2> gpurun_out/ab_$name.err | python -c "
 import sys, json
 l = sys.stdin.readline()

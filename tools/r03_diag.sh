@@ -6,7 +6,7 @@ mkdir -p $OUT
 cd $R
 echo "== occupancy sweep (resident blocks per CU)"
 for b in 1 2 3 4; do
-  VSRMC_MAX_BPC=$b VSRMC_LIB=$R/vsr-tlaplus_amd/ab/libvsrmc_e2.so python bench.py --no-verify --no-config3 --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | python -c "
+  VSRMC_MAX_BPC=$b VSRMC_LIB=$R/vsr_tlaplus_amd/ab/libvsrmc_e2.so python bench.py --no-verify --no-config3 --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); print('bpc $b k_expand ms/run', d['roofline']['kernel_ms_per_step']['k_expand'])"
 done
@@ -15,7 +15,7 @@ tools/r03_ab.sh e2 dblprobe dblwrite 2>&1 | grep -v amdgpu.ids
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $OUT/r03_counters_list.txt 2>&1
 PROF="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-config3 --no-verify"
-export VSRMC_LIB=$R/vsr-tlaplus_amd/ab/libvsrmc_e2.so
+export VSRMC_LIB=$R/vsr_tlaplus_amd/ab/libvsrmc_e2.so
 one() {
   local name=$1; shift
   rm -rf $OUT/prof_$name

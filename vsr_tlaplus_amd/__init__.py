@@ -1,7 +1,8 @@
-"""Import shim: the package directory is `vsr-tlaplus_amd/` (not a valid Python identifier); this makes it importable
-as `vsr_tlaplus_amd`."""
-import os as _os
+"""vsr-tlaplus_amd — MI355X-native explicit-state model checker for Vanlightly/vsr-tlaplus's VSR.tla.
 
-__path__ = [_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "vsr-tlaplus_amd")]
-with open(_os.path.join(__path__[0], "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(__path__[0], "__init__.py"), "exec"))
+Package contents: csrc/ (HIP kernels + the C ABI of include/vsrmc.h), capi.py (ctypes binding), checker.py (host-side
+mirror of the TLC interfaces the path replaces), sharded.py (multi-GPU level loop over torch.distributed), build.py.
+`vsr-tlaplus_amd` at the repo root is a symbolic link to this directory (the name the task layout uses; a dash is not importable).
+"""
+from .capi import VsrmcError, load  # noqa: F401
+from .checker import ACTION_NAMES, FPSet, Model, ModelChecker, StateQueue  # noqa: F401

@@ -134,7 +134,7 @@ def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise ImportError("%s is missing: build it with `python vsr-tlaplus_amd/build.py` (hipcc, gfx950); "
+            raise ImportError("%s is missing: build it with `python vsr_tlaplus_amd/build.py` (hipcc, gfx950); "
                               "there is no CPU fallback" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():

@@ -377,7 +377,7 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
 // for the slowest wave of its tile, and the 16 waves of a CU drift apart so that their memory and issue phases interleave.
 template <bool FUSED, int SPEC = 0, int PLAIN = 0, int BLK = VSR_BLOCK>
 // (hipcc turns the second bound into waves per SIMD as blocks * max(1, threads / 256): 4 = 128 VGPRs for either block size)
-__global__ void __launch_bounds__(BLK, FUSED ? (SPEC ? 4 : 2) : 3)
+__global__ void __launch_bounds__(BLK, (FUSED ? (SPEC ? 4 : 2) : 3) / (BLK > VSR_BLOCK ? BLK / VSR_BLOCK : 1))
 k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world_arg, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
@@ -409,7 +409,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
   u32* s_cand2 = s_cand + ccap;                        // the same, sorted by action
   __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv;
-  constexpr int TILE_MAX = BLK == VSR_BLOCK ? VSR_TILE_MAX : BLK / 2;
+  constexpr int TILE_MAX = BLK >= VSR_BLOCK ? VSR_TILE_MAX : BLK / 2;
   __shared__ u32 s_alive[TILE_MAX];
   __shared__ u64 s_ref[TILE_MAX];
   __shared__ u64 s_pfp[TILE_MAX];                          // canonical fingerprint of every staged record (the parent part of its successors' keys)

@@ -1071,15 +1071,23 @@ MaterializeKernel materialize_kernel_for(const Model& M) {
   }
 }
 ExpandKernel plain_kernel_for(const Model& M, int blk) {      // unsharded ordinary levels: modes and sharding compiled out
+#if VSRMC_EXPERIMENTAL_BLK    // measured and rejected block shapes, kept buildable for A/B runs: -DVSRMC_EXPERIMENTAL_BLK=1, VSRMC_BLK=64 / 512
+  if (blk == 512) {                                            // eight waves per block, 128-record tiles, two blocks per CU
+    switch (M.R * 100 + M.C * 10 + M.n) {
+      case 312: return k_expand<true, 312, true, 512>;
+      default: return nullptr;
+    }
+  }
   if (blk == 64) {                                             // one wave per block, 16-record tiles (vsr_kernels.hpp, BLK)
-    if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true, 64> : nullptr;
-    if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302, true, 64> : nullptr;
     switch (M.R * 100 + M.C * 10 + M.n) {
       case 312: return k_expand<true, 312, true, 64>;
       case 313: return k_expand<true, 313, true, 64>;
       default: return nullptr;
     }
   }
+#else
+  if (blk != VSR_BLOCK) return nullptr;
+#endif
   if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true> : nullptr;   // the shipped VR_STATE_TRANSFER.cfg
   if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302, true> : nullptr;   // the shipped VR_APP_STATE.cfg
   switch (M.R * 100 + M.C * 10 + M.n) {
@@ -1138,6 +1146,12 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
     return nb;
   };
   f.blk = blk;
+  if (blk == 512) {
+    f.tile = 128;
+    f.ccap = 3072u;
+    f.blocks_per_cu = (unsigned)std::max(1, std::min(occupancy(128, f.ccap, &f.lds), 2));
+    return f;
+  }
   if (blk == 64) {                                              // one wave, 16 records, 24 (R <= 3) or 32 work-list entries per record
     f.tile = 16;
     f.ccap = M.R <= 3 ? 384u : 512u;
@@ -1268,10 +1282,10 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
   c->fused_kernel = (void*)fused_kernel_for(M);
   c->modes_kernel = (void*)modes_kernel_for(M);
   {
-    // VSRMC_BLK=256 selects the four-wave blocks (64-record tiles, block barriers) for A/B runs; default: one wave per block
+    // VSRMC_BLK=64 / 512 select the experimental block shapes of a -DVSRMC_EXPERIMENTAL_BLK=1 build (A/B runs); default 256
     const char* e = std::getenv("VSRMC_BLK");
     const int want = e ? std::atoi(e) : VSRMC_DEFAULT_BLK;
-    c->plain_blk = (want == 64 && plain_kernel_for(M, 64)) ? 64 : VSR_BLOCK;
+    c->plain_blk = ((want == 64 || want == 512) && plain_kernel_for(M, want)) ? want : VSR_BLOCK;
     c->plain_kernel = (void*)plain_kernel_for(M, c->plain_blk);
   }
   rc = checker_seed(c);
@@ -1318,7 +1332,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     // sharded: records arrive from other ranks (rebalancing), the local maximum says nothing -> the format's capacity
     const bool use_plain = fused && !io && mode == MODE_NORMAL && c->plain_kernel;
     const FusedShape fs = fused_shape(c, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, use_plain);
-    const int cdiv = VSR_BLOCK / fs.blk;                         // one-wave blocks: four times the blocks, a quarter of the chunk sizes
+    const int cdiv = std::max(1, VSR_BLOCK / fs.blk);            // one-wave blocks: four times the blocks, a quarter of the chunk sizes
     const int tile = fused ? fs.tile : (M.R <= 3 ? 128 : 64);
     const int stride = fused ? fs.stride : c->lds_stride;
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
