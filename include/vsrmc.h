@@ -204,7 +204,9 @@ int32_t vsrmc_model_replay(const vsrmc_model* m, int32_t device, const uint32_t*
                            uint64_t cap_words, uint64_t* off, int32_t* actions, uint64_t cap_states, uint64_t* n_states);
 /* one step of a trace walk through this checker's (shard of the) seen-set — what a walk that crosses ranks is made of.
  * by_low_bits = 0: the slot of fingerprint `key`; 1: the slot of the level-`level` state whose fingerprint ends in the 45 bits
- * `key`.  meta = level(9) << 55 | auxkey(9) << 46 | parent fingerprint bits(45) << 1 | taken(1). */
+ * `key` — *found = the number of such states in this shard: more than one (over all shards) is an ambiguous predecessor pointer,
+ * which the walks report instead of following the first match.  meta = level(9) << 55 | auxkey(9) << 46 | parent fingerprint
+ * bits(45) << 1 | taken(1). */
 int32_t vsrmc_checker_lookup(vsrmc_checker* c, uint64_t key, int32_t level, int32_t by_low_bits, int32_t* found, uint64_t* fp,
                              uint64_t* meta);
 /* index of fingerprint `fp` in the newest level (~0 if absent) */

@@ -207,10 +207,8 @@ class FakeShardEngine:
         """one step of a trace walk through this rank's part of the seen-set -> (fingerprint, meta) or None"""
         if not by_low_bits:
             return (key, self.seen[key]) if key in self.seen else None
-        for fp, meta in self.seen.items():
-            if (fp & ((1 << 45) - 1)) == key and (meta >> 55) == level:
-                return (fp, meta)
-        return None
+        hits = [(fp, meta) for fp, meta in self.seen.items() if (fp & ((1 << 45) - 1)) == key and (meta >> 55) == level]
+        return (hits[0][0], hits[0][1], len(hits)) if hits else None
 
     def level_fps(self):
         return np.array(sorted(f for f in self.fps if f is not None), dtype=np.uint64)

@@ -292,12 +292,20 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, key):
     # indices).  A last level whose records do not fit a 100-GB buffer (config 5, level 13: 5.96e8 states) is taken as a VIRTUAL level:
     # claimed in the seen-set, counted and checked, never stored (vsrmc_checker_probe2).
     need = lambda lv: int(lv["new"] * (m.layout.fixed_words + m.layout.permutations + lv["max_bag"]) * 1.1) + (1 << 29)   # noqa: E731
-    stored = [lv for lv in g["levels"] if need(lv) <= 12.5e9]
-    virtual = g["levels"][len(stored):]
-    assert len(virtual) <= 1 and stored == g["levels"][: len(stored)]
-    biggest = max(lv["new"] for lv in stored)
-    mc = vt.ModelChecker(m, table_log2=max(20, int(np.ceil(np.log2(2.5 * g["distinct"])))), frontier_words=max(need(lv) for lv in stored),
-                         frontier_states=int(biggest * 1.3) + (1 << 24), pending_entries=1 << 15, keep_trace=False)
+    deep = g.get("probe") is not None and len(g["levels"]) >= 3 and need(g["levels"][-2]) > 12.5e9
+    if deep:
+        # a fixture that ends in two levels no GPU can store plus a probed one (the README configuration: levels 22 / 23 / 24 from the
+        # memory-lean oracle driver): everything before them is materialised, then vsrmc_checker_probe3 — virtual, streamed, probed
+        stored, virtual = g["levels"][:-2], g["levels"][-2:]
+        mc = vt.ModelChecker(m, table_log2=32, frontier_words=int(12.8e9), frontier_words_b=int(7.0e9), frontier_states=int(2.85e8),
+                             pending_entries=1 << 16, keep_trace=False)
+    else:
+        stored = [lv for lv in g["levels"] if need(lv) <= 12.5e9]
+        virtual = g["levels"][len(stored):]
+        assert len(virtual) <= 1 and stored == g["levels"][: len(stored)]
+        biggest = max(lv["new"] for lv in stored)
+        mc = vt.ModelChecker(m, table_log2=max(20, int(np.ceil(np.log2(2.5 * g["distinct"])))), frontier_words=max(need(lv) for lv in stored),
+                             frontier_states=int(biggest * 1.3) + (1 << 24), pending_entries=1 << 15, keep_trace=False)
     assert mc.level_checksum()[2] == 1
     for lv in stored[1:]:
         d = mc.step()
@@ -308,6 +316,20 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, key):
         assert n == lv["new"]
         if g["checksums"]:
             assert ("%016x" % x, "%016x" % s) == (lv["fp_xor"], lv["fp_sum"]), lv["level"]
+    if deep:
+        v1, v2, pr = mc.probe3()
+        for v, lv in ((v1, virtual[0]), (v2, virtual[1])):
+            assert (v["level"], v["n_new"], v["generated"], v["deadlocks"], v["max_bag"], v["viol_mask"]) == \
+                (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"], 0), lv["level"]
+            if g["checksums"]:
+                assert ("%016x" % v["fp_xor"], "%016x" % v["fp_sum"]) == (lv["fp_xor"], lv["fp_sum"]), lv["level"]
+        assert v2["distinct"] == g["distinct"]
+        want = g["probe"]
+        assert (pr["level"], pr["generated"], pr["deadlocks"], pr["viol_mask"]) == (want["level"], want["generated"], want["deadlocks"], want["viol_mask"])
+        if g["checksums"]:
+            assert "%016x" % pr["viol_fp"] == want["viol_fp"]
+        mc.close()
+        return
     for lv in virtual:
         v, _ = mc.probe2()
         assert (v["level"], v["n_new"], v["generated"], v["deadlocks"], v["max_bag"], v["viol_mask"]) == \
@@ -871,3 +893,37 @@ def test_exists_on_majority_fails_at_depth_19_on_the_shipped_constants(vt, orc):
     assert len(tr) == 19
     _check_walk_with_oracle(orc, P, tr, 2)
     mc.close()
+
+
+def test_ambiguous_predecessor_pointer_is_reported(vt, tmp_path):
+    """A slot names its state's parent by level + the low 45 bits of the parent's fingerprint.  Two states of one level that share
+    those bits (about level size / 2^45 per step) make the pointer ambiguous: the walk must say so, not follow the first match.
+    Forced here by adding, to a checkpoint's seen-set section, a second level-6 entry with the low 45 bits of a real parent."""
+    import struct
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    a = vt.ModelChecker(m, table_log2=16, frontier_words=1 << 20, frontier_states=1 << 14)
+    for _ in range(6):
+        a.step()
+    child = int(a.level_fps()[0])
+    hit = a.lookup(child)
+    assert hit is not None and hit[1] >> 55 == 7
+    pbits = (hit[1] >> 1) & ((1 << 45) - 1)
+    parent = a.lookup(pbits, level=6, by_low_bits=True)
+    assert parent is not None and parent[2] == 1 and len(a.trace_fp(7, child)) == 7
+    path = str(tmp_path / "amb.chk")
+    a.save(path)
+    a.close()
+    raw = bytearray(open(path, "rb").read())
+    n_entries, = struct.unpack_from("<Q", raw, 112)              # ChkHeader: magic 8, consts 48, level / shard 8, then 8 x u64; table_entries is the 7th
+    fake = struct.pack("<QQ", parent[0] ^ (1 << 50), parent[1])  # same low 45 bits, same level, another state
+    pos = 128 + 16 * n_entries
+    raw[pos:pos] = fake
+    struct.pack_into("<Q", raw, 112, n_entries + 1)
+    open(path, "wb").write(bytes(raw))
+    b = vt.ModelChecker(m, table_log2=16, frontier_words=1 << 20, frontier_states=1 << 14, recover=path)
+    assert b.lookup(parent[0] ^ (1 << 50)) is not None, ("the added entry was not imported", n_entries, len(raw), b.distinct)
+    again = b.lookup(pbits, level=6, by_low_bits=True)
+    assert again is not None and again[2] == 2, (again, n_entries, len(raw))
+    with pytest.raises(vt.VsrmcError, match="ambiguous predecessor pointer"):
+        b.trace_fp(7, child)
+    b.close()

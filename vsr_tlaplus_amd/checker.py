@@ -400,10 +400,13 @@ class ModelChecker:
         return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(n.value)]
 
     def lookup(self, key, level=0, by_low_bits=False):
-        """one step of a trace walk through the seen-set -> (fingerprint, meta) or None"""
+        """one step of a trace walk through the seen-set -> (fingerprint, meta) or None; by_low_bits: a third element = the number
+        of states of that level whose fingerprint ends in those 45 bits (> 1: the predecessor pointer is ambiguous)"""
         found, fp, meta = C.c_int32(), C.c_uint64(), C.c_uint64()
         check(capi.load().vsrmc_checker_lookup(self._h, int(key), int(level), int(by_low_bits), C.byref(found), C.byref(fp), C.byref(meta)))
-        return (fp.value, meta.value) if found.value else None
+        if not found.value:
+            return None
+        return (fp.value, meta.value, found.value) if by_low_bits else (fp.value, meta.value)
 
     def trace(self, level, index):
         """TLCTrace.getTrace -> list of (action name, record words) from Init to state `index` of the newest level."""

@@ -148,6 +148,10 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #define VSR_HOME_FIRST 1
 #endif
 // successor write: parent words copied eight per trip (four LDS reads in flight) instead of two
+// intra-tile duplicate filter in LDS ahead of the seen-set probes of k_expand (single-pass levels)
+#ifndef VSR_DEDUP
+#define VSR_DEDUP 0
+#endif
 #ifndef VSR_COPY_PIPE
 #define VSR_COPY_PIPE 1
 #endif
@@ -760,12 +764,89 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
       VSR_SYNC();
     }
+    const u32 ncand_apply = s_skip ? 0u : ncand;                // s_skip: the tile was refused (see the word-chunk reservation)
+#if VSR_DEDUP
+    // Intra-tile duplicate filter.  A tile of the frontier is a family — the children of a few neighbouring states — and about a
+    // third of the successors it generates are generated more than once INSIDE the tile (A;B = B;A).  The candidates of a pass meet
+    // in a small LDS hash table: the fingerprint claims an entry (64-bit compare-and-swap), the keys are min-merged into it, and
+    // after one barrier only the lane that holds the smallest key goes on to the seen-set in HBM — with exactly the key the
+    // min-merge in the slot's meta word would have kept, so the predecessor pointers do not change.  One 128-byte line of HBM and
+    // up to two device-scope atomics less per removed duplicate.  (Passes of more than BLK candidates, sharded runs and the
+    // lookup-only modes go without.)  dkey = auxkey(9) << 54 | parent fingerprint bits(45) << 9 | thread(9): unique per lane.
+    constexpr u32 NDD = 2 * BLK;
+    u64* dd_fp = (u64*)s_cand;                                  // s_cand is free after the sort; s_cand2 holds <= BLK sorted codes
+    u64* dd_key = (u64*)(s_cand2 + BLK);
+    u32* dd_akmax = s_cand + 2 * NDD;                           // behind dd_fp, still inside s_cand (ccap >= 6 BLK)
+    const bool dd_on = fused && world == 1 && ncand_apply <= (u32)BLK && ncand_apply > 0 && (mode == MODE_NORMAL || mode == MODE_INSERT) &&
+                       ccap >= 6u * BLK;
+    if (dd_on)
+      for (u32 k = tid; k < NDD; k += BLK) { dd_fp[k] = 0; dd_key[k] = ~(u64)0; dd_akmax[k] = 0; }   // (s_cand was last read by the sort's scatter, a barrier ago)
+#else
+    constexpr bool dd_on = false;
+#endif
     if (tid == 0) { s_tile_base = s_chunk_used; s_tile_cursor = 0; }
     VSR_SYNC();
     // ---- apply + fingerprint + seen-set claim: one lane per enabled instance
     u32 my_probes = 0, my_maxbag = 0, my_words = 0;
     u64 my_fx = 0, my_fs = 0;                                   // virtual level: checksums of the fingerprints this lane inserted
-    const u32 ncand_apply = s_skip ? 0u : ncand;                // s_skip: the tile was refused (see the word-chunk reservation)
+#if VSR_DEDUP
+    for (u32 c0 = 0; c0 < ncand_apply; c0 += BLK) {              // block-uniform trip count: the filter's barrier sits inside
+      const u32 c = c0 + tid;
+      bool act = c < ncand_apply;
+      const u32 code = act ? s_cand2[c] : 0u;
+      const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
+      const u64* rec = s_rec + p * stride;
+      Delta D;
+      u64 Hc[6];
+      u64 fp = 0, key = 0;
+      u32 ak = 0;
+      bool dd_tie = false;
+      const u64 a_0 = VSR_CLK();
+      if (act) {
+        if (!Ops::template gen_<false>(M, rec, ord, D) || D.action != (int)(code >> 18)) {
+          raise_error(ctl, ERR_INTERNAL, ((p_base + (u64)p) << 16) | (u64)ord);
+          act = false;
+        } else if (D.err) {
+          raise_error(ctl, D.err, ((p_base + (u64)p) << 16) | (u64)ord);
+          act = false;
+        }
+      }
+      const u64 a_1 = VSR_CLK();
+      if (act) {
+        Ops::hash_child_(M, rec, D, Hc);
+        canonical_fp(M, D.hdr, Hc, &fp, &ak);
+        key = meta_make(level, ak, s_pfp[p]);
+      }
+#if VSR_DIAG_DBLPROBE     // diagnostic build: one more random seen-set line per successor (marginal cost of a probe)
+      if (act) { u64 m_ = 0; if (probe_lookup(table, tmask, fp * 0x9E3779B97F4A7C15ull + 1, &m_, &my_probes)) my_maxbag += (u32)(m_ & 1); }
+#endif
+      const u64 a_2 = VSR_CLK();
+      if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
+#if VSR_DEDUP
+      if (dd_on) {
+        u32 h = 0;
+        u64 dkey = 0;
+        if (act) {
+          h = (u32)(fp >> 17) & (NDD - 1);
+          for (;;) {
+            const u64 old = atomicCAS((unsigned long long*)&dd_fp[h], 0ull, (unsigned long long)fp);
+            if (old == 0 || old == fp) break;
+            h = (h + 1) & (NDD - 1);
+          }
+          dkey = ((u64)ak << 54) | ((s_pfp[p] & PFP_MASK) << 9) | (u64)(tid & 511);
+          atomicMin((unsigned long long*)&dd_key[h], (unsigned long long)dkey);
+          atomicMax(&dd_akmax[h], ak);
+        }
+        VSR_SYNC();
+        if (act) {
+          const u64 won = dd_key[h];
+          if (won != dkey) act = false;                         // a duplicate inside the tile: the lane with the smallest key carries it
+          else dd_tie = dd_akmax[h] != ak;                      // copies with other aux variables: a VIEW tie IF the state is of this level
+        }
+      }
+#endif
+      if (!act) continue;
+#else
     for (u32 c = tid; c < ncand_apply; c += BLK) {
       const u32 code = s_cand2[c];
       const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
@@ -792,6 +873,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
 #endif
       const u64 a_2 = VSR_CLK();
       if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
+#endif
       if (!fused && world > 1) {                                // sharded seen-set, exact scheme: route to the owner of fp
         const int owner = owner_of(fp, world);
         if (owner != rank) {
@@ -810,7 +892,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
       }
       if (fused) {
-        bool do_write = false, remote = false, check = false;
+        bool do_write = false, remote = false, check = false, claimed_now = false;
         u64 prev_meta = META_EMPTY;
         const int owner = world > 1 ? owner_of(fp, world) : rank;
         if (mode == MODE_PROBE) {                               // probe level: looked up, not inserted; unseen successors are checked
@@ -842,6 +924,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             continue;
           }
           do_write = claimed;
+          claimed_now = claimed;
         }
         // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
         const int bad = (check || do_write) ? Ops::invariants(M, rec, D) : 0;
@@ -983,6 +1066,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
         // same-level duplicate with a different canonical auxkey = the tie the single-pass scheme cannot arbitrate
         if (prev_meta != META_EMPTY && meta_level(prev_meta) == level && meta_auxkey(prev_meta) != meta_auxkey(key)) atomicAdd(&s_acc[8], 1ull);
+#if VSR_DEDUP
+        else if (dd_tie && (claimed_now || (prev_meta != META_EMPTY && meta_level(prev_meta) == level))) atomicAdd(&s_acc[8], 1ull);
+#endif
         if (tid == 0) s_acc[13] += VSR_CLK() - a_3;
         continue;
       }
@@ -1541,14 +1627,22 @@ __global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl
 // Slot of the state whose fingerprint has the low bits `pfp` and whose level is `level` (the parent a meta word names): linear
 // probing stores a fingerprint at or after its home slot fp & mask with no empty slot in between, and the home slot only needs
 // the bits the meta word keeps (table_log2 <= 36 < 45).  ~0 = no such state.
-__device__ __forceinline__ u64 find_by_low_bits(const Slot* table, u64 tmask, u64 pfp, int level) {
-  u64 i = pfp & tmask;
+// *n_match (optional) = how many states of that level carry those 45 bits: the whole probe run (up to the first empty slot) is
+// scanned, and a second match means the predecessor pointer is AMBIGUOUS (about level size / 2^45 per step: 2e-5 for the 7.9e8
+// states of the README configuration's level 23) — the caller reports it instead of walking on through the first match.
+__device__ __forceinline__ u64 find_by_low_bits(const Slot* table, u64 tmask, u64 pfp, int level, u32* n_match = nullptr) {
+  u64 i = pfp & tmask, first = ~(u64)0;
+  u32 n = 0;
   for (u64 step = 0; step <= tmask; step++, i = (i + 1) & tmask) {
     const u64 f = table[i].fp;
-    if (f == 0) return ~(u64)0;
-    if ((f & PFP_MASK) == pfp && meta_level(table[i].meta) == level) return i;
+    if (f == 0) break;
+    if ((f & PFP_MASK) == pfp && meta_level(table[i].meta) == level) {
+      if (n++ == 0) first = i;
+      if (!n_match) break;
+    }
   }
-  return ~(u64)0;
+  if (n_match) *n_match = n;
+  return first;
 }
 __device__ __forceinline__ u64 find_exact(const Slot* table, u64 tmask, u64 fp) {
   u64 i = fp & tmask;
@@ -1560,26 +1654,36 @@ __device__ __forceinline__ u64 find_exact(const Slot* table, u64 tmask, u64 fp) 
   return ~(u64)0;
 }
 // TLCTrace.getTrace, backwards half: follow the predecessor pointers in the seen-set from the state with fingerprint `fp` of
-// level `level` back to Init.  fps[l-1] = fingerprint of the path's level-l state; fps[0] = 0 on a broken chain (cannot happen
-// on a table the search itself filled).
+// level `level` back to Init.  fps[l-1] = fingerprint of the path's level-l state; fps[level] = status: 0 ok, 1 broken chain (cannot
+// happen on a table the search itself filled), 2 | l << 8 | matches << 16 = the pointer of the path's level-(l+1) state is ambiguous.
 __global__ void k_trace_walk(const Slot* table, u64 tmask, u64 fp, int level, u64* fps) {
   if (threadIdx.x || blockIdx.x) return;
   u64 slot = find_exact(table, tmask, fp);
+  fps[level] = 0;
   for (int l = level; l >= 1; l--) {
     if (slot == ~(u64)0 || meta_level(table[slot].meta) != l) {
       fps[0] = 0;
+      fps[level] = 1;
       return;
     }
     fps[l - 1] = table[slot].fp;
-    if (l > 1) slot = find_by_low_bits(table, tmask, meta_pfp(table[slot].meta), l - 1);
+    if (l > 1) {
+      u32 n = 0;
+      slot = find_by_low_bits(table, tmask, meta_pfp(table[slot].meta), l - 1, &n);
+      if (n > 1) {
+        fps[level] = 2 | ((u64)(l - 1) << 8) | ((u64)n << 16);
+        return;
+      }
+    }
   }
 }
 // one step of the same walk, for walks that cross ranks (sharded runs): mode 0: exact fingerprint -> (fp, meta); mode 1: the 45
 // low fingerprint bits a child keeps of its parent + the parent's level -> (fp, meta).  out[0] = found (0 / 1), out[1] = fingerprint, out[2] = meta.
 __global__ void k_table_lookup(const Slot* table, u64 tmask, u64 key, int level, int mode, u64* out) {
   if (threadIdx.x || blockIdx.x) return;
-  const u64 slot = mode == 0 ? find_exact(table, tmask, key) : find_by_low_bits(table, tmask, key & PFP_MASK, level);
-  out[0] = slot != ~(u64)0 ? 1 : 0;
+  u32 n = 1;
+  const u64 slot = mode == 0 ? find_exact(table, tmask, key) : find_by_low_bits(table, tmask, key & PFP_MASK, level, &n);
+  out[0] = slot != ~(u64)0 ? (mode == 0 ? 1 : (u64)n) : 0;    // by low bits: the number of matching states of this shard (> 1: ambiguous)
   out[1] = slot != ~(u64)0 ? table[slot].fp : 0;
   out[2] = slot != ~(u64)0 ? table[slot].meta : 0;
 }

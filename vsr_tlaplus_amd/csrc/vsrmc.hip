@@ -1596,7 +1596,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
 
 // one step of a trace walk through the seen-set (k_table_lookup): by_low_bits = 0: the slot of fingerprint `key`; 1: the slot of
 // the level-`level` state whose fingerprint ends in the 45 bits `key` (what a child's meta word knows of its parent)
-int table_lookup(vsrmc_checker* c, u64 key, int level, int by_low_bits, bool* found, u64* fp, u64* meta) {
+int table_lookup(vsrmc_checker* c, u64 key, int level, int by_low_bits, int* found, u64* fp, u64* meta) {   // *found = matching states
   u64* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, 24));
   hipLaunchKernelGGL(k_table_lookup, dim3(1), dim3(64), 0, c->stream, c->table, c->tmask, key, level, by_low_bits, d);
@@ -1605,7 +1605,7 @@ int table_lookup(vsrmc_checker* c, u64 key, int level, int by_low_bits, bool* fo
                   hipMemcpy(h, d, 24, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(d);
   if (!ok) return fail(VSRMC_E_HIP, "k_table_lookup failed");
-  *found = h[0] != 0;
+  *found = (int32_t)std::min<u64>(h[0], 0x7FFFFFFF);          // by_low_bits: the number of matching states (> 1: ambiguous)
   *fp = h[1];
   *meta = h[2];
   return 0;
@@ -1613,16 +1613,25 @@ int table_lookup(vsrmc_checker* c, u64 key, int level, int by_low_bits, bool* fo
 // TLCTrace.getTrace, backwards half: the fingerprints of the path Init -> the level-`level` state with fingerprint `fp`
 int walk_trace(vsrmc_checker* c, u64 fp, int level, std::vector<u64>* fps) {
   if (level < 1) return fail(VSRMC_E_ARG, "no such level");
-  fps->assign((size_t)level, 0);
+  fps->assign((size_t)level + 1, 0);
   u64* d_fps = nullptr;
-  HIPCHK(hipMalloc((void**)&d_fps, (u64)level * 8));
-  bool ok = hipMemsetAsync(d_fps, 0, (u64)level * 8, c->stream) == hipSuccess;
+  HIPCHK(hipMalloc((void**)&d_fps, ((u64)level + 1) * 8));
+  bool ok = hipMemsetAsync(d_fps, 0, ((u64)level + 1) * 8, c->stream) == hipSuccess;
   hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->table, c->tmask, fp, level, d_fps);
   ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
-       hipMemcpy(fps->data(), d_fps, (u64)level * 8, hipMemcpyDeviceToHost) == hipSuccess;
+       hipMemcpy(fps->data(), d_fps, ((u64)level + 1) * 8, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(d_fps);
   if (!ok) return fail(VSRMC_E_HIP, "k_trace_walk failed");
-  if ((*fps)[0] == 0) return fail(VSRMC_E_STATE, "the seen-set holds no path from Init to this state at this level");
+  const u64 status = fps->back();
+  fps->pop_back();
+  if ((status & 0xFF) == 2) {
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "ambiguous predecessor pointer: %llu states of level %llu share the 45 fingerprint bits a successor keeps of its "
+                  "parent (expected about once in 2^45 / level size steps); the counter-example cannot be walked through the seen-set",
+                  (unsigned long long)(status >> 16), (unsigned long long)((status >> 8) & 0xFF));
+    return fail(VSRMC_E_STATE, buf);
+  }
+  if (status != 0 || (*fps)[0] == 0) return fail(VSRMC_E_STATE, "the seen-set holds no path from Init to this state at this level");
   return 0;
 }
 
@@ -1714,10 +1723,11 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
         rc = min_violator(c, c->h.viol_fp, &k2);
         if (rc) return rc;
         if (k2 != ~(u64)0) {                                    // its parent is a state of the virtual level: in the seen-set, found by its fingerprint bits
-          bool found = false;
+          int found = 0;
           u64 pfp = 0, pmeta = 0;
           rc = table_lookup(c, meta_pfp(k2), c->level + 1, 1, &found, &pfp, &pmeta);
           if (rc) return rc;
+          if (found > 1) return fail(VSRMC_E_STATE, "ambiguous predecessor pointer: several states of the parent's level share the 45 fingerprint bits the violating successor keeps of its parent");
           if (found) {
             best_fp = c->h.viol_fp;
             c->probe_fp = pfp;
@@ -1982,10 +1992,11 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
       }
     }
     if (first != ~(u64)0) {
-      bool found = false;
+      int found = 0;
       u64 pfp = 0, pmeta = 0;                                  // its parent: the level-(L+2) state with these fingerprint bits, in the seen-set
       rc = table_lookup(c, meta_pfp(k3), L + 2, 1, &found, &pfp, &pmeta);
       if (rc) return rc;
+      if (found > 1) return fail(VSRMC_E_STATE, "ambiguous predecessor pointer: several states of the parent's level share the 45 fingerprint bits the violating successor keeps of its parent");
       probe->viol_fp = first;
       probe->viol_mask = (int32_t)mask3;
       if (found) {
@@ -2037,10 +2048,11 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
     rc = min_violator(c, c->h.viol_fp, &key);
     if (rc) return rc;
     if (key != ~(u64)0 && c->opt.world <= 1) {                  // its parent: the newest level's state with these fingerprint bits
-      bool found = false;
+      int found = 0;
       u64 pfp = 0, pmeta = 0;
       rc = table_lookup(c, meta_pfp(key), c->level, 1, &found, &pfp, &pmeta);
       if (rc) return rc;
+      if (found > 1) return fail(VSRMC_E_STATE, "ambiguous predecessor pointer: several states of the parent's level share the 45 fingerprint bits the violating successor keeps of its parent");
       if (found) {
         c->probe_fp = pfp;
         c->probe_level = c->level;
@@ -2490,9 +2502,9 @@ int32_t vsrmc_checker_lookup(vsrmc_checker* c, uint64_t key, int32_t level, int3
                              uint64_t* meta) {
   if (!c || !found || !fp || !meta) return fail(VSRMC_E_ARG, "NULL argument");
   HIPCHK(hipSetDevice(c->opt.device));
-  bool f = false;
+  int f = 0;
   int rc = table_lookup(c, key, level, by_low_bits, &f, fp, meta);
-  *found = f ? 1 : 0;
+  *found = f;
   return rc;
 }
 

@@ -325,7 +325,7 @@ class ShardedChecker:
             mask = 0
             for r in rows:
                 mask |= r[6]
-            parent = self._agree(e.lookup((gbest[1] >> 1) & ((1 << 45) - 1), L, True))
+            parent = self._agree(e.lookup((gbest[1] >> 1) & ((1 << 45) - 1), L, True), "parent")
             if parent is None:
                 raise ShardError("probe: the parent of the violating successor %016x is in no shard" % gbest[0])
             out.update(viol_fp=gbest[0], viol_mask=mask)
@@ -397,12 +397,22 @@ class ShardedChecker:
         self.replicated, self.replicate_below = d["replicated"], d["replicate_below"]
         return self
 
-    def _agree(self, hit):
-        """hit = (a, b) 64-bit values on the rank(s) that found something, None elsewhere -> the pair on every rank (or None).
-        64-bit values cross ranks as 32-bit halves (signed int64 all-reduce); ranks that hold the same state hold the same pair."""
-        a, b = hit if hit is not None else (0, 0)
-        parts = self.x.allreduce([1 if hit is not None else 0, a >> 32, a & 0xFFFFFFFF, b >> 32, b & 0xFFFFFFFF], dist.ReduceOp.MAX)
-        return ((parts[1] << 32) | parts[2], (parts[3] << 32) | parts[4]) if parts[0] else None
+    def _agree(self, hit, what="state"):
+        """hit = (fingerprint, meta[, matches]) on the rank(s) that found something, None elsewhere -> the one pair on every rank
+        (or None).  Whole (fingerprint, meta) pairs are gathered — a per-field reduction would splice halves of different states
+        when two ranks answer — and more than one answer over all ranks is an AMBIGUOUS pointer (the 45 fingerprint bits a child
+        keeps of its parent match states of that level on several ranks, or several on one): reported, not guessed."""
+        n = 0 if hit is None else (hit[2] if len(hit) > 2 else 1)
+        a, b = (hit[0], hit[1]) if hit is not None else (0, 0)
+        rows = self.x.allgather([n, a >> 32, a & 0xFFFFFFFF, b >> 32, b & 0xFFFFFFFF])
+        answers = sorted({((r[1] << 32) | r[2], (r[3] << 32) | r[4]) for r in rows if r[0]})
+        if not answers:
+            return None
+        # the states of the replicated early levels sit in every rank's table: identical answers are one answer
+        if len({f for f, _ in answers}) > 1 or any(r[0] > 1 for r in rows):
+            raise ShardError("trace walk: ambiguous predecessor pointer — %d different states match the 45 fingerprint bits of one %s over "
+                             "the ranks (expected about once in 2^45 / level size steps)" % (max(len(answers), max(r[0] for r in rows)), what))
+        return answers[0]                                       # same fingerprint: same slot content up to the `taken` bit; the smallest
 
     def trace_fps(self, level, fp):
         """Walk the predecessor pointers — they live in the seen-set slots, i.e. on the owner of each state — from the level-`level`
@@ -414,7 +424,7 @@ class ShardedChecker:
             hit = self._agree(self.e.lookup(fp, l, False))
             if hit is None or (hit[1] >> 55) != l:
                 raise ShardError("trace walk: no level-%d state with fingerprint %016x in any shard" % (l, fp))
-            parent = self._agree(self.e.lookup((hit[1] >> 1) & ((1 << 45) - 1), l - 1, True))
+            parent = self._agree(self.e.lookup((hit[1] >> 1) & ((1 << 45) - 1), l - 1, True), "parent")
             if parent is None:
                 raise ShardError("trace walk: the parent of %016x is in no shard" % fp)
             fp = parent[0]
@@ -610,7 +620,7 @@ class HipShardEngine:
         found, fp, meta = C.c_int32(), C.c_uint64(), C.c_uint64()
         check(capi.load().vsrmc_checker_lookup(self._h, int(key), int(level), int(bool(by_low_bits)), C.byref(found), C.byref(fp),
                                                C.byref(meta)))
-        return (fp.value, meta.value) if found.value else None
+        return (fp.value, meta.value, found.value) if found.value else None   # found = matching states of this shard (by low bits: > 1 = ambiguous)
 
     def level_fps(self):
         rc, n = self._frontier_counts()
