@@ -331,6 +331,46 @@ int32_t vsrmc_shard_append(vsrmc_checker* c, const uint64_t* d_words, uint64_t n
                            const uint64_t* d_fp, uint64_t n);
 int32_t vsrmc_shard_commit(vsrmc_checker* c, vsrmc_level_info* info);
 
+/* ---- the level loop of a sharded run, natively (csrc/vsr_shard_loop.hpp) ≙ TLC's distributed mode (TLCServer / TLCWorker / FPSet servers)
+ * The loop sequences the phases above on one rank and talks to the other ranks through a vsrmc_comm: two functions and a flag.
+ *   alltoallv  element p of every array = peer p; `send + send_offs[p] * elem_bytes` holds send_counts[p] elements for p, what p sends
+ *              arrives at `recv + recv_offs[p] * elem_bytes` (recv_counts[p] elements, known to the caller); nothing is ever addressed to
+ *              oneself.  host_buffers = 0: the pointers are DEVICE memory and `stream` is the hipStream_t to order the transfer on (the
+ *              function returns when it has completed); host_buffers = 1: HOST memory, stream = NULL (the loop stages the buckets).
+ *   allgather  `bytes` of host memory from every rank, rank order, blocking.
+ * Return 0, or non-zero on failure.  vsrmc_comm_rccl_* is the RCCL transport (grouped ncclSend / ncclRecv over xGMI; librccl is
+ * dlopen'ed on first use): rank 0 makes the 128-byte id, the caller's bootstrap (torch.distributed, MPI, a file) hands it to every rank. */
+typedef struct vsrmc_comm {
+  void* ctx;
+  int32_t rank, world;
+  int32_t host_buffers;
+  int32_t reserved0;
+  int32_t (*alltoallv)(void* ctx, const void* send, const uint64_t* send_counts, const uint64_t* send_offs, void* recv,
+                       const uint64_t* recv_counts, const uint64_t* recv_offs, uint32_t elem_bytes, void* stream);
+  int32_t (*allgather)(void* ctx, const void* send, void* recv, uint32_t bytes);
+} vsrmc_comm;
+int32_t vsrmc_comm_rccl_unique_id(uint8_t* id128);
+int32_t vsrmc_comm_rccl_create(const uint8_t* id128, int32_t rank, int32_t world, int32_t device, vsrmc_comm** out);
+void vsrmc_comm_rccl_destroy(vsrmc_comm* comm);
+
+typedef struct vsrmc_shard_loop vsrmc_shard_loop;
+/* c: a sharded checker (vsrmc_options.world / rank, exact_ties = 0) in its initial state; cand_cap: (fp, key) candidates per peer and
+ * level; rec_cap / rec_words_cap: records / words one rebalancing round may move; replicate_below: levels with fewer new states are
+ * explored by every rank on its own (0 / 1: sharded from Init on).  The comm struct is copied; its ctx must outlive the loop. */
+int32_t vsrmc_shard_loop_create(vsrmc_checker* c, const vsrmc_comm* comm, uint64_t cand_cap, uint64_t rec_cap, uint64_t rec_words_cap,
+                                uint64_t replicate_below, vsrmc_shard_loop** out);
+void vsrmc_shard_loop_destroy(vsrmc_shard_loop* l);
+/* one BFS level on every rank (collective): global = the level's figures over all ranks (viol_fp = smallest violating fingerprint of
+ * any rank, ~0 if none; n_new == 0: exhausted), local = this rank's own */
+int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsrmc_level_info* local);
+/* ≙ vsrmc_check: stop_reason 0 exhausted, 1 invariant violated, 2 max_depth */
+int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t stop_on_violation, int32_t* stop_reason, vsrmc_level_info* last);
+int32_t vsrmc_shard_loop_status(vsrmc_shard_loop* l, int32_t* level, uint64_t* distinct, uint64_t* n_frontier, int32_t* replicated,
+                                uint64_t* viol_fp, int32_t* viol_mask, int32_t* viol_level, uint64_t* moved, uint64_t* bytes_sent);
+/* TLCTrace.getTrace across ranks (collective): fps[0 .. level) = fingerprints of the path Init -> the level-`level` state `fp`;
+ * vsrmc_model_replay_fps re-executes it on one GPU */
+int32_t vsrmc_shard_loop_trace_fps(vsrmc_shard_loop* l, int32_t level, uint64_t fp, uint64_t* fps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,9 +38,13 @@ def main():
         def make_engine(recover=None):
             return sharded.HipShardEngine(m, rank, world, device=0, table_log2=20, frontier_words=1 << 22, frontier_states=1 << 17,
                                           pending_entries=1 << 19, cand_cap=1 << 18, rec_cap=1 << 17, rec_words_cap=1 << 22,
-                                          exact_ties=engine_kind == "hip-exact", filter_log2=16, recover=recover)
+                                          exact_ties=engine_kind == "hip-exact", filter_log2=16, recover=recover)   # "native": the same engine under the C++ loop
     eng = make_engine()
-    sc = sharded.ShardedChecker(eng, sharded.Exchanger(), replicate_below=replicate_below)
+    if engine_kind == "native":                                # the C++ level loop (csrc/vsr_shard_loop.hpp) over gloo callbacks
+        sc = sharded.NativeShardedChecker(eng, sharded.TorchHostComm(), replicate_below=replicate_below)
+        sc.x = sharded.Exchanger()
+    else:
+        sc = sharded.ShardedChecker(eng, sharded.Exchanger(), replicate_below=replicate_below)
     # "replicated": the level's states are on every rank (the ranks explored it on their own), else each state is on one rank
     levels = [dict(level=1, n_new=sc.distinct, generated=0, deadlocks=0, replicated=sc.replicated,
                    fps=["%016x" % int(f) for f in eng.level_fps()])]

@@ -154,7 +154,9 @@ def test_balance_plan_is_deterministic_and_conservative():
 @pytest.mark.parametrize("engine,world,params,depth,rb", [
     ("hip", 2, (3, 1, 2, 2), 11, 0), ("hip", 3, (3, 1, 3, 3), 9, 0), ("hip", 2, (5, 1, 2, 2), 6, 0),
     ("hip", 2, (3, 1, 2, 2), 12, 200), ("hip", 3, (3, 1, 2, 2), 9, 10 ** 9),
-    ("hip-exact", 2, (3, 1, 2, 2), 11, 0), ("hip-exact", 3, (3, 1, 3, 3), 8, 50)])
+    ("hip-exact", 2, (3, 1, 2, 2), 11, 0), ("hip-exact", 3, (3, 1, 3, 3), 8, 50),
+    # the level loop in C++ (csrc/vsr_shard_loop.hpp) over two gloo callbacks, buckets staged through pinned host memory
+    ("native", 2, (3, 1, 2, 2), 11, 0), ("native", 3, (3, 1, 3, 3), 9, 0), ("native", 2, (3, 1, 2, 2), 12, 200), ("native", 3, (3, 1, 2, 2), 9, 10 ** 9)])
 def test_sharded_hip_engine_on_one_gpu(tmp_path, engine, world, params, depth, rb):
     """All ranks share device 0 and exchange over gloo (staged through the host): every HIP kernel of the sharded protocol
     runs.  "hip" = single-pass levels (k_expand<true> with the sent-filter and speculative writes, k_claim_batch_fused,
@@ -229,19 +231,21 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [4])
-def test_bench_sharded_leg_at_full_scale(world):
+@pytest.mark.parametrize("world,native", [(4, False), (2, True)])
+def test_bench_sharded_leg_at_full_scale(world, native):
     """`bench.py --gpus N` (the driver's scaling run) with N ranks sharing this GPU over gloo: the whole 319 M-state workload
     with the buffer sizes the leg computes for that world size; bench asserts the distinct-state count, the depth, the
-    violating fingerprint and the trace replay itself."""
+    violating fingerprint and the trace replay itself.  native: the level loop in C++ (on a multi-GPU node it talks RCCL directly;
+    here its two collectives are gloo callbacks and the buckets are staged through the host)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(29680 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
-                       env=dict(os.environ, OMP_NUM_THREADS="1", VSR_BENCH_BACKEND="gloo"))
+                       env=dict(os.environ, OMP_NUM_THREADS="1", VSR_BENCH_BACKEND="gloo", **({"VSR_BENCH_NATIVE": "1"} if native else {})))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["launches"] >= 27
+    assert out["config"]["level_loop"].startswith("native C++" if native else "Python")   # the C++ loop over gloo callbacks / the Python loop
 
 
 @pytest.mark.gpu

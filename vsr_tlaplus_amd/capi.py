@@ -41,6 +41,17 @@ class ShardIO(C.Structure):
     _fields_ = [("cand_send", C.c_void_p), ("cand_cap", C.c_uint64)]
 
 
+A2AV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                       C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p)
+AG_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32)
+
+
+class Comm(C.Structure):
+    """vsrmc_comm: the transport of the native sharded level loop (include/vsrmc.h)"""
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("host_buffers", C.c_int32), ("reserved0", C.c_int32),
+                ("alltoallv", A2AV_FN), ("allgather", AG_FN)]
+
+
 class SimResult(C.Structure):
     _fields_ = [("found", C.c_int32), ("viol_mask", C.c_int32), ("viol_steps", C.c_int32), ("reserved", C.c_int32),
                 ("steps", C.c_uint64), ("walks", C.c_uint64), ("seconds", C.c_double), ("ords", C.c_uint32 * 512)]
@@ -117,6 +128,17 @@ SYMBOLS = {
     "vsrmc_shard_local_step": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_shard_partition": (C.c_int32, [V, C.POINTER(C.c_uint64)]),
     "vsrmc_shard_set_max_bag": (C.c_int32, [V, C.c_uint64]),
+    "vsrmc_comm_rccl_unique_id": (C.c_int32, [V]),
+    "vsrmc_comm_rccl_create": (C.c_int32, [V, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.POINTER(Comm))]),
+    "vsrmc_comm_rccl_destroy": (None, [C.POINTER(Comm)]),
+    "vsrmc_shard_loop_create": (C.c_int32, [V, C.POINTER(Comm), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(V)]),
+    "vsrmc_shard_loop_destroy": (None, [V]),
+    "vsrmc_shard_loop_step": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo)]),
+    "vsrmc_shard_loop_run": (C.c_int32, [V, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(LevelInfo)]),
+    "vsrmc_shard_loop_status": (C.c_int32, [V, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64)]),
+    "vsrmc_shard_loop_trace_fps": (C.c_int32, [V, C.c_int32, C.c_uint64, V]),
 }
 
 _lib = None

@@ -152,6 +152,9 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #ifndef VSR_DEDUP
 #define VSR_DEDUP 0
 #endif
+#ifndef VSR_WAVE_COMPACT
+#define VSR_WAVE_COMPACT 0
+#endif
 #ifndef VSR_COPY_PIPE
 #define VSR_COPY_PIPE 1
 #endif
@@ -961,8 +964,35 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         if (do_write) {                                         // new state (or: possibly new, the owner decides): write it out
           const int plen = (int)(s_ref[p] & 255);
           const int clen = M.fixed + hdr_nmsg(D.hdr);
+#if VSR_WAVE_COMPACT     // the north-star's "wavefront ballot / prefix-sum compaction" of the new states: one LDS atomic per wave and counter
+          u32 io, wo;
+          {
+            // the lanes that write a successor are a sparse, divergent subset of the wave (the others left the loop body earlier), so
+            // a shuffle scan has nobody to forward partial sums: ranks come from the ballot, word offsets from a walk over the
+            // active lanes with a wave-uniform trip count (readlane of a uniform lane index)
+            const u64 active = __ballot(1);
+            const int leader = __ffsll((long long)active) - 1;
+            u32 tot = 0, my_w = 0;
+            for (u64 mset = active; mset; mset &= mset - 1) {
+              const int src = __ffsll((long long)mset) - 1;
+              const u32 v = (u32)__builtin_amdgcn_readlane((int)clen, src);
+              my_w += src < lane ? v : 0u;
+              tot += v;
+            }
+            u32 base_i = 0, base_w = 0;
+            if (lane == leader) {
+              base_i = atomicAdd(&s_tile_icur, (u32)__popcll(active));
+              base_w = atomicAdd(&s_tile_wcur, tot);
+            }
+            base_i = (u32)__builtin_amdgcn_readlane((int)base_i, leader);
+            base_w = (u32)__builtin_amdgcn_readlane((int)base_w, leader);
+            io = base_i + (u32)__popcll(active & (((u64)1 << lane) - 1));
+            wo = base_w + my_w;
+          }
+#else
           const u32 io = atomicAdd(&s_tile_icur, 1u);
           const u32 wo = atomicAdd(&s_tile_wcur, (u32)clen);
+#endif
           const u64 idx = s_ich_base + s_tile_ibase + io;
           const u64 dst = s_wch_base + s_tile_wbase + wo;
           u64* out = nx_words + dst;

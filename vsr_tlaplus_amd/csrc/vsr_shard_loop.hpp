@@ -1,0 +1,532 @@
+// vsr_shard_loop.hpp — the level loop of a sharded run in C++ (included by vsrmc.hip: it drives the vsrmc_shard_* phases of one rank's
+// checker and talks to the other ranks through a vsrmc_comm).
+//
+// TLC role replaced: the distributed mode's TLCServer / TLCWorker round trip (fingerprints shipped to the FPSet servers that own them,
+// SURVEY §8e) — here one rank per GPU, owner(fp) = high fingerprint bits mod world, 16-byte (fp, key) candidates to the owner and one
+// verdict byte back per BFS level.  Round 2 ran this protocol as a Python loop over torch.distributed (vsr_tlaplus_amd/sharded.py,
+// kept: it is what the CPU gloo tests drive against a stand-in engine); this is the same protocol without the interpreter between
+// the phases: per sharded level one count all-gather, two all-to-all-v (candidates out, verdict bytes back), one all-gather to
+// compare frontier sizes (+ three all-to-all-v when records have to move), one all-gather with the level's figures.
+//
+// Transport = vsrmc_comm (include/vsrmc.h): (a) RCCL — grouped ncclSend / ncclRecv on the checker's stream, small all-gathers through
+// a device staging buffer; librccl is dlopen'ed when such a comm is created, libvsrmc.so itself does not link it; (b) any caller-
+// supplied pair of functions moving HOST buffers (the tests run gloo through ctypes callbacks with every rank on one GPU): the loop
+// then stages the buckets through host memory.
+#pragma once
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---- RCCL transport ------------------------------------------------------------------------------------------------------------
+struct RcclId128 { char b[128]; };   // ncclUniqueId: 128 opaque bytes, passed by value
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+typedef decltype(RcclApi::CommInitRank) RcclInitFn;
+
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {   // a librccl a framework loaded already serves this too
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = (int (*)(void*))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (RcclInitFn)dlsym(api.lib, "ncclCommInitRank");
+      api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+      api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
+      api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
+      api.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(api.lib, "ncclSend");
+      api.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(api.lib, "ncclRecv");
+      api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
+      api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv || !api.AllGather)
+        api.lib = nullptr;
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+
+struct RcclCtx {
+  void* comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  char* d_stage = nullptr;       // (world + 1) * STAGE bytes: small all-gathers
+  hipStream_t stream = nullptr;  // for the small all-gathers; all-to-all-v runs on the stream the loop passes
+  enum { STAGE = 512 };
+};
+const int NCCL_CHAR = 0;         // ncclInt8 / ncclChar
+
+int rccl_alltoallv(void* vctx, const void* send, const uint64_t* scnt, const uint64_t* soff, void* recv, const uint64_t* rcnt,
+                   const uint64_t* roff, uint32_t eb, void* stream) {
+  RcclCtx* x = (RcclCtx*)vctx;
+  RcclApi* a = rccl_api();
+  int rc = a->GroupStart();
+  for (int p = 0; p < x->world && rc == 0; p++) {
+    if (p == x->rank) continue;
+    if (scnt[p]) rc = a->Send((const char*)send + soff[p] * eb, scnt[p] * eb, NCCL_CHAR, p, x->comm, (hipStream_t)stream);
+    if (rc == 0 && rcnt[p]) rc = a->Recv((char*)recv + roff[p] * eb, rcnt[p] * eb, NCCL_CHAR, p, x->comm, (hipStream_t)stream);
+  }
+  const int rc2 = a->GroupEnd();
+  if (rc == 0) rc = rc2;
+  if (rc == 0 && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = -1;
+  return rc == 0 ? 0 : fail(VSRMC_E_HIP, std::string("RCCL all-to-all-v: ") + (rc > 0 && a->GetErrorString ? a->GetErrorString(rc) : "stream error"));
+}
+int rccl_allgather(void* vctx, const void* send, void* recv, uint32_t bytes) {
+  RcclCtx* x = (RcclCtx*)vctx;
+  RcclApi* a = rccl_api();
+  if (bytes > RcclCtx::STAGE) return fail(VSRMC_E_ARG, "all-gather record larger than the staging buffer");
+  if (hipMemcpyAsync(x->d_stage, send, bytes, hipMemcpyHostToDevice, x->stream) != hipSuccess) return fail(VSRMC_E_HIP, "all-gather staging copy");
+  const int rc = a->AllGather(x->d_stage, x->d_stage + RcclCtx::STAGE, bytes, NCCL_CHAR, x->comm, x->stream);
+  if (rc != 0) return fail(VSRMC_E_HIP, std::string("RCCL all-gather: ") + (a->GetErrorString ? a->GetErrorString(rc) : "?"));
+  if (hipMemcpyAsync(recv, x->d_stage + RcclCtx::STAGE, (size_t)bytes * x->world, hipMemcpyDeviceToHost, x->stream) != hipSuccess ||
+      hipStreamSynchronize(x->stream) != hipSuccess)
+    return fail(VSRMC_E_HIP, "all-gather result copy");
+  return 0;
+}
+
+// deterministic plan (the same on every rank): move k states from src to dst so that every rank ends within `tol` of the mean
+struct Move { int src, dst; u64 k; };
+std::vector<Move> balance_plan(const std::vector<u64>& counts, double tol = 1.25, u64 min_per_rank = 64) {
+  const int w = (int)counts.size();
+  u64 total = 0, hi = 0, lo = ~(u64)0;
+  for (u64 c : counts) { total += c; hi = std::max(hi, c); lo = std::min(lo, c); }
+  std::vector<Move> plan;
+  if (w < 2 || total < (u64)w * min_per_rank) return plan;
+  const double mean = (double)total / w;
+  if ((double)hi <= tol * mean && (double)lo >= mean / tol) return plan;
+  std::vector<std::pair<int, u64>> surplus, deficit;
+  for (int r = 0; r < w; r++) {
+    const u64 target = total / w + ((u64)r < total % w ? 1 : 0);
+    if (counts[r] > target) surplus.push_back({r, counts[r] - target});
+    else if (counts[r] < target) deficit.push_back({r, target - counts[r]});
+  }
+  for (auto& s : surplus)
+    for (auto& d : deficit) {
+      if (s.second == 0) break;
+      const u64 k = std::min(s.second, d.second);
+      if (k) { plan.push_back(Move{s.first, d.first, k}); s.second -= k; d.second -= k; }
+    }
+  return plan;
+}
+
+}  // namespace
+
+struct vsrmc_shard_loop {
+  vsrmc_checker* c = nullptr;
+  vsrmc_comm comm;
+  int rank = 0, world = 1;
+  u64 cand_cap = 0, rec_cap = 0, rec_words_cap = 0, replicate_below = 0;
+  bool replicated = true;
+  int level = 1;
+  u64 distinct = 1, n_frontier = 1, moved = 0, bytes_sent = 0;
+  bool has_violation = false;
+  u64 viol_fp = 0;
+  int viol_mask = 0, viol_level = 0;
+  // device buffers
+  u64* cand_send = nullptr;      // [world][cand_cap][2]
+  u64* cand_recv = nullptr;      // up to world * cand_cap pairs, packed by source rank
+  uint8_t* verdict_out = nullptr;  // one byte per received candidate
+  uint8_t* verdict_in = nullptr;   // [world][cand_cap]
+  u64 *mv_words = nullptr, *mv_off = nullptr, *mv_fp = nullptr, *rv_words = nullptr, *rv_off = nullptr, *rv_fp = nullptr;   // rebalancing streams (allocated on first use)
+  // host staging for transports that move host memory
+  char* h_send = nullptr;
+  char* h_recv = nullptr;
+  u64 h_cap = 0;
+};
+
+namespace {
+
+int loop_stage_cap(vsrmc_shard_loop* l, u64 bytes) {
+  if (bytes <= l->h_cap) return 0;
+  if (l->h_send) (void)hipHostFree(l->h_send);
+  if (l->h_recv) (void)hipHostFree(l->h_recv);
+  l->h_send = l->h_recv = nullptr;
+  l->h_cap = 0;
+  if (hipHostMalloc((void**)&l->h_send, bytes) != hipSuccess || hipHostMalloc((void**)&l->h_recv, bytes) != hipSuccess)
+    return fail(VSRMC_E_HIP, "hipHostMalloc of the exchange staging buffers failed");
+  l->h_cap = bytes;
+  return 0;
+}
+
+// all-to-all-v of device buffers through the loop's transport (element offsets / counts; nothing is sent to oneself)
+int loop_alltoallv(vsrmc_shard_loop* l, const void* d_send, const u64* scnt, const u64* soff, void* d_recv, const u64* rcnt, const u64* roff, u32 eb) {
+  for (int p = 0; p < l->world; p++)
+    if (p != l->rank) l->bytes_sent += scnt[p] * eb;
+  if (!l->comm.host_buffers) return l->comm.alltoallv(l->comm.ctx, d_send, scnt, soff, d_recv, rcnt, roff, eb, (void*)l->c->stream);
+  // host transport: pack the non-empty buckets contiguously on the host, exchange, unpack
+  std::vector<u64> hs(l->world, 0), hr(l->world, 0);
+  u64 st = 0, rt = 0;
+  for (int p = 0; p < l->world; p++) {
+    hs[p] = st; hr[p] = rt;
+    if (p != l->rank) { st += scnt[p]; rt += rcnt[p]; }
+  }
+  int rc = loop_stage_cap(l, std::max<u64>(1, std::max(st, rt)) * eb);
+  if (rc) return rc;
+  for (int p = 0; p < l->world; p++)
+    if (p != l->rank && scnt[p] && hipMemcpyAsync(l->h_send + hs[p] * eb, (const char*)d_send + soff[p] * eb, scnt[p] * eb, hipMemcpyDeviceToHost, l->c->stream) != hipSuccess)
+      return fail(VSRMC_E_HIP, "staging copy (device to host)");
+  if (hipStreamSynchronize(l->c->stream) != hipSuccess) return fail(VSRMC_E_HIP, "stream synchronisation");
+  std::vector<u64> sc(scnt, scnt + l->world), rcv(rcnt, rcnt + l->world);
+  sc[l->rank] = rcv[l->rank] = 0;
+  rc = l->comm.alltoallv(l->comm.ctx, l->h_send, sc.data(), hs.data(), l->h_recv, rcv.data(), hr.data(), eb, nullptr);
+  if (rc) return rc > 0 ? fail(VSRMC_E_HIP, "the caller's all-to-all-v failed") : rc;
+  for (int p = 0; p < l->world; p++)
+    if (p != l->rank && rcnt[p] && hipMemcpyAsync((char*)d_recv + roff[p] * eb, l->h_recv + hr[p] * eb, rcnt[p] * eb, hipMemcpyHostToDevice, l->c->stream) != hipSuccess)
+      return fail(VSRMC_E_HIP, "staging copy (host to device)");
+  if (hipStreamSynchronize(l->c->stream) != hipSuccess) return fail(VSRMC_E_HIP, "stream synchronisation");
+  return 0;
+}
+
+int loop_allgather(vsrmc_shard_loop* l, const void* mine, void* all, u32 bytes) {
+  const int rc = l->comm.allgather(l->comm.ctx, mine, all, bytes);
+  return rc > 0 ? fail(VSRMC_E_HIP, "the caller's all-gather failed") : rc;
+}
+
+// every rank learns the largest error code; a failing rank never leaves the others inside a collective
+int loop_fail_together(vsrmc_shard_loop* l, int phase_rc, const char* phase, bool gather) {
+  u64 mine = phase_rc ? (u64)(phase_rc < 0 ? -phase_rc : phase_rc) : 0, worst = mine;
+  if (gather) {
+    std::vector<u64> all(l->world, 0);
+    const int rc = loop_allgather(l, &mine, all.data(), 8);
+    if (rc) return rc;
+    for (u64 e : all) worst = std::max(worst, e);
+  }
+  if (!worst) return 0;
+  if (phase_rc) return phase_rc;                                 // this rank's own message stays in vsrmc_last_error()
+  return fail(VSRMC_E_STATE, std::string("level ") + std::to_string(l->level + 1) + ", phase " + phase + ": error " + std::to_string((long long)worst) + " on another rank");
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vsrmc_comm_rccl_unique_id(uint8_t* id128) {
+  if (!id128) return fail(VSRMC_E_ARG, "NULL argument");
+  RcclApi* a = rccl_api();
+  if (!a) return fail(VSRMC_E_HIP, "librccl.so could not be loaded");
+  const int rc = a->GetUniqueId(id128);
+  return rc == 0 ? 0 : fail(VSRMC_E_HIP, std::string("ncclGetUniqueId: ") + (a->GetErrorString ? a->GetErrorString(rc) : "?"));
+}
+
+int32_t vsrmc_comm_rccl_create(const uint8_t* id128, int32_t rank, int32_t world, int32_t device, vsrmc_comm** out) {
+  if (!id128 || !out || world < 1 || world > 8 || rank < 0 || rank >= world) return fail(VSRMC_E_ARG, "bad RCCL communicator arguments (1 <= world <= 8)");
+  RcclApi* a = rccl_api();
+  if (!a) return fail(VSRMC_E_HIP, "librccl.so could not be loaded");
+  HIPCHK(hipSetDevice(device));
+  RcclCtx* x = new RcclCtx();
+  x->rank = rank; x->world = world; x->device = device;
+  RcclId128 id;
+  std::memcpy(id.b, id128, 128);
+  int rc = a->CommInitRank(&x->comm, world, id, rank);
+  if (rc != 0) { delete x; return fail(VSRMC_E_HIP, std::string("ncclCommInitRank: ") + (a->GetErrorString ? a->GetErrorString(rc) : "?")); }
+  if (hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&x->d_stage, (size_t)(world + 1) * RcclCtx::STAGE) != hipSuccess) {
+    a->CommDestroy(x->comm);
+    delete x;
+    return fail(VSRMC_E_HIP, "RCCL communicator: stream / staging buffer");
+  }
+  vsrmc_comm* cm = new vsrmc_comm();
+  cm->ctx = x; cm->rank = rank; cm->world = world; cm->host_buffers = 0;
+  cm->alltoallv = rccl_alltoallv;
+  cm->allgather = rccl_allgather;
+  *out = cm;
+  return 0;
+}
+
+void vsrmc_comm_rccl_destroy(vsrmc_comm* cm) {
+  if (!cm) return;
+  RcclCtx* x = (RcclCtx*)cm->ctx;
+  if (x) {
+    RcclApi* a = rccl_api();
+    if (a && x->comm) a->CommDestroy(x->comm);
+    if (x->d_stage) (void)hipFree(x->d_stage);
+    if (x->stream) (void)hipStreamDestroy(x->stream);
+    delete x;
+  }
+  delete cm;
+}
+
+int32_t vsrmc_shard_loop_create(vsrmc_checker* c, const vsrmc_comm* comm, uint64_t cand_cap, uint64_t rec_cap, uint64_t rec_words_cap,
+                                uint64_t replicate_below, vsrmc_shard_loop** out) {
+  if (!c || !comm || !out || !comm->alltoallv || !comm->allgather) return fail(VSRMC_E_ARG, "NULL argument");
+  if (comm->world != c->opt.world || comm->rank != c->opt.rank) return fail(VSRMC_E_ARG, "the communicator and the checker disagree about rank / world");
+  if (c->opt.exact_ties) return fail(VSRMC_E_STATE, "the native level loop runs single-pass levels (exact_ties = 0)");
+  if (cand_cap < 1024) return fail(VSRMC_E_ARG, "cand_cap too small");
+  HIPCHK(hipSetDevice(c->opt.device));
+  vsrmc_shard_loop* l = new vsrmc_shard_loop();
+  l->c = c; l->comm = *comm; l->rank = comm->rank; l->world = comm->world;
+  l->cand_cap = cand_cap; l->rec_cap = rec_cap; l->rec_words_cap = rec_words_cap; l->replicate_below = replicate_below;
+  const u64 w = (u64)l->world;
+  hipError_t e = hipMalloc((void**)&l->cand_send, w * cand_cap * 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&l->cand_recv, w * cand_cap * 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&l->verdict_out, w * cand_cap);
+  if (e == hipSuccess) e = hipMalloc((void**)&l->verdict_in, w * cand_cap);
+  if (e != hipSuccess) { vsrmc_shard_loop_destroy(l); return fail(VSRMC_E_HIP, std::string("hipMalloc of the exchange buffers: ") + hipGetErrorString(e)); }
+  l->level = c->level; l->distinct = c->distinct; l->n_frontier = c->n_frontier;
+  if (replicate_below <= 1) {
+    u64 kept = 0;
+    const int rc = vsrmc_shard_partition(c, &kept);
+    if (rc) { vsrmc_shard_loop_destroy(l); return rc; }
+    l->replicated = false;
+  }
+  *out = l;
+  return 0;
+}
+
+void vsrmc_shard_loop_destroy(vsrmc_shard_loop* l) {
+  if (!l) return;
+  for (void* p : {(void*)l->cand_send, (void*)l->cand_recv, (void*)l->verdict_out, (void*)l->verdict_in, (void*)l->mv_words, (void*)l->mv_off,
+                  (void*)l->mv_fp, (void*)l->rv_words, (void*)l->rv_off, (void*)l->rv_fp})
+    if (p) (void)hipFree(p);
+  if (l->h_send) (void)hipHostFree(l->h_send);
+  if (l->h_recv) (void)hipHostFree(l->h_recv);
+  delete l;
+}
+
+// One BFS level on every rank (collective).  global = the level's figures summed / maximised over the ranks (viol_fp = the smallest
+// violating fingerprint of any rank, ~0 if none); local = this rank's own.  global->n_new == 0: the search is exhausted.
+int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsrmc_level_info* local) {
+  if (!l || !global || !local) return fail(VSRMC_E_ARG, "NULL argument");
+  vsrmc_checker* c = l->c;
+  const int w = l->world, me = l->rank;
+  std::memset(global, 0, sizeof(*global));
+  std::memset(local, 0, sizeof(*local));
+  if (l->replicated) {                                           // every rank explores the small early levels on its own: no collective
+    int rc = vsrmc_shard_local_step(c, local);
+    if (rc) return rc;
+    vsrmc_shard_set_max_bag(c, local->max_bag);
+    *global = *local;
+    l->level += 1;
+    l->n_frontier = local->n_new;
+    l->distinct += local->n_new;
+    global->distinct = l->distinct;
+    if (local->viol_mask && !l->has_violation) {
+      l->has_violation = true; l->viol_fp = local->viol_fp; l->viol_mask = local->viol_mask; l->viol_level = l->level;
+    } else if (local->n_new >= l->replicate_below) {
+      u64 kept = 0;
+      rc = vsrmc_shard_partition(c, &kept);
+      if (rc) return rc;
+      l->replicated = false;
+    }
+    return 0;
+  }
+  // ---- 1. expand; candidates owned by other ranks are bucketed per owner
+  vsrmc_shard_io io;
+  io.cand_send = l->cand_send;
+  io.cand_cap = l->cand_cap;
+  uint64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int rc = vsrmc_shard_expand(c, &io, counts);
+  struct CountRow { u64 cnt[8]; u64 err; } mine, zero;
+  std::memset(&zero, 0, sizeof(zero));
+  mine = zero;
+  for (int p = 0; p < w; p++) mine.cnt[p] = (p == me || rc) ? 0 : std::min<u64>(counts[p], l->cand_cap);
+  mine.err = rc ? (u64)(rc < 0 ? -rc : rc) : 0;
+  std::vector<CountRow> all(w, zero);
+  int crc = loop_allgather(l, &mine, all.data(), (u32)sizeof(CountRow));
+  if (crc) return crc;
+  u64 worst = 0;
+  for (const CountRow& r : all) worst = std::max(worst, r.err);
+  if (worst) return rc ? rc : fail(VSRMC_E_STATE, "level " + std::to_string(l->level + 1) + ", phase expand: error " + std::to_string((long long)worst) + " on another rank");
+  // ---- 2. candidates to their owners
+  u64 scnt[8], soff[8], rcnt[8], roff[8], n_recv = 0;
+  for (int p = 0; p < w; p++) {
+    scnt[p] = mine.cnt[p];
+    soff[p] = (u64)p * l->cand_cap;
+    rcnt[p] = p == me ? 0 : all[p].cnt[me];
+    roff[p] = n_recv;
+    n_recv += rcnt[p];
+  }
+  if (n_recv > (u64)w * l->cand_cap) return fail(VSRMC_E_REP, "more candidates received than the exchange buffer holds");
+  rc = loop_alltoallv(l, l->cand_send, scnt, soff, l->cand_recv, rcnt, roff, 16);
+  // ---- 3. claim them in this rank's shard; 4. verdict bytes back to the generators
+  if (!rc) rc = vsrmc_shard_claim(c, l->cand_recv, n_recv, l->verdict_out);
+  int rc2 = loop_fail_together(l, rc, "claim", true);
+  if (rc2) return rc2;
+  rc = loop_alltoallv(l, l->verdict_out, rcnt, roff, l->verdict_in, scnt, soff, 1);
+  // ---- 5. withdraw the announced successors that lost
+  if (!rc) rc = vsrmc_shard_materialize(c, &io, l->verdict_in);
+  // ---- 6. compare the frontier sizes; move records where they are missing (rare)
+  u64 valid = 0, range = 0;
+  if (!rc) rc = vsrmc_shard_count(c, &valid, &range);
+  struct BalRow { u64 valid, err; } bmine = {valid, rc ? (u64)(rc < 0 ? -rc : rc) : 0};
+  std::vector<BalRow> ball(w);
+  crc = loop_allgather(l, &bmine, ball.data(), (u32)sizeof(BalRow));
+  if (crc) return crc;
+  worst = 0;
+  std::vector<u64> sizes(w);
+  for (int p = 0; p < w; p++) { worst = std::max(worst, ball[p].err); sizes[p] = ball[p].valid; }
+  if (worst) return rc ? rc : fail(VSRMC_E_STATE, "level " + std::to_string(l->level + 1) + ", phase materialize: error " + std::to_string((long long)worst) + " on another rank");
+  const std::vector<Move> plan = balance_plan(sizes);
+  if (!plan.empty()) {
+    if (!l->mv_words) {
+      hipError_t e = hipMalloc((void**)&l->mv_words, l->rec_words_cap * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&l->mv_off, l->rec_cap * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&l->mv_fp, l->rec_cap * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&l->rv_words, l->rec_words_cap * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&l->rv_off, l->rec_cap * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&l->rv_fp, l->rec_cap * 8);
+      if (e != hipSuccess) rc = fail(VSRMC_E_HIP, "hipMalloc of the rebalancing buffers failed");
+    }
+    // this rank's exports, packed one after the other: (records, words) per destination
+    struct MvRow { u64 n[8], nw[8], err; } mrow;
+    std::memset(&mrow, 0, sizeof(mrow));
+    u64 on = 0, ow = 0, hi = range;
+    u64 so_n[8] = {0}, so_w[8] = {0};
+    for (const Move& mv : plan) {
+      if (mv.src != me || rc) continue;
+      const u64 width = std::min<u64>(hi, (mv.k * range + std::max<u64>(1, valid) - 1) / std::max<u64>(1, valid));   // index window holding about k valid records
+      u64 got = 0, gotw = 0;
+      if (on >= l->rec_cap || ow >= l->rec_words_cap) break;
+      rc = vsrmc_shard_export(c, hi - width, width, l->mv_words + ow, l->rec_words_cap - ow, l->mv_off + on, l->mv_fp + on, l->rec_cap - on, &got, &gotw);
+      if (rc) break;
+      hi -= width;
+      so_n[mv.dst] = on; so_w[mv.dst] = ow;
+      mrow.n[mv.dst] = got; mrow.nw[mv.dst] = gotw;
+      on += got; ow += gotw;
+    }
+    mrow.err = rc ? (u64)(rc < 0 ? -rc : rc) : 0;
+    std::vector<MvRow> mall(w);
+    crc = loop_allgather(l, &mrow, mall.data(), (u32)sizeof(MvRow));
+    if (crc) return crc;
+    worst = 0;
+    for (const MvRow& r : mall) worst = std::max(worst, r.err);
+    if (worst) return rc ? rc : fail(VSRMC_E_STATE, "level " + std::to_string(l->level + 1) + ", phase rebalance: error " + std::to_string((long long)worst) + " on another rank");
+    u64 rn[8], rnw[8], ro_n[8], ro_w[8], tn = 0, tw = 0;
+    for (int p = 0; p < w; p++) {
+      rn[p] = p == me ? 0 : mall[p].n[me];
+      rnw[p] = p == me ? 0 : mall[p].nw[me];
+      ro_n[p] = tn; ro_w[p] = tw;
+      tn += rn[p]; tw += rnw[p];
+    }
+    if (tn > l->rec_cap || tw > l->rec_words_cap) rc = fail(VSRMC_E_REP, "received records exceed the rebalancing buffers");
+    if (!rc) rc = loop_alltoallv(l, l->mv_words, mrow.nw, so_w, l->rv_words, rnw, ro_w, 8);
+    if (!rc) rc = loop_alltoallv(l, l->mv_off, mrow.n, so_n, l->rv_off, rn, ro_n, 8);
+    if (!rc) rc = loop_alltoallv(l, l->mv_fp, mrow.n, so_n, l->rv_fp, rn, ro_n, 8);
+    for (int p = 0; p < w && !rc; p++)
+      if (p != me && rn[p]) {
+        rc = vsrmc_shard_append(c, l->rv_words + ro_w[p], rnw[p], l->rv_off + ro_n[p], l->rv_fp + ro_n[p], rn[p]);
+        l->moved += rn[p];
+      }
+  }
+  // ---- 7. commit; one all-gather carries every figure of the level
+  if (!rc) rc = vsrmc_shard_commit(c, local);
+  struct InfoRow { u64 n_new, generated, deadlocks, pending, viol_fp, err, viol_mask, max_bag, probes; } irow;
+  irow.n_new = local->n_new; irow.generated = local->generated; irow.deadlocks = local->deadlocks; irow.pending = local->pending;
+  irow.viol_fp = local->viol_mask ? local->viol_fp : ~(u64)0; irow.err = rc ? (u64)(rc < 0 ? -rc : rc) : 0;
+  irow.viol_mask = (u64)local->viol_mask; irow.max_bag = local->max_bag; irow.probes = local->probes;
+  std::vector<InfoRow> iall(w);
+  crc = loop_allgather(l, &irow, iall.data(), (u32)sizeof(InfoRow));
+  if (crc) return crc;
+  worst = 0;
+  u64 gviol = ~(u64)0, gbag = 0;
+  for (const InfoRow& r : iall) {
+    worst = std::max(worst, r.err);
+    global->n_new += r.n_new; global->generated += r.generated; global->deadlocks += r.deadlocks; global->pending += r.pending; global->probes += r.probes;
+    gviol = std::min(gviol, r.viol_fp);
+    gbag = std::max(gbag, r.max_bag);
+  }
+  if (worst) return rc ? rc : fail(VSRMC_E_STATE, "level " + std::to_string(l->level + 1) + ", phase commit: error " + std::to_string((long long)worst) + " on another rank");
+  vsrmc_shard_set_max_bag(c, gbag);
+  l->level += 1;
+  l->n_frontier = global->n_new;
+  l->distinct += global->n_new;
+  global->level = l->level;
+  global->distinct = l->distinct;
+  global->max_bag = gbag;
+  global->viol_fp = gviol;
+  global->frontier = local->frontier;
+  global->expand_ms = local->expand_ms;
+  global->materialize_ms = local->materialize_ms;
+  if (gviol != ~(u64)0) {
+    for (const InfoRow& r : iall)
+      if (r.viol_fp == gviol) global->viol_mask |= (int32_t)r.viol_mask;
+    if (!l->has_violation) { l->has_violation = true; l->viol_fp = gviol; l->viol_mask = global->viol_mask; l->viol_level = l->level; }
+  }
+  return 0;
+}
+
+// vsrmc_check for a sharded run (collective): stop_reason 0 exhausted, 1 invariant violated, 2 max_depth
+int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t stop_on_violation, int32_t* stop_reason, vsrmc_level_info* last) {
+  if (!l || !stop_reason || !last) return fail(VSRMC_E_ARG, "NULL argument");
+  vsrmc_level_info local;
+  for (;;) {
+    if (max_depth > 0 && l->level >= max_depth) { *stop_reason = 2; return 0; }
+    const int rc = vsrmc_shard_loop_step(l, last, &local);
+    if (rc) return rc;
+    if (last->n_new == 0) { *stop_reason = 0; return 0; }
+    if (l->has_violation && stop_on_violation) { *stop_reason = 1; return 0; }
+  }
+}
+
+int32_t vsrmc_shard_loop_status(vsrmc_shard_loop* l, int32_t* level, uint64_t* distinct, uint64_t* n_frontier, int32_t* replicated, uint64_t* viol_fp,
+                                int32_t* viol_mask, int32_t* viol_level, uint64_t* moved, uint64_t* bytes_sent) {
+  if (!l) return fail(VSRMC_E_ARG, "NULL argument");
+  if (level) *level = l->level;
+  if (distinct) *distinct = l->distinct;
+  if (n_frontier) *n_frontier = l->n_frontier;
+  if (replicated) *replicated = l->replicated ? 1 : 0;
+  if (viol_fp) *viol_fp = l->has_violation ? l->viol_fp : ~(u64)0;
+  if (viol_mask) *viol_mask = l->has_violation ? l->viol_mask : 0;
+  if (viol_level) *viol_level = l->viol_level;
+  if (moved) *moved = l->moved;
+  if (bytes_sent) *bytes_sent = l->bytes_sent;
+  return 0;
+}
+
+// Walk the predecessor pointers — they live in the seen-set slots, i.e. on the owner of each state — from the level-`level` state with
+// fingerprint `fp` back to Init (collective).  fps[0 .. level) = the fingerprints of the path, Init first.  Two small all-gathers per level;
+// whole (matches, fingerprint, meta) rows are gathered: identical answers (the replicated early levels live in every table) are one
+// answer, different ones are an ambiguous pointer and are reported.
+int32_t vsrmc_shard_loop_trace_fps(vsrmc_shard_loop* l, int32_t level, uint64_t fp, uint64_t* fps) {
+  if (!l || !fps || level < 1) return fail(VSRMC_E_ARG, "bad trace arguments");
+  struct Row { u64 n, fp, meta; };
+  auto agree = [&](u64 key, int lvl, int by_low, Row* out) -> int {
+    int32_t found = 0;
+    u64 f = 0, m = 0;
+    int rc = vsrmc_checker_lookup(l->c, key, lvl, by_low, &found, &f, &m);
+    Row mine = {rc ? 0 : (u64)found, f, m};
+    std::vector<Row> all(l->world);
+    const int crc = loop_allgather(l, &mine, all.data(), (u32)sizeof(Row));
+    if (crc) return crc;
+    out->n = 0;
+    for (const Row& r : all) {
+      if (!r.n) continue;
+      if (r.n > 1 || (out->n && r.fp != out->fp))
+        return fail(VSRMC_E_STATE, "trace walk: ambiguous predecessor pointer — several states match the 45 fingerprint bits of one parent over the ranks");
+      if (!out->n || r.meta < out->meta) { out->fp = r.fp; out->meta = r.meta; }
+      out->n = 1;
+    }
+    return 0;
+  };
+  fps[level - 1] = fp;
+  for (int lv = level; lv > 1; lv--) {
+    Row hit, parent;
+    int rc = agree(fp, lv, 0, &hit);
+    if (rc) return rc;
+    if (!hit.n || (int)meta_level(hit.meta) != lv) return fail(VSRMC_E_STATE, "trace walk: no state with this fingerprint at this level in any shard");
+    rc = agree(meta_pfp(hit.meta), lv - 1, 1, &parent);
+    if (rc) return rc;
+    if (!parent.n) return fail(VSRMC_E_STATE, "trace walk: the parent of a state of the path is in no shard");
+    fp = parent.fp;
+    fps[lv - 2] = fp;
+  }
+  return 0;
+}
+
+}  // extern "C"

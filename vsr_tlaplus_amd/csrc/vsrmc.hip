@@ -2742,3 +2742,5 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
 }
 
 }  // extern "C"
+
+#include "vsr_shard_loop.hpp"

@@ -14,6 +14,7 @@ drives any engine that implements the phase methods; `HipShardEngine` is the pro
 import ctypes as C
 
 import os
+import sys
 
 import numpy as np
 import torch
@@ -664,3 +665,146 @@ def replay(model, ords, device=0):
     check(capi.load().vsrmc_model_replay(model._h, device, C.c_void_p(o.ctypes.data), n, C.c_void_p(words.ctypes.data), cap_w,
                                          C.c_void_p(off.ctypes.data), C.c_void_p(acts.ctypes.data), len(off), C.byref(ns)))
     return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(ns.value)]
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The native level loop (csrc/vsr_shard_loop.hpp): the same protocol as ShardedChecker.step, sequenced in C++ with RCCL called
+# directly (grouped ncclSend / ncclRecv), or — for runs with every rank on one GPU — over torch.distributed / gloo through two callbacks.
+# ---------------------------------------------------------------------------------------------------------------------------
+class RcclComm:
+    """vsrmc_comm over RCCL.  The 128-byte communicator id is made by rank 0 and handed round with torch.distributed (any backend)."""
+
+    def __init__(self, device, group=None):
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            check(capi.load().vsrmc_comm_rccl_unique_id(buf))
+            ident = [bytes(buf)]
+        dist.broadcast_object_list(ident, src=0, group=group)
+        buf = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        self._p = C.POINTER(capi.Comm)()
+        check(capi.load().vsrmc_comm_rccl_create(buf, self.rank, self.world, int(device), C.byref(self._p)))
+        self.ptr = self._p
+
+    def close(self):
+        if self._p:
+            capi.load().vsrmc_comm_rccl_destroy(self._p)
+            self._p = None
+
+
+class TorchHostComm:
+    """vsrmc_comm over torch.distributed on HOST buffers (gloo): the loop stages its buckets through pinned host memory and calls
+    back into Python for the two collectives.  What the one-GPU tests run the native loop on; not a production transport."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+        def a2av(ctx, send, scnt, soff, recv, rcnt, roff, eb, stream):
+            try:
+                w = self.world
+                sc = [int(scnt[p]) * eb for p in range(w)]
+                rc = [int(rcnt[p]) * eb for p in range(w)]
+                st = torch.frombuffer((C.c_uint8 * max(1, sum(sc))).from_address(send), dtype=torch.uint8)[: sum(sc)] if sum(sc) else torch.empty(0, dtype=torch.uint8)
+                rt = torch.empty(sum(rc), dtype=torch.uint8)
+                # every bucket travels with one padding byte: gloo does not take empty splits from every peer at once
+                pad = torch.zeros(1, dtype=torch.uint8)
+                parts, pos = [], 0
+                for p in range(w):
+                    parts += [st[pos: pos + sc[p]], pad]
+                    pos += sc[p]
+                out = torch.empty(sum(rc) + w, dtype=torch.uint8)
+                dist.all_to_all_single(out, torch.cat(parts), [x + 1 for x in rc], [x + 1 for x in sc], group=self.group)
+                pos = opos = 0
+                for p in range(w):
+                    rt[opos: opos + rc[p]] = out[pos: pos + rc[p]]
+                    pos += rc[p] + 1
+                    opos += rc[p]
+                if sum(rc):
+                    C.memmove(recv, rt.numpy().ctypes.data, sum(rc))
+                return 0
+            except Exception as e:                              # an exception must not cross the C boundary
+                print("TorchHostComm.alltoallv: %s" % e, file=sys.stderr)
+                return 1
+
+        def ag(ctx, send, recv, nbytes):
+            try:
+                t = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
+                out = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+                dist.all_gather(out, t, group=self.group)
+                flat = torch.cat(out)                             # (a named tensor: the bytes must outlive the expression that takes their address)
+                C.memmove(recv, flat.numpy().ctypes.data, nbytes * self.world)
+                return 0
+            except Exception as e:
+                print("TorchHostComm.allgather: %s" % e, file=sys.stderr)
+                return 1
+
+        self._a2av, self._ag = capi.A2AV_FN(a2av), capi.AG_FN(ag)          # keep the callbacks alive
+        self.comm = capi.Comm(None, self.rank, self.world, 1, 0, self._a2av, self._ag)
+        self.ptr = C.pointer(self.comm)
+
+    def close(self):
+        pass
+
+
+class NativeShardedChecker:
+    """ShardedChecker's surface (step / run / violation / trace_fps / level / distinct / replicated) over the C++ level loop.
+    engine: a HipShardEngine of this rank (single-pass levels); comm: RcclComm or TorchHostComm."""
+
+    def __init__(self, engine, comm, replicate_below=0, cand_cap=None, rec_cap=None, rec_words_cap=None):
+        self.e, self.comm = engine, comm
+        self.rank, self.world = comm.rank, comm.world
+        self._l = C.c_void_p()
+        check(capi.load().vsrmc_shard_loop_create(engine._h, comm.ptr, int(cand_cap or engine.cand_cap), int(rec_cap or engine.rec_cap),
+                                                  int(rec_words_cap or engine.rec_words_cap), int(replicate_below), C.byref(self._l)))
+        self.levels, self.violation = [], None
+        self._sync()
+
+    def _sync(self):
+        lv, rep, vm, vl = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        d, nf, vf, mv, bs = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(capi.load().vsrmc_shard_loop_status(self._l, C.byref(lv), C.byref(d), C.byref(nf), C.byref(rep), C.byref(vf), C.byref(vm),
+                                                  C.byref(vl), C.byref(mv), C.byref(bs)))
+        self.level, self.distinct, self.n_frontier, self.replicated = lv.value, d.value, nf.value, bool(rep.value)
+        self.moved, self.bytes_sent = mv.value, bs.value
+        if vm.value and self.violation is None:
+            self.violation = dict(level=vl.value, fp=vf.value, mask=vm.value)
+
+    def step(self):
+        g, loc = capi.LevelInfo(), capi.LevelInfo()
+        rc = capi.load().vsrmc_shard_loop_step(self._l, C.byref(g), C.byref(loc))
+        if rc != 0:
+            raise ShardError("level %d: %s" % (self.level + 1, capi.load().vsrmc_last_error().decode()))
+        was_replicated = self.replicated
+        self._sync()
+        gd, ld = g.as_dict(), loc.as_dict()
+        if hasattr(self.e, "kernel_ms"):
+            self.e.kernel_ms["expand"] += ld["expand_ms"]
+            self.e.kernel_ms["materialize"] += ld["materialize_ms"]
+        out = dict(level=self.level, n_new=gd["n_new"], generated=gd["generated"], deadlocks=gd["deadlocks"], pending=gd["pending"],
+                   distinct=self.distinct, local=ld, viol_fp=gd["viol_fp"] if gd["viol_mask"] else None, replicated=was_replicated)
+        if gd["n_new"]:
+            self.levels.append(out)
+        return out
+
+    def run(self, max_depth=None, stop_on_violation=True):
+        while True:
+            if max_depth is not None and self.level >= max_depth:
+                return "max-depth"
+            d = self.step()
+            if d["n_new"] == 0:
+                return "exhausted"
+            if self.violation is not None and stop_on_violation:
+                return "violation"
+
+    def trace_fps(self, level, fp):
+        out = np.zeros(level, dtype=np.uint64)
+        rc = capi.load().vsrmc_shard_loop_trace_fps(self._l, int(level), int(fp), C.c_void_p(out.ctypes.data))
+        if rc != 0:
+            raise ShardError("trace walk: %s" % capi.load().vsrmc_last_error().decode())
+        return [int(f) for f in out]
+
+    def close(self):
+        if self._l:
+            capi.load().vsrmc_shard_loop_destroy(self._l)
+            self._l = C.c_void_p()

@@ -48,13 +48,23 @@ def main(args, CONFIG, EXPECT):
         rec_cap=1 << 22, rec_words_cap=1 << 28,
         keep_trace=True, trace_entries=per_rank(TOTAL, 16 * tail_idx))
     x = sharded.Exchanger()
+    # the level loop: native (C++, csrc/vsr_shard_loop.hpp) over RCCL called directly — the default on "nccl" — or the Python loop over
+    # torch.distributed (VSR_BENCH_PYLOOP=1; always on "gloo" unless VSR_BENCH_NATIVE=1 asks for the native loop over gloo callbacks)
+    native = (backend == "nccl" and not os.environ.get("VSR_BENCH_PYLOOP")) or bool(os.environ.get("VSR_BENCH_NATIVE"))
+    comm = None
+    if native:
+        comm = sharded.RcclComm(local_rank) if backend == "nccl" else sharded.TorchHostComm()
     S = dict(alg_bytes=0.0, launches=0, distinct=0, ttfv=[])
     moved = [0]
+    sent = [0]
 
     def one_run(record):
         eng.reset()
         eng.kernel_ms = dict(expand=0.0, materialize=0.0)
-        sc = sharded.ShardedChecker(eng, x, replicate_below=REPLICATE_BELOW)
+        if native:
+            sc = sharded.NativeShardedChecker(eng, comm, replicate_below=REPLICATE_BELOW)
+        else:
+            sc = sharded.ShardedChecker(eng, x, replicate_below=REPLICATE_BELOW)
         t0 = time.perf_counter()
         cur_words = (int(m.layout.fixed_words) + int(m.layout.permutations)) if sc.e.local_distinct() else 0
         while True:
@@ -75,6 +85,9 @@ def main(args, CONFIG, EXPECT):
         assert sc.distinct == EXPECT["distinct"] and sc.level == EXPECT["depth"], (sc.distinct, sc.level)
         assert sc.violation and (EXPECT["viol_fp"] is None or sc.violation["fp"] == EXPECT["viol_fp"])
         moved[0] = sc.moved
+        sent[0] += sc.bytes_sent if native else 0
+        if native:
+            sc.close()
         if record:
             S["distinct"] += sc.distinct
             S["ttfv"].append(dt)
@@ -106,9 +119,11 @@ def main(args, CONFIG, EXPECT):
                                    "(BASELINE configs[1] = shipped VSR.cfg), VIEW+SYMMETRY, to first violation: 28 levels, "
                                    "319228361 distinct states", "parallelism": "seen-set sharded by fingerprint over %d ranks, "
                                    "all-to-all of (fp, key) candidates per level (RCCL), levels below %d new states replicated"
-                                   % (world, REPLICATE_BELOW), "table_slots_log2_per_rank": table_log2},
+                                   % (world, REPLICATE_BELOW), "table_slots_log2_per_rank": table_log2,
+                       "level_loop": ("native C++ (csrc/vsr_shard_loop.hpp), " + ("direct RCCL: grouped ncclSend/ncclRecv" if backend == "nccl" else "gloo callbacks, host-staged"))
+                                     if native else "Python over torch.distributed (vsr_tlaplus_amd/sharded.py)"},
             "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
-            "xgmi_bytes_sent_rank0_per_step": int(x.bytes_sent / max(1, args.steps + args.warmup)),
+            "xgmi_bytes_sent_rank0_per_step": int((sent[0] if native else x.bytes_sent) / max(1, args.steps + args.warmup)),
             "records_moved_by_rebalancing_rank0": moved[0],
             "roofline": {"bound": "hbm", "kernel": "k_expand (rank 0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
