@@ -1,6 +1,6 @@
 """The README defect configuration of the reference (3 replicas, Values = {v1, v2, v3}, StartViewOnTimerLimit = 3; README:13-18,
-BASELINE configs[2]): the 24-state counter-example the GPU BFS found on one MI355X — levels 2-22 materialised (level 22 in
-pinned host memory), level 23 as a virtual level, level 24 probed (tests/golden/config3_violation.json).
+BASELINE configs[2]): the 24-state counter-example the GPU BFS found on one MI355X (tests/golden/config3_violation.json); its level
+table, the probe of level 24 and the violating fingerprint equal the CPU oracle's own run (oracle_levels_config3.json).
 
 CPU: both restatements of the spec accept every step under the recorded action name; AcknowledgedWriteNotLost holds in states
 1..23 and fails in state 24; the violating fingerprint is the oracle's; the level counts agree with the oracle's own BFS as deep
@@ -43,6 +43,13 @@ def test_config3_counterexample_is_a_behaviour(fx, golden_counts, golden_trace):
     # level counts against the oracle's own BFS of this configuration, as deep as it went
     mine = fx["levels"]
     assert [l["level"] for l in mine] == list(range(1, 24)) and sum(l["n_new"] for l in mine) == fx["distinct_through_level_23"]
+    # no level figure of this fixture has a GPU run as its only source any more (round 3: levels 22-23, the probe of level 24 and the
+    # violating fingerprint come from the memory-lean oracle driver, tests/golden/oracle_levels_config3.json)
+    assert all(l["source"] == "oracle" for l in mine) and fx["probe"]["source"] == "oracle"
+    with open(os.path.join(GOLDEN, "oracle_levels_config3.json")) as f:
+        o = json.load(f)
+    assert len(o["levels"]) == 23 and o["probe"]["viol_fp"] == fx["viol_fp"] and o["probe"]["generated"] == fx["probe"]["generated"]
+    assert [(l["new"], l["generated"], l["deadlocks"]) for l in o["levels"]] == [(l["n_new"], l["generated"], l["deadlocks"]) for l in mine]
     g = golden_counts["config3 (3,1,{v1,v2,v3},3)"]
     assert len(g["levels"]) >= 12
     for lv, m in zip(g["levels"], mine):

@@ -70,6 +70,7 @@ struct RcclCtx {
   char* d_stage = nullptr;       // (world + 1) * STAGE bytes: small all-gathers
   hipStream_t stream = nullptr;  // for the small all-gathers; all-to-all-v runs on the stream the loop passes
   enum { STAGE = 512 };
+  bool always_call = false;      // issue the collectives even at world 1 (latency measurements)
 };
 const int NCCL_CHAR = 0;         // ncclInt8 / ncclChar
 
@@ -77,6 +78,7 @@ int rccl_alltoallv(void* vctx, const void* send, const uint64_t* scnt, const uin
                    const uint64_t* roff, uint32_t eb, void* stream) {
   RcclCtx* x = (RcclCtx*)vctx;
   RcclApi* a = rccl_api();
+  if (x->world == 1 && !x->always_call) return 0;                // nobody to talk to
   int rc = a->GroupStart();
   for (int p = 0; p < x->world && rc == 0; p++) {
     if (p == x->rank) continue;
@@ -92,6 +94,7 @@ int rccl_allgather(void* vctx, const void* send, void* recv, uint32_t bytes) {
   RcclCtx* x = (RcclCtx*)vctx;
   RcclApi* a = rccl_api();
   if (bytes > RcclCtx::STAGE) return fail(VSRMC_E_ARG, "all-gather record larger than the staging buffer");
+  if (x->world == 1 && !x->always_call) { std::memcpy(recv, send, bytes); return 0; }   // VSRMC_COMM_ALWAYS_CALL=1: measure the collective's latency at world 1
   if (hipMemcpyAsync(x->d_stage, send, bytes, hipMemcpyHostToDevice, x->stream) != hipSuccess) return fail(VSRMC_E_HIP, "all-gather staging copy");
   const int rc = a->AllGather(x->d_stage, x->d_stage + RcclCtx::STAGE, bytes, NCCL_CHAR, x->comm, x->stream);
   if (rc != 0) return fail(VSRMC_E_HIP, std::string("RCCL all-gather: ") + (a->GetErrorString ? a->GetErrorString(rc) : "?"));
@@ -199,20 +202,6 @@ int loop_allgather(vsrmc_shard_loop* l, const void* mine, void* all, u32 bytes) 
   return rc > 0 ? fail(VSRMC_E_HIP, "the caller's all-gather failed") : rc;
 }
 
-// every rank learns the largest error code; a failing rank never leaves the others inside a collective
-int loop_fail_together(vsrmc_shard_loop* l, int phase_rc, const char* phase, bool gather) {
-  u64 mine = phase_rc ? (u64)(phase_rc < 0 ? -phase_rc : phase_rc) : 0, worst = mine;
-  if (gather) {
-    std::vector<u64> all(l->world, 0);
-    const int rc = loop_allgather(l, &mine, all.data(), 8);
-    if (rc) return rc;
-    for (u64 e : all) worst = std::max(worst, e);
-  }
-  if (!worst) return 0;
-  if (phase_rc) return phase_rc;                                 // this rank's own message stays in vsrmc_last_error()
-  return fail(VSRMC_E_STATE, std::string("level ") + std::to_string(l->level + 1) + ", phase " + phase + ": error " + std::to_string((long long)worst) + " on another rank");
-}
-
 }  // namespace
 
 extern "C" {
@@ -232,6 +221,7 @@ int32_t vsrmc_comm_rccl_create(const uint8_t* id128, int32_t rank, int32_t world
   HIPCHK(hipSetDevice(device));
   RcclCtx* x = new RcclCtx();
   x->rank = rank; x->world = world; x->device = device;
+  x->always_call = std::getenv("VSRMC_COMM_ALWAYS_CALL") != nullptr;
   RcclId128 id;
   std::memcpy(id.b, id128, 128);
   int rc = a->CommInitRank(&x->comm, world, id, rank);
@@ -355,10 +345,13 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
   if (n_recv > (u64)w * l->cand_cap) return fail(VSRMC_E_REP, "more candidates received than the exchange buffer holds");
   rc = loop_alltoallv(l, l->cand_send, scnt, soff, l->cand_recv, rcnt, roff, 16);
   // ---- 3. claim them in this rank's shard; 4. verdict bytes back to the generators
+  // (a failed claim still answers: the sizes of the verdict exchange are fixed by the candidate counts, so no rank is left waiting; the
+  // error code rides on the next all-gather)
   if (!rc) rc = vsrmc_shard_claim(c, l->cand_recv, n_recv, l->verdict_out);
-  int rc2 = loop_fail_together(l, rc, "claim", true);
-  if (rc2) return rc2;
-  rc = loop_alltoallv(l, l->verdict_out, rcnt, roff, l->verdict_in, scnt, soff, 1);
+  {
+    const int xrc = loop_alltoallv(l, l->verdict_out, rcnt, roff, l->verdict_in, scnt, soff, 1);
+    if (!rc) rc = xrc;
+  }
   // ---- 5. withdraw the announced successors that lost
   if (!rc) rc = vsrmc_shard_materialize(c, &io, l->verdict_in);
   // ---- 6. compare the frontier sizes; move records where they are missing (rare)
