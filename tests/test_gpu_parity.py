@@ -321,6 +321,7 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, key):
         for v, lv in ((v1, virtual[0]), (v2, virtual[1])):
             assert (v["level"], v["n_new"], v["generated"], v["deadlocks"], v["max_bag"], v["viol_mask"]) == \
                 (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"], 0), lv["level"]
+            assert [int(x) for x in v["act_generated"][1:16]] == lv["act_generated"][1:16], lv["level"]
             if g["checksums"]:
                 assert ("%016x" % v["fp_xor"], "%016x" % v["fp_sum"]) == (lv["fp_xor"], lv["fp_sum"]), lv["level"]
         assert v2["distinct"] == g["distinct"]

@@ -1680,6 +1680,7 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
   virt->total_generated = c->total_generated + c->h.generated;
   virt->probes = c->h.probes;
   virt->max_bag = c->h.max_bag;
+  for (int a = 0; a < 16; a++) virt->act_generated[a] = c->h.act_generated[a];
   virt->fp_xor = c->h.fp_xor;
   virt->fp_sum = c->h.fp_sum;
   virt->expand_ms = c->expand_ms;
@@ -1803,6 +1804,7 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
   virt1->total_generated = c->total_generated + c->h.generated;
   virt1->probes = c->h.probes;
   virt1->max_bag = c->h.max_bag;
+  for (int a = 0; a < 16; a++) virt1->act_generated[a] = c->h.act_generated[a];   // per action, like a stored level
   virt1->fp_xor = c->h.fp_xor;
   virt1->fp_sum = c->h.fp_sum;
   virt1->expand_ms = c->expand_ms;
@@ -1858,7 +1860,7 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
   u64 sub = worst_size(B.cap, B.words_cap);
   double yield_n = 0, yield_w = 0;
   u64 n2 = 0, gen2 = 0, dead2 = 0, probes2 = 0, bag2 = 0, viol2 = ~(u64)0, words2 = 0, n_slices = 0, n_subs = 0;
-  u64 gen3 = 0, dead3 = 0, probes3 = 0, fx2 = 0, fs2 = 0;
+  u64 gen3 = 0, dead3 = 0, probes3 = 0, fx2 = 0, fs2 = 0, act2[16] = {0}, act3[16] = {0};
   u64* d_sum = nullptr;
   if (hipMalloc((void**)&d_sum, 24) != hipSuccess) return fail(VSRMC_E_HIP, "hipMalloc");
   struct FreeSum { u64* p; ~FreeSum() { (void)hipFree(p); } } free_sum{d_sum};
@@ -1884,6 +1886,7 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
       n_subs++;
       const u64 part2 = c->h.n_new;
       gen2 += c->h.generated;
+      for (int a = 0; a < 16; a++) act2[a] += c->h.act_generated[a];
       dead2 += c->h.deadlocks;
       probes2 += c->h.probes;
       words2 += c->h.rec_words;
@@ -1918,6 +1921,7 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
       if (rc) break;
       ms3 += c->expand_ms;
       gen3 += c->h.generated;
+      for (int a = 0; a < 16; a++) act3[a] += c->h.act_generated[a];
       dead3 += c->h.deadlocks;
       probes3 += c->h.probes;
       if (c->h.n_pending) {
@@ -1937,6 +1941,7 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
   virt2->level = L + 2;
   virt2->frontier = virt1->n_new;
   virt2->generated = gen2;
+  for (int a = 0; a < 16; a++) virt2->act_generated[a] = act2[a];
   virt2->deadlocks = dead2;
   virt2->n_new = n2;
   virt2->distinct = virt1->distinct + n2;
@@ -1960,6 +1965,7 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
   probe->level = L + 3;
   probe->frontier = n2;
   probe->generated = gen3;
+  for (int a = 0; a < 16; a++) probe->act_generated[a] = act3[a];
   probe->deadlocks = dead3;
   probe->probes = probes3;
   probe->distinct = virt2->distinct;
