@@ -114,6 +114,25 @@ int32_t vsrmc_model_check_trace(const vsrmc_model* m, int32_t device, const uint
 int32_t vsrmc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off,
                                 uint64_t n, uint64_t* fps, uint32_t* auxkeys);
 
+/* ---- TLC's own fingerprint: tlc2.util.FP64 over Value.fingerPrint of the `view` value (VSR.tla:140-150) ------------
+ * A characterisation mode (VSR.tla only): the seen-set never uses it.  Everything TLC-specific is recalled, not pinned — see
+ * vsr_tlcfp.hpp.  With SYMMETRY the state fingerprinted is the permuted state TLC picks (TLCStateMut.fingerPrint: the smallest under
+ * Value.compareTo, variable by variable in declaration order).
+ * vsrmc_tlc_fingerprint_batch: n wire records -> FP64s, computed on the GPU.
+ * vsrmc_tlc_view_bytes: the byte stream the fingerprint of ONE wire record is taken over, under value permutation `permutation`
+ *   (0 = identity, < permutations); *n_bytes = its length, the first `cap` bytes stored.  Host code (a diagnostic).
+ * vsrmc_tlc_min_permutation: the number of the permutation whose permuted state TLC fingerprints (host code).
+ * vsrmc_fp64_new / vsrmc_fp64_extend: FP64.New() / FP64.Extend(fp, byte[]) (≙ tlc2.util.FP64).
+ * vsrmc_checker_tlc_level_fps: FP64 of every state of the newest level, from the frontier in HBM, sorted; out may be NULL (time only);
+ *   *kernel_ms = duration of the kernel. */
+int32_t vsrmc_tlc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint64_t* words, const uint64_t* off, uint64_t n,
+                                    uint64_t* fps);
+int32_t vsrmc_tlc_view_bytes(const vsrmc_model* m, const uint64_t* record, int32_t permutation, uint8_t* out, uint64_t cap,
+                             uint64_t* n_bytes);
+int32_t vsrmc_tlc_min_permutation(const vsrmc_model* m, const uint64_t* record, int32_t* permutation);
+uint64_t vsrmc_fp64_new(void);
+uint64_t vsrmc_fp64_extend(uint64_t fp, const uint8_t* bytes, uint64_t n);
+
 /* ---- the checker ≙ tlc2.tool.ModelChecker + Worker.run + StateQueue + TLCTrace ---------------------------------- */
 typedef struct vsrmc_options {
   int32_t device;                /* HIP device ordinal */
@@ -174,6 +193,7 @@ int32_t vsrmc_checker_reset(vsrmc_checker* c);
 int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info);
 /* sorted fingerprints of the newest level */
 int32_t vsrmc_checker_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, uint64_t* n);
+int32_t vsrmc_checker_tlc_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, uint64_t* n, double* kernel_ms);
 /* xor, sum (mod 2^64) and number of the fingerprints of the newest level, computed on the device (order-independent checksums
  * of a level's fingerprint SET: what the whole-workload fixtures of the CPU oracle hold per level) */
 int32_t vsrmc_checker_level_checksum(vsrmc_checker* c, uint64_t* fp_xor, uint64_t* fp_sum, uint64_t* n_states);

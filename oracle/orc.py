@@ -27,6 +27,68 @@ def build(force=False):
     return LIB
 
 
+LIB_TLC = os.path.join(HERE, "build", "liborc_tlc.so")
+_tlc = None
+
+
+def tlc_lib():
+    """oracle/tlc_fp64.cpp: TLC-style fingerprints from the unpacked state (value tree + bit-serial FP64)."""
+    global _tlc
+    if _tlc is None:
+        src = [os.path.join(HERE, f) for f in ("tlc_fp64.cpp", "vsr_oracle.cpp", "vsr_oracle.hpp")]
+        if not os.path.exists(LIB_TLC) or any(os.path.getmtime(f) > os.path.getmtime(LIB_TLC) for f in src):
+            subprocess.run(["make", "-C", HERE, "-s", "build/liborc_tlc.so"], check=True)
+        L = C.CDLL(LIB_TLC)
+        L.orc_tlc_last_error.restype = C.c_char_p
+        L.orc_tlc_view_bytes.restype = C.c_longlong
+        L.orc_tlc_view_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+        L.orc_tlc_fingerprint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_tlc_permute_record.restype = C.c_longlong
+        L.orc_tlc_permute_record.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+        L.orc_fp64_bytes.restype = C.c_uint64
+        L.orc_fp64_bytes.argtypes = [C.c_void_p, C.c_longlong]
+        _tlc = L
+    return _tlc
+
+
+def tlc_view_bytes(params, record, perm=0):
+    rec = np.ascontiguousarray(record, dtype=np.uint64)
+    L = tlc_lib()
+    n = L.orc_tlc_view_bytes(params.arr.ctypes.data, rec.ctypes.data, perm, None, 0)
+    if n < 0:
+        raise OracleError(-1, L.orc_tlc_last_error().decode())
+    out = np.zeros(n, dtype=np.uint8)
+    L.orc_tlc_view_bytes(params.arr.ctypes.data, rec.ctypes.data, perm, out.ctypes.data, n)
+    return out.tobytes()
+
+
+def tlc_fingerprint(params, record, with_perm=False):
+    """FP64 of the view of the permuted state TLC fingerprints (the smallest by compareTo, variable by variable); with_perm: -> (fp, permutation number)"""
+    rec = np.ascontiguousarray(record, dtype=np.uint64)
+    fp = C.c_uint64()
+    perm = C.c_int()
+    L = tlc_lib()
+    if L.orc_tlc_fingerprint(params.arr.ctypes.data, rec.ctypes.data, C.byref(fp), C.byref(perm)):
+        raise OracleError(-1, L.orc_tlc_last_error().decode())
+    return (fp.value, perm.value) if with_perm else fp.value
+
+
+def tlc_permute_record(params, record, perm):
+    """the wire record of the state under value permutation number `perm`: another member of its symmetry class"""
+    rec = np.ascontiguousarray(record, dtype=np.uint64)
+    out = np.zeros(len(rec) + 8, dtype=np.uint64)
+    L = tlc_lib()
+    n = L.orc_tlc_permute_record(params.arr.ctypes.data, rec.ctypes.data, perm, out.ctypes.data, len(out))
+    if n < 0:
+        raise OracleError(-1, L.orc_tlc_last_error().decode())
+    return out[:n].copy()
+
+
+def fp64_bytes(data):
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    return tlc_lib().orc_fp64_bytes(buf.ctypes.data, len(data))
+
+
 ACTIONS = ["Initial predicate", "TimerSendSVC", "ReceiveHigherSVC", "ReceiveMatchingSVC", "SendDVC",
            "ReceiveHigherDVC", "ReceiveMatchingDVC", "SendSV", "ReceiveSV", "ReceiveClientRequest",
            "ReceivePrepareMsg", "ReceivePrepareOkMsg", "ExecuteOp", "SendGetState", "ReceiveGetState",

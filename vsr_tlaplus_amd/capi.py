@@ -82,6 +82,12 @@ SYMBOLS = {
     "vsrmc_expand_batch": (C.c_int32, [V, C.c_int32, V, V, C.c_uint64, V, C.c_uint64, V, C.c_uint64,
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vsrmc_fingerprint_batch": (C.c_int32, [V, C.c_int32, V, V, C.c_uint64, V, V]),
+    "vsrmc_tlc_fingerprint_batch": (C.c_int32, [V, C.c_int32, V, V, C.c_uint64, V]),
+    "vsrmc_tlc_view_bytes": (C.c_int32, [V, V, C.c_int32, V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_tlc_min_permutation": (C.c_int32, [V, V, C.POINTER(C.c_int32)]),
+    "vsrmc_fp64_new": (C.c_uint64, []),
+    "vsrmc_fp64_extend": (C.c_uint64, [C.c_uint64, V, C.c_uint64]),
+    "vsrmc_checker_tlc_level_fps": (C.c_int32, [V, V, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "vsrmc_options_default": (None, [C.POINTER(Options)]),
     "vsrmc_checker_create": (C.c_int32, [V, C.POINTER(Options), C.POINTER(V)]),
     "vsrmc_checker_reset": (C.c_int32, [V]),

@@ -112,6 +112,32 @@ class Model:
         check(capi.load().vsrmc_fingerprint_batch(self._h, device, _p(words), _p(off), n, _p(fps), _p(aks)))
         return fps, aks
 
+    def tlc_fingerprints(self, words, off, device=0):
+        """TLC's own fingerprint (tlc2.util.FP64 over Value.fingerPrint of `view`; [TLC-RECALLED], csrc/vsr_tlcfp.hpp) of a batch of states,
+        computed on the GPU.  With SYMMETRY: of the permuted state TLC picks (tlc_min_permutation)."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        fps = np.zeros(n, dtype=np.uint64)
+        check(capi.load().vsrmc_tlc_fingerprint_batch(self._h, device, _p(words), _p(off), n, _p(fps)))
+        return fps
+
+    def tlc_min_permutation(self, record):
+        """Number of the value permutation whose permuted state TLC fingerprints under SYMMETRY (host code)."""
+        record = np.ascontiguousarray(record, dtype=np.uint64)
+        perm = C.c_int32()
+        check(capi.load().vsrmc_tlc_min_permutation(self._h, _p(record), C.byref(perm)))
+        return perm.value
+
+    def tlc_view_bytes(self, record, permutation=0):
+        """The byte stream TLC's fingerprint of one wire record is taken over (host code, a diagnostic)."""
+        record = np.ascontiguousarray(record, dtype=np.uint64)
+        n = C.c_uint64()
+        check(capi.load().vsrmc_tlc_view_bytes(self._h, _p(record), permutation, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        check(capi.load().vsrmc_tlc_view_bytes(self._h, _p(record), permutation, _p(out), len(out), C.byref(n)))
+        return out.tobytes()
+
     def simulate(self, n_walkers=1 << 16, max_depth=100, seed=1, max_seconds=10.0, device=0):
         """≙ `tlc2.TLC -simulate -depth max_depth`: random walks on the GPU until an invariant fails or time runs out.
         -> dict(found, viol_mask, steps, walks, seconds, trace=[(action name, wire record)] or None)."""
@@ -354,6 +380,14 @@ class ModelChecker:
         n = C.c_uint64()
         check(capi.load().vsrmc_checker_level_fps(self._h, _p(out), len(out), C.byref(n)))
         return out[: n.value].copy()
+
+    def tlc_level_fps(self, fetch=True):
+        """FP64 (TLC's fingerprint, [TLC-RECALLED]) of every state of the newest level, from the frontier in HBM -> (sorted fps or None, kernel ms)."""
+        out = np.zeros(max(1, self.n_frontier), dtype=np.uint64) if fetch else None
+        n = C.c_uint64()
+        ms = C.c_double()
+        check(capi.load().vsrmc_checker_tlc_level_fps(self._h, _p(out) if fetch else None, len(out) if fetch else 0, C.byref(n), C.byref(ms)))
+        return (out[: n.value].copy() if fetch else None), ms.value
 
     def frontier(self):
         """The newest level in wire layout -> (words, offsets)."""

@@ -92,27 +92,29 @@ inline std::string fmt_msg(const std::vector<std::string>& vals, u64 w) {
   return s + "]";
 }
 
-// TLC's order between two message records: fewer fields first, then the field-name sequence, then values in field order.
+// TLC's order between two message records (RecordValue.compareTo, [TLC-RECALLED]): fewer fields first, then field by field the name and the value —
+// every type starts [view_number, type, ...], so: arity, view_number, type (model values: cfg order), then the remaining fields of that one type.
 inline std::vector<int> msg_sort_key(u64 w) {
   int t = m_type(w);
   std::vector<int> k;
   static const int TYPE_ORDER[8] = {0, 6, 3, 4, 7, 8, 9, 10};   // declaration order of the type constants VSR.tla:104-115
   switch (t) {
-    case T_SVC: k = {4, 0, m_view(w), TYPE_ORDER[t], m_dest(w), m_source(w)}; break;
+    case T_SVC: k = {4, m_view(w), TYPE_ORDER[t], m_dest(w), m_source(w)}; break;
     case T_PREPAREOK:
-    case T_GETSTATE: k = {5, 0, m_view(w), TYPE_ORDER[t], m_op(w), m_dest(w), m_source(w)}; break;
+    case T_GETSTATE: k = {5, m_view(w), TYPE_ORDER[t], m_op(w), m_dest(w), m_source(w)}; break;
     case T_PREPARE: {
       int e = (int)(m_lg(w) & 0xFF);
-      k = {7, 0, m_view(w), TYPE_ORDER[t], e & 7, entry_val(e), entry_client(e), entry_req(e), m_op(w), m_commit(w), m_dest(w), m_source(w)};
+      k = {7, m_view(w), TYPE_ORDER[t], e & 7, entry_val(e), entry_client(e), entry_req(e), m_op(w), m_commit(w), m_dest(w), m_source(w)};
       break;
     }
     case T_SV:
     case T_DVC:
     case T_NEWSTATE: {
       int arity = t == T_SV ? 7 : 8;
-      k = {arity, t == T_SV ? 1 : (t == T_DVC ? 0 : 1), m_view(w), TYPE_ORDER[t], m_op(w), m_commit(w), m_dest(w), m_source(w)};
+      k = {arity, m_view(w), TYPE_ORDER[t], m_op(w), m_commit(w), m_dest(w), m_source(w)};
       u32 lg = m_lg(w) & 0xFFFFFF;
-      k.push_back(log_len(lg));            // sequences: shorter first, then element-wise
+      k.push_back(log_len(lg));            // sequences: shorter first, then element-wise; NewState.log (a function over first_op..op_number): then the lower bound
+      if (t == T_NEWSTATE) k.push_back(m_first_op(w));
       for (int i = 1; i <= 3; i++) {
         int e = log_byte(lg, i);
         if (e) { k.push_back(e & 7); k.push_back(entry_val(e)); k.push_back(entry_client(e)); k.push_back(entry_req(e)); }
