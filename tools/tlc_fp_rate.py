@@ -14,7 +14,7 @@ import vsr_tlaplus_amd as vt
 def main():
     level = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
-    mc = vt.ModelChecker(m, table_log2=27, frontier_words=1 << 29, frontier_states=1 << 24, pending_entries=1 << 25, keep_trace=False)
+    mc = vt.ModelChecker(m, table_log2=27, frontier_words=1 << 30, frontier_states=1 << 25, pending_entries=1 << 26, keep_trace=False)
     info = None
     while mc.level < level:
         info = mc.step()

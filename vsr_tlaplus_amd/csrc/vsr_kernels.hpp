@@ -155,6 +155,9 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #ifndef VSR_WAVE_COMPACT
 #define VSR_WAVE_COMPACT 0
 #endif
+#ifndef VSR_OCC            // resident blocks per CU the specialised fused kernels are compiled for (4 = 128 VGPRs; 5 = 96: experiment)
+#define VSR_OCC 4
+#endif
 #ifndef VSR_COPY_PIPE
 #define VSR_COPY_PIPE 1
 #endif
@@ -384,7 +387,7 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
 // for the slowest wave of its tile, and the 16 waves of a CU drift apart so that their memory and issue phases interleave.
 template <bool FUSED, int SPEC = 0, int PLAIN = 0, int BLK = VSR_BLOCK>
 // (hipcc turns the second bound into waves per SIMD as blocks * max(1, threads / 256): 4 = 128 VGPRs for either block size)
-__global__ void __launch_bounds__(BLK, (FUSED ? (SPEC ? 4 : 2) : 3) / (BLK > VSR_BLOCK ? BLK / VSR_BLOCK : 1))
+__global__ void __launch_bounds__(BLK, (FUSED ? (SPEC ? VSR_OCC : 2) : 3) / (BLK > VSR_BLOCK ? BLK / VSR_BLOCK : 1))
 k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world_arg, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,

@@ -1125,6 +1125,9 @@ ExpandKernel fused_kernel_for(const Model& M) {
 // level that is being expanded (stride = fixed words + its largest bag, made odd: conflict-free columns), not the format's
 // worst case, so deep levels of small bags leave room for more resident blocks.  64-record tiles when that gives at least
 // three blocks per CU (registers and LDS, asked from the runtime), else 128-record tiles (R <= 3) at two.
+#ifndef VSR_CCAP64          // work-list entries of a 64-record tile, R <= 3 (24 per record; an overflow is ERR_FRONTIER_FULL, never silent)
+#define VSR_CCAP64 1536
+#endif
 struct FusedShape {
   int blk;
   int tile;
@@ -1159,13 +1162,13 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
     return f;
   }
   size_t lds64 = 0, lds128 = 0;
-  const u32 ccap64 = M.R <= 3 ? 1536u : (u32)VSR_CAND_CAP;      // work-list entries per tile (24 resp. 32 per record)
+  const u32 ccap64 = M.R <= 3 ? (u32)VSR_CCAP64 : (u32)VSR_CAND_CAP;      // work-list entries per tile (24 resp. 32 per record)
   const int occ64 = occupancy(64, ccap64, &lds64);
   const int occ128 = M.R <= 3 ? occupancy(128, 1536u, &lds128) : 0;
   if (M.R <= 3 && occ64 < 3 && occ128 >= 1) {
     f.tile = 128; f.ccap = 1536u; f.lds = lds128; f.blocks_per_cu = (unsigned)std::min(occ128, 2);
   } else {
-    f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, 4));
+    f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, VSR_OCC));
   }
   if (const char* e = std::getenv("VSRMC_MAX_BPC"))            // diagnostic: fewer resident blocks per CU (occupancy sweeps)
     f.blocks_per_cu = (unsigned)std::max(1, std::min<int>((int)f.blocks_per_cu, std::atoi(e)));
