@@ -40,6 +40,13 @@ struct ModelOps<0> {
   static VSR_HD void hash_full_(const Model& M, PTR rec, u64* H) { hash_full(M, rec, H); }
   template <typename PTR>
   static VSR_HD int invariants(const Model& M, PTR rec, const Delta& D) { return check_invariants_child(M, rec, D); }
+  // The invariants (VSR.tla:933-950) read rep_log and aux_client_acked only: a successor whose action writes neither has its parent's verdict, and
+  // every expanded parent has passed.  These are the actions that write one of the two (or can raise a TLC evaluation error): the probe level runs
+  // only them (tests/test_probe_footprint.py holds the claim against the oracle's successors, action by action).
+  static VSR_HD u32 probe_actions() {
+    return (1u << A_SendSV) | (1u << A_ExecuteOp) | (1u << A_ReceiveClientRequest) | (1u << A_SendGetState) | (1u << A_ReceiveSV) |
+           (1u << A_ReceivePrepareMsg) | (1u << A_ReceiveGetState) | (1u << A_ReceiveNewState);
+  }
 };
 template <>
 struct ModelOps<1> {
@@ -58,6 +65,7 @@ struct ModelOps<1> {
   static VSR_HD void hash_full_(const Model& M, PTR rec, u64* H) { vrst::hash_full(M, rec, H); }
   template <typename PTR>
   static VSR_HD int invariants(const Model& M, PTR rec, const Delta& D) { return vrst::check_invariants_child(M, rec, D); }
+  static VSR_HD u32 probe_actions() { return ~0u; }               // not analysed: every action is run
 };
 
 template <>
@@ -77,6 +85,7 @@ struct ModelOps<2> {   // analysis/04-application-state/VR_APP_STATE.tla (vras_a
   static VSR_HD void hash_full_(const Model& M, PTR rec, u64* H) { vras::hash_full(M, rec, H); }
   template <typename PTR>
   static VSR_HD int invariants(const Model& M, PTR rec, const Delta& D) { return vras::check_invariants_child(M, rec, D); }
+  static VSR_HD u32 probe_actions() { return ~0u; }
 };
 
 struct Slot {       // one seen-set slot: 16 bytes, fp == 0 means empty
@@ -157,6 +166,9 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #endif
 #ifndef VSR_OCC            // resident blocks per CU the specialised fused kernels are compiled for (4 = 128 VGPRs; 5 = 96: experiment)
 #define VSR_OCC 4
+#endif
+#ifndef VSR_PROBE_FOOTPRINT   // probe level: only the actions that write what the invariants read are applied (Ops::probe_actions)
+#define VSR_PROBE_FOOTPRINT 1
 #endif
 #ifndef VSR_COPY_PIPE
 #define VSR_COPY_PIPE 1
@@ -418,7 +430,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
   u32* s_cand2 = s_cand + ccap;                        // the same, sorted by action
-  __shared__ u32 s_ncand, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv;
+  __shared__ u32 s_ncand, s_napply, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv;
   constexpr int TILE_MAX = BLK >= VSR_BLOCK ? VSR_TILE_MAX : BLK / 2;
   __shared__ u32 s_alive[TILE_MAX];
   __shared__ u64 s_ref[TILE_MAX];
@@ -426,6 +438,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   __shared__ u32 s_kcount[16], s_kbase[16];
   __shared__ int s_slotinfo[64];                               // decode of the replica-bound slots (m0 <= 50), see slot_info()
   // per-block accumulators (flushed once at the end: no hot global counters inside the tile loop)
+  __shared__ unsigned long long s_fxs[2];                      // virtual level: xor / sum of the fingerprints this block inserted (flushed once, in the epilogue)
   __shared__ unsigned long long s_acc[32];                     // 0 generated, 1 deadlocks, 2 probes, 3..7 phase cycles, 16..31 per action
   // pending list: the block owns a chunk of pchunk entries at a time; unused entries are invalidated (key = ~0)
   __shared__ u64 s_chunk_base;
@@ -443,6 +456,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   const u64 ntiles = (n_parents + tile - 1) / tile;
   const int tshift = 31 - __clz(tile);                           // tile is a power of two
   if (tid < 32) s_acc[tid] = 0;
+  if (tid < 2) s_fxs[tid] = 0;
   if (tid == 0) s_maxbag_out = 0;
   if (tid < 64) s_slotinfo[tid] = (SPEC / 1000 == 0 && tid < M.m0) ? slot_info(M, tid) : 0;
   if (tid == 0) {                                              // "no chunk yet"
@@ -701,9 +715,29 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     if (tid == 0) {
       if (s_ncand >= 0x40000000u) raise_error(ctl, ERR_FRONTIER_FULL, p_base);
       u32 acc = 0;
-      for (int a = 0; a < 16; a++) {
-        s_kbase[a] = acc;
-        acc += s_kcount[a];
+      // probe level: an action outside the invariants' footprint cannot turn a passing parent into a violating successor (Ops::probe_actions):
+      // its instances are counted and sorted behind the others, and the apply loop stops in front of them.  (Compiled into the mode-capable
+      // kernels only: the plain kernels sit on a register-allocation cliff — one more LDS word here cost the README configuration's 20
+      // stored levels 22 ms.)
+      if constexpr (PLAIN != 1 && FUSED && VSR_PROBE_FOOTPRINT) {
+        const u32 keep = mode == MODE_PROBE ? Ops::probe_actions() : ~0u;
+        for (int a = 0; a < 16; a++)
+          if ((keep >> a) & 1u) {
+            s_kbase[a] = acc;
+            acc += s_kcount[a];
+          }
+        s_napply = acc > ccap ? ccap : acc;
+        if (keep != ~0u)
+          for (int a = 0; a < 16; a++)
+            if (!((keep >> a) & 1u)) {
+              s_kbase[a] = acc;
+              acc += s_kcount[a];
+            }
+      } else {
+        for (int a = 0; a < 16; a++) {
+          s_kbase[a] = acc;
+          acc += s_kcount[a];
+        }
       }
       s_ncand = acc > ccap ? ccap : acc;
       if (fused) s_wneed = s_ncand * (u32)(M.fixed + (int)s_maxbag + 5);   // upper bound of the successors' total length
@@ -770,7 +804,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
       VSR_SYNC();
     }
-    const u32 ncand_apply = s_skip ? 0u : ncand;                // s_skip: the tile was refused (see the word-chunk reservation)
+    const u32 ncand_apply = s_skip ? 0u : ((PLAIN != 1 && FUSED && VSR_PROBE_FOOTPRINT) ? s_napply : ncand);                // s_skip: the tile was refused (see the word-chunk reservation)
 #if VSR_DEDUP
     // Intra-tile duplicate filter.  A tile of the frontier is a family — the children of a few neighbouring states — and about a
     // third of the successors it generates are generated more than once INSIDE the tile (A;B = B;A).  The candidates of a pass meet
@@ -868,6 +902,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         continue;
       }
       const u64 a_1 = VSR_CLK();
+      // Probe level: nothing is inserted, so the fingerprint and the seen-set matter only for a successor that VIOLATES an invariant — it is
+      // reported unless it is a state of an earlier level.  Invariants first, then (for the handful that fail) hash and lookup: the README
+      // configuration's level 24 has 3.8e9 successors of which 8 violate; hashing them under six permutations and fetching a 128-byte line
+      // of the seen-set for each was a third of that run.
+      if (PLAIN != 1 && fused && mode == MODE_PROBE && Ops::invariants(M, rec, D) == 0) continue;
       u64 Hc[6];
       Ops::hash_child_(M, rec, D, Hc);
       u64 fp;
@@ -1138,9 +1177,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         my_fx ^= __shfl_down(my_fx, o);
         my_fs += __shfl_down(my_fs, o);
       }
+      // into LDS, not into the control block: two global atomics per wave and tile on ONE address queued behind those of every other block, and
+      // the barrier below waits for them (the virtual level of the README configuration ran at half the rate of a stored level)
       if (lane == 0 && (my_fx | my_fs)) {
-        atomicXor((unsigned long long*)&ctl->fp_xor, (unsigned long long)my_fx);
-        atomicAdd((unsigned long long*)&ctl->fp_sum, (unsigned long long)my_fs);
+        atomicXor(&s_fxs[0], (unsigned long long)my_fx);
+        atomicAdd(&s_fxs[1], (unsigned long long)my_fs);
       }
     }
     if (lane == 0 && my_probes) atomicAdd(&s_acc[2], (unsigned long long)my_probes);
@@ -1196,6 +1237,10 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         if (s_acc[14]) atomicAdd((unsigned long long*)&ctl->n_written, s_acc[14]);
         if (s_acc[9]) atomicAdd((unsigned long long*)(mode == MODE_INSERT ? &ctl->n_new : &ctl->rec_words), s_acc[9]);
         if (s_maxbag_out) atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)s_maxbag_out);
+        if (PLAIN != 1 && (s_fxs[0] | s_fxs[1])) {
+          atomicXor((unsigned long long*)&ctl->fp_xor, s_fxs[0]);
+          atomicAdd((unsigned long long*)&ctl->fp_sum, s_fxs[1]);
+        }
       }
     } else {
       const u32 used = s_chunk_used;
