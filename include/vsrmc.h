@@ -236,7 +236,10 @@ void vsrmc_checker_destroy(vsrmc_checker* c);
 /* Probe level: expand the newest level without storing its successors — invariants are evaluated on every successor that is
  * not a state of an earlier level, nothing is inserted or written, so the level costs no frontier memory; the search cannot
  * continue afterwards.  Finds a violation one level beyond what memory can hold.  Also valid right after a step that failed
- * with "frontier full".  info: level (the probed one), generated, viol_fp / viol_mask, viol_index = index of the violator's
+ * with "frontier full".  Order of evaluation (the result is that of the sentence above): every enabled instance is enumerated and
+ * counted; only the actions that write a variable the invariants read are applied (VSR.tla: rep_log, aux_client_acked — a successor
+ * of any other action has the verdict of its parent, which passed); of their successors the invariants are evaluated first, and
+ * only a successor that fails one is fingerprinted and looked up in the seen-set.  `probes` counts those lookups only.  info: level (the probed one), generated, viol_fp / viol_mask, viol_index = index of the violator's
  * PARENT in the newest level, pending = violating successors seen.  vsrmc_checker_probe_trace: Init .. violator.
  * On a sharded checker (world > 1) the call probes this rank's part of the newest level against this rank's part of the seen-set and
  * resolves nothing: a violating successor owned by another rank may be a state that rank has seen, so the candidates

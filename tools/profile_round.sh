@@ -10,8 +10,6 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 5 --warmup 1 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-tail -c 900 $OUT/${TAG}_bench.json
 one() {   # name, workload flags, rocprofv3 flags...
   local name=$1 wl=$2; shift 2
   local PROF="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify $wl"
@@ -29,8 +27,12 @@ for W in config2 readme; do
   one ${W}_pmc_wr "$FL" --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_ATOMIC_sum
   python $R/tools/make_traffic.py $TAG $W $OUT/${TAG}_${W}_pmc_rd.db $OUT/${TAG}_${W}_pmc_wr.db "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify $FL" > $OUT/${TAG}_${W}_traffic.json
   cat $OUT/${TAG}_${W}_traffic.json
+  cp $OUT/${TAG}_${W}_traffic.json $R/profiles/${TAG}_${W}_traffic.json     # on the box: the bench line below reads the traffic of THIS build (same source hash)
 done
 rm -f $OUT/${TAG}_*.db
 one sq_counters_a "--workload config2" --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 one sq_counters_b "--workload config2" --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
 rm -f $OUT/${TAG}_*.db
+# the driver-style line last: its roofline.traffic comes from the request counters measured above on the same sources
+python $R/bench.py --steps 5 --warmup 1 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+tail -c 1200 $OUT/${TAG}_bench.json

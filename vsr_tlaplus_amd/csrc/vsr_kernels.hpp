@@ -42,7 +42,7 @@ struct ModelOps<0> {
   static VSR_HD int invariants(const Model& M, PTR rec, const Delta& D) { return check_invariants_child(M, rec, D); }
   // The invariants (VSR.tla:933-950) read rep_log and aux_client_acked only: a successor whose action writes neither has its parent's verdict, and
   // every expanded parent has passed.  These are the actions that write one of the two (or can raise a TLC evaluation error): the probe level runs
-  // only them (tests/test_probe_footprint.py holds the claim against the oracle's successors, action by action).
+  // only them (tests/test_probe_footprint.py holds the claim against the CPU oracle, successor by successor).
   static VSR_HD u32 probe_actions() {
     return (1u << A_SendSV) | (1u << A_ExecuteOp) | (1u << A_ReceiveClientRequest) | (1u << A_SendGetState) | (1u << A_ReceiveSV) |
            (1u << A_ReceivePrepareMsg) | (1u << A_ReceiveGetState) | (1u << A_ReceiveNewState);
@@ -166,6 +166,9 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #endif
 #ifndef VSR_OCC            // resident blocks per CU the specialised fused kernels are compiled for (4 = 128 VGPRs; 5 = 96: experiment)
 #define VSR_OCC 4
+#endif
+#ifndef VSR_INV_FOOTPRINT     // stored levels: the invariants are evaluated only for new states reached by an action inside their footprint
+#define VSR_INV_FOOTPRINT 0
 #endif
 #ifndef VSR_PROBE_FOOTPRINT   // probe level: only the actions that write what the invariants read are applied (Ops::probe_actions)
 #define VSR_PROBE_FOOTPRINT 1
@@ -410,7 +413,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
          u64* filter, u64 fmask, u64* cand_idx, u32 cchunk /* candidate entries a block reserves per owner and global atomic */,
          // fused, unsharded passes that do not materialise a level the normal way (vsrmc_checker_probe / _probe2):
          //   MODE_PROBE   nothing is inserted or written; every successor that is not a state of an EARLIER level gets its
-         //                invariants checked
+         //                invariants checked — evaluated the cheap way round: only the actions inside the invariants' footprint are
+         //                applied (Ops::probe_actions), their successors' invariants come first, and only a failing successor is
+         //                fingerprinted and looked up
          //   MODE_INSERT  "virtual level": fingerprints are claimed (min-merged keys, as always) and the invariants of the
          //                new states checked, but no record, ref or trace key is written; ctl->n_new = exact number of new states
          //   MODE_REGEN   re-expansion of (a slice of) the same parents after a MODE_INSERT pass: the successor whose key IS
@@ -972,7 +977,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           claimed_now = claimed;
         }
         // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
+#if VSR_INV_FOOTPRINT   // a new state reached by an action outside the invariants' footprint has the verdict of its parent, which passed when it was new
+        const int bad = ((check || do_write) && ((Ops::probe_actions() >> D.action) & 1u)) ? Ops::invariants(M, rec, D) : 0;
+#else
         const int bad = (check || do_write) ? Ops::invariants(M, rec, D) : 0;
+#endif
         if (mode == MODE_PROBE) {
           if (bad) {
             const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);

@@ -3,8 +3,8 @@
 // EVERYTHING here that concerns TLC is [TLC-RECALLED]: TLC (tla2tools.jar) is not in /root/reference, no JVM exists in the build image, the
 // reference pins no TLC version and no fingerprint; nothing below could be checked against a single bit TLC produces.  What IS pinned:
 // the Rabin arithmetic against an independent bit-by-bit polynomial division (tests/test_tlc_fp64.py: known answers, GF(2) linearity,
-// concatenation), and this serialiser — which walks the PACKED record — against the CPU oracle's, which builds a generic value tree from
-// the UNPACKED state (oracle/tlc_fp64.cpp): the two share no code and must produce the same byte stream for every state of configs 1-2.
+// concatenation), and this serialiser — which walks the PACKED record — against the one of the CPU oracle, which builds a generic value tree from
+// the UNPACKED state (tlc_fp64.cpp of the test infrastructure): the two share no code and must produce the same byte stream for every state of configs 1-2.
 //
 // (1) tlc2.util.FP64: a 64-bit Rabin fingerprint in reflected bit order (bit 63 = x^0).  IrredPoly = Polys[0] = 0x911498AE0E66BAD6 (`-fp 0`);
 //     New() = IrredPoly; Extend(fp, byte b) = (fp >>> 8) ^ ByteModTable_7[(b ^ fp) & 0xFF], ByteModTable_7[i] = XOR over the set bits k of i of
