@@ -2,8 +2,9 @@
 """BASELINE.json configs[4] — ReplicaCount=5, ClientCount=1, Values={v1,v2}, StartViewOnTimerLimit=2, the "288 GB/GPU FPSet sizing
 stress" — on ONE MI355X as deep as its HBM allows: levels 1-12 materialised (every figure asserted against the CPU oracle's fixture,
 tests/golden/oracle_levels_config5.json), level 13 as a virtual level (oracle-pinned: 596 058 668 new states), level 14 streamed
-(inserted, never stored), level 15 probed (vsrmc_checker_probe3).  Prints one JSON object: per-level figures, seen-set load, record
-bytes per state, states/s.  Levels 14-15 have no CPU counterpart (3e9 / 1e10 states): GPU-sourced, labelled so.
+(inserted, never stored; oracle-pinned since the memory-lean driver reached it: 2 403 817 813 new states), level 15 probed
+(vsrmc_checker_probe3).  Prints one JSON object: per-level figures, seen-set load, record bytes per state, states/s.  Level 15 has no CPU
+counterpart (3.7e10 successors): GPU-sourced, labelled so.
 
     python tools/run_config5.py [--table-log2 33] [--probe-from 12]"""
 import argparse
@@ -19,8 +20,8 @@ import vsr_tlaplus_amd as vt  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--table-log2", type=int, default=33)
 ap.add_argument("--probe-from", type=int, default=12, help="newest materialised level; 13 / 14 / 15 become virtual / streamed / probed")
-ap.add_argument("--words-a", type=float, default=4.0e9, help="record buffer of the odd levels (words)")
-ap.add_argument("--words-b", type=float, default=9.6e9, help="record buffer of the even levels (words): level 12 = 8.8e9")
+ap.add_argument("--words-a", type=float, default=3.0e9, help="record buffer of the odd levels (words)")
+ap.add_argument("--words-b", type=float, default=11.6e9, help="record buffer of the even levels (words): level 12 = 8.8e9 + the blocks' unfinished chunks")
 ap.add_argument("--states", type=float, default=1.6e8)
 a = ap.parse_args()
 with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_config5.json")) as f:
@@ -48,6 +49,7 @@ for v, kind in ((v1, "virtual"), (v2, "streamed"), (p, "probed")):
     w = g["levels"][v["level"] - 1] if 0 < v["level"] <= len(g["levels"]) else None
     if w is not None and kind != "probed":
         assert (v["n_new"], v["generated"], v["deadlocks"], v["max_bag"]) == (w["new"], w["generated"], w["deadlocks"], w["max_bag"]), v["level"]
+        assert [int(x) for x in v["act_generated"][1:16]] == w["act_generated"][1:16], v["level"]
         if g.get("fp_version") == 2 and v["fp_xor"]:
             assert ("%016x" % v["fp_xor"], "%016x" % v["fp_sum"]) == (w["fp_xor"], w["fp_sum"]), v["level"]
     levels.append(dict(level=v["level"], kind=kind, new=v["n_new"], generated=v["generated"], deadlocks=v["deadlocks"], max_bag=v["max_bag"],
