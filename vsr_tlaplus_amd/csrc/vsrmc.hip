@@ -1557,7 +1557,10 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
   c->h.viol_fp = ~(u64)0;
   HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
   if (n_parents > 0) {
-    const FusedShape fs = fused_shape(c, src_max_bag);
+    // an ordinary level into other buffers (the streamed level's sub-slices) runs the plain instantiation: the code of a stored level
+    static const bool plain_normal = std::getenv("VSRMC_STREAM_MODES_KERNEL") == nullptr;
+    const bool use_plain = mode == MODE_NORMAL && plain_normal && c->plain_kernel && c->plain_blk == VSR_BLOCK;
+    const FusedShape fs = fused_shape(c, src_max_bag, use_plain);
     const int tile = fs.tile;
     const u64 ntiles = (n_parents + tile - 1) / tile;
     const u32 ccap = fs.ccap;
@@ -1575,7 +1578,8 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
     const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL((ExpandKernel)(c->modes_kernel ? c->modes_kernel : c->fused_kernel), dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
+    const void* kern = use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
+    hipLaunchKernelGGL((ExpandKernel)kern, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
                        ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0, mode, p_offset);
