@@ -343,7 +343,7 @@ def readme_object(args, elapsed, S):
         value=distinct * k / elapsed, ms_per_step=1e3 * elapsed / k, time_to_first_violation_s=round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
         distinct=int(distinct), generated=int(S["generated"] / k), setup_s=round(S["setup_s"], 2), oracle_pinned_levels=S["oracle_levels"],
         violation_pinned_by=S["probe_source"], trace_equals_fixture=S["same_trace"],
-        roofline={"bound": "hbm", "kernel": "k_expand (all launches of a run: PLAIN instantiation for levels 2-21, mode-capable one for the virtual / regenerated / streamed / probed passes)",
+        roofline={"bound": "hbm", "kernel": "k_expand (all launches of a run: PLAIN instantiation for levels 2-21 and the sub-slices of the streamed level, mode-capable one for the virtual / regenerated / probed passes)",
                   "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                   "traffic": tr["bytes_per_launch"], "traffic_source": tr["source"],
                   "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": launches, "alg_bytes_per_launch": round(alg_run / launches),
