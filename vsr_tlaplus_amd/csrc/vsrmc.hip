@@ -1575,7 +1575,12 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), d_wcap / (4 * 16384))));
     const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(fs.stride + 5));   // see phase_expand
     grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, d_wcap / (4 * wmin)));
-    const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
+    // index chunks: a block leaves the unused tail of its last chunk behind as invalid refs, and the NEXT pass stages those holes like records.
+    // A whole level (2.6e8 states) loses 1-3 % to 8192-index chunks; a sub-slice of a streamed level (7e6 states from 1024 blocks) lost a third
+    // of its index range, and the probe pass over it 16 % of its time (VSRMC_ICHUNK=8192: the old size, for A/B runs).
+    static const u64 ichunk_small = std::getenv("VSRMC_ICHUNK") ? (u64)std::atoll(std::getenv("VSRMC_ICHUNK")) : 2048;
+    const u64 ichunk_max = (dst || mode == MODE_REGEN) ? std::max<u64>(VSR_CAND_CAP, ichunk_small) : 8192;
+    const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(ichunk_max, nx_cap / (4 * (u64)grid)));
     const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     const void* kern = use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
