@@ -12,7 +12,12 @@ import vsr_tlaplus_amd as vt
 def split(d):
     pc = [int(x) for x in d["phase_cycles"][:5]]
     tot = float(sum(pc)) or 1.0
-    return dict(zip(("stage", "enumerate", "sort", "apply", "tail"), [round(x / tot, 3) for x in pc]))
+    out = dict(zip(("stage", "enumerate", "sort", "apply", "tail"), [round(x / tot, 3) for x in pc]))
+    # thread 0's clock inside the apply loop: gen, hash, seen-set probe + claim, successor write (the last one arrives in act_generated[0])
+    inner = [int(d["phase_cycles"][5]), int(d["phase_cycles"][6]), int(d["phase_cycles"][7]), int(d["act_generated"][0])]
+    it = float(sum(inner)) or 1.0
+    out["apply_split"] = dict(zip(("gen", "hash", "probe_claim", "write"), [round(x / it, 3) for x in inner]))
+    return out
 
 
 def main():
