@@ -177,6 +177,7 @@ VSR_HD int cmp_msg(const Model& M, u64 a, u32 pa, u64 b, u32 pb) {
 
 // ord[k] = index of the k-th smallest of n message records under permutation pt (keys distinct: rank = number of smaller ones)
 VSR_HD void msg_order(const Model& M, const u64* w, int n, u32 pt, unsigned char* ord) {
+  for (int j = 0; j < n && j < MAX_MSGS; j++) ord[j] = (unsigned char)j;   // a record with two equal keys (never a reachable state) leaves a rank unused: still an index inside the bag
   for (int j = 0; j < n && j < MAX_MSGS; j++) {
     int smaller = 0;
     for (int i = 0; i < n; i++) smaller += (i != j && cmp_msg(M, w[i], pt, w[j], pt) < 0) ? 1 : 0;
