@@ -69,6 +69,14 @@ int32_t vsrmc_model2_from_constants(int32_t replica_count, int32_t value_count, 
 int32_t vsrmc_model3_from_constants(int32_t replica_count, int32_t value_count, int32_t start_view_on_timer_limit,
                                     int32_t no_progress_change_limit, int32_t symmetry, int32_t invariant_mask, vsrmc_model** out);
 int32_t vsrmc_model_info(const vsrmc_model* m, vsrmc_layout* out);
+/* Second-hash audit (TLC: a run repeated with another -fp N polynomial).  The seen-set knows a state by 64 bits of a hash; a false
+ * merge of two states would drop one of them from every count, silently, in this checker AND in an oracle keyed by the same function.
+ * `seed` is xor-ed into every salt of the view hash (csrc/vsr_model.hpp): seed 0 is the function the committed fixtures were made
+ * with, every other seed an independent member of the same family — fingerprints, checksums and the counter-example's tie-breaks
+ * change, distinct-state counts, generated / deadlock / per-action counts must not.  Set it before a checker is created from the
+ * model (a checker copies the model); a checkpoint written under one seed is refused under another. */
+int32_t vsrmc_model_set_fp_seed(vsrmc_model* m, uint64_t seed);
+uint64_t vsrmc_model_fp_seed(const vsrmc_model* m);
 /* Init (VSR.tla:323-348) in wire layout */
 int32_t vsrmc_model_init_state(const vsrmc_model* m, uint64_t* rec, int32_t cap_words, int32_t* n_words);
 /* TLC-syntax text of one state (the format of state_transfer_violation_trace.txt); returns needed size in *n */
@@ -239,7 +247,10 @@ void vsrmc_checker_destroy(vsrmc_checker* c);
  * with "frontier full".  Order of evaluation (the result is that of the sentence above): every enabled instance is enumerated and
  * counted; only the actions that write a variable the invariants read are applied (VSR.tla: rep_log, aux_client_acked — a successor
  * of any other action has the verdict of its parent, which passed); of their successors the invariants are evaluated first, and
- * only a successor that fails one is fingerprinted and looked up in the seen-set.  `probes` counts those lookups only.  info: level (the probed one), generated, viol_fp / viol_mask, viol_index = index of the violator's
+ * only a successor that fails one is fingerprinted and looked up in the seen-set.  "Which passed" is the premise: when a level this
+ * checker committed held a violating state (a caller that steps on after a reported violation), the probe passes apply EVERY action.
+ * Representation errors (ERR_REP_*) of an action outside the footprint are not raised by a footprint pass — its instances are counted,
+ * not applied.  `probes` counts those lookups only.  info: level (the probed one), generated, viol_fp / viol_mask, viol_index = index of the violator's
  * PARENT in the newest level, pending = violating successors seen.  vsrmc_checker_probe_trace: Init .. violator.
  * On a sharded checker (world > 1) the call probes this rank's part of the newest level against this rank's part of the seen-set and
  * resolves nothing: a violating successor owned by another rank may be a state that rank has seen, so the candidates

@@ -116,9 +116,20 @@ def lib():
         L.orc_bfs_frontier.restype = C.c_longlong
         L.orc_bfs_frontier.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
         L.orc_bfs_trace_fps.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_set_fp_seed.argtypes = [C.c_uint64]
+        L.orc_fp_seed.restype = C.c_uint64
         assert L.orc_fp_version() == FP_VERSION, "oracle/orc.py and oracle/vsr_oracle.hpp disagree on FP_VERSION"
         _lib = L
     return _lib
+
+
+def set_fp_seed(seed):
+    """second-hash audit: a seed xor-ed into every salt of the oracle's fingerprint (process-global; 0 = the fixtures' function)"""
+    lib().orc_set_fp_seed(C.c_uint64(int(seed) & (2 ** 64 - 1)))
+
+
+def fp_seed():
+    return int(lib().orc_fp_seed())
 
 
 FP_VERSION = 2     # == vsr_oracle.hpp FP_VERSION (checked when the library loads): which fingerprint function fixtures were made with

@@ -34,6 +34,8 @@ def install(ns, libname, actions, default_mask, words_per_replica, params_doc):
             L.orc_bfs_frontier.restype = C.c_longlong
             L.orc_bfs_frontier.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
             L.orc_bfs_trace_fps.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+            L.orc_set_fp_seed.argtypes = [C.c_uint64]
+            L.orc_fp_seed.restype = C.c_uint64
             state["lib"] = L
         return state["lib"]
 
@@ -85,4 +87,4 @@ def install(ns, libname, actions, default_mask, words_per_replica, params_doc):
             return with_lib(super().close)
 
     ns.update(LIB=LIB, ACTIONS=actions, OracleError=_orc.OracleError, lib=lib, Params=Params, Bfs=Bfs,
-              **{name: bind(name) for name in ("init_record", "fingerprint", "invariants", "normalise", "successors")})
+              **{name: bind(name) for name in ("init_record", "fingerprint", "invariants", "normalise", "successors", "set_fp_seed", "fp_seed")})

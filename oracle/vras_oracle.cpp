@@ -1,6 +1,7 @@
 // oracle/vras_oracle.cpp — CPU ORACLE for VR_APP_STATE.tla (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See vras_oracle.hpp.
 // Every function cites the lines of /root/reference/vsr-revisited/paper/analysis/04-application-state/VR_APP_STATE.tla it
 // restates (VRAS.tla:NNN).  Unpacked structs, sorted bag, whole-state copies: nothing here is shared with the HIP path.
+#include <cstdlib>
 #include "vras_oracle.hpp"
 
 #include <algorithm>
@@ -707,6 +708,11 @@ u64 fmix64(u64 x) {
   return x;
 }
 static const u64 SALT_MSG = 0x9E3779B97F4A7C15ULL;
+// Second-hash audit (vsrmc_model_set_fp_seed in the product): a seed xor-ed into every salt.  0 = the function of the committed fixtures.
+// Process-global; the stand-alone drivers read VSR_ORACLE_FP_SEED (hex) once.
+static u64 g_fp_seed = [] { const char* e = std::getenv("VSR_ORACLE_FP_SEED"); return e ? (u64)std::strtoull(e, nullptr, 16) : (u64)0; }();
+void set_fp_seed(u64 seed) { g_fp_seed = seed; }
+u64 fp_seed() { return g_fp_seed; }
 static u64 salt_word(int r, int k) { return fmix64(0xA0761D6478BD642FULL + (u64)(8 * r + k)); }
 
 Fp fingerprint(const Params& P, const State& s) {
@@ -714,8 +720,8 @@ Fp fingerprint(const Params& P, const State& s) {
   encode(P, s, rec);
   u64 sum = 0;
   for (int r = 1; r <= P.R; r++)
-    for (int k = 0; k < 2; k++) sum += fmix64(rec[1 + 2 * (r - 1) + k] ^ salt_word(r, k));
-  for (size_t j = fixed_words(P); j < rec.size(); j++) sum += fmix64(rec[j] ^ SALT_MSG);
+    for (int k = 0; k < 2; k++) sum += fmix64(rec[1 + 2 * (r - 1) + k] ^ (salt_word(r, k) ^ g_fp_seed));
+  for (size_t j = fixed_words(P); j < rec.size(); j++) sum += fmix64(rec[j] ^ (SALT_MSG ^ g_fp_seed));
   Fp f;
   f.fp = sum ? sum : 1;
   f.auxkey = (u32)s.aux_svc;

@@ -127,5 +127,7 @@ State decode(const Params& P, const u64* rec, int* nwords);
 struct Fp { u64 fp; u32 auxkey; int argmin; };
 Fp fingerprint(const Params& P, const State& s);                           // VIEW view, VRST.tla:96 / VRST.cfg:23
 u64 fmix64(u64 x);
+void set_fp_seed(u64 seed);   // second-hash audit: xor-ed into every salt (process-global; 0 = the fixtures' function)
+u64 fp_seed();
 
 }  // namespace vrst_oracle

@@ -1,5 +1,6 @@
 // oracle/vsr_oracle.cpp — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See vsr_oracle.hpp.
 // Every function cites the VSR.tla lines it restates.  "parity unpinned" vs TLC (see header).
+#include <cstdlib>
 #include "vsr_oracle.hpp"
 
 #include <algorithm>
@@ -849,6 +850,11 @@ u64 fmix64(u64 x) {
   return x;
 }
 static const u64 SALT_MSG = 0x9E3779B97F4A7C15ULL;
+// Second-hash audit (vsrmc_model_set_fp_seed in the product): a seed xor-ed into every salt.  0 = the function of the committed fixtures.
+// Process-global; the stand-alone drivers read VSR_ORACLE_FP_SEED (hex) once.
+static u64 g_fp_seed = [] { const char* e = std::getenv("VSR_ORACLE_FP_SEED"); return e ? (u64)std::strtoull(e, nullptr, 16) : (u64)0; }();
+void set_fp_seed(u64 seed) { g_fp_seed = seed; }
+u64 fp_seed() { return g_fp_seed; }
 // position salt of word k of replica r's column (Zobrist-style: every (position, word) pair contributes one independent term)
 static u64 salt_word(int r, int k) { return fmix64(0xA0761D6478BD642FULL + (u64)(8 * r + k)); }
 
@@ -859,9 +865,9 @@ static u64 view_hash(const Params& P, const State& s) {
   u64 sum = 0;
   for (int r = 1; r <= P.R; r++) {
     const u64* b = &rec[1 + (size_t)(r - 1) * wpr];
-    for (int k = 0; k < wpr; k++) sum += fmix64(b[k] ^ salt_word(r, k));
+    for (int k = 0; k < wpr; k++) sum += fmix64(b[k] ^ (salt_word(r, k) ^ g_fp_seed));
   }
-  for (size_t j = fixed_words(P); j < rec.size(); j++) sum += fmix64(rec[j] ^ SALT_MSG);
+  for (size_t j = fixed_words(P); j < rec.size(); j++) sum += fmix64(rec[j] ^ (SALT_MSG ^ g_fp_seed));
   return sum;
 }
 

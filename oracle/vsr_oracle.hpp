@@ -160,6 +160,8 @@ State decode(const Params& P, const u64* rec, int* nwords);
 struct Fp { u64 fp; u32 auxkey; int argmin; };
 Fp fingerprint(const Params& P, const State& s);
 u64 fmix64(u64 x);
+void set_fp_seed(u64 seed);   // second-hash audit: xor-ed into every salt (process-global; 0 = the fixtures' function)
+u64 fp_seed();
 // version of the fingerprint FUNCTION (not of the state identity it hashes): 1 = per-replica chained hash (round 1),
 // 2 = one salted term per word (Zobrist-style sum).  Fixtures that hold fingerprint values say which one they were made with.
 const int FP_VERSION = 2;

@@ -182,6 +182,8 @@ extern "C" {
 
 const char* orc_last_error() { return g_err.c_str(); }
 int orc_fp_version() { return FP_VERSION; }
+void orc_set_fp_seed(u64 seed) { set_fp_seed(seed); }
+u64 orc_fp_seed() { return fp_seed(); }
 
 int orc_layout(const int* params, int* wpr, int* fixed) {
   Params P = params_from(params);

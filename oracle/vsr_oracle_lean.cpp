@@ -117,7 +117,7 @@ struct FastFp {
   u64 calls = 0, verify_every = 4096;
   FastFp() {
     for (int r = 0; r < 8; r++)
-      for (int k = 0; k < 4; k++) salt[r][k] = fmix64(0xA0761D6478BD642FULL + (u64)(8 * r + k));
+      for (int k = 0; k < 4; k++) salt[r][k] = fmix64(0xA0761D6478BD642FULL + (u64)(8 * r + k)) ^ fp_seed();   // (VSR_ORACLE_FP_SEED: second-hash audit)
   }
   Fp operator()(const Params& P, const State& st, const u64* rec, size_t nwords) {
     const int wpr = words_per_replica(P), fixed = fixed_words(P);
@@ -137,7 +137,7 @@ struct FastFp {
       add(b + 1, 0x0101010000010101ULL, salt[r][1]);
       for (int k = 2; k < wpr; k++) add(b + k, 0x0101010001010100ULL, salt[r][k]);
     }
-    for (size_t j = fixed; j < nwords; j++) add(rec + j, 0x0001010100000000ULL, 0x9E3779B97F4A7C15ULL);
+    for (size_t j = fixed; j < nwords; j++) add(rec + j, 0x0001010100000000ULL, 0x9E3779B97F4A7C15ULL ^ fp_seed());
     int pi[4] = {0, 1, 2, 3};
     Fp best;
     best.fp = 0; best.auxkey = 0; best.argmin = -1;

@@ -68,6 +68,8 @@ SYMBOLS = {
     "vsrmc_model2_from_constants": (C.c_int32, [C.c_int32] * 6 + [C.POINTER(V)]),
     "vsrmc_model3_from_constants": (C.c_int32, [C.c_int32] * 6 + [C.POINTER(V)]),
     "vsrmc_model_info": (C.c_int32, [V, C.POINTER(Layout)]),
+    "vsrmc_model_set_fp_seed": (C.c_int32, [V, C.c_uint64]),
+    "vsrmc_model_fp_seed": (C.c_uint64, [V]),
     "vsrmc_model_init_state": (C.c_int32, [V, V, C.c_int32, C.POINTER(C.c_int32)]),
     "vsrmc_model_format_state": (C.c_int32, [V, V, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     "vsrmc_action_name": (C.c_char_p, [C.c_int32]),

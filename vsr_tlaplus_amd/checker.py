@@ -67,6 +67,17 @@ class Model:
         check(capi.load().vsrmc_model3_from_constants(R, n, L, no_progress_limit, int(symmetry), invariant_mask, C.byref(h)))
         return cls(h)
 
+    def set_fp_seed(self, seed):
+        """Second-hash audit (TLC: a rerun under another -fp N): `seed` is xor-ed into every salt of the view hash.  Seed 0 is the
+        function of the committed fixtures; under any other seed fingerprints and checksums change, counts must not.  Checkers
+        created afterwards see it (a checker copies the model).  Returns self."""
+        check(capi.load().vsrmc_model_set_fp_seed(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
+        return self
+
+    @property
+    def fp_seed(self):
+        return int(capi.load().vsrmc_model_fp_seed(self._h))
+
     def init_state(self):
         out = np.zeros(256, dtype=np.uint64)
         n = C.c_int32()

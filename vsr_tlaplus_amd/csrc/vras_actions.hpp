@@ -104,6 +104,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
     D.hdr = hdr;
     D.r = r;
     D.used = 0;
+    D.clear_pj();
     D.err = 0;
     D.rep[0] = A;
     D.rep[1] = B;
@@ -347,7 +348,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
   if (!GUARD_ONLY) {
     int na = 0;
 #pragma unroll
-    for (int k = 0; k < VSR_NSLOT; k++) na += (((D.used >> k) & 1) && D.pj[k] < 0) ? 1 : 0;
+    for (int k = 0; k < VSR_NSLOT; k++) na += (((D.used >> k) & 1) && D.pj(k) < 0) ? 1 : 0;
     if (nmsg + na > M.max_bag) D.err = D.err ? D.err : ERR_REP_BAG;
     D.hdr = hdr_set_nmsg(D.hdr, nmsg + na);
   }
@@ -382,21 +383,21 @@ template <typename PTR>
 VSR_HD void hash_full(const Model& M, PTR rec, u64* H) {
   const int nmsg = hdr_nmsg(rec[0]);
   u64 sum = 0;
-  for (int r = 1; r <= M.R; r++) sum += fmix64(rec[c_ia(r)] ^ salt_word<0>(r)) + fmix64(rec[c_ia(r) + 1] ^ salt_word<1>(r));
-  for (int j = 0; j < nmsg; j++) sum += fmix64(rec[M.fixed + j] ^ SALT_MSG);
+  for (int r = 1; r <= M.R; r++) sum += fmix64(rec[c_ia(r)] ^ (salt_word<0>(r) ^ M.fp_seed)) + fmix64(rec[c_ia(r) + 1] ^ (salt_word<1>(r) ^ M.fp_seed));
+  for (int j = 0; j < nmsg; j++) sum += fmix64(rec[M.fixed + j] ^ (SALT_MSG ^ M.fp_seed));
   H[0] = sum;
 }
 template <typename PTR>
 VSR_HD void hash_child(const Model& M, PTR rec, const Delta& D, u64* Hc) {
   u64 h = rec[M.h0];
   const u64 oldA = rec[c_ia(D.r)], oldB = rec[c_ia(D.r) + 1];
-  if (oldA != D.rep[0]) h += fmix64(D.rep[0] ^ salt_word<0>(D.r)) - fmix64(oldA ^ salt_word<0>(D.r));
-  if (oldB != D.rep[1]) h += fmix64(D.rep[1] ^ salt_word<1>(D.r)) - fmix64(oldB ^ salt_word<1>(D.r));
+  if (oldA != D.rep[0]) h += fmix64(D.rep[0] ^ (salt_word<0>(D.r) ^ M.fp_seed)) - fmix64(oldA ^ (salt_word<0>(D.r) ^ M.fp_seed));
+  if (oldB != D.rep[1]) h += fmix64(D.rep[1] ^ (salt_word<1>(D.r) ^ M.fp_seed)) - fmix64(oldB ^ (salt_word<1>(D.r) ^ M.fp_seed));
 #pragma unroll
   for (int k = 0; k < VSR_NSLOT; k++)
     if ((D.used >> k) & 1) {
-      h += fmix64(D.pnew[k] ^ SALT_MSG);
-      if (D.pj[k] >= 0) h -= fmix64(D.pold[k] ^ SALT_MSG);
+      h += fmix64(D.pnew[k] ^ (SALT_MSG ^ M.fp_seed));
+      if (D.pj(k) >= 0) h -= fmix64(rec[M.fixed + D.pj(k)] ^ (SALT_MSG ^ M.fp_seed));
     }
   Hc[0] = h;
 }

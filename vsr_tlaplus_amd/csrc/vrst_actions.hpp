@@ -86,16 +86,14 @@ VSR_HD void bag_send_cnt(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, i
       return;
     }
   D.used |= 1 << 1;
-  D.pj[1] = -1;
-  D.pold[1] = 0;
+  D.set_pj(1, -1);
   D.pnew[1] = m_set_count(key, cnt0);
   for (int j = 0; j < nmsg; j++) {
     const u64 w = bag[j];
     if ((w & KEYMASK) == key) {
       int c = m_count(w) + 1;
       if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
-      D.pj[1] = j;
-      D.pold[1] = w;
+      D.set_pj(1, j);
       D.pnew[1] = m_set_count(w, c);
       return;
     }
@@ -134,6 +132,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
     D.hdr = hdr;
     D.r = r;
     D.used = 0;
+    D.clear_pj();
     D.err = 0;
     D.rep[0] = A;
     D.rep[1] = D.rep[2] = D.rep[3] = 0;
@@ -354,7 +353,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
   if (!GUARD_ONLY) {
     int na = 0;
 #pragma unroll
-    for (int k = 0; k < VSR_NSLOT; k++) na += (((D.used >> k) & 1) && D.pj[k] < 0) ? 1 : 0;
+    for (int k = 0; k < VSR_NSLOT; k++) na += (((D.used >> k) & 1) && D.pj(k) < 0) ? 1 : 0;
     if (nmsg + na > M.max_bag) D.err = D.err ? D.err : ERR_REP_BAG;
     D.hdr = hdr_set_nmsg(D.hdr, nmsg + na);
   }
@@ -391,20 +390,20 @@ template <typename PTR>
 VSR_HD void hash_full(const Model& M, PTR rec, u64* H) {
   const int nmsg = hdr_nmsg(rec[0]);
   u64 sum = 0;
-  for (int r = 1; r <= M.R; r++) sum += fmix64(rec[r] ^ salt_word<0>(r));
-  for (int j = 0; j < nmsg; j++) sum += fmix64(rec[M.fixed + j] ^ SALT_MSG);
+  for (int r = 1; r <= M.R; r++) sum += fmix64(rec[r] ^ (salt_word<0>(r) ^ M.fp_seed));
+  for (int j = 0; j < nmsg; j++) sum += fmix64(rec[M.fixed + j] ^ (SALT_MSG ^ M.fp_seed));
   H[0] = sum;
 }
 template <typename PTR>
 VSR_HD void hash_child(const Model& M, PTR rec, const Delta& D, u64* Hc) {
   u64 h = rec[M.h0];
   const u64 oldA = rec[D.r];
-  if (oldA != D.rep[0]) h += fmix64(D.rep[0] ^ salt_word<0>(D.r)) - fmix64(oldA ^ salt_word<0>(D.r));
+  if (oldA != D.rep[0]) h += fmix64(D.rep[0] ^ (salt_word<0>(D.r) ^ M.fp_seed)) - fmix64(oldA ^ (salt_word<0>(D.r) ^ M.fp_seed));
 #pragma unroll
   for (int k = 0; k < VSR_NSLOT; k++)
     if ((D.used >> k) & 1) {
-      h += fmix64(D.pnew[k] ^ SALT_MSG);
-      if (D.pj[k] >= 0) h -= fmix64(D.pold[k] ^ SALT_MSG);
+      h += fmix64(D.pnew[k] ^ (SALT_MSG ^ M.fp_seed));
+      if (D.pj(k) >= 0) h -= fmix64(rec[M.fixed + D.pj(k)] ^ (SALT_MSG ^ M.fp_seed));
     }
   Hc[0] = h;
 }

@@ -26,16 +26,32 @@ namespace vsr {
                            // slot d = the copy addressed to replica d (1..5).  Slots are compile-time indices everywhere
                            // (fully unrolled loops), so a Delta lives in registers, never in scratch memory.
 
+#ifndef VSR_PACK_DELTA      // 1: the small fields of a Delta share registers (bit-fields; the patched bag indices one byte each in one 64-bit word)
+#define VSR_PACK_DELTA 1
+#endif
 struct Delta {
   u64 hdr;                 // new header (nmsg already updated)
   u64 rep[4];              // new replica block of replica r (wpr <= 4 words; rep[3] is 0 when wpr == 3)
+#if VSR_PACK_DELTA
+  u32 r : 3;               // the one replica an action updates
+  u32 action : 5;          // A_* id (for traces)
+  u32 used : 8;            // bit s: patch slot s is in use
+  int err;                 // ERR_* (a word of its own: the analysis models' helpers take its address)
+  u64 pjw;                 // byte s: 1 + the bag index slot s patches, 0 = appended entry
+  VSR_HD int pj(int s) const { return (int)((pjw >> (8 * s)) & 0xFF) - 1; }
+  VSR_HD void set_pj(int s, int j) { pjw = (pjw & ~((u64)0xFF << (8 * s))) | ((u64)(u32)(j + 1) << (8 * s)); }
+  VSR_HD void clear_pj() { pjw = 0; }
+#else
   int r;                   // the one replica an action updates
   int action;              // A_* id (for traces)
   int used;                // bit s: patch slot s is in use
-  int pj[VSR_NSLOT];       // bag index patched, or -1 = appended entry
-  u64 pold[VSR_NSLOT];     // previous word (0 for appended entries)
-  u64 pnew[VSR_NSLOT];
   int err;
+  int pj_[VSR_NSLOT];      // bag index patched, or -1 = appended entry
+  VSR_HD int pj(int s) const { return pj_[s]; }
+  VSR_HD void set_pj(int s, int j) { pj_[s] = j; }
+  VSR_HD void clear_pj() {}
+#endif
+  u64 pnew[VSR_NSLOT];     // the new word of slot s (the previous one is the parent's bag word pj(s), read where it is needed)
 };
 
 // ---- x-slot access: replica block in memory (parent record) ... ------------------------------------------------------
@@ -68,8 +84,7 @@ VSR_HD void rep_clear_dvc(u64* b) {                            // rep_dvc_recv[r
 // DiscardFunc (VSR.tla:244-245): count - 1, the key stays in the domain.  Always slot 0.
 VSR_HD void bag_discard(Delta& D, int j, u64 w) {
   D.used |= 1;
-  D.pj[0] = j;
-  D.pold[0] = w;
+  D.set_pj(0, j);
   D.pnew[0] = m_set_count(w, m_count(w) - 1);
 }
 // SendFunc (VSR.tla:228-231): existing key -> count + 1 (even from 0), new key -> count 1.  SLOT is a compile-time constant
@@ -85,8 +100,7 @@ VSR_HD void bag_send_at(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, co
       return;
     }
   D.used |= 1 << SLOT;
-  D.pj[SLOT] = -1;
-  D.pold[SLOT] = 0;
+  D.set_pj(SLOT, -1);
   D.pnew[SLOT] = m_set_count(key, 1);
   // four bag words per trip: the loads are independent, so a trip costs one LDS latency instead of four (keys are unique in a bag:
   // at most one entry matches; 0 is no key)
@@ -97,8 +111,7 @@ VSR_HD void bag_send_at(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, co
       const u64 w = h0 ? w0 : h1 ? w1 : h2 ? w2 : w3;
       int c = m_count(w) + 1;
       if (c > 3) { D.err = ERR_REP_COUNT; c = 3; }
-      D.pj[SLOT] = j0 + (h0 ? 0 : h1 ? 1 : h2 ? 2 : 3);
-      D.pold[SLOT] = w;
+      D.set_pj(SLOT, j0 + (h0 ? 0 : h1 ? 1 : h2 ? 2 : 3));
       D.pnew[SLOT] = m_set_count(w, c);
       return;
     }
@@ -114,8 +127,7 @@ VSR_HD void bag_broadcast(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, 
   for (int d = 1; d <= 5; d++)
     if (d <= M.R && d != source) {
       D.used |= 1 << d;
-      D.pj[d] = -1;
-      D.pold[d] = 0;
+      D.set_pj(d, -1);
       D.pnew[d] = m_set_count(m_set_dest(key, d), 1);
     }
   const u64 nodest = ~((u64)7 << 6);
@@ -139,8 +151,7 @@ VSR_HD void bag_broadcast(const Model& M, PTR bag, int nmsg, Delta& D, u64 key, 
 #pragma unroll
       for (int q = 1; q <= 5; q++)
         if (q == d && ((D.used >> q) & 1)) {
-          D.pj[q] = j0 + u;
-          D.pold[q] = w;
+          D.set_pj(q, j0 + u);
           D.pnew[q] = m_set_count(w, c);
         }
     }
@@ -221,6 +232,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
     D.hdr = hdr;
     D.r = r;
     D.used = 0;
+    D.clear_pj();
     D.err = 0;
     D.action = 0;
     D.rep[0] = pb[0];
@@ -504,7 +516,7 @@ VSR_HD bool gen(const Model& M, PTR rec, int ord, Delta& D) {
     else if (send_mode == 2) bag_broadcast(M, bag, nmsg, D, send_key, r);
     int na = 0;
 #pragma unroll
-    for (int k = 0; k < VSR_NSLOT; k++) na += (((D.used >> k) & 1) && D.pj[k] < 0) ? 1 : 0;
+    for (int k = 0; k < VSR_NSLOT; k++) na += (((D.used >> k) & 1) && D.pj(k) < 0) ? 1 : 0;
     if (nmsg + na > M.max_bag) D.err = D.err ? D.err : ERR_REP_BAG;
     D.hdr = hdr_set_nmsg(D.hdr, nmsg + na);
   }
@@ -658,7 +670,7 @@ template <int K>
 VSR_HD void hash_word_delta(const Model& M, u64 w_old, u64 w_new, int r, u64& dinv, u64* d) {
   if (w_old == w_new) return;
   constexpr u64 m01 = K == 0 ? (u64)0 : K == 1 ? LOGB_REP1 : LOGB_REPK;
-  const u64 s = salt_word<K>(r);
+  const u64 s = salt_word<K>(r) ^ M.fp_seed;
   if (K == 0 || !(word_has_values(w_old, m01) | word_has_values(w_new, m01))) {
     dinv += fmix64(w_new ^ s) - fmix64(w_old ^ s);
     return;
@@ -672,14 +684,14 @@ VSR_HD void hash_word_delta(const Model& M, u64 w_old, u64 w_new, int r, u64& di
 }
 VSR_HD void hash_msg_term(const Model& M, u64 w, bool add, u64& dinv, u64* d) {
   if (!word_has_values(w, LOGB_MSG)) {
-    const u64 h = fmix64(w ^ SALT_MSG);
+    const u64 h = fmix64(w ^ (SALT_MSG ^ M.fp_seed));
     dinv += add ? h : (u64)0 - h;
     return;
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     if (i >= M.np) break;
-    const u64 h = hash_msg(w, M.pitab[i]);
+    const u64 h = hash_msg(M, w, M.pitab[i]);
     d[i] += add ? h : (u64)0 - h;
   }
 }
@@ -696,7 +708,7 @@ VSR_HD void hash_child(const Model& M, PTR rec, const Delta& D, u64* Hc) {
   for (int k = 0; k < VSR_NSLOT; k++)
     if ((D.used >> k) & 1) {
       hash_msg_term(M, D.pnew[k], true, dinv, d);
-      if (D.pj[k] >= 0) hash_msg_term(M, D.pold[k], false, dinv, d);
+      if (D.pj(k) >= 0) hash_msg_term(M, rec[M.fixed + D.pj(k)], false, dinv, d);
     }
 #pragma unroll
   for (int i = 0; i < 6; i++) {

@@ -121,7 +121,7 @@ struct LevelCtl {   // device-resident counters of one BFS level
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
 __host__ __device__ __forceinline__ int owner_of(u64 fp, int world) { return (int)(((fp >> 40) & 0xFFFFFF) % (u64)world); }
 
-enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
+enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO_FOOTPRINT = 0x100 /* flag, or-ed to MODE_PROBE */ };
 #define VSR_TILE_MAX 128     // frontier records staged per block iteration: 64 or 128 (kernel parameter `tile`)
 #define VSR_BLOCK 256
 // per-phase shader clocks of k_expand (vsrmc_level_info.phase_cycles; tools/run_bfs.py prints the breakdown): every read is an
@@ -136,59 +136,22 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3 };
 #endif
 #define VSR_CAND_CAP 2048    // enabled instances per tile the LDS work list can hold
 // two-stage enumeration of the enabled instances in k_expand (VSR.tla model): 0 = the full guard for every (record, slot) pair
-#ifndef VSR_ENUM2
-#define VSR_ENUM2 1
-#endif
 // Block barriers of k_expand.  __syncthreads() is "s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier": every barrier also waits until the
 // wave's outstanding GLOBAL stores have been acknowledged — after the apply phase that is the drain of ~28 scattered stores per
 // new state.  Nothing in k_expand hands data from wave to wave through global memory inside a launch (the waves of a block talk
 // through LDS, blocks through atomics), so the barriers only have to order LDS: wait for the wave's LDS operations, then s_barrier.
 // The stores keep draining underneath the next tile's staging loads.
-#ifndef VSR_RELAXED_SYNC
-#define VSR_RELAXED_SYNC 0
-#endif
-#if VSR_RELAXED_SYNC
-#define VSR_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#else
 #define VSR_SYNC() __syncthreads()
-#endif
 // seen-set probes read the home slot (16 B) first and the rest of its 64-byte line only when that slot holds another fingerprint
-#ifndef VSR_HOME_FIRST
-#define VSR_HOME_FIRST 1
-#endif
 // successor write: parent words copied eight per trip (four LDS reads in flight) instead of two
 // intra-tile duplicate filter in LDS ahead of the seen-set probes of k_expand (single-pass levels)
-#ifndef VSR_DEDUP
-#define VSR_DEDUP 0
-#endif
-#ifndef VSR_WAVE_COMPACT
-#define VSR_WAVE_COMPACT 0
-#endif
 #ifndef VSR_OCC            // resident blocks per CU the specialised fused kernels are compiled for (4 = 128 VGPRs; 5 = 96: experiment)
 #define VSR_OCC 4
-#endif
-#ifndef VSR_INV_FOOTPRINT     // stored levels: the invariants are evaluated only for new states reached by an action inside their footprint
-#define VSR_INV_FOOTPRINT 0
 #endif
 #ifndef VSR_PROBE_FOOTPRINT   // probe level: only the actions that write what the invariants read are applied (Ops::probe_actions)
 #define VSR_PROBE_FOOTPRINT 1
 #endif
-#ifndef VSR_COPY_PIPE
-#define VSR_COPY_PIPE 1
-#endif
 // frontier refs of a tile are loaded one tile ahead (tiles are drawn two ahead): the staging of a tile starts with its record loads
-#ifndef VSR_REF_AHEAD
-#define VSR_REF_AHEAD 0
-#endif
-#ifndef VSR_COPY8
-#define VSR_COPY8 0
-#endif
-#ifndef VSR_DIAG_DBLPROBE
-#define VSR_DIAG_DBLPROBE 0
-#endif
-#ifndef VSR_DIAG_DBLWRITE
-#define VSR_DIAG_DBLWRITE 0
-#endif
 
 __device__ __forceinline__ void raise_error(LevelCtl* ctl, int code, u64 info) {
   if (atomicCAS(&ctl->err, 0u, (u32)code) == 0u) ctl->err_info = info;
@@ -217,6 +180,19 @@ __device__ __forceinline__ u64 wave_alloc(u64* counter) {
 // Find-or-insert of a fingerprint: linear probing from fp & mask, one 64-byte line (4 slots) per memory round trip.
 // A loaded line may be stale with respect to concurrent inserts, which is harmless: a slot only ever goes empty -> fp and
 // never changes afterwards, so "other key" and "this key" are final, and "empty" is re-checked by the atomicCAS.
+// how a probe sequence is counted (vsrmc_level_info.probes, informational): in a register of the lane (small kernels), or — in k_expand, where
+// every register of the apply loop counts — not at all for the home slot (the caller adds one per candidate) and with an LDS atomic per
+// further slot (one candidate in ten gets that far)
+struct CntReg {
+  u32* p;
+  __device__ __forceinline__ void home() const { (*p)++; }
+  __device__ __forceinline__ void extra() const { (*p)++; }
+};
+struct CntLds {
+  unsigned long long* p;
+  __device__ __forceinline__ void home() const {}
+  __device__ __forceinline__ void extra() const { atomicAdd(p, 1ull); }
+};
 struct Probe {
   u64 slot;         // index of the slot that holds fp
   u64 meta;         // its meta word as loaded with the line (valid unless `claimed` or `reload`)
@@ -224,15 +200,15 @@ struct Probe {
   bool reload;      // fp was inserted by someone else between the load and our CAS: meta must be re-read
   bool full;
 };
-__device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32* nprobe) {
+template <typename CNT>
+__device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, CNT nprobe) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   Probe r;
   r.slot = 0; r.meta = META_EMPTY; r.claimed = false; r.reload = false; r.full = false;
   u64 i = fp & mask;
-#if VSR_HOME_FIRST
   {
     const u64x2 sk = *(const u64x2*)&table[i];
-    (*nprobe)++;
+    nprobe.home();
     u64 cur = sk.x;
     if (cur == 0) {
       cur = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
@@ -245,7 +221,6 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32
     }
     i = (i + 1) & mask;
   }
-#endif
   for (u32 lines = 0; lines < 2048; lines++) {
     const u64 lb = i & ~(u64)3;
     const u64x2* lp = (const u64x2*)&table[lb];
@@ -254,7 +229,7 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32
     for (int k = 0; k < 4; k++) {
       if (lb + k < i) continue;                                 // slots of the line before the probe start
       const u64x2 sk = k == 0 ? s0 : k == 1 ? s1 : k == 2 ? s2 : s3;
-      (*nprobe)++;
+      nprobe.extra();
       u64 cur = sk.x;
       if (cur == 0) {
         cur = atomicCAS((unsigned long long*)&table[lb + k].fp, 0ull, (unsigned long long)fp);
@@ -283,13 +258,13 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, u32
 }
 
 // Lookup without insertion (probe level, vsrmc_checker_probe): is fp in the table, and with which meta word?
-__device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp, u64* meta, u32* nprobe, u64* slot_out = nullptr) {
+template <typename CNT>
+__device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp, u64* meta, CNT nprobe, u64* slot_out = nullptr) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   u64 i = fp & mask;
-#if VSR_HOME_FIRST
   {
     const u64x2 sk = *(const u64x2*)&table[i];
-    (*nprobe)++;
+    nprobe.home();
     if (sk.x == fp) {
       *meta = sk.y;
       if (slot_out) *slot_out = i;
@@ -298,7 +273,6 @@ __device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp
     if (sk.x == 0) return false;
     i = (i + 1) & mask;
   }
-#endif
   for (u32 lines = 0; lines < 2048; lines++) {
     const u64 lb = i & ~(u64)3;
     const u64x2* lp = (const u64x2*)&table[lb];
@@ -307,7 +281,7 @@ __device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp
     for (int k = 0; k < 4; k++) {
       if (lb + k < i) continue;
       const u64x2 sk = k == 0 ? s0 : k == 1 ? s1 : k == 2 ? s2 : s3;
-      (*nprobe)++;
+      nprobe.extra();
       if (sk.x == fp) {
         *meta = sk.y;
         if (slot_out) *slot_out = lb + k;
@@ -323,8 +297,9 @@ __device__ __forceinline__ bool probe_lookup(const Slot* table, u64 mask, u64 fp
 // Seen-set claim of the two-kernel scheme.  Returns the slot index; *found_old = true when the candidate cannot win (the
 // fingerprint belongs to an earlier level, or a smaller key of this level already holds the slot), otherwise the caller's key
 // has been min-merged into the slot's meta word and the candidate goes to the pending list.
+template <typename CNT>
 __device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 key, int level, bool* found_old,
-                                           u32* nprobe, bool* full) {
+                                           CNT nprobe, bool* full) {
   const Probe p = probe_insert(table, mask, fp, nprobe);
   *full = p.full;
   *found_old = true;
@@ -343,8 +318,9 @@ __device__ __forceinline__ u64 table_claim(Slot* table, u64 mask, u64 fp, u64 ke
 // has done its other work, so that the returning atomic's latency overlaps with the successor write.  A same-level
 // duplicate with a different canonical auxkey is the VIEW collision of SURVEY F2 inside one level, which the single-pass
 // scheme cannot arbitrate — the host then asks for the exact two-kernel scheme (never observed: `ties` is 0 everywhere).
+template <typename CNT>
 __device__ __forceinline__ void table_claim_fused(Slot* table, u64 mask, u64 fp, u64 key, int level, bool* claimed, u64* prev_meta,
-                                                  u32* nprobe, bool* full) {
+                                                  CNT nprobe, bool* full) {
   const Probe p = probe_insert(table, mask, fp, nprobe);
   *full = p.full;
   *claimed = p.claimed;
@@ -426,7 +402,10 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   // code: the specialised kernel then fits the 64-KB instruction cache with room to spare)
   // PLAIN == 2: unsharded with the modes (the probe / virtual / regenerated / streamed passes of vsrmc_checker_probe*): only the
   // sharded branches are compiled out — the mode-capable kernel of the README configuration then fits the 64-KB instruction cache
-  const int mode = PLAIN == 1 ? (int)MODE_NORMAL : mode_arg;
+  const int mode = PLAIN == 1 ? (int)MODE_NORMAL : (mode_arg & 0xFF);
+  // MODE_NO_FOOTPRINT: the probe pass applies every action — the caller has seen a violating state among the parents' levels (a search that
+  // went on after a reported violation), and a violating parent hands its verdict to successors of actions outside the footprint
+  const bool no_footprint = PLAIN != 1 && (mode_arg & MODE_NO_FOOTPRINT) != 0;
   const int world = PLAIN ? 1 : world_arg;
   Model M = Marg;
   specialise<SPEC>(M, Marg);
@@ -480,36 +459,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   __shared__ u64 s_tile_cur;
   u64 my_next = 0;
   if (tid == 0) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
-#if VSR_REF_AHEAD
-  // wave 0 keeps a two-deep queue: my_next = the tile of the coming trip (its refs already loaded into ref_pref), my_next2 = the
-  // tile after it (drawn, its refs are loaded during the coming trip).  Lane 0 draws, the wave shares the index by readfirstlane.
-  u64 my_next2 = 0, ref_pref = 0;
-  if (tid < 64) {
-    my_next = readlane64(my_next, 0);
-    if (tid < tile && my_next < ntiles && my_next * (u64)tile + tid < n_parents) ref_pref = fr_off[my_next * (u64)tile + tid];
-    if (tid == 0 && my_next < ntiles) my_next2 = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
-  }
-#endif
   for (;;) {
-#if VSR_REF_AHEAD
-    u64 ref_now = 0;
-    if (tid < 64) {
-      if (tid == 0) s_tile_cur = my_next;
-      ref_now = ref_pref;
-      const u64 done = my_next;
-      my_next = readlane64(my_next2, 0);                          // waits for the draw issued one trip ago
-      ref_pref = 0;
-      if (done < ntiles) {
-        if (tid < tile && my_next < ntiles && my_next * (u64)tile + tid < n_parents) ref_pref = fr_off[my_next * (u64)tile + tid];
-        if (tid == 0 && my_next < ntiles) my_next2 = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
-      }
-    }
-#else
     if (tid == 0) {
       s_tile_cur = my_next;
       if (my_next < ntiles) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
     }
-#endif
     const u64 t_0 = VSR_CLK();
     if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; s_nsurv = 0; }
     if (tid < tile) s_alive[tid] = 0;
@@ -523,11 +477,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     // ---- stage the tile.  Frontier refs are (word offset << 8 | length): one coalesced load of 64 refs, then 16 lanes per
     // record / 16 records per pass, all 16 loads of a thread issued before the first LDS store (one HBM latency per tile)
     if (tid < np_tile) {
-#if VSR_REF_AHEAD
-      const u64 ref = tile <= 64 ? ref_now : fr_off[p_base + tid];   // 128-record tiles (two waves of refs) load them here
-#else
       const u64 ref = fr_off[p_base + tid];
-#endif
       s_ref[tid] = ref;
       if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
       if ((int)(ref & 255) > stride) raise_error(ctl, ERR_INTERNAL, (p_base + (u64)tid) << 16);   // LDS slots sized for shorter records
@@ -599,7 +549,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       VSR_SYNC();
       u32 nmine = 0;
       bool alive = false;
-#if VSR_ENUM2
       if constexpr (SPEC / 1000 == 0) {
         // Two-stage enumeration.  Evaluating the full guard for every (record, slot) pair was more than half of the kernel's
         // instructions although 1 pair in 20 is enabled.  Stage 1, per bag entry: delivery count > 0 and one bit of a 64-bit table
@@ -675,7 +624,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           }
         }
       } else
-#endif
       {
       // four independent guard evaluations per trip
       for (int item0 = tid; item0 < nitems; item0 += 4 * BLK) {
@@ -725,7 +673,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       // kernels only: the plain kernels sit on a register-allocation cliff — one more LDS word here cost the README configuration's 20
       // stored levels 22 ms.)
       if constexpr (PLAIN != 1 && FUSED && VSR_PROBE_FOOTPRINT) {
-        const u32 keep = mode == MODE_PROBE ? Ops::probe_actions() : ~0u;
+        const u32 keep = (mode == MODE_PROBE && !no_footprint) ? Ops::probe_actions() : ~0u;
         for (int a = 0; a < 16; a++)
           if ((keep >> a) & 1u) {
             s_kbase[a] = acc;
@@ -810,88 +758,14 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       VSR_SYNC();
     }
     const u32 ncand_apply = s_skip ? 0u : ((PLAIN != 1 && FUSED && VSR_PROBE_FOOTPRINT) ? s_napply : ncand);                // s_skip: the tile was refused (see the word-chunk reservation)
-#if VSR_DEDUP
-    // Intra-tile duplicate filter.  A tile of the frontier is a family — the children of a few neighbouring states — and about a
-    // third of the successors it generates are generated more than once INSIDE the tile (A;B = B;A).  The candidates of a pass meet
-    // in a small LDS hash table: the fingerprint claims an entry (64-bit compare-and-swap), the keys are min-merged into it, and
-    // after one barrier only the lane that holds the smallest key goes on to the seen-set in HBM — with exactly the key the
-    // min-merge in the slot's meta word would have kept, so the predecessor pointers do not change.  One 128-byte line of HBM and
-    // up to two device-scope atomics less per removed duplicate.  (Passes of more than BLK candidates, sharded runs and the
-    // lookup-only modes go without.)  dkey = auxkey(9) << 54 | parent fingerprint bits(45) << 9 | thread(9): unique per lane.
-    constexpr u32 NDD = 2 * BLK;
-    u64* dd_fp = (u64*)s_cand;                                  // s_cand is free after the sort; s_cand2 holds <= BLK sorted codes
-    u64* dd_key = (u64*)(s_cand2 + BLK);
-    u32* dd_akmax = s_cand + 2 * NDD;                           // behind dd_fp, still inside s_cand (ccap >= 6 BLK)
-    const bool dd_on = fused && world == 1 && ncand_apply <= (u32)BLK && ncand_apply > 0 && (mode == MODE_NORMAL || mode == MODE_INSERT) &&
-                       ccap >= 6u * BLK;
-    if (dd_on)
-      for (u32 k = tid; k < NDD; k += BLK) { dd_fp[k] = 0; dd_key[k] = ~(u64)0; dd_akmax[k] = 0; }   // (s_cand was last read by the sort's scatter, a barrier ago)
-#else
     constexpr bool dd_on = false;
-#endif
     if (tid == 0) { s_tile_base = s_chunk_used; s_tile_cursor = 0; }
     VSR_SYNC();
     // ---- apply + fingerprint + seen-set claim: one lane per enabled instance
-    u32 my_probes = 0, my_maxbag = 0, my_words = 0;
-    u64 my_fx = 0, my_fs = 0;                                   // virtual level: checksums of the fingerprints this lane inserted
-#if VSR_DEDUP
-    for (u32 c0 = 0; c0 < ncand_apply; c0 += BLK) {              // block-uniform trip count: the filter's barrier sits inside
-      const u32 c = c0 + tid;
-      bool act = c < ncand_apply;
-      const u32 code = act ? s_cand2[c] : 0u;
-      const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
-      const u64* rec = s_rec + p * stride;
-      Delta D;
-      u64 Hc[6];
-      u64 fp = 0, key = 0;
-      u32 ak = 0;
-      bool dd_tie = false;
-      const u64 a_0 = VSR_CLK();
-      if (act) {
-        if (!Ops::template gen_<false>(M, rec, ord, D) || D.action != (int)(code >> 18)) {
-          raise_error(ctl, ERR_INTERNAL, ((p_base + (u64)p) << 16) | (u64)ord);
-          act = false;
-        } else if (D.err) {
-          raise_error(ctl, D.err, ((p_base + (u64)p) << 16) | (u64)ord);
-          act = false;
-        }
-      }
-      const u64 a_1 = VSR_CLK();
-      if (act) {
-        Ops::hash_child_(M, rec, D, Hc);
-        canonical_fp(M, D.hdr, Hc, &fp, &ak);
-        key = meta_make(level, ak, s_pfp[p]);
-      }
-#if VSR_DIAG_DBLPROBE     // diagnostic build: one more random seen-set line per successor (marginal cost of a probe)
-      if (act) { u64 m_ = 0; if (probe_lookup(table, tmask, fp * 0x9E3779B97F4A7C15ull + 1, &m_, &my_probes)) my_maxbag += (u32)(m_ & 1); }
-#endif
-      const u64 a_2 = VSR_CLK();
-      if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
-#if VSR_DEDUP
-      if (dd_on) {
-        u32 h = 0;
-        u64 dkey = 0;
-        if (act) {
-          h = (u32)(fp >> 17) & (NDD - 1);
-          for (;;) {
-            const u64 old = atomicCAS((unsigned long long*)&dd_fp[h], 0ull, (unsigned long long)fp);
-            if (old == 0 || old == fp) break;
-            h = (h + 1) & (NDD - 1);
-          }
-          dkey = ((u64)ak << 54) | ((s_pfp[p] & PFP_MASK) << 9) | (u64)(tid & 511);
-          atomicMin((unsigned long long*)&dd_key[h], (unsigned long long)dkey);
-          atomicMax(&dd_akmax[h], ak);
-        }
-        VSR_SYNC();
-        if (act) {
-          const u64 won = dd_key[h];
-          if (won != dkey) act = false;                         // a duplicate inside the tile: the lane with the smallest key carries it
-          else dd_tie = dd_akmax[h] != ak;                      // copies with other aux variables: a VIEW tie IF the state is of this level
-        }
-      }
-#endif
-      if (!act) continue;
-#else
+    // (no per-lane statistics: a lane runs this body once per tile, so every loop-carried register is a register of the body's peak — words
+    // written come from the tile's word cursor, the largest bag / the virtual level's checksums go to LDS when a state is new, probes are counted
+    // as one per candidate plus an LDS atomic per slot beyond the home slot)
+    const CntLds my_probes{&s_acc[2]};
     for (u32 c = tid; c < ncand_apply; c += BLK) {
       const u32 code = s_cand2[c];
       const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
@@ -918,12 +792,8 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
       const u64 key = meta_make(level, ak, s_pfp[p]);
-#if VSR_DIAG_DBLPROBE     // diagnostic build: one more random seen-set line per successor (marginal cost of a probe)
-      { u64 m_ = 0; if (probe_lookup(table, tmask, fp * 0x9E3779B97F4A7C15ull + 1, &m_, &my_probes)) my_maxbag += (u32)(m_ & 1); }
-#endif
       const u64 a_2 = VSR_CLK();
       if (tid == 0) { s_acc[10] += a_1 - a_0; s_acc[11] += a_2 - a_1; }
-#endif
       if (!fused && world > 1) {                                // sharded seen-set, exact scheme: route to the owner of fp
         const int owner = owner_of(fp, world);
         if (owner != rank) {
@@ -947,7 +817,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         const int owner = world > 1 ? owner_of(fp, world) : rank;
         if (mode == MODE_PROBE) {                               // probe level: looked up, not inserted; unseen successors are checked
           u64 m = META_EMPTY;
-          check = !(probe_lookup(table, tmask, fp, &m, &my_probes) && meta_level(m) < level);
+          check = !(probe_lookup(table, tmask, fp, &m, my_probes) && meta_level(m) < level);
           if (!check) continue;
         } else if (owner != rank) {
           // sent-filter: a direct-mapped, lossy set of (fingerprint, auxkey) tags this rank has announced before (any level).
@@ -956,7 +826,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           u64 tag = fp ^ ((u64)(ak + 1) * 0x9E3779B97F4A7C15ull);
           if (tag == 0) tag = 1;
           u64* fs = filter + ((fp >> 6) & fmask);
-          my_probes++;
           if (__hip_atomic_load(fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) continue;
           __hip_atomic_store(fs, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           remote = true;
@@ -964,11 +833,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         } else if (mode == MODE_REGEN) {
           u64 m = META_EMPTY;
           u64 slot_i = 0;
-          do_write = probe_lookup(table, tmask, fp, &m, &my_probes, &slot_i) && m == key &&
+          do_write = probe_lookup(table, tmask, fp, &m, my_probes, &slot_i) && m == key &&
                      atomicCAS((unsigned long long*)&table[slot_i].meta, (unsigned long long)key, (unsigned long long)(key | META_TAKEN)) == key;
         } else {
           bool claimed, full;
-          table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, &my_probes, &full);
+          table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, my_probes, &full);
           if (full) {
             raise_error(ctl, ERR_TABLE_FULL, fp);
             continue;
@@ -977,11 +846,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           claimed_now = claimed;
         }
         // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
-#if VSR_INV_FOOTPRINT   // a new state reached by an action outside the invariants' footprint has the verdict of its parent, which passed when it was new
-        const int bad = ((check || do_write) && ((Ops::probe_actions() >> D.action) & 1u)) ? Ops::invariants(M, rec, D) : 0;
-#else
         const int bad = (check || do_write) ? Ops::invariants(M, rec, D) : 0;
-#endif
         if (mode == MODE_PROBE) {
           if (bad) {
             const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
@@ -1004,10 +869,10 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
             atomicOr(&ctl->viol_mask, (u32)bad);
           }
-          my_maxbag = my_maxbag > (u32)hdr_nmsg(D.hdr) ? my_maxbag : (u32)hdr_nmsg(D.hdr);
-          my_words++;                                           // counts states in this mode
-          my_fx ^= fp;
-          my_fs += fp;
+          if ((u32)hdr_nmsg(D.hdr) > s_maxbag_out) atomicMax(&s_maxbag_out, (u32)hdr_nmsg(D.hdr));
+          atomicAdd(&s_acc[9], 1ull);                           // counts states in this mode
+          atomicXor(&s_fxs[0], (unsigned long long)fp);         // into LDS, not into the control block (flushed once per block, in the epilogue)
+          atomicAdd(&s_fxs[1], (unsigned long long)fp);
           do_write = false;
         }
         const u64 a_3 = VSR_CLK();
@@ -1015,42 +880,14 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         if (do_write) {                                         // new state (or: possibly new, the owner decides): write it out
           const int plen = (int)(s_ref[p] & 255);
           const int clen = M.fixed + hdr_nmsg(D.hdr);
-#if VSR_WAVE_COMPACT     // the north-star's "wavefront ballot / prefix-sum compaction" of the new states: one LDS atomic per wave and counter
-          u32 io, wo;
-          {
-            // the lanes that write a successor are a sparse, divergent subset of the wave (the others left the loop body earlier), so
-            // a shuffle scan has nobody to forward partial sums: ranks come from the ballot, word offsets from a walk over the
-            // active lanes with a wave-uniform trip count (readlane of a uniform lane index)
-            const u64 active = __ballot(1);
-            const int leader = __ffsll((long long)active) - 1;
-            u32 tot = 0, my_w = 0;
-            for (u64 mset = active; mset; mset &= mset - 1) {
-              const int src = __ffsll((long long)mset) - 1;
-              const u32 v = (u32)__builtin_amdgcn_readlane((int)clen, src);
-              my_w += src < lane ? v : 0u;
-              tot += v;
-            }
-            u32 base_i = 0, base_w = 0;
-            if (lane == leader) {
-              base_i = atomicAdd(&s_tile_icur, (u32)__popcll(active));
-              base_w = atomicAdd(&s_tile_wcur, tot);
-            }
-            base_i = (u32)__builtin_amdgcn_readlane((int)base_i, leader);
-            base_w = (u32)__builtin_amdgcn_readlane((int)base_w, leader);
-            io = base_i + (u32)__popcll(active & (((u64)1 << lane) - 1));
-            wo = base_w + my_w;
-          }
-#else
           const u32 io = atomicAdd(&s_tile_icur, 1u);
           const u32 wo = atomicAdd(&s_tile_wcur, (u32)clen);
-#endif
           const u64 idx = s_ich_base + s_tile_ibase + io;
           const u64 dst = s_wch_base + s_tile_wbase + wo;
           u64* out = nx_words + dst;
           // parent from LDS, 16 bytes per store (records are 8-byte aligned), then the patches on top (same lane: ordered)
           typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
           int k = 0;
-#if VSR_COPY_PIPE     // the next pair of words is read from LDS before the current pair is stored: one LDS latency per two trips
           if (plen >= 2) {
             u64x2_a8 cur;
             cur.x = rec[0];
@@ -1065,18 +902,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             *(u64x2_a8*)(out + k) = cur;
             k += 2;
           }
-#endif
-#if VSR_COPY8
-          for (; k + 7 < plen; k += 8) {
-            u64x2_a8 a2, b2, c2, d2;
-            a2.x = rec[k]; a2.y = rec[k + 1]; b2.x = rec[k + 2]; b2.y = rec[k + 3];
-            c2.x = rec[k + 4]; c2.y = rec[k + 5]; d2.x = rec[k + 6]; d2.y = rec[k + 7];
-            *(u64x2_a8*)(out + k) = a2;
-            *(u64x2_a8*)(out + k + 2) = b2;
-            *(u64x2_a8*)(out + k + 4) = c2;
-            *(u64x2_a8*)(out + k + 6) = d2;
-          }
-#endif
           for (; k + 1 < plen; k += 2) {
             u64x2_a8 v2;
             v2.x = rec[k];
@@ -1084,17 +909,6 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             *(u64x2_a8*)(out + k) = v2;
           }
           if (k < plen) out[k] = rec[k];
-#if VSR_DIAG_DBLWRITE     // diagnostic build: the parent copy is stored a second time, half a buffer away (marginal cost of the successor write)
-          {
-            u64* out2 = nx_words + ((dst + (nx_words_cap >> 1)) % (nx_words_cap - 256));
-            for (int k2 = 0; k2 + 1 < plen; k2 += 2) {
-              u64x2_a8 v2;
-              v2.x = rec[k2];
-              v2.y = rec[k2 + 1];
-              *(u64x2_a8*)(out2 + k2) = v2;
-            }
-          }
-#endif
           out[0] = D.hdr;
           u64* ob = out + 1 + (D.r - 1) * M.wpr;
           ob[0] = D.rep[0];
@@ -1108,7 +922,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
 #pragma unroll
           for (int k = 0; k < VSR_NSLOT; k++)
             if ((D.used >> k) & 1) {
-              if (D.pj[k] >= 0) out[M.fixed + D.pj[k]] = D.pnew[k];
+              if (D.pj(k) >= 0) out[M.fixed + D.pj(k)] = D.pnew[k];
               else out[plen + (a++)] = D.pnew[k];
             }
           nx_off[idx] = (dst << 8) | (u64)clen;
@@ -1117,8 +931,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
             atomicOr(&ctl->viol_mask, (u32)bad);
           }
-          my_maxbag = my_maxbag > (u32)hdr_nmsg(D.hdr) ? my_maxbag : (u32)hdr_nmsg(D.hdr);
-          my_words += (u32)clen;
+          if ((u32)hdr_nmsg(D.hdr) > s_maxbag_out) atomicMax(&s_maxbag_out, (u32)hdr_nmsg(D.hdr));
           if (remote) {
             // announce (fp, key) to the owner: entry i of the block's chunk of that owner's bucket
             u64 i = 0;
@@ -1147,14 +960,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
         // same-level duplicate with a different canonical auxkey = the tie the single-pass scheme cannot arbitrate
         if (prev_meta != META_EMPTY && meta_level(prev_meta) == level && meta_auxkey(prev_meta) != meta_auxkey(key)) atomicAdd(&s_acc[8], 1ull);
-#if VSR_DEDUP
-        else if (dd_tie && (claimed_now || (prev_meta != META_EMPTY && meta_level(prev_meta) == level))) atomicAdd(&s_acc[8], 1ull);
-#endif
         if (tid == 0) s_acc[13] += VSR_CLK() - a_3;
         continue;
       }
       bool found_old, full;
-      u64 slot = table_claim(table, tmask, fp, key, level, &found_old, &my_probes, &full);
+      u64 slot = table_claim(table, tmask, fp, key, level, &found_old, my_probes, &full);
       if (full) {
         raise_error(ctl, ERR_TABLE_FULL, fp);
         continue;
@@ -1172,43 +982,19 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
     }
     const u64 t_4 = VSR_CLK();
-    // wave-level reduction of the per-lane statistics (probes; fused: words written, largest bag)
-    for (int o = 32; o > 0; o >>= 1) {
-      my_probes += __shfl_down(my_probes, o);
-      if (fused) {
-        my_words += __shfl_down(my_words, o);
-        const u32 t = __shfl_down(my_maxbag, o);
-        my_maxbag = t > my_maxbag ? t : my_maxbag;
-      }
-    }
-    if (PLAIN != 1 && mode == MODE_INSERT) {
-      for (int o = 32; o > 0; o >>= 1) {
-        my_fx ^= __shfl_down(my_fx, o);
-        my_fs += __shfl_down(my_fs, o);
-      }
-      // into LDS, not into the control block: two global atomics per wave and tile on ONE address queued behind those of every other block, and
-      // the barrier below waits for them (the virtual level of the README configuration ran at half the rate of a stored level)
-      if (lane == 0 && (my_fx | my_fs)) {
-        atomicXor(&s_fxs[0], (unsigned long long)my_fx);
-        atomicAdd(&s_fxs[1], (unsigned long long)my_fs);
-      }
-    }
-    if (lane == 0 && my_probes) atomicAdd(&s_acc[2], (unsigned long long)my_probes);
-    if (fused && lane == 0 && my_words) {
-      atomicAdd(&s_acc[9], (unsigned long long)my_words);
-      atomicMax(&s_maxbag_out, my_maxbag);
-    }
     VSR_SYNC();
     if (tid == 0) {
       if (fused) {
         s_ich_used += s_tile_icur;
         s_wch_used += s_tile_wcur;
         s_acc[14] += s_tile_icur;
+        if (mode == MODE_NORMAL || mode == MODE_REGEN) s_acc[9] += s_tile_wcur;   // words of the records this tile wrote
       } else {
         s_chunk_used += s_tile_cursor;
       }
       s_acc[0] += s_ncand;
       s_acc[1] += s_dead;
+      s_acc[2] += ncand_apply;                                   // one home-slot probe per applied candidate
       const u64 t_5 = VSR_CLK();
       s_acc[3] += t_1 - t_0;
       s_acc[4] += t_2 - t_1;
@@ -1281,7 +1067,7 @@ __device__ __forceinline__ void write_child_serial(const Model& M, const u64* re
 #pragma unroll
   for (int k = 0; k < VSR_NSLOT; k++)
     if ((D.used >> k) & 1) {
-      if (D.pj[k] >= 0) dst[M.fixed + D.pj[k]] = D.pnew[k];
+      if (D.pj(k) >= 0) dst[M.fixed + D.pj(k)] = D.pnew[k];
       else dst[M.fixed + nmsg + (a++)] = D.pnew[k];
     }
 }
@@ -1395,7 +1181,7 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
 #pragma unroll
       for (int k = 0; k < VSR_NSLOT; k++)
         if ((D.used >> k) & 1) {
-          if (D.pj[k] >= 0) rec[M.fixed + D.pj[k]] = D.pnew[k];
+          if (D.pj(k) >= 0) rec[M.fixed + D.pj(k)] = D.pnew[k];
           else if (plen + a < stride) rec[plen + (a++)] = D.pnew[k];
         }
     }
@@ -1537,7 +1323,7 @@ __global__ void k_claim_batch(Slot* table, u64 tmask, const u64* __restrict__ en
   if (i >= n) return;
   bool found_old, full;
   u32 np = 0;
-  u64 slot = table_claim(table, tmask, entries[2 * i], entries[2 * i + 1], level, &found_old, &np, &full);
+  u64 slot = table_claim(table, tmask, entries[2 * i], entries[2 * i + 1], level, &found_old, CntReg{&np}, &full);
   if (full) raise_error(ctl, ERR_TABLE_FULL, entries[2 * i]);
   rslot[i] = found_old ? ~(u64)0 : slot;
   atomicAdd((unsigned long long*)&ctl->probes, (unsigned long long)np);
@@ -1567,7 +1353,7 @@ __global__ void k_claim_batch_fused(Slot* table, u64 tmask, const u64* __restric
   bool claimed, full;
   u64 prev_meta;
   u32 np = 0;
-  table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, &np, &full);
+  table_claim_fused(table, tmask, fp, key, level, &claimed, &prev_meta, CntReg{&np}, &full);
   if (full) raise_error(ctl, ERR_TABLE_FULL, fp);
   verdict[i] = claimed ? 1 : 0;
   if (prev_meta != META_EMPTY && meta_level(prev_meta) == level && meta_auxkey(prev_meta) != meta_auxkey(key))
@@ -1688,7 +1474,7 @@ __global__ void k_table_import(Slot* table, u64 tmask, const Slot* __restrict__ 
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 np = 0;
-  const Probe p = probe_insert(table, tmask, in[i].fp, &np);
+  const Probe p = probe_insert(table, tmask, in[i].fp, CntReg{&np});
   if (p.full) {
     atomicExch(err, (u32)ERR_TABLE_FULL);
     return;
@@ -1705,7 +1491,7 @@ __global__ void k_seed(Model M, const u64* rec, Slot* table, u64 tmask, u64* lvl
   u64 key = meta_make(1, ak, 0);
   bool found_old, full;
   u32 np = 0;
-  table_claim(table, tmask, fp, key, 1, &found_old, &np, &full);
+  table_claim(table, tmask, fp, key, 1, &found_old, CntReg{&np}, &full);
   lvl_fp[0] = fp;
   ctl->n_new = 1;
   ctl->words_new = (u64)(M.fixed + hdr_nmsg(rec[0]));
@@ -1995,7 +1781,7 @@ k_simulate(Model Marg, const u64* __restrict__ init_rec, int init_len, u64* walk
 #pragma unroll
     for (int k = 0; k < VSR_NSLOT; k++)
       if ((D.used >> k) & 1) {
-        if (D.pj[k] >= 0) w[M.fixed + D.pj[k]] = D.pnew[k];
+        if (D.pj(k) >= 0) w[M.fixed + D.pj(k)] = D.pnew[k];
         else w[plen + (a++)] = D.pnew[k];
       }
     my_ords[depth] = (u16)ord;

@@ -69,6 +69,8 @@ struct Model {
   int m0;                // first message-bound ordinal = 4R + R*C*n
   u32 primtab;           // Primary(v) for v = 0..7, 3 bits each (a table: `%` by a run-time R costs ~20 instructions)
   u32 pitab[6];          // permutation i: pi[v] in bits 2v..2v+1
+  u64 fp_seed;           // xor-ed into every salt of the view hash: 0 = the function the fixtures were made with; any other value is an
+                         // independent member of the same family (second-hash audit: counts must not depend on it, vsrmc_model_set_fp_seed)
 };
 
 static const u64 SALT_MSG = 0x9E3779B97F4A7C15ULL;
@@ -191,7 +193,7 @@ VSR_HD u64 permute_word(u64 w, u64 m01, u32 pt) {
 }
 
 // hash of one bag word under permutation pt
-VSR_HD u64 hash_msg(u64 w, u32 pt) { return fmix64(permute_word(w, LOGB_MSG, pt) ^ SALT_MSG); }
+VSR_HD u64 hash_msg(const Model& M, u64 w, u32 pt) { return fmix64(permute_word(w, LOGB_MSG, pt) ^ (SALT_MSG ^ M.fp_seed)); }
 
 // does a word hold any value (an in-use log entry byte)?  If not, its hash term is the same under every permutation.
 VSR_HD bool word_has_values(u64 w, u64 m01) { return ((w | (w >> 1) | (w >> 2)) & m01) != 0; }
@@ -200,14 +202,14 @@ VSR_HD bool word_has_values(u64 w, u64 m01) { return ((w | (w >> 1) | (w >> 2)) 
 //                                + sum over the bag of fmix64(pi(word) ^ SALT_MSG)
 // hash term of word K of replica r's block under permutation pt
 template <int K>
-VSR_HD u64 hash_rep_word(u64 w, int r, u32 pt) {
-  return fmix64(permute_word(w, K == 0 ? (u64)0 : K == 1 ? LOGB_REP1 : LOGB_REPK, pt) ^ salt_word<K>(r));
+VSR_HD u64 hash_rep_word(const Model& M, u64 w, int r, u32 pt) {
+  return fmix64(permute_word(w, K == 0 ? (u64)0 : K == 1 ? LOGB_REP1 : LOGB_REPK, pt) ^ (salt_word<K>(r) ^ M.fp_seed));
 }
 template <typename PTR>
 VSR_HD u64 hash_rep_block(const Model& M, PTR b, int r, u32 pt) {
-  u64 h = hash_rep_word<0>(b[0], r, pt) + hash_rep_word<1>(b[1], r, pt);
-  if (M.wpr > 2) h += hash_rep_word<2>(b[2], r, pt);              // written out: b may be a register array
-  if (M.wpr > 3) h += hash_rep_word<3>(b[3], r, pt);
+  u64 h = hash_rep_word<0>(M, b[0], r, pt) + hash_rep_word<1>(M, b[1], r, pt);
+  if (M.wpr > 2) h += hash_rep_word<2>(M, b[2], r, pt);           // written out: b may be a register array
+  if (M.wpr > 3) h += hash_rep_word<3>(M, b[3], r, pt);
   return h;
 }
 
@@ -226,7 +228,7 @@ VSR_HD void hash_full(const Model& M, PTR rec, u64* H) {
     u32 pt = M.pitab[i];
     u64 sum = 0;
     for (int r = 1; r <= M.R; r++) sum += hash_rep_block(M, rec + 1 + (r - 1) * M.wpr, r, pt);
-    for (int j = 0; j < nmsg; j++) sum += hash_msg(rec[M.fixed + j], pt);
+    for (int j = 0; j < nmsg; j++) sum += hash_msg(M, rec[M.fixed + j], pt);
     H[i] = sum;
   }
 }

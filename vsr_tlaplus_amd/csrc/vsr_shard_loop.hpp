@@ -258,6 +258,8 @@ int32_t vsrmc_shard_loop_create(vsrmc_checker* c, const vsrmc_comm* comm, uint64
   if (comm->world != c->opt.world || comm->rank != c->opt.rank) return fail(VSRMC_E_ARG, "the communicator and the checker disagree about rank / world");
   if (c->opt.exact_ties) return fail(VSRMC_E_STATE, "the native level loop runs single-pass levels (exact_ties = 0)");
   if (cand_cap < 1024) return fail(VSRMC_E_ARG, "cand_cap too small");
+  if (replicate_below > 1 && (c->level != 1 || c->n_valid != c->n_frontier || c->n_frontier != 1))
+    return fail(VSRMC_E_STATE, "a loop that starts in the replicated phase needs a checker in its initial state (level 1, Init on every rank)");
   HIPCHK(hipSetDevice(c->opt.device));
   vsrmc_shard_loop* l = new vsrmc_shard_loop();
   l->c = c; l->comm = *comm; l->rank = comm->rank; l->world = comm->world;
@@ -383,9 +385,14 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
     u64 so_n[8] = {0}, so_w[8] = {0};
     for (const Move& mv : plan) {
       if (mv.src != me || rc) continue;
-      const u64 width = std::min<u64>(hi, (mv.k * range + std::max<u64>(1, valid) - 1) / std::max<u64>(1, valid));   // index window holding about k valid records
-      u64 got = 0, gotw = 0;
+      u64 width = std::min<u64>(hi, (mv.k * range + std::max<u64>(1, valid) - 1) / std::max<u64>(1, valid));   // index window holding about k valid records
+      // all of this rank's moves share one export buffer: a window never holds more records than indices, nor more words than indices x
+      // the longest record — clamp it to what is left, so that a large imbalance is exported in part (the next level moves the rest)
+      // instead of failing in k_export
       if (on >= l->rec_cap || ow >= l->rec_words_cap) break;
+      width = std::min<u64>(width, std::min<u64>(l->rec_cap - on, (l->rec_words_cap - ow) / (u64)std::max(1, c->lds_stride)));
+      if (width == 0) break;
+      u64 got = 0, gotw = 0;
       rc = vsrmc_shard_export(c, hi - width, width, l->mv_words + ow, l->rec_words_cap - ow, l->mv_off + on, l->mv_fp + on, l->rec_cap - on, &got, &gotw);
       if (rc) break;
       hi -= width;
@@ -407,7 +414,15 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
       ro_n[p] = tn; ro_w[p] = tw;
       tn += rn[p]; tw += rnw[p];
     }
-    if (tn > l->rec_cap || tw > l->rec_words_cap) rc = fail(VSRMC_E_REP, "received records exceed the rebalancing buffers");
+    // every rank holds `mall`: the receive totals of EVERY rank are checked by every rank, so that all of them skip the three
+    // exchanges together (a rank that found out alone would leave its peers waiting in a collective addressed to it)
+    for (int q = 0; q < w && !rc; q++) {
+      u64 qn = 0, qw = 0;
+      for (int p2 = 0; p2 < w; p2++)
+        if (p2 != q) { qn += mall[p2].n[q]; qw += mall[p2].nw[q]; }
+      if (qn > l->rec_cap || qw > l->rec_words_cap)
+        rc = fail(VSRMC_E_REP, "rank " + std::to_string(q) + " would receive more records than its rebalancing buffers hold (rec_cap / rec_words_cap)");
+    }
     if (!rc) rc = loop_alltoallv(l, l->mv_words, mrow.nw, so_w, l->rv_words, rnw, ro_w, 8);
     if (!rc) rc = loop_alltoallv(l, l->mv_off, mrow.n, so_n, l->rv_off, rn, ro_n, 8);
     if (!rc) rc = loop_alltoallv(l, l->mv_fp, mrow.n, so_n, l->rv_fp, rn, ro_n, 8);
@@ -488,15 +503,17 @@ int32_t vsrmc_shard_loop_status(vsrmc_shard_loop* l, int32_t* level, uint64_t* d
 // answer, different ones are an ambiguous pointer and are reported.
 int32_t vsrmc_shard_loop_trace_fps(vsrmc_shard_loop* l, int32_t level, uint64_t fp, uint64_t* fps) {
   if (!l || !fps || level < 1) return fail(VSRMC_E_ARG, "bad trace arguments");
-  struct Row { u64 n, fp, meta; };
+  struct Row { u64 n, fp, meta, err; };
   auto agree = [&](u64 key, int lvl, int by_low, Row* out) -> int {
     int32_t found = 0;
     u64 f = 0, m = 0;
     int rc = vsrmc_checker_lookup(l->c, key, lvl, by_low, &found, &f, &m);
-    Row mine = {rc ? 0 : (u64)found, f, m};
+    Row mine = {rc ? 0 : (u64)found, f, m, rc ? (u64)(rc < 0 ? -rc : rc) : 0};
     std::vector<Row> all(l->world);
     const int crc = loop_allgather(l, &mine, all.data(), (u32)sizeof(Row));
     if (crc) return crc;
+    for (const Row& r : all)                                    // a failed lookup on any rank is that error on every rank, not "not found"
+      if (r.err) return rc ? rc : fail(VSRMC_E_STATE, "trace walk: the seen-set lookup failed on another rank (error " + std::to_string((long long)r.err) + ")");
     out->n = 0;
     for (const Row& r : all) {
       if (!r.n) continue;

@@ -244,6 +244,10 @@ void init_record_wire(const Model& M, std::vector<u64>& rec) {   // Init, VSR.tl
 }
 
 // view hashes of a device-layout record on the host (pure arithmetic, the same functions the kernels run)
+// identity of the fingerprint function in a checkpoint header: its version, and 23 bits of the seed's hash when the model carries one
+int32_t fp_function_id(const Model& M) {
+  return (int32_t)VSRMC_FP_VERSION | (M.fp_seed ? (int32_t)((fmix64(M.fp_seed) & 0x7FFFFF) << 8) : 0);
+}
 void hash_full_host(const Model& M, const u64* rec, u64* H) {
   if (M.model_id == 1) vrst::hash_full(M, rec, H);
   else if (M.model_id == 2) vras::hash_full(M, rec, H);
@@ -475,6 +479,13 @@ int32_t vsrmc_model_load(const char* tla_path, const char* cfg_path, vsrmc_model
   *out = m;
   return 0;
 }
+
+int32_t vsrmc_model_set_fp_seed(vsrmc_model* m, uint64_t seed) {
+  if (!m) return fail(VSRMC_E_ARG, "NULL argument");
+  m->M.fp_seed = seed;
+  return 0;
+}
+uint64_t vsrmc_model_fp_seed(const vsrmc_model* m) { return m ? m->M.fp_seed : 0; }
 
 int32_t vsrmc_model_info(const vsrmc_model* m, vsrmc_layout* out) {
   if (!m || !out) return fail(VSRMC_E_ARG, "NULL argument");
@@ -1038,6 +1049,7 @@ struct vsrmc_checker {
   u64 probe_fp = 0, probe_extra_fp = 0;
   int probe_level = 0;
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
+  bool saw_violation = false;            // a committed level held a violating state (the caller went on): probe passes apply every action
   u64 words_cap(int b) const { return (b == 1 && opt.frontier_words_b) ? opt.frontier_words_b : opt.frontier_words; }
 };
 
@@ -1071,23 +1083,7 @@ MaterializeKernel materialize_kernel_for(const Model& M) {
   }
 }
 ExpandKernel plain_kernel_for(const Model& M, int blk) {      // unsharded ordinary levels: modes and sharding compiled out
-#if VSRMC_EXPERIMENTAL_BLK    // measured and rejected block shapes, kept buildable for A/B runs: -DVSRMC_EXPERIMENTAL_BLK=1, VSRMC_BLK=64 / 512
-  if (blk == 512) {                                            // eight waves per block, 128-record tiles, two blocks per CU
-    switch (M.R * 100 + M.C * 10 + M.n) {
-      case 312: return k_expand<true, 312, true, 512>;
-      default: return nullptr;
-    }
-  }
-  if (blk == 64) {                                             // one wave per block, 16-record tiles (vsr_kernels.hpp, BLK)
-    switch (M.R * 100 + M.C * 10 + M.n) {
-      case 312: return k_expand<true, 312, true, 64>;
-      case 313: return k_expand<true, 313, true, 64>;
-      default: return nullptr;
-    }
-  }
-#else
   if (blk != VSR_BLOCK) return nullptr;
-#endif
   if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true> : nullptr;   // the shipped VR_STATE_TRANSFER.cfg
   if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302, true> : nullptr;   // the shipped VR_APP_STATE.cfg
   switch (M.R * 100 + M.C * 10 + M.n) {
@@ -1178,6 +1174,7 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
 // Put the checker in its initial state (ModelChecker.doInit): empty seen-set, Init in frontier 0 and in the set.
 int checker_seed(vsrmc_checker* c) {
   const Model& M = c->model.M;
+  c->saw_violation = false;
   HIPCHK(hipSetDevice(c->opt.device));
   hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
   HIPCHK(hipGetLastError());
@@ -1379,7 +1376,8 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, ichunk,
-                         wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk, mode, (u64)0);
+                         wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk,
+                         mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), (u64)0);
     else
       hipLaunchKernelGGL(exact_kernel_for(M), dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
@@ -1499,6 +1497,7 @@ int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
   if (h.viol_fp != ~(u64)0) {
     info->viol_fp = h.viol_fp;
     info->viol_mask = (int32_t)h.viol_mask;
+    c->saw_violation = true;
   }
   info->level = c->level;
   info->distinct = c->distinct;
@@ -1587,7 +1586,8 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     hipLaunchKernelGGL((ExpandKernel)kern, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
-                       ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0, mode, p_offset);
+                       ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0,
+                       mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -2377,7 +2377,7 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   ChkHeader h;
   std::memset(&h, 0, sizeof(h));
   std::memcpy(h.magic, "VSRMCCK3", 8);
-  const int32_t consts[12] = {M.R, M.C, M.n, M.L, c->model.symmetry, M.inv_mask, M.assume_commit, M.np, M.model_id, M.wpr, M.fixed, VSRMC_FP_VERSION};
+  const int32_t consts[12] = {M.R, M.C, M.n, M.L, c->model.symmetry, M.inv_mask, M.assume_commit, M.np, M.model_id, M.wpr, M.fixed, fp_function_id(M)};
   std::memcpy(h.consts, consts, sizeof(consts));
   h.level = c->level;
   h.shard = c->opt.world > 1 ? (c->opt.world << 16 | c->opt.rank) : 0;
@@ -2439,7 +2439,7 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
     return fail(VSRMC_E_CFG, std::string(path) + " is not a (consistent) vsrmc checkpoint");
   }
   const Model& M = m->M;
-  const int32_t consts[12] = {M.R, M.C, M.n, M.L, m->symmetry, M.inv_mask, M.assume_commit, M.np, M.model_id, M.wpr, M.fixed, VSRMC_FP_VERSION};
+  const int32_t consts[12] = {M.R, M.C, M.n, M.L, m->symmetry, M.inv_mask, M.assume_commit, M.np, M.model_id, M.wpr, M.fixed, fp_function_id(M)};
   if (std::memcmp(h.consts, consts, sizeof(consts)) != 0) {
     std::fclose(f);
     return fail(VSRMC_E_CFG, "the checkpoint was written for another module, other model constants or another fingerprint function");
