@@ -195,6 +195,8 @@ typedef struct vsrmc_level_info {
 
 void vsrmc_options_default(vsrmc_options* o);
 int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc_checker** out);
+/* the options the checker runs with: the caller's, with every size that was left 0 replaced by what was derived from the free memory */
+int32_t vsrmc_checker_options(const vsrmc_checker* c, vsrmc_options* out);
 /* back to the initial state: clears the seen-set and the trace log, keeps every allocation (≙ a fresh TLC run) */
 int32_t vsrmc_checker_reset(vsrmc_checker* c);
 /* expand the newest level by one BFS step; info->n_new == 0 means the search is exhausted */
@@ -269,6 +271,24 @@ int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_lev
  * in level L+1 or L+2 is reported in that level's info (a violating level is still completed; nothing deeper is reported);
  * vsrmc_checker_probe_trace reconstructs the counter-example in every case. */
 int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_level_info* virt2, vsrmc_level_info* probe);
+/* The general form of the two calls above (≙ TLC going on with DiskStateQueue / DiskFPSet when the frontier outgrows memory; here
+ * nothing leaves the HBM): ONE MORE LEVEL beyond the record buffers per call.  The first call after the last vsrmc_checker_step makes
+ * level L+1 a virtual level (inserted->level = L+1, probed->level = 0).  Every further call descends from the newest materialised
+ * level L — regenerating levels L+1 .. L+j-1 slice inside slice from the seen-set's predecessor keys, each state exactly once —
+ * inserts level L+j (exact count, per-action counts, checksums, invariants; its records pass through a scratch buffer) and probes level
+ * L+j+1 (probed->level).  The search rolls on past the memory horizon at about 2.2 x the expansions of a stored BFS until the
+ * seen-set is full, a level comes back empty (inserted->n_new == 0: exhausted) or an invariant fails (viol_mask of whichever info;
+ * vsrmc_checker_probe_trace reconstructs the counter-example).  inserted->pending = k_expand launches of the pass, ->materialize_ms =
+ * kernel time spent regenerating, ->words_new = (slices of level L) << 32 | slices of the levels below it.  vsrmc_checker_step and
+ * vsrmc_checker_save are refused from the first call on (the seen-set holds levels that have no frontier); vsrmc_checker_reset starts over. */
+int32_t vsrmc_checker_deepen(vsrmc_checker* c, vsrmc_level_info* inserted, vsrmc_level_info* probed);
+/* One unit of progress of the AUTOMATIC level scheme — no level numbers and no sizes from the caller: an ordinary BFS level while
+ * the next one is predicted to fit the idle record buffer (*what = 1, a = its info), otherwise vsrmc_checker_deepen (*what = 2,
+ * a = the inserted level, b = the probed one or b->level == 0).  The prediction: a level grows by at most the factor the last one
+ * grew by (the factor falls from level to level in these models, tests/golden/oracle_levels_*.json) and by at most one bag entry
+ * per record.  vsrmc_check is the loop over this call; vsrmc_options with table_log2 = 0 / frontier_words = 0 / frontier_states = 0 /
+ * pending_entries = 0 are sized from the free memory of the device. */
+int32_t vsrmc_checker_advance(vsrmc_checker* c, vsrmc_level_info* a, vsrmc_level_info* b, int32_t* what);
 /* the (fingerprint, key) pairs of the violating successors the last vsrmc_checker_probe saw and did not find in this checker's
  * seen-set (duplicates included; *n = their number; pairs == NULL asks for the number only).  Sharded runs show them to their owners. */
 int32_t vsrmc_checker_probe_candidates(vsrmc_checker* c, uint64_t* pairs, uint64_t cap_pairs, uint64_t* n);

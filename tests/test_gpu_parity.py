@@ -277,74 +277,57 @@ def test_golden_level_checksums(vt, golden_counts):
         mc.close()
 
 
-@pytest.mark.parametrize("key", ["config2", "config3", "config5"])
-def test_whole_workload_against_the_oracle(vt, oracle_levels, key):
-    """Every level the CPU oracle reached on the GPU box's host cores (tests/golden/oracle_levels_*.json, written by
-    tools/make_oracle_levels.py — config 2 = the bench workload, all 28 levels to its first violation): new states, successors
-    generated in total and PER ACTION (VSR.tla:896-918 order), deadlocks, largest bag, and the xor / sum of the level's
-    fingerprints, computed on the device."""
+@pytest.mark.parametrize("key,seed", [("config2", 0), ("config3", 0), ("config5", 0), ("config3", 0x5EED5EED5EED5EED), ("config5", 0x0123456789ABCDEF)])
+def test_whole_workload_against_the_oracle(vt, oracle_levels, key, seed):
+    """Every level the CPU oracle reached (tests/golden/oracle_levels_*.json, written by tools/make_oracle_levels.py and the memory-lean
+    driver — config 2 = all 28 levels to its first violation, config 3 = the README configuration: 23 levels + the probe of level 24,
+    config 5: 14 levels): new states, successors generated in total and PER ACTION (VSR.tla:896-918 order), deadlocks, largest bag, and
+    the xor / sum of the level's fingerprints, computed on the device.  Through the AUTOMATIC level scheme: no level number and no buffer
+    size comes from this test — the checker sizes itself from the free HBM and ModelChecker.advance stores a level while the next one is
+    predicted to fit, then goes on through the seen-set alone (virtual / streamed / probed levels, csrc/vsr_deep.hpp).
+    seed != 0: the second-hash audit — the same counts under another member of the fingerprint family (checksums not compared)."""
     if key not in oracle_levels:
         pytest.skip("no oracle fixture for %s yet" % key)
     g = oracle_levels[key]
     p = g["params"]
     m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=p["n"], L=p["L"], symmetry=p["symmetry"], invariant_mask=p["inv_mask"])
-    # record = fixed words + H words + at most the level's largest bag; + the partly used chunks every block leaves behind (words and
-    # indices).  A last level whose records do not fit a 100-GB buffer (config 5, level 13: 5.96e8 states) is taken as a VIRTUAL level:
-    # claimed in the seen-set, counted and checked, never stored (vsrmc_checker_probe2).
-    need = lambda lv: int(lv["new"] * (m.layout.fixed_words + m.layout.permutations + lv["max_bag"]) * 1.1) + (1 << 29)   # noqa: E731
-    # fixtures that end in two levels no GPU can store (from the memory-lean oracle driver; the README configuration also has the probe of the level
-    # after them): everything before them is materialised, then vsrmc_checker_probe3 — virtual, streamed, probed.  Buffer sizes as bench.py /
-    # tools/run_config5.py use them (the two record buffers are sized apart: the last stored level decides which one is the large one).
-    plans = {"config3": dict(table_log2=32, frontier_words=int(12.8e9), frontier_words_b=int(7.0e9), frontier_states=int(2.85e8)),
-             "config5": dict(table_log2=33, frontier_words=int(3.0e9), frontier_words_b=int(11.6e9), frontier_states=int(1.6e8))}
-    deep = key in plans and len(g["levels"]) >= 3 and need(g["levels"][-2]) > 12.5e9 and need(g["levels"][-1]) > 12.5e9
-    if deep:
-        stored, virtual = g["levels"][:-2], g["levels"][-2:]
-        mc = vt.ModelChecker(m, pending_entries=1 << 16, keep_trace=False, **plans[key])
-    else:
-        stored = [lv for lv in g["levels"] if need(lv) <= 12.5e9]
-        virtual = g["levels"][len(stored):]
-        assert len(virtual) <= 1 and stored == g["levels"][: len(stored)]
-        biggest = max(lv["new"] for lv in stored)
-        mc = vt.ModelChecker(m, table_log2=max(20, int(np.ceil(np.log2(2.5 * g["distinct"])))), frontier_words=max(need(lv) for lv in stored),
-                             frontier_states=int(biggest * 1.3) + (1 << 24), pending_entries=1 << 15, keep_trace=False)
+    if seed:
+        m.set_fp_seed(seed)
+    mc = vt.ModelChecker.auto(m)
+    sums = g["checksums"] and not seed
     assert mc.level_checksum()[2] == 1
-    for lv in stored[1:]:
-        d = mc.step()
-        assert d["level"] == lv["level"]
-        assert (d["n_new"], d["generated"], d["deadlocks"], d["max_bag"]) == (lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"]), lv["level"]
+    last = g["levels"][-1]["level"]
+    kinds, probed = [], None
+    while mc.depth < last and mc.violation is None:
+        kind, d, b = mc.advance()
+        kinds.append(kind)
+        lv = g["levels"][d["level"] - 1]
+        assert (d["level"], d["n_new"], d["generated"], d["deadlocks"], d["max_bag"]) == (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"]), lv["level"]
         assert [int(x) for x in d["act_generated"][1:16]] == lv["act_generated"][1:16], lv["level"]
-        x, s, n = mc.level_checksum()
-        assert n == lv["new"]
-        if g["checksums"]:
-            assert ("%016x" % x, "%016x" % s) == (lv["fp_xor"], lv["fp_sum"]), lv["level"]
-    if deep:
-        v1, v2, pr = mc.probe3()
-        for v, lv in ((v1, virtual[0]), (v2, virtual[1])):
-            assert (v["level"], v["n_new"], v["generated"], v["deadlocks"], v["max_bag"], v["viol_mask"]) == \
-                (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"], 0), lv["level"]
-            assert [int(x) for x in v["act_generated"][1:16]] == lv["act_generated"][1:16], lv["level"]
-            if g["checksums"]:
-                assert ("%016x" % v["fp_xor"], "%016x" % v["fp_sum"]) == (lv["fp_xor"], lv["fp_sum"]), lv["level"]
-        assert v2["distinct"] == g["distinct"]
-        want = g.get("probe")
-        if want:
-            assert (pr["level"], pr["generated"], pr["deadlocks"], pr["viol_mask"]) == (want["level"], want["generated"], want["deadlocks"], want["viol_mask"])
-            if g["checksums"]:
-                assert "%016x" % pr["viol_fp"] == want["viol_fp"]
+        if kind == "level":
+            x, s_, n = mc.level_checksum()
+            assert n == lv["new"]
         else:
-            assert pr["level"] == virtual[1]["level"] + 1 and pr["viol_mask"] == 0      # no CPU counterpart of the probed level: GPU-sourced
-        mc.close()
-        return
-    for lv in virtual:
-        v, _ = mc.probe2()
-        assert (v["level"], v["n_new"], v["generated"], v["deadlocks"], v["max_bag"], v["viol_mask"]) == \
-            (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"], 0), lv["level"]
-        assert v["distinct"] == g["distinct"]
-    if g["stop"] == "violation":
-        assert mc.violation is not None and mc.violation["mask"] == g["viol_mask"] and mc.distinct == g["distinct"]
-        if g["checksums"]:
+            x, s_ = d["fp_xor"], d["fp_sum"]
+        if sums:
+            assert ("%016x" % x, "%016x" % s_) == (lv["fp_xor"], lv["fp_sum"]), lv["level"]
+        probed = b
+    assert mc.distinct == g["distinct"]
+    assert kinds == sorted(kinds, key=lambda k: k == "deep")                 # stored levels first, then the seen-set alone: one switch
+    want = g.get("probe")
+    if want:                                                                  # the README configuration: the probe of level 24 finds the violation
+        assert probed is not None and (probed["level"], probed["generated"], probed["deadlocks"], probed["viol_mask"]) == \
+            (want["level"], want["generated"], want["deadlocks"], want["viol_mask"])
+        if sums:
+            assert "%016x" % probed["viol_fp"] == want["viol_fp"]
+        tr = mc.violation_trace()
+        assert len(tr) == want["level"]
+    elif g["stop"] == "violation":
+        assert mc.violation is not None and mc.violation["mask"] == g["viol_mask"]
+        if sums:
             assert "%016x" % mc.violation["fp"] == g["viol_fp"]
+    elif probed is not None:
+        assert probed["level"] == last + 1 and probed["viol_mask"] == 0        # no CPU counterpart of the probed level: GPU-sourced
     mc.close()
 
 

@@ -306,9 +306,17 @@ class StateQueue:
 class ModelChecker:
     """≙ tlc2.tool.ModelChecker: level-synchronous BFS; `step()` = every Worker draining one level of the StateQueue."""
 
+    @classmethod
+    def auto(cls, model, device=0, **kw):
+        """every buffer sized from the free memory of the device (vsrmc_options with zeros): seen-set = the largest power of two of
+        slots within 30 % of it, the rest in two equal record buffers; pass table_log2 / frontier_words / .. to pin one of them"""
+        kw = dict(dict(table_log2=0, frontier_words=0, frontier_states=0, pending_entries=0), **kw)
+        return cls(model, device=device, **kw)
+
     def __init__(self, model, device=0, table_log2=24, frontier_words=1 << 25, frontier_states=1 << 20,
                  pending_entries=1 << 21, keep_trace=True, trace_entries=0, exact_ties=False, recover=None, host_frontier=False, frontier_words_b=0):
-        """recover: path of a checkpoint written by save() — continue that search (≙ `tlc2.TLC -recover`)."""
+        """recover: path of a checkpoint written by save() — continue that search (≙ `tlc2.TLC -recover`).
+        table_log2 = 0 / frontier_words = 0 / frontier_states = 0 / pending_entries = 0: sized from the free device memory (auto())."""
         self.model = model
         o = capi.Options()
         capi.load().vsrmc_options_default(C.byref(o))
@@ -332,12 +340,15 @@ class ModelChecker:
             self.level, self.n_frontier, self.distinct = info.level, info.n_new, info.distinct
             self.levels = [dict(level=info.level, n_new=info.n_new, generated=0, deadlocks=0, recovered=True)]
             self.violation = None
+            self.depth = self.level
+        check(capi.load().vsrmc_checker_options(self._h, C.byref(o)))       # sizes left 0 were derived from the free device memory
 
     def save(self, path):
         """Checkpoint between two levels (≙ TLC's checkpoint of FPSet + StateQueue + TLCTrace): one file."""
         check(capi.load().vsrmc_checker_save(self._h, os.fsencode(path)))
 
     def _fresh(self):
+        self.depth = 1
         self.level = 1
         self.n_frontier = 1
         self.distinct = 1
@@ -354,6 +365,7 @@ class ModelChecker:
         check(capi.load().vsrmc_checker_step(self._h, C.byref(info)))
         d = info.as_dict()
         self.level, self.n_frontier, self.distinct = d["level"], d["n_new"], d["distinct"]
+        self.depth = self.level
         if d["n_new"]:
             self.levels.append(d)
         if d["viol_mask"] and self.violation is None:
@@ -361,30 +373,77 @@ class ModelChecker:
         return d
 
     def check(self, max_depth=0, max_seconds=0.0):
-        """≙ ModelChecker.runTLC in one native call (vsrmc_check) -> "exhausted" | "violation" | "max-depth" | "max-seconds"."""
+        """≙ ModelChecker.runTLC in one native call (vsrmc_check: the automatic level scheme)
+        -> "exhausted" | "violation" | "max-depth" | "max-seconds" | "seen-set-full"."""
         reason = C.c_int32()
         info = capi.LevelInfo()
         check(capi.load().vsrmc_check(self._h, max_depth, max_seconds, C.byref(reason), C.byref(info)))
         d = info.as_dict()
-        self.level, self.n_frontier, self.distinct = d["level"], d["n_new"], d["distinct"]
+        self.level = self.depth = d["level"]                              # the deepest level that is complete (stored or in the seen-set only)
+        self.distinct = d["distinct"]
         if reason.value == 1:
-            self.violation = dict(level=d["level"], index=d["viol_index"], fp=d["viol_fp"], mask=d["viol_mask"])
-        return ["exhausted", "violation", "max-depth", "max-seconds"][reason.value]
+            self.violation = dict(level=d["level"], index=d["viol_index"], fp=d["viol_fp"], mask=d["viol_mask"],
+                                  probed=d["viol_index"] == (1 << 64) - 1)
+        return ["exhausted", "violation", "max-depth", "max-seconds", "seen-set-full"][reason.value]
+
+    def _deep_dict(self, info):
+        d = info.as_dict()
+        d["ancestor_index"] = d.pop("viol_index")
+        if d["level"] and d["viol_mask"] and self.violation is None:
+            self.violation = dict(level=d["level"], index=None, fp=d["viol_fp"], mask=d["viol_mask"], probed=True)
+        return d
+
+    def deepen(self):
+        """One more level beyond the record buffers (vsrmc_checker_deepen): the next level is inserted into the seen-set only — counted,
+        checked, checksummed, its records regenerated from the newest stored level whenever they are needed — and the level after it is
+        probed.  -> (inserted dict, probed dict or None).  `self.depth` = the deepest level that is complete in the seen-set."""
+        a, b = capi.LevelInfo(), capi.LevelInfo()
+        check(capi.load().vsrmc_checker_deepen(self._h, C.byref(a), C.byref(b)))
+        da, db = self._deep_dict(a), self._deep_dict(b)
+        self.depth, self.distinct = da["level"], da["distinct"]
+        return da, (db if db["level"] else None)
+
+    def advance(self):
+        """One unit of progress of the automatic level scheme (vsrmc_checker_advance): an ordinary level while the next one is
+        predicted to fit the record buffers, else a deepen() pass.  -> ("level", dict, None) | ("deep", inserted dict, probed dict or None)."""
+        a, b = capi.LevelInfo(), capi.LevelInfo()
+        what = C.c_int32()
+        check(capi.load().vsrmc_checker_advance(self._h, C.byref(a), C.byref(b), C.byref(what)))
+        if what.value == 1:
+            d = a.as_dict()
+            self.level, self.n_frontier, self.distinct = d["level"], d["n_new"], d["distinct"]
+            self.depth = self.level
+            if d["n_new"]:
+                self.levels.append(d)
+            if d["viol_mask"] and self.violation is None:
+                self.violation = dict(level=d["level"], index=d["viol_index"], fp=d["viol_fp"], mask=d["viol_mask"])
+            return "level", d, None
+        da, db = self._deep_dict(a), self._deep_dict(b)
+        self.depth, self.distinct = da["level"], da["distinct"]
+        return "deep", da, (db if db["level"] else None)
 
     def run(self, max_depth=None, max_seconds=None, stop_on_violation=True):
-        """Worker.run until the queue is empty, an invariant is violated, or a bound is hit."""
+        """Worker.run until the queue is empty, an invariant is violated, or a bound is hit — the automatic level scheme: levels are
+        stored while they fit the record buffers, the search goes on beyond them through the seen-set alone (deepen)."""
         import time
         t0 = time.time()
         while True:
-            if max_depth is not None and self.level >= max_depth:
+            if max_depth is not None and self.depth >= max_depth:
                 return "max-depth"
             if max_seconds is not None and time.time() - t0 > max_seconds:
                 return "max-seconds"
-            d = self.step()
+            if self.distinct > 0.85 * (1 << int(self.options.table_log2)):
+                return "seen-set-full"
+            kind, d, p = self.advance()
             if d["n_new"] == 0:
                 return "exhausted"
             if self.violation is not None and stop_on_violation:
                 return "violation"
+
+    def violation_trace(self):
+        """the counter-example of the violation run() / advance() reported, wherever it was found"""
+        v = self.violation
+        return self.probe_trace() if v.get("probed") else self.trace(v["level"], v["index"])
 
     def level_fps(self):
         out = np.zeros(max(1, self.n_frontier), dtype=np.uint64)
@@ -505,7 +564,7 @@ class ModelChecker:
     def probe_trace(self):
         """The counter-example of the violation probe() reported: [(action name, record)] from Init to the violator."""
         lay = self.model.layout
-        n_max = self.level + 3
+        n_max = max(self.level, self.depth) + 3                 # (the deepest level in the seen-set + the probed state beyond it)
         cap_w = (n_max + 1) * int(lay.max_record_words)
         words = np.zeros(cap_w, dtype=np.uint64)
         off = np.zeros(n_max + 2, dtype=np.uint64)

@@ -1,0 +1,456 @@
+// vsr_deep.hpp — the search beyond the last level whose records fit the HBM (included by vsrmc.hip after the level phases).
+//
+// TLC role replaced: DiskStateQueue + DiskFPSet — what lets TLC go on when the frontier outgrows memory.  Here nothing leaves the HBM:
+// a level beyond the last materialised one ("base", level L) exists only as seen-set entries (16 B per state instead of ~350 B of
+// record), and its records are REGENERATED from the base level whenever they are needed, slice by slice, never all at once:
+//
+//   pass 1            level L expanded, MODE_INSERT                  -> level L+1 in the seen-set (exact count, final min-merged keys)
+//   pass j (j >= 2)   descend from the base:
+//                       for each slice of L:        MODE_REGEN       = that slice's part of level L+1 (the successor whose key IS the
+//                         for each slice of L+1:    MODE_REGEN         slot's meta word takes it with a compare-and-swap: exactly once)
+//                           ...                                      = ... of level L+j-1
+//                             for each sub-slice:   MODE_NORMAL      = new level-(L+j) states: inserted, counted, checked, checksummed,
+//                                                                      written to a scratch buffer and dropped after
+//                                                   MODE_PROBE       = invariants of THEIR successors (level L+j+1), nothing inserted
+//   Level L+j-1 is complete in the seen-set before the first level-(L+j) state is inserted (else a state of L+j-1 met first as a
+//   successor of L+j-1 would be filed one level too deep) — that is what the separate passes are for.  Level L+j is NOT complete
+//   while level L+j+1 is probed, and that matters: the invariants read aux variables outside the VIEW (VSR.tla:102-104), so a
+//   successor with the fingerprint of a level-(L+j) state that is not inserted yet can look violating although the search never
+//   visits it (TLC drops it as seen).  The probe passes therefore only COLLECT violating successors (fingerprint, key); when the
+//   level is complete the ones that are states of a level < L+j+1 are dropped (k_table_seen) and the smallest remaining fingerprint
+//   is the violation.
+// Every pass inserts one more level and probes the one after it, so the search ROLLS ON past the memory horizon: the cost of level
+// L+j is the re-expansion of levels L .. L+j-1, about 1 + 1/g + 1/g^2 .. = 2.2 x its own expansion at the growth g = 1.8 of this
+// model — until the seen-set is full (16 B per state: 1e10 states on one MI355X), a level comes back empty (the search is
+// exhausted) or an invariant fails.  A regenerated state takes its slot with key -> key | taken; the taken bits of the levels
+// beyond the base are cleared by one pass over the table before every descent (k_table_untake).
+//
+// vsrmc_checker_probe2 / _probe3 (rounds 2-3: virtual + probed, virtual + streamed + probed) are two and three steps of this.
+#pragma once
+
+namespace {
+
+typedef DeepLevelRec DeepLevel;   // a level beyond the base that is complete in the seen-set (vsrmc_checker::deep_lv)
+
+// how large the next slice of a source may be so that what it yields fits the target buffer: the first one for the worst case
+// (every generated successor new, of the largest size), later ones by the largest yield per source index seen so far (x 3 headroom;
+// a target loses up to a quarter to the blocks' unfinished chunks)
+struct Slicer {
+  u64 cap_n, cap_w, g1, stride;
+  u64 cap_c = ~(u64)0;          // sharded: parents whose successors fit one owner's candidate bucket (half of it: the blocks' chunks)
+  double yield_n = 0, yield_w = 0;
+  u64 worst() const {
+    const u64 sz = std::min<u64>(std::min<u64>(cap_n / (4 * g1), cap_w / (4 * g1 * stride)), cap_c);
+    return std::max<u64>(128, sz & ~(u64)127);
+  }
+  u64 next() const {
+    if (yield_n <= 0) return worst();
+    const double sz = std::min((double)cap_n / (3.0 * std::max(yield_n, 1e-3)), (double)cap_w / (3.0 * std::max(yield_w, 1e-3)));
+    return std::max<u64>(worst(), std::min<u64>(cap_c, std::max<u64>(128, (u64)std::min(sz, 1e15) & ~(u64)127)));
+  }
+  void expect(double per_n, double per_w) { yield_n = std::max(yield_n, per_n); yield_w = std::max(yield_w, per_w); }
+  void observe(u64 n_src, u64 n_out, u64 w_out) {
+    if (!n_src) return;
+    yield_n = std::max(yield_n, (double)n_out / (double)n_src);
+    yield_w = std::max(yield_w, (double)w_out / (double)n_src);
+  }
+};
+
+struct DeepRun;
+// A sharded run (vsr_shard_loop.hpp) supplies these: every pass is then a collective — successors owned by other ranks are announced to
+// their owners, claimed / answered there, and the verdicts applied here — and every loop runs as long as ANY rank has work left.
+struct DeepIo {
+  void* ctx = nullptr;
+  int world = 1;
+  u64 cand_cap = 0;              // candidates per owner the exchange buffers hold
+  int (*pass)(void* ctx, const u64* sw, const u64* so, u64 n, u64 p_off, int level, int mode, u64 bag, const PassDst* dst) = nullptr;
+  int (*any)(void* ctx, u64* flag) = nullptr;                   // *flag = its maximum over the ranks
+  int (*reduce)(void* ctx, DeepRun* R) = nullptr;               // R->ins / R->prb: this rank's figures -> the level's
+  int (*resolve)(void* ctx, DeepRun* R) = nullptr;              // the probe's violating successors shown to their owners
+};
+
+struct DeepRun {
+  vsrmc_checker* c;
+  const DeepIo* io = nullptr;
+  int base;                    // level L: the newest materialised level
+  int last_regen;              // levels base+1 .. last_regen are regenerated (they are complete in the seen-set)
+  bool insert;                 // the level last_regen + 1 is inserted (MODE_NORMAL into scratch); false: it is only probed (probe2)
+  vsrmc_level_info ins, prb;   // figures of the inserted and of the probed level
+  u64 viol_ins = ~(u64)0;
+  u32 mask_ins = 0, mask_prb = 0;
+  std::vector<u64> bad;        // (fingerprint, key) of the violating successors the probe passes saw
+  u64 launches = 0, n_slices = 0, n_subs = 0;
+  u64* d_sum = nullptr;
+  int probed_level() const { return last_regen + (insert ? 2 : 1); }
+};
+
+// scratch buffer k (k >= 1) of the descent: a quarter of the one above it (k = 0 = the idle frontier buffers); allocated on first use, kept
+int deep_buffer(vsrmc_checker* c, int k, PassDst* out) {
+  const int nxt = c->cur ^ 1;
+  if (k == 0) {
+    out->words = c->words[nxt]; out->words_cap = c->words_cap(nxt); out->off = c->off[nxt]; out->fp = c->lvl_fp; out->cap = c->opt.frontier_states;
+    return 0;
+  }
+  if (k > 400) return fail(VSRMC_E_REP, "deep search: more than 400 nested levels");
+  if ((size_t)k > c->scratch.size()) c->scratch.resize((size_t)k);
+  PassDst& B = c->scratch[(size_t)k - 1];
+  if (!B.words) {
+    u64 wcap = c->words_cap(nxt), ncap = c->opt.frontier_states;
+    for (int i = 0; i < k && wcap > ((u64)1 << 21); i++) { wcap /= 4; ncap /= 4; }
+    wcap = std::max<u64>((u64)1 << (k <= 2 ? 22 : 21), wcap);        // floor: 16 MB of records, 32 768 states — nested deeper than the sizes shrink
+    ncap = std::max<u64>((u64)1 << (k <= 2 ? 16 : 15), ncap);       // only tiny spaces get (tests: 36 levels through the seen-set alone)
+    hipError_t e = hipErrorOutOfMemory;
+    for (int attempt = 0; attempt < 6 && e != hipSuccess; attempt++, wcap /= 2, ncap /= 2) {   // less free memory than a quarter: take what there is
+      if (wcap < ((u64)1 << 20) || ncap < ((u64)1 << 14)) break;
+      B.words_cap = wcap; B.cap = ncap;
+      e = hipMalloc((void**)&B.words, wcap * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&B.off, (ncap + 1) * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&B.fp, ncap * 8);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (B.words) (void)hipFree(B.words);
+        if (B.off) (void)hipFree(B.off);
+        if (B.fp) (void)hipFree(B.fp);
+        B = PassDst();
+      }
+    }
+    if (e != hipSuccess) return fail(VSRMC_E_HIP, std::string("hipMalloc of a deep-search scratch buffer: ") + hipGetErrorString(e));
+  }
+  *out = B;
+  return 0;
+}
+
+void deep_acc(vsrmc_level_info* t, const LevelCtl& h, double ms) {
+  t->generated += h.generated;
+  t->deadlocks += h.deadlocks;
+  t->probes += h.probes;
+  for (int a = 0; a < 16; a++) t->act_generated[a] += h.act_generated[a];
+  t->expand_ms += ms;
+}
+
+int deep_run_pass(DeepRun& R, const u64* sw, const u64* so, u64 n, u64 p_off, int level, int mode, u64 bag, const PassDst* dst) {
+  if (R.io) return R.io->pass(R.io->ctx, sw, so, n, p_off, level, mode, bag, dst);
+  return expand_pass(R.c, sw, so, n, p_off, level, mode, bag, dst);
+}
+bool deep_more(DeepRun& R, bool mine, int* rc) {               // does ANY rank have another slice?  (unsharded: this one)
+  u64 f = mine ? 1 : 0;
+  if (R.io) *rc = R.io->any(R.io->ctx, &f);
+  return f != 0;
+}
+u64 deep_cand_bound(const DeepRun& R, u64 g1) {
+  if (!R.io || R.io->world <= 1) return ~(u64)0;
+  return std::max<u64>(128, (u64)(0.45 * (double)R.io->cand_cap * (double)R.io->world / (double)std::max<u64>(1, g1)) & ~(u64)127);
+}
+
+// one probe pass over `n` indices of a buffer holding (part of) level lv: the invariants of their successors, nothing inserted
+int deep_probe(DeepRun& R, const PassDst& B, u64 n, int lv, u64 bag) {
+  vsrmc_checker* c = R.c;
+  if (!n) return 0;
+  c->expand_ms = 0;
+  int rc = expand_pass(c, B.words, B.off, n, 0, lv + 1, MODE_PROBE, bag);
+  if (rc) return rc;
+  R.launches++;
+  deep_acc(&R.prb, c->h, c->expand_ms);
+  if (c->h.n_pending) {
+    R.mask_prb |= c->h.viol_mask;
+    if (c->h.n_pending > c->opt.pending_entries || R.bad.size() / 2 + c->h.n_pending > ((u64)1 << 24))
+      return fail(VSRMC_E_REP, "more violating successors in the probed level than the pending list holds (pending_entries)");
+    const size_t at = R.bad.size();
+    R.bad.resize(at + 2 * c->h.n_pending);
+    HIPCHK(hipMemcpy(R.bad.data() + at, c->pending, 16 * c->h.n_pending, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+// `n_idx` indices (holes included) of level lv in (src_words, src_off); k = nesting depth = which buffer takes what this level yields
+int deep_descend(DeepRun& R, const u64* src_words, const u64* src_off, u64 n_idx, u64 src_bag, int lv, int k) {
+  vsrmc_checker* c = R.c;
+  const Model& M = c->model.M;
+  PassDst B;
+  int rc = deep_buffer(c, k, &B);
+  if (rc) return rc;
+  Slicer sl;
+  sl.cap_n = B.cap; sl.cap_w = B.words_cap; sl.g1 = std::max<u64>(1, c->deep_g); sl.stride = (u64)c->lds_stride;
+  sl.cap_c = deep_cand_bound(R, sl.g1);
+  const bool regen = lv + 1 <= R.last_regen;
+  const DeepLevel& next = c->deep_lv[(size_t)(lv - R.base)];   // level lv + 1
+  if (regen) {
+    // MODE_REGEN writes a state where its min-key parent sits — keys order by the parent's fingerprint, so the states of the next level
+    // spread evenly over the parents: (states of level lv+1 per valid parent, known exactly) x (a record of the source + 2 words)
+    const u64 parents = lv == R.base ? c->n_valid : c->deep_lv[(size_t)(lv - R.base - 1)].n_local;   // (a rank regenerates about what it inserted)
+    const double per_n = (double)next.n_local / (double)std::max<u64>(1, parents);
+    const double wbar = (lv == R.base ? (double)c->cur_w / (double)std::max<u64>(1, c->n_valid) : (double)(M.fixed + (int)src_bag)) + 2.0;
+    sl.expect(per_n, per_n * wbar);
+  }
+  const u64 out_bag = regen ? std::min<u64>(next.max_bag, (u64)M.max_bag) : 0;
+  for (u64 a = 0; deep_more(R, a < n_idx, &rc);) {
+    if (rc) return rc;
+    const u64 n = a < n_idx ? std::min<u64>(sl.next(), n_idx - a) : 0;   // (a rank that has run out still takes part in the others' exchanges)
+    c->expand_ms = 0;
+    rc = deep_run_pass(R, src_words, src_off + a, n, R.io ? 0 : a, lv + 1, regen ? MODE_REGEN : MODE_NORMAL, src_bag, &B);
+    if (rc) return rc;
+    if (n) R.launches++;
+    a += n;
+    if (n) (k == 0 ? R.n_slices : R.n_subs)++;
+    const u64 part = c->h.n_new;                               // index range written (holes included)
+    sl.observe(n, part, c->h.words_new);
+    if (regen) {
+      R.ins.materialize_ms += c->expand_ms;                    // time spent regenerating (reported beside the level's own expansion)
+      if (lv + 1 == R.last_regen && !R.insert) rc = deep_probe(R, B, part, lv + 1, out_bag);
+      else rc = deep_descend(R, B.words, B.off, part, out_bag, lv + 1, k + 1);
+      if (rc) return rc;
+      continue;
+    }
+    // ---- the level that is inserted: new states of level lv + 1, in B until the next sub-slice overwrites them
+    deep_acc(&R.ins, c->h, c->expand_ms);
+    R.ins.record_words += c->h.rec_words;
+    R.ins.max_bag = std::max<u64>(R.ins.max_bag, c->h.max_bag);
+    if (c->h.viol_fp != ~(u64)0) {
+      R.mask_ins |= c->h.viol_mask;
+      R.viol_ins = std::min<u64>(R.viol_ins, c->h.viol_fp);
+    }
+    if (!part) continue;
+    const u64 bag_new = std::min<u64>(c->h.max_bag, (u64)M.max_bag);
+    {   // checksums of the level: the sub-slice's fingerprints sit in the scratch buffer until it is reused
+      u64 hsum[3] = {0, 0, 0};
+      if (hipMemsetAsync(R.d_sum, 0, 24, c->stream) != hipSuccess) return fail(VSRMC_E_HIP, "deep search: hipMemsetAsync");
+      hipLaunchKernelGGL(k_level_checksum, dim3(1024), dim3(256), 0, c->stream, B.fp, part, R.d_sum);
+      if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hsum, R.d_sum, 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipStreamSynchronize(c->stream) != hipSuccess)
+        return fail(VSRMC_E_HIP, "deep search: k_level_checksum");
+      R.ins.fp_xor ^= hsum[0];
+      R.ins.fp_sum += hsum[1];
+      R.ins.n_new += hsum[2];                                  // the states that stayed (a sharded pass has withdrawn the announced ones that lost)
+    }
+    if (R.viol_ins != ~(u64)0) continue;                       // a violation in the inserted level: it is completed, nothing deeper is probed
+    rc = deep_probe(R, B, part, lv + 1, bag_new);
+    if (rc) return rc;
+  }
+  return rc;
+}
+
+// which of the collected violating successors are states of the probed level (not of an earlier one)?  The smallest such fingerprint is
+// the violation; the smallest key among its copies names its parent, a state of the level below that is in the seen-set.
+int deep_resolve(DeepRun& R) {
+  vsrmc_checker* c = R.c;
+  const u64 nbad = R.bad.size() / 2;
+  if (!nbad) return 0;
+  const int plevel = R.probed_level();
+  std::vector<std::pair<u64, u64>> pairs(nbad);
+  for (u64 i = 0; i < nbad; i++) pairs[i] = std::make_pair(R.bad[2 * i], R.bad[2 * i + 1]);
+  std::sort(pairs.begin(), pairs.end());                       // by fingerprint, then key
+  std::vector<u64> fps;
+  for (u64 i = 0; i < nbad; i++)
+    if (i == 0 || pairs[i].first != pairs[i - 1].first) fps.push_back(pairs[i].first);
+  std::vector<uint8_t> seen8(fps.size(), 0);
+  int rc = vsrmc_checker_seen_batch(c, fps.data(), (u64)fps.size(), plevel, seen8.data());
+  if (rc) return rc;
+  u64 first = ~(u64)0, key = ~(u64)0;
+  size_t g = 0;
+  for (u64 i = 0; i < nbad; i++) {
+    if (i && pairs[i].first != pairs[i - 1].first) g++;
+    if (seen8[g]) continue;
+    R.prb.pending++;                                           // violating successors seen, duplicates included
+    if (first == ~(u64)0) { first = pairs[i].first; key = pairs[i].second; }
+  }
+  if (first == ~(u64)0) return 0;
+  int found = 0;
+  u64 pfp = 0, pmeta = 0;
+  rc = table_lookup(c, meta_pfp(key), plevel - 1, 1, &found, &pfp, &pmeta);
+  if (rc) return rc;
+  if (found > 1) return fail(VSRMC_E_STATE, "ambiguous predecessor pointer: several states of the parent's level share the 45 fingerprint bits the violating successor keeps of its parent");
+  R.prb.viol_fp = first;
+  R.prb.viol_mask = (int32_t)R.mask_prb;
+  if (found) { c->probe_fp = pfp; c->probe_level = plevel - 1; c->probe_extra_fp = first; }
+  return 0;
+}
+
+int deep_check_ready(vsrmc_checker* c, int extra_levels, bool sharded) {
+  if (c->opt.exact_ties) return fail(VSRMC_E_STATE, "levels beyond the record buffers need a single-pass checker");
+  if (!sharded && c->opt.world > 1) return fail(VSRMC_E_STATE, "a sharded checker goes beyond its record buffers with vsrmc_shard_loop_deepen");
+  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  if (c->level + c->deep + extra_levels >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
+  return 0;
+}
+
+// pass 1: the newest materialised level expanded in MODE_INSERT — level L+1 exists as seen-set entries from here on.  One launch over
+// the whole level; a sharded run slices it so that a slice's announcements fit the exchange buffers.
+int deep_first_pass(vsrmc_checker* c, vsrmc_level_info* ins, const DeepIo* io = nullptr) {
+  const Model& M = c->model.M;
+  DeepRun R;
+  R.c = c; R.io = io; R.base = c->level; R.last_regen = c->level; R.insert = true;
+  std::memset(&R.ins, 0, sizeof(R.ins));
+  std::memset(&R.prb, 0, sizeof(R.prb));
+  R.ins.viol_fp = R.ins.viol_index = R.prb.viol_fp = R.prb.viol_index = ~(u64)0;
+  const double t0 = now_s();
+  const u64 bagL = c->bag_known ? c->cur_max_bag : (u64)M.max_bag;
+  // whatever happens next, the seen-set holds a level that has no frontier from here on: vsrmc_checker_step is refused
+  c->deep = 1;
+  c->deep_lv.assign(1, DeepLevel());
+  const u64 cb = deep_cand_bound(R, std::max<u64>(c->deep_g, c->g_last));
+  int rc = 0;
+  for (u64 a = 0; deep_more(R, a < c->n_frontier, &rc);) {
+    if (rc) break;
+    const u64 n = a < c->n_frontier ? std::min<u64>(cb, c->n_frontier - a) : 0;
+    c->expand_ms = 0;
+    rc = deep_run_pass(R, c->words[c->cur], c->off[c->cur] + a, n, io ? 0 : a, c->level + 1, MODE_INSERT, bagL, nullptr);
+    if (rc) break;
+    a += n;
+    if (n) R.launches++;
+    deep_acc(&R.ins, c->h, c->expand_ms);
+    R.ins.n_new += c->h.n_new;
+    R.ins.max_bag = std::max<u64>(R.ins.max_bag, c->h.max_bag);
+    R.ins.fp_xor ^= c->h.fp_xor;
+    R.ins.fp_sum += c->h.fp_sum;
+    if (c->h.viol_fp != ~(u64)0) { R.mask_ins |= c->h.viol_mask; R.viol_ins = std::min<u64>(R.viol_ins, c->h.viol_fp); }
+  }
+  if (rc) { c->failed = 1; return rc; }
+  const u64 n_local = R.ins.n_new, frontier_local = c->n_valid;
+  R.ins.frontier = c->n_valid;
+  R.ins.viol_fp = R.viol_ins;
+  R.ins.viol_mask = (int32_t)R.mask_ins;
+  if (io && (rc = io->reduce(io->ctx, &R)) != 0) { c->failed = 1; return rc; }
+  DeepLevel& d = c->deep_lv[0];
+  d.n_new = R.ins.n_new; d.n_local = n_local; d.generated = R.ins.generated; d.max_bag = R.ins.max_bag; d.frontier = R.ins.frontier;
+  c->deep_g = std::max<u64>(c->deep_g, (R.ins.generated + R.ins.frontier - 1) / std::max<u64>(1, R.ins.frontier) + 1);
+  (void)frontier_local;
+  *ins = R.ins;
+  ins->level = c->level + (R.ins.n_new ? 1 : 0);               // like vsrmc_checker_step: an empty level leaves the depth where it was
+  if (R.ins.n_new == 0) { c->deep = 0; c->deep_lv.clear(); }   // exhausted: nothing was inserted, the checker is where it was
+  ins->pending = R.launches;                                   // k_expand launches of this pass
+  c->deep_distinct = c->distinct + R.ins.n_new;                // (sharded: c->distinct is this rank's share; the loop keeps the run's total)
+  c->deep_generated = c->total_generated + R.ins.generated;
+  ins->distinct = c->deep_distinct;
+  ins->total_generated = c->deep_generated;
+  ins->seconds = now_s() - t0;
+  ins->viol_index = ~(u64)0;
+  if (ins->viol_fp != ~(u64)0) {                               // the violator is in the seen-set: walk from the violator itself
+    c->probe_fp = ins->viol_fp;
+    c->probe_level = c->level + 1;
+    c->probe_extra_fp = 0;
+  } else {
+    ins->viol_mask = 0;
+  }
+  return 0;
+}
+
+// a descent from the base: regenerates levels base+1 .. last_regen, then inserts (insert) or only probes the level after them
+int deep_pass(vsrmc_checker* c, int last_regen, bool insert, vsrmc_level_info* ins, vsrmc_level_info* prb, const DeepIo* io = nullptr) {
+  const Model& M = c->model.M;
+  DeepRun R;
+  R.c = c; R.io = io; R.base = c->level; R.last_regen = last_regen; R.insert = insert;
+  std::memset(&R.ins, 0, sizeof(R.ins));
+  std::memset(&R.prb, 0, sizeof(R.prb));
+  R.ins.viol_fp = R.ins.viol_index = R.prb.viol_fp = R.prb.viol_index = ~(u64)0;
+  const double t0 = now_s();
+  if (c->deep_regen_done) {                                    // the taken bits an earlier descent left in the levels beyond the base
+    hipLaunchKernelGGL(k_table_untake, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1, c->level + 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));                   // (sharded: before any rank's first announcement can reach this table)
+  }
+  c->deep_regen_done = true;
+  HIPCHK(hipMalloc((void**)&R.d_sum, 24));
+  struct FreeSum { u64* p; ~FreeSum() { (void)hipFree(p); } } free_sum{R.d_sum};
+  if (insert) { c->deep_lv.resize((size_t)(last_regen + 1 - c->level)); c->deep_lv.back() = DeepLevel(); }
+  int rc = 0;
+  if (io) { u64 sync = 0; rc = io->any(io->ctx, &sync); }      // every rank has cleared its taken bits
+  if (!rc) rc = deep_descend(R, c->words[c->cur], c->off[c->cur], c->n_frontier, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, c->level, 0);
+  if (rc) { c->failed = 1; return rc; }
+  const u64 n_local = R.ins.n_new;
+  R.ins.viol_fp = R.viol_ins;
+  R.ins.viol_mask = (int32_t)R.mask_ins;
+  R.prb.viol_mask = (int32_t)R.mask_prb;
+  if (io && (rc = io->reduce(io->ctx, &R)) != 0) { c->failed = 1; return rc; }
+  const double dt = now_s() - t0;
+  const DeepLevel& below = c->deep_lv[(size_t)(last_regen - c->level - 1)];
+  if (insert) {
+    DeepLevel& d = c->deep_lv.back();
+    d.n_new = R.ins.n_new; d.n_local = n_local; d.generated = R.ins.generated; d.max_bag = R.ins.max_bag; d.frontier = below.n_new;
+    c->deep_g = std::max<u64>(c->deep_g, (R.ins.generated + below.n_new - 1) / std::max<u64>(1, below.n_new) + 1);
+    c->deep_distinct += R.ins.n_new;
+    c->deep_generated += R.ins.generated;
+    *ins = R.ins;
+    ins->level = last_regen + (R.ins.n_new ? 1 : 0);            // like vsrmc_checker_step: an empty level leaves the depth where it was
+    ins->frontier = below.n_new;
+    ins->distinct = c->deep_distinct;
+    ins->total_generated = c->deep_generated;
+    ins->pending = R.launches;                                 // k_expand launches of the whole pass (regenerating, inserting and probing ones)
+    ins->words_new = (R.n_slices << 32) | (R.n_subs & 0xFFFFFFFFull);   // (slices of the base level) << 32 | slices of the levels below it
+    ins->viol_index = ~(u64)0;
+    const double ms_all = R.ins.expand_ms + R.ins.materialize_ms + R.prb.expand_ms;
+    ins->seconds = dt * ((R.ins.expand_ms + R.ins.materialize_ms) / std::max(1e-9, ms_all));   // the levels share the pass: split by kernel time
+    if (R.ins.n_new) c->deep = last_regen + 1 - c->level;        // an empty level is no level: the search is exhausted at the one below
+    else c->deep_lv.pop_back();
+    if (ins->viol_fp != ~(u64)0) {
+      c->probe_fp = ins->viol_fp;
+      c->probe_level = last_regen + 1;
+      c->probe_extra_fp = 0;
+      return 0;
+    }
+    ins->viol_mask = 0;
+  }
+  R.prb.level = R.probed_level();
+  R.prb.frontier = insert ? R.ins.n_new : below.n_new;
+  R.prb.distinct = c->deep_distinct;
+  R.prb.total_generated = c->deep_generated + R.prb.generated;
+  R.prb.seconds = insert ? dt - ins->seconds : dt;
+  R.prb.viol_fp = R.prb.viol_index = ~(u64)0;
+  R.prb.viol_mask = 0;
+  if (!insert) {                                               // probe2: the regeneration is this level's cost
+    R.prb.record_words = R.ins.record_words;
+    R.prb.materialize_ms = R.ins.materialize_ms;
+    R.prb.words_new = (R.n_slices << 32) | (R.n_subs & 0xFFFFFFFFull);
+  }
+  rc = io ? io->resolve(io->ctx, &R) : deep_resolve(R);        // the level below the probed one is complete now: which collected successors are new states?
+  if (rc) return rc;
+  *prb = R.prb;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// One more level beyond the record buffers (see the head of this file).  The first call after the last vsrmc_checker_step inserts level
+// L+1 as a virtual level (inserted->level = L+1, probed->level = 0: nothing probed); every further call descends from the base level,
+// inserts the next level and probes the one after it.  A violation is reported in whichever of the two infos it falls
+// (vsrmc_checker_probe_trace reconstructs the counter-example); inserted->n_new == 0: the search is exhausted.
+int32_t vsrmc_checker_deepen(vsrmc_checker* c, vsrmc_level_info* inserted, vsrmc_level_info* probed) {
+  if (!c || !inserted || !probed) return fail(VSRMC_E_ARG, "NULL argument");
+  int rc = deep_check_ready(c, 2, false);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->opt.device));
+  std::memset(inserted, 0, sizeof(*inserted));
+  std::memset(probed, 0, sizeof(*probed));
+  inserted->viol_fp = inserted->viol_index = probed->viol_fp = probed->viol_index = ~(u64)0;
+  c->probe_fp = 0;
+  c->probe_level = 0;
+  c->probe_extra_fp = 0;
+  if (c->deep == 0) return deep_first_pass(c, inserted);
+  return deep_pass(c, c->level + c->deep, true, inserted, probed);
+}
+
+// Two levels beyond the last materialised one: level L+1 a virtual level, level L+2 probed from its regenerated slices.  Costs one extra
+// expansion of the newest level and no memory beyond a slice.
+int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_level_info* probe) {
+  if (!c || !virt || !probe) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->deep) return fail(VSRMC_E_STATE, "vsrmc_checker_probe2 starts from a materialised level");
+  vsrmc_level_info none;
+  int rc = vsrmc_checker_deepen(c, virt, probe);
+  if (rc || virt->viol_mask || virt->n_new == 0) return rc;
+  rc = deep_pass(c, c->level + 1, false, &none, probe);
+  return rc;
+}
+
+// Three levels: level L+1 virtual, level L+2 streamed through a scratch buffer (inserted, counted, never kept), level L+3 probed.
+int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_level_info* virt2, vsrmc_level_info* probe) {
+  if (!c || !virt1 || !virt2 || !probe) return fail(VSRMC_E_ARG, "NULL argument");
+  if (c->deep) return fail(VSRMC_E_STATE, "vsrmc_checker_probe3 starts from a materialised level");
+  std::memset(virt2, 0, sizeof(*virt2));
+  virt2->viol_fp = virt2->viol_index = ~(u64)0;
+  int rc = vsrmc_checker_deepen(c, virt1, probe);
+  if (rc || virt1->viol_mask || virt1->n_new == 0) return rc;
+  return vsrmc_checker_deepen(c, virt2, probe);
+}
+
+}  // extern "C"

@@ -822,14 +822,17 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         } else if (owner != rank) {
           // sent-filter: a direct-mapped, lossy set of (fingerprint, auxkey) tags this rank has announced before (any level).
           // A hit = an exact repeat, dropped; a miss (or an evicted tag) only costs a redundant announcement.  Plain 8-byte
-          // loads / stores: a lost update has the same effect as an eviction.
-          u64 tag = fp ^ ((u64)(ak + 1) * 0x9E3779B97F4A7C15ull);
-          if (tag == 0) tag = 1;
-          u64* fs = filter + ((fp >> 6) & fmask);
-          if (__hip_atomic_load(fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) continue;
-          __hip_atomic_store(fs, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // loads / stores: a lost update has the same effect as an eviction.  (MODE_REGEN asks the owner about EVERY candidate: which
+          // of the copies of a state carries the slot's final key is not a question a repeat filter can answer.)
+          if (mode != MODE_REGEN) {
+            u64 tag = fp ^ ((u64)(ak + 1) * 0x9E3779B97F4A7C15ull);
+            if (tag == 0) tag = 1;
+            u64* fs = filter + ((fp >> 6) & fmask);
+            if (__hip_atomic_load(fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) continue;
+            __hip_atomic_store(fs, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           remote = true;
-          do_write = true;
+          do_write = mode == MODE_NORMAL;                       // virtual / regenerated levels: announced, not written (vsr_deep.hpp, sharded)
         } else if (mode == MODE_REGEN) {
           u64 m = META_EMPTY;
           u64 slot_i = 0;
@@ -846,7 +849,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           claimed_now = claimed;
         }
         // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
-        const int bad = (check || do_write) ? Ops::invariants(M, rec, D) : 0;
+        const int bad = (check || do_write || (remote && mode == MODE_INSERT)) ? Ops::invariants(M, rec, D) : 0;
         if (mode == MODE_PROBE) {
           if (bad) {
             const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
@@ -877,12 +880,13 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
         const u64 a_3 = VSR_CLK();
         if (tid == 0) s_acc[12] += a_3 - a_2;
+        u64 idx = 0;
         if (do_write) {                                         // new state (or: possibly new, the owner decides): write it out
           const int plen = (int)(s_ref[p] & 255);
           const int clen = M.fixed + hdr_nmsg(D.hdr);
           const u32 io = atomicAdd(&s_tile_icur, 1u);
           const u32 wo = atomicAdd(&s_tile_wcur, (u32)clen);
-          const u64 idx = s_ich_base + s_tile_ibase + io;
+          idx = s_ich_base + s_tile_ibase + io;
           const u64 dst = s_wch_base + s_tile_wbase + wo;
           u64* out = nx_words + dst;
           // parent from LDS, 16 bytes per store (records are 8-byte aligned), then the patches on top (same lane: ordered)
@@ -932,31 +936,34 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             atomicOr(&ctl->viol_mask, (u32)bad);
           }
           if ((u32)hdr_nmsg(D.hdr) > s_maxbag_out) atomicMax(&s_maxbag_out, (u32)hdr_nmsg(D.hdr));
-          if (remote) {
-            // announce (fp, key) to the owner: entry i of the block's chunk of that owner's bucket
-            u64 i = 0;
-            for (;;) {
-              const unsigned long long old = atomicAdd(&s_cstate[owner], 1ull);
-              const u32 pos = (u32)(old & 0xFFFFFFull);
-              if (pos == cchunk) {                              // drew the "chunk is full" ticket: fetch the next chunk
-                u64 nb = atomicAdd((unsigned long long*)&ctl->cand_cnt[owner], (unsigned long long)cchunk);
-                if (nb + cchunk > cand_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
-                const u64 ob_ = (u64)(old >> 24);
-                (void)ob_;                                      // the old chunk was used up completely: nothing to invalidate
-                i = nb;
-                atomicExch(&s_cstate[owner], ((unsigned long long)nb << 24) | 1ull);
-                break;
-              }
-              if (pos < cchunk) {
-                i = (u64)(old >> 24) + pos;
-                break;
-              }
-            }                                                   // pos > cchunk: another lane is fetching the chunk; draw again
-            const u64 e = (u64)owner * cand_cap + i;
-            cand_send[2 * e] = fp;
-            cand_send[2 * e + 1] = key;
-            cand_idx[e] = cand_pack(idx, (u32)bad);
-          }
+        }
+        if (PLAIN == 0 && remote) {
+          // announce (fp, key) to the owner: entry i of the block's chunk of that owner's bucket
+          u64 i = 0;
+          for (;;) {
+            const unsigned long long old = atomicAdd(&s_cstate[owner], 1ull);
+            const u32 pos = (u32)(old & 0xFFFFFFull);
+            if (pos == cchunk) {                              // drew the "chunk is full" ticket: fetch the next chunk
+              u64 nb = atomicAdd((unsigned long long*)&ctl->cand_cnt[owner], (unsigned long long)cchunk);
+              if (nb + cchunk > cand_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
+              const u64 ob_ = (u64)(old >> 24);
+              (void)ob_;                                      // the old chunk was used up completely: nothing to invalidate
+              i = nb;
+              atomicExch(&s_cstate[owner], ((unsigned long long)nb << 24) | 1ull);
+              break;
+            }
+            if (pos < cchunk) {
+              i = (u64)(old >> 24) + pos;
+              break;
+            }
+          }                                                   // pos > cchunk: another lane is fetching the chunk; draw again
+          const u64 e = (u64)owner * cand_cap + i;
+          cand_send[2 * e] = fp;
+          cand_send[2 * e + 1] = key;
+          // what the generator keeps beside the candidate: where it wrote the record speculatively (ordinary level), the size of the state's bag
+          // (virtual level: nothing is written), or the instance that regenerates it (parent index in this launch's source, ordinal)
+          cand_idx[e] = mode == MODE_REGEN ? origin_make(p_base + (u64)p, ord)
+                                           : cand_pack(mode == MODE_INSERT ? (u64)hdr_nmsg(D.hdr) : idx, (u32)bad);
         }
         // same-level duplicate with a different canonical auxkey = the tie the single-pass scheme cannot arbitrate
         if (prev_meta != META_EMPTY && meta_level(prev_meta) == level && meta_auxkey(prev_meta) != meta_auxkey(key)) atomicAdd(&s_acc[8], 1ull);
@@ -1306,6 +1313,16 @@ __global__ void k_level_checksum(const u64* __restrict__ fps, u64 n, u64* out) {
   }
 }
 
+// clears the taken bit of every state of level >= min_level (vsr_deep.hpp: before a descent regenerates those levels again)
+__global__ void k_table_untake(Slot* table, u64 n_slots, int min_level) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n_slots; i += stride) {
+    const u64 m = table[i].meta;
+    if (table[i].fp != 0 && (m & META_TAKEN) && m != META_EMPTY && meta_level(m) >= min_level) table[i].meta = m & ~META_TAKEN;
+  }
+}
+
 // empty seen-set: fp = 0, meta = all ones
 __global__ void k_table_init(Slot* table, u64 slots) {
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (u64)gridDim.x * blockDim.x) {
@@ -1381,6 +1398,53 @@ __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __re
   } else {
     nx_off[idx] = 0;
     lvl_fp[idx] = 0;
+  }
+}
+__device__ __forceinline__ u64 find_exact(const Slot* table, u64 tmask, u64 fp);
+// The same two roles for the levels of a sharded run that exist in the seen-set only (vsr_deep.hpp).
+// k_regen_verdict, owner side of a regenerated level: of all the copies of a state the ranks re-generate, the one whose key IS the slot's
+// final meta word materialises it — taken with a compare-and-swap, so that two instances carrying the same 64 bits yield one state.
+__global__ void k_regen_verdict(Slot* table, u64 tmask, const u64* __restrict__ entries, u64 n, uint8_t* verdict) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 fp = entries[2 * i], key = entries[2 * i + 1];
+  uint8_t v = 0;
+  if (fp != 0) {
+    const u64 slot = find_exact(table, tmask, fp);
+    if (slot != ~(u64)0 && table[slot].meta == key)
+      v = atomicCAS((unsigned long long*)&table[slot].meta, (unsigned long long)key, (unsigned long long)(key | META_TAKEN)) == key ? 1 : 0;
+  }
+  verdict[i] = v;
+}
+// k_count_verdict, generator side of a virtual level: nothing was written, so the winners among the announced successors are only
+// counted — new states, checksums of their fingerprints, largest bag (cand_idx: bag size | violated-invariant mask << 56), violators.
+__global__ void k_count_verdict(const u64* __restrict__ entries, const u64* __restrict__ cand_idx, const uint8_t* __restrict__ verdict, u64 n,
+                                u64* pending, u64 pending_cap, LevelCtl* ctl) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 cnt = 0, fx = 0, fs = 0, bag = 0;
+  if (i < n && entries[2 * i] != 0 && verdict[i]) {
+    const u64 fp = entries[2 * i], e = cand_idx[i];
+    cnt = 1; fx = fp; fs = fp; bag = cand_index(e);
+    const u32 bad = cand_bad(e);
+    if (bad) {
+      const u64 k = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
+      if (k < pending_cap) { pending[2 * k] = fp; pending[2 * k + 1] = entries[2 * i + 1]; }
+      atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
+      atomicOr(&ctl->viol_mask, bad);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_down(cnt, o);
+    fx ^= __shfl_down(fx, o);
+    fs += __shfl_down(fs, o);
+    const u64 t = __shfl_down(bag, o);
+    bag = t > bag ? t : bag;
+  }
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicAdd((unsigned long long*)&ctl->n_new, (unsigned long long)cnt);
+    atomicXor((unsigned long long*)&ctl->fp_xor, (unsigned long long)fx);
+    atomicAdd((unsigned long long*)&ctl->fp_sum, (unsigned long long)fs);
+    atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)bag);
   }
 }
 // k_partition: end of the replicated phase of a sharded run (every rank explored the small early levels by itself): keep

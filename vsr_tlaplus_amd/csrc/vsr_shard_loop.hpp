@@ -142,6 +142,10 @@ struct vsrmc_shard_loop {
   bool has_violation = false;
   u64 viol_fp = 0;
   int viol_mask = 0, viol_level = 0;
+  // levels beyond the record buffers (vsr_deep.hpp, sharded): `deep` levels above `level` are complete in the seen-sets
+  int deep = 0;
+  u64 probe_parent_fp = 0;       // a violation found by a probe pass: its parent (a state of level viol_level - 1, in some shard) ...
+  bool viol_probed = false;      // ... and that it was found that way (the violator itself is in no seen-set)
   // device buffers
   u64* cand_send = nullptr;      // [world][cand_cap][2]
   u64* cand_recv = nullptr;      // up to world * cand_cap pairs, packed by source rank
@@ -540,3 +544,290 @@ int32_t vsrmc_shard_loop_trace_fps(vsrmc_shard_loop* l, int32_t level, uint64_t 
 }
 
 }  // extern "C"
+
+// ================================================================================================================================
+// Levels beyond the record buffers on a sharded run (vsr_deep.hpp with the collective hooks).  Every pass of the descent is the
+// protocol of a sharded level with other sources / targets: k_expand over a slice announces the successors other ranks own (virtual
+// level: through the sent-filter, nothing written; regenerated level: every candidate, with the instance that can rebuild it; inserted
+// level: through the filter, written speculatively into the scratch buffer), the owners claim (k_claim_batch_fused) or, for a
+// regenerated level, grant the one candidate whose key is the slot's final meta word (k_regen_verdict), and the verdict bytes come
+// back: winners are counted (k_count_verdict), rebuilt from their parents (k_materialize) or kept (k_apply_verdict withdraws the rest).
+// Loops run as long as ANY rank has a slice left; a rank that has run out takes part in the others' exchanges with empty buckets.
+// ================================================================================================================================
+namespace {
+
+int loop_deep_any(void* ctx, u64* flag) {
+  vsrmc_shard_loop* l = (vsrmc_shard_loop*)ctx;
+  u64 all[8] = {0};
+  const int rc = loop_allgather(l, flag, all, 8);
+  if (rc) return rc;
+  u64 m = 0;
+  for (int p = 0; p < l->world; p++) m = std::max(m, all[p]);
+  *flag = m;
+  return 0;
+}
+
+int loop_deep_pass(void* ctx, const u64* sw, const u64* so, u64 n, u64 p_off, int level, int mode, u64 bag, const PassDst* dst) {
+  vsrmc_shard_loop* l = (vsrmc_shard_loop*)ctx;
+  vsrmc_checker* c = l->c;
+  const int w = l->world, me = l->rank;
+  vsrmc_shard_io io;
+  io.cand_send = l->cand_send;
+  io.cand_cap = l->cand_cap;
+  int rc = expand_pass(c, sw, so, n, p_off, level, mode, bag, dst, &io);
+  struct CountRow { u64 cnt[8]; u64 err; } mine;
+  std::memset(&mine, 0, sizeof(mine));
+  for (int p = 0; p < w; p++) mine.cnt[p] = (p == me || rc) ? 0 : std::min<u64>(c->h.cand_cnt[p], l->cand_cap);
+  mine.err = rc ? (u64)(rc < 0 ? -rc : rc) : 0;
+  std::vector<CountRow> all((size_t)w);
+  int crc = loop_allgather(l, &mine, all.data(), (u32)sizeof(CountRow));
+  if (crc) return crc;
+  u64 worst = 0;
+  for (const CountRow& r : all) worst = std::max(worst, r.err);
+  if (worst) return rc ? rc : fail(VSRMC_E_STATE, "deep pass (level " + std::to_string(level) + "), phase expand: error " + std::to_string((long long)worst) + " on another rank");
+  u64 scnt[8], soff[8], rcnt[8], roff[8], n_recv = 0;
+  for (int p = 0; p < w; p++) {
+    scnt[p] = mine.cnt[p];
+    soff[p] = (u64)p * l->cand_cap;
+    rcnt[p] = p == me ? 0 : all[(size_t)p].cnt[me];
+    roff[p] = n_recv;
+    n_recv += rcnt[p];
+  }
+  rc = loop_alltoallv(l, l->cand_send, scnt, soff, l->cand_recv, rcnt, roff, 16);
+  // the owner's side: claim (virtual / inserted level) or grant the regeneration (the candidate that carries the slot's final key)
+  if (!rc && n_recv) {
+    const unsigned grid = (unsigned)((n_recv + 255) / 256);
+    if (mode == MODE_REGEN) hipLaunchKernelGGL(k_regen_verdict, dim3(grid), dim3(256), 0, c->stream, c->table, c->tmask, l->cand_recv, n_recv, l->verdict_out);
+    else hipLaunchKernelGGL(k_claim_batch_fused, dim3(grid), dim3(256), 0, c->stream, c->table, c->tmask, l->cand_recv, n_recv, level, l->verdict_out, c->ctl);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(VSRMC_E_HIP, "deep pass: claim kernel");
+  }
+  {
+    const int xrc = loop_alltoallv(l, l->verdict_out, rcnt, roff, l->verdict_in, scnt, soff, 1);
+    if (!rc) rc = xrc;
+  }
+  // the generator's side
+  for (int o = 0; o < w && !rc; o++) {
+    if (o == me || scnt[o] == 0) continue;
+    const u64 k = scnt[o];
+    const u64* ent = l->cand_send + 2 * (u64)o * l->cand_cap;
+    const u64* cidx = c->cand_idx + (u64)o * l->cand_cap;
+    const uint8_t* ver = l->verdict_in + (u64)o * l->cand_cap;
+    if (mode == MODE_REGEN) {
+      rc = phase_materialize(c, ent, k, ver, dst->words, dst->words_cap, dst->off, dst->cap, dst->fp, &c->ctl->n_new, &c->ctl->words_new, 2, cidx, sw, so);
+    } else {
+      if (mode == MODE_INSERT)
+        hipLaunchKernelGGL(k_count_verdict, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, ent, cidx, ver, k, c->pending, c->opt.pending_entries, c->ctl);
+      else
+        hipLaunchKernelGGL(k_apply_verdict, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, ent, cidx, ver, k, dst->off, dst->fp, c->ctl);
+      if (hipGetLastError() != hipSuccess) rc = fail(VSRMC_E_HIP, "deep pass: verdict kernel");
+    }
+  }
+  if (!rc && (hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
+    rc = fail(VSRMC_E_HIP, "deep pass: control block");
+  if (!rc && c->h.err) rc = level_error(c, c->h, level);
+  if (!rc && c->h.ties) rc = fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables (SURVEY F2)");
+  // nobody goes on alone: the error codes of the claim / apply half
+  u64 e1 = rc ? (u64)(rc < 0 ? -rc : rc) : 0, eall[8] = {0};
+  crc = loop_allgather(l, &e1, eall, 8);
+  if (crc) return crc;
+  for (int p = 0; p < w; p++)
+    if (eall[p] && !rc) rc = fail(VSRMC_E_STATE, "deep pass (level " + std::to_string(level) + "), phase claim: error " + std::to_string((long long)eall[p]) + " on another rank");
+  return rc;
+}
+
+// this rank's figures of the pass -> the level's (sums; largest bag; smallest violating fingerprint; masks or-ed; checksums xor / sum)
+int loop_deep_reduce(void* ctx, DeepRun* R) {
+  vsrmc_shard_loop* l = (vsrmc_shard_loop*)ctx;
+  struct Row { u64 n_new, generated, deadlocks, probes, words, fx, fs, bag, viol, mask, frontier, act[16], p_gen, p_dead, p_probes, p_mask, p_act[16]; };
+  static_assert(sizeof(Row) <= 512, "one all-gather record");
+  Row mine;
+  std::memset(&mine, 0, sizeof(mine));
+  const vsrmc_level_info& a = R->ins;
+  const vsrmc_level_info& b = R->prb;
+  mine.n_new = a.n_new; mine.generated = a.generated; mine.deadlocks = a.deadlocks; mine.probes = a.probes; mine.words = a.record_words;
+  mine.fx = a.fp_xor; mine.fs = a.fp_sum; mine.bag = a.max_bag; mine.viol = a.viol_fp; mine.mask = (u64)(u32)a.viol_mask; mine.frontier = a.frontier;
+  for (int i = 0; i < 16; i++) { mine.act[i] = a.act_generated[i]; mine.p_act[i] = b.act_generated[i]; }
+  mine.p_gen = b.generated; mine.p_dead = b.deadlocks; mine.p_probes = b.probes; mine.p_mask = (u64)(u32)b.viol_mask;
+  std::vector<Row> all((size_t)l->world);
+  const int rc = loop_allgather(l, &mine, all.data(), (u32)sizeof(Row));
+  if (rc) return rc;
+  Row t;
+  std::memset(&t, 0, sizeof(t));
+  t.viol = ~(u64)0;
+  for (const Row& r : all) {
+    t.n_new += r.n_new; t.generated += r.generated; t.deadlocks += r.deadlocks; t.probes += r.probes; t.words += r.words;
+    t.fx ^= r.fx; t.fs += r.fs; t.bag = std::max(t.bag, r.bag); t.frontier += r.frontier;
+    if (r.viol < t.viol) t.viol = r.viol;
+    t.p_gen += r.p_gen; t.p_dead += r.p_dead; t.p_probes += r.p_probes; t.p_mask |= r.p_mask;
+    for (int i = 0; i < 16; i++) { t.act[i] += r.act[i]; t.p_act[i] += r.p_act[i]; }
+  }
+  for (const Row& r : all)
+    if (t.viol != ~(u64)0 && r.viol == t.viol) t.mask |= r.mask;
+  vsrmc_level_info& A = R->ins;
+  vsrmc_level_info& B = R->prb;
+  A.n_new = t.n_new; A.generated = t.generated; A.deadlocks = t.deadlocks; A.probes = t.probes; A.record_words = t.words;
+  A.fp_xor = t.fx; A.fp_sum = t.fs; A.max_bag = t.bag; A.viol_fp = t.viol; A.viol_mask = (int32_t)t.mask; A.frontier = t.frontier;
+  B.generated = t.p_gen; B.deadlocks = t.p_dead; B.probes = t.p_probes; B.viol_mask = (int32_t)t.p_mask;
+  for (int i = 0; i < 16; i++) { A.act_generated[i] = t.act[i]; B.act_generated[i] = t.p_act[i]; }
+  R->viol_ins = t.viol; R->mask_ins = (u32)t.mask; R->mask_prb = (u32)t.p_mask;
+  return 0;
+}
+
+// Every rank holds the violating successors ITS probe passes could not find in its own shard.  A rank can only vouch for fingerprints it
+// owns, so every (fingerprint, smallest key) pair is shown to all ranks, 30 per round; the owner drops what it has seen at a level below
+// the probed one; the smallest surviving fingerprint is the violation, the smallest key among its copies names its parent.
+int loop_deep_resolve(void* ctx, DeepRun* R) {
+  vsrmc_shard_loop* l = (vsrmc_shard_loop*)ctx;
+  vsrmc_checker* c = l->c;
+  const int w = l->world, plevel = R->probed_level();
+  std::vector<std::pair<u64, u64>> pairs;
+  for (size_t i = 0; i + 1 < R->bad.size(); i += 2) pairs.push_back(std::make_pair(R->bad[i], R->bad[i + 1]));
+  std::sort(pairs.begin(), pairs.end());
+  std::vector<std::pair<u64, u64>> uniq;                       // one entry per fingerprint: its smallest key
+  for (const auto& pr : pairs)
+    if (uniq.empty() || uniq.back().first != pr.first) uniq.push_back(pr);
+  struct Round { u64 n; u64 fp[30], key[30]; };
+  static_assert(sizeof(Round) <= 512, "one all-gather record");
+  u64 best_fp = ~(u64)0, best_key = ~(u64)0, seen_total = 0;
+  for (size_t at = 0;; at += 30) {
+    u64 more = at < uniq.size() ? 1 : 0;
+    int rc = loop_deep_any(l, &more);
+    if (rc) return rc;
+    if (!more) break;
+    Round mine;
+    std::memset(&mine, 0, sizeof(mine));
+    for (size_t i = at; i < uniq.size() && i < at + 30; i++) { mine.fp[mine.n] = uniq[i].first; mine.key[mine.n] = uniq[i].second; mine.n++; }
+    std::vector<Round> all((size_t)w);
+    rc = loop_allgather(l, &mine, all.data(), (u32)sizeof(Round));
+    if (rc) return rc;
+    std::vector<u64> fps, keys;
+    for (const Round& r : all)
+      for (u64 i = 0; i < r.n; i++)
+        if (owner_of(r.fp[i], w) == l->rank) { fps.push_back(r.fp[i]); keys.push_back(r.key[i]); }
+    std::vector<uint8_t> seen(fps.size(), 0);
+    rc = vsrmc_checker_seen_batch(c, fps.data(), (u64)fps.size(), plevel, seen.data());
+    u64 e1 = rc ? 1 : 0;
+    int crc = loop_deep_any(l, &e1);
+    if (crc) return crc;
+    if (e1) return rc ? rc : fail(VSRMC_E_STATE, "deep pass: the seen-set lookup of the probe's candidates failed on another rank");
+    for (size_t i = 0; i < fps.size(); i++) {
+      if (seen[i]) continue;
+      seen_total++;
+      if (fps[i] < best_fp || (fps[i] == best_fp && keys[i] < best_key)) { best_fp = fps[i]; best_key = keys[i]; }
+    }
+  }
+  struct Best { u64 fp, key, cnt; } bm = {best_fp, best_key, seen_total};
+  std::vector<Best> ball((size_t)w);
+  int rc = loop_allgather(l, &bm, ball.data(), (u32)sizeof(Best));
+  if (rc) return rc;
+  Best g = {~(u64)0, ~(u64)0, 0};
+  for (const Best& b : ball) {
+    g.cnt += b.cnt;
+    if (b.fp < g.fp || (b.fp == g.fp && b.key < g.key)) { g.fp = b.fp; g.key = b.key; }
+  }
+  R->prb.pending = g.cnt;
+  if (g.fp == ~(u64)0) return 0;
+  R->prb.viol_fp = g.fp;
+  R->prb.viol_mask = (int32_t)R->mask_prb;
+  l->probe_parent_fp = 0;
+  // its parent: the state of the level below whose fingerprint ends in the key's 45 bits, in whichever shard (collective lookup)
+  struct Row { u64 n, fp, meta, err; };
+  int32_t found = 0;
+  u64 f = 0, m = 0;
+  rc = vsrmc_checker_lookup(c, meta_pfp(g.key), plevel - 1, 1, &found, &f, &m);
+  Row mine = {rc ? 0 : (u64)found, f, m, rc ? (u64)1 : 0};
+  std::vector<Row> rows((size_t)w);
+  const int crc = loop_allgather(l, &mine, rows.data(), (u32)sizeof(Row));
+  if (crc) return crc;
+  u64 hits = 0, pfp = 0;
+  for (const Row& r : rows) {
+    if (r.err) return rc ? rc : fail(VSRMC_E_STATE, "deep pass: the parent lookup failed on another rank");
+    if (!r.n) continue;
+    if (r.n > 1 || (hits && r.fp != pfp)) return fail(VSRMC_E_STATE, "ambiguous predecessor pointer: several states of the parent's level share the 45 fingerprint bits the violating successor keeps of its parent");
+    hits = 1; pfp = r.fp;
+  }
+  if (!hits) return fail(VSRMC_E_STATE, "deep pass: the parent of the violating successor is in no shard");
+  l->probe_parent_fp = pfp;
+  return 0;
+}
+
+DeepIo loop_deep_io(vsrmc_shard_loop* l) {
+  DeepIo io;
+  io.ctx = l; io.world = l->world; io.cand_cap = l->cand_cap;
+  io.pass = loop_deep_pass; io.any = loop_deep_any; io.reduce = loop_deep_reduce; io.resolve = loop_deep_resolve;
+  return io;
+}
+
+}  // namespace
+
+extern "C" {
+
+// vsrmc_checker_deepen for a sharded run (collective): one more level beyond the ranks' record buffers.  inserted / probed = the level's
+// figures over all ranks.  A violation found by the probe: vsrmc_shard_loop_probe_trace_fps walks from its parent.
+int32_t vsrmc_shard_loop_deepen(vsrmc_shard_loop* l, vsrmc_level_info* inserted, vsrmc_level_info* probed) {
+  if (!l || !inserted || !probed) return fail(VSRMC_E_ARG, "NULL argument");
+  vsrmc_checker* c = l->c;
+  int rc = deep_check_ready(c, 2, true);
+  // (every rank reaches the same verdict here: level, deep and failed move in lock-step; a rank that failed alone has reported it in a collective)
+  if (rc) return rc;
+  if (l->replicated) return fail(VSRMC_E_STATE, "the replicated phase of a sharded run stores its levels (they are small by definition)");
+  HIPCHK(hipSetDevice(c->opt.device));
+  std::memset(inserted, 0, sizeof(*inserted));
+  std::memset(probed, 0, sizeof(*probed));
+  inserted->viol_fp = inserted->viol_index = probed->viol_fp = probed->viol_index = ~(u64)0;
+  const DeepIo io = loop_deep_io(l);
+  const u64 distinct_before = l->distinct;
+  if (c->deep == 0) rc = deep_first_pass(c, inserted, &io);
+  else rc = deep_pass(c, c->level + c->deep, true, inserted, probed, &io);
+  if (rc) return rc;
+  l->deep = c->deep;
+  l->distinct = distinct_before + inserted->n_new;
+  inserted->distinct = l->distinct;
+  if (probed->level) probed->distinct = l->distinct;
+  if (!l->has_violation) {
+    if (inserted->viol_mask) {
+      l->has_violation = true; l->viol_fp = inserted->viol_fp; l->viol_mask = inserted->viol_mask; l->viol_level = inserted->level; l->viol_probed = false;
+    } else if (probed->level && probed->viol_mask) {
+      l->has_violation = true; l->viol_fp = probed->viol_fp; l->viol_mask = probed->viol_mask; l->viol_level = probed->level; l->viol_probed = true;
+    }
+  }
+  return 0;
+}
+
+// One unit of progress of the automatic level scheme on a sharded run (collective): an ordinary sharded level while EVERY rank predicts
+// that its part of the next one fits its idle record buffer (*what = 1: a = the level over all ranks), else vsrmc_shard_loop_deepen
+// (*what = 2: a = the inserted level, b = the probed one or b->level == 0).
+int32_t vsrmc_shard_loop_advance(vsrmc_shard_loop* l, vsrmc_level_info* a, vsrmc_level_info* b, int32_t* what) {
+  if (!l || !a || !b || !what) return fail(VSRMC_E_ARG, "NULL argument");
+  std::memset(b, 0, sizeof(*b));
+  b->viol_fp = b->viol_index = ~(u64)0;
+  u64 deep_wanted = 0;
+  if (!l->replicated) {
+    // a rank's share of the next level: what its own states generate and win — about its share of this one times the level's growth
+    deep_wanted = (l->c->deep || !next_level_fits(l->c)) ? 1 : 0;
+    const int rc = loop_deep_any(l, &deep_wanted);
+    if (rc) return rc;
+  }
+  if (!deep_wanted) {
+    vsrmc_level_info local;
+    *what = 1;
+    return vsrmc_shard_loop_step(l, a, &local);
+  }
+  *what = 2;
+  return vsrmc_shard_loop_deepen(l, a, b);
+}
+
+// the fingerprints of the counter-example of a violation a probe pass found (collective): Init .. the violator's parent, then the violator
+int32_t vsrmc_shard_loop_probe_trace_fps(vsrmc_shard_loop* l, uint64_t* fps, int32_t cap, int32_t* n) {
+  if (!l || !fps || !n) return fail(VSRMC_E_ARG, "NULL argument");
+  if (!l->has_violation || !l->viol_probed || !l->probe_parent_fp) return fail(VSRMC_E_STATE, "no violation recorded by a probe pass");
+  if (cap < l->viol_level) return fail(VSRMC_E_ARG, "buffer too small");
+  const int rc = vsrmc_shard_loop_trace_fps(l, l->viol_level - 1, l->probe_parent_fp, fps);
+  if (rc) return rc;
+  fps[l->viol_level - 1] = l->viol_fp;
+  *n = l->viol_level;
+  return 0;
+}
+
+}  // extern "C"
+

@@ -1001,6 +1001,14 @@ extern "C" int32_t vsrmc_simulate(const vsrmc_model* m, int32_t device, uint32_t
 // ---------------------------------------------------------------------------------------------------------------
 // checker
 // ---------------------------------------------------------------------------------------------------------------
+struct PassDst {            // where a pass writes (records, refs, fingerprints)
+  u64* words = nullptr;
+  u64 words_cap = 0;
+  u64* off = nullptr;
+  u64* fp = nullptr;
+  u64 cap = 0;
+};
+struct DeepLevelRec { u64 n_new = 0, n_local = 0, generated = 0, max_bag = 0, frontier = 0; };   // n_local: this rank's share (unsharded: all)   // a level that exists in the seen-set only (vsr_deep.hpp)
 struct vsrmc_checker {
   vsrmc_model model;
   vsrmc_options opt;
@@ -1050,6 +1058,15 @@ struct vsrmc_checker {
   int probe_level = 0;
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
   bool saw_violation = false;            // a committed level held a violating state (the caller went on): probe passes apply every action
+  // levels beyond the record buffers (vsr_deep.hpp): `deep` levels above `level` are complete in the seen-set and have no frontier
+  int deep = 0;
+  std::vector<DeepLevelRec> deep_lv;     // [i] = level + 1 + i
+  u64 deep_g = 2;                        // successors generated per expanded state, rounded up, the largest any level showed (worst-case slice sizes)
+  u64 deep_distinct = 0, deep_generated = 0;
+  bool deep_regen_done = false;          // a descent has set taken bits in the levels beyond the base: cleared before the next one
+  std::vector<PassDst> scratch;          // scratch buffers of the descent, each a quarter of the one above down to a floor (allocated on first use)
+  u64 hist_new[2] = {0, 0};              // new states of the last two levels (growth estimate of vsrmc_checker_advance)
+  u64 g_last = 16, cur_rec_w = 0;        // successors generated per expanded state of the last level (rounded up, + 1); words of the newest level's records
   u64 words_cap(int b) const { return (b == 1 && opt.frontier_words_b) ? opt.frontier_words_b : opt.frontier_words; }
 };
 
@@ -1175,6 +1192,16 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
 int checker_seed(vsrmc_checker* c) {
   const Model& M = c->model.M;
   c->saw_violation = false;
+  c->deep = 0;
+  c->deep_lv.clear();
+  c->deep_g = 2;
+  c->deep_distinct = c->deep_generated = 0;
+  c->deep_regen_done = false;
+  c->hist_new[0] = c->hist_new[1] = 0;
+  c->g_last = 16;
+  c->cur_rec_w = 0;
+  c->failed = 0;
+  c->failed_code = 0;
   HIPCHK(hipSetDevice(c->opt.device));
   hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
   HIPCHK(hipGetLastError());
@@ -1233,8 +1260,52 @@ void vsrmc_options_default(vsrmc_options* o) {
   o->world = 1;
 }
 
-int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc_checker** out) {
-  if (!m || !o || !out) return fail(VSRMC_E_ARG, "NULL argument");
+// vsrmc_options with table_log2 == 0 and / or frontier_words == 0: sized from the free memory of the device.  Seen-set: the largest power
+// of two of 16-byte slots within 30 % of what is free (1.7e9 states at load 0.4 on an empty MI355X); sharded runs on ONE device (tests)
+// take their share.  Records: what is left after the seen-set, the index arrays (24 B per state index), the sent-filter and a reserve
+// for the scratch buffers of the deep search (vsr_deep.hpp: 1/4 + 1/16 + .. of one record buffer) and the exchange buffers of a sharded
+// run, in two equal buffers — the last two levels differ by the growth factor, but which of the two buffers holds the last one is not
+// known in advance; pending list: only the exact scheme needs one worth the name.
+static int autosize_options(vsrmc_options* o, const Model& M) {
+  if (o->table_log2 != 0 && o->frontier_words != 0) return 0;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipSetDevice(o->device));
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  const char* share_env = std::getenv("VSRMC_AUTOSIZE_SHARE");     // several checkers on one device (tests: ranks sharing a GPU): 1 / share each
+  const double share = share_env ? std::max(1.0, std::atof(share_env)) : 1.0;
+  double avail = ((double)free_b - 3.0e9) / share;                 // runtime, code objects, small allocations
+  if (avail < 256e6) return fail(VSRMC_E_HIP, "less than 256 MB of free device memory to size the checker from");
+  if (o->table_log2 == 0) {
+    int lg = 8;
+    while (lg < 36 && (double)((u64)1 << (lg + 1)) * 16.0 <= 0.30 * avail) lg++;
+    o->table_log2 = lg;
+  }
+  avail -= (double)((u64)1 << o->table_log2) * 16.0;
+  if (o->world > 1 && !o->exact_ties) avail -= (double)((u64)1 << (o->filter_log2 > 0 ? o->filter_log2 : o->table_log2)) * 8.0;
+  if (o->pending_entries == 0) o->pending_entries = o->exact_ties ? (u64)1 << 24 : (u64)1 << 16;
+  avail -= (double)o->pending_entries * 24.0;
+  if (o->frontier_words == 0) {
+    if (o->world > 1) avail *= 0.80;                               // candidate / verdict / rebalancing buffers of the level loop
+    // per record word: 8 B in each of two buffers, 1/24 state index (3 arrays of 8 B), a third of one buffer for the scratch buffers
+    const double per_word = 2.0 * 8.0 + 8.0 / 3.0 + 24.0 / 24.0;
+    const double words = avail / per_word;
+    if (words < 4096.0 * (M.fixed + M.max_bag)) return fail(VSRMC_E_HIP, "not enough free device memory for the record buffers");
+    o->frontier_words = (u64)words;
+    o->frontier_words_b = 0;
+    if (o->frontier_states == 0) o->frontier_states = std::max<u64>((u64)1 << 16, o->frontier_words / 24);
+  }
+  if (o->frontier_states == 0) o->frontier_states = std::max<u64>((u64)1 << 16, o->frontier_words / 24);
+  return 0;
+}
+
+int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o_in, vsrmc_checker** out) {
+  if (!m || !o_in || !out) return fail(VSRMC_E_ARG, "NULL argument");
+  vsrmc_options sized = *o_in;
+  {
+    const int rc0 = autosize_options(&sized, m->M);
+    if (rc0) return rc0;
+  }
+  const vsrmc_options* o = &sized;
   if (o->table_log2 < 8 || o->table_log2 > 36 || o->frontier_states < 1 || o->frontier_words < 256 ||
       o->pending_entries < 4 * (uint64_t)VSR_CAND_CAP)
     return fail(VSRMC_E_ARG, "bad options");
@@ -1291,6 +1362,12 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o, vsrmc
   rc = checker_seed(c);
   if (rc) { vsrmc_checker_destroy(c); return rc; }
   *out = c;
+  return 0;
+}
+
+int32_t vsrmc_checker_options(const vsrmc_checker* c, vsrmc_options* out) {
+  if (!c || !out) return fail(VSRMC_E_ARG, "NULL argument");
+  *out = c->opt;
   return 0;
 }
 
@@ -1409,9 +1486,12 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
 }
 
 // phase 2: k_materialize over a list of (slot-or-fp, key) entries into one target (next frontier or a peer's bucket)
+// (src_words / src_off: where the parents are read from — default: the current frontier; a slice of another buffer in the deep search)
 int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t* verdict, u64* t_words, u64 t_words_cap,
-                      u64* t_off, u64 t_cap, u64* t_fp, u64* cnt_n, u64* cnt_w, int entry_words, const u64* pidx_arr) {
+                      u64* t_off, u64 t_cap, u64* t_fp, u64* cnt_n, u64* cnt_w, int entry_words, const u64* pidx_arr,
+                      const u64* src_words = nullptr, const u64* src_off = nullptr) {
   if (n == 0) return 0;
+  if (!src_words) { src_words = c->words[c->cur]; src_off = c->off[c->cur]; }
   const Model& M = c->model.M;
   // persistent waves: each keeps private output chunks, so the grid is sized to what is resident (LDS: 5 waves / CU)
   u64 grid64 = std::min<u64>((n + VSR_MAT_BLOCK - 1) / VSR_MAT_BLOCK, (u64)c->num_cus * 5);
@@ -1422,7 +1502,7 @@ int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t
   unsigned grid = (unsigned)grid64;
   size_t lds = (size_t)VSR_MAT_BLOCK * c->lds_stride * 8;
   HIPCHK(hipEventRecord(c->ev[2], c->stream));
-  hipLaunchKernelGGL(materialize_kernel_for(M), dim3(grid), dim3(VSR_MAT_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur], entries, n,
+  hipLaunchKernelGGL(materialize_kernel_for(M), dim3(grid), dim3(VSR_MAT_BLOCK), lds, c->stream, M, src_words, src_off, entries, n,
                      c->table, t_words, t_words_cap, t_off, t_cap, t_fp, c->ctl, verdict, cnt_n, cnt_w, c->lds_stride, ichunk, wchunk,
                      entry_words, pidx_arr);
   HIPCHK(hipGetLastError());
@@ -1490,6 +1570,10 @@ int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
     c->cur_w = c->nx_w;
     c->cur_max_bag = h.max_bag;
     c->bag_known = c->opt.world == 1;
+    c->hist_new[0] = c->hist_new[1];
+    c->hist_new[1] = n_new;
+    c->g_last = (h.generated + std::max<u64>(1, info->frontier) - 1) / std::max<u64>(1, info->frontier) + 1;
+    c->cur_rec_w = h.rec_words;
   } else {
     c->n_frontier = 0;
     c->n_valid = 0;
@@ -1542,15 +1626,9 @@ static int32_t step_local(vsrmc_checker* c, vsrmc_level_info* info) {
 namespace {
 // One single-pass launch over an arbitrary source (a slice of the newest level, or the partial next frontier a MODE_REGEN
 // slice just wrote), unsharded.  Resets the level counters, returns them in c->h.  Destination = the next-frontier buffers.
-struct PassDst {            // where a MODE_REGEN pass writes (records, refs, fingerprints); nullptr members = the next-frontier buffers
-  u64* words = nullptr;
-  u64 words_cap = 0;
-  u64* off = nullptr;
-  u64* fp = nullptr;
-  u64 cap = 0;
-};
+// io != nullptr: a pass of a sharded run (vsr_deep.hpp) — successors owned by other ranks are announced into io's buckets
 int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 n_parents, u64 p_offset, int level, int mode,
-                u64 src_max_bag, const PassDst* dst = nullptr) {
+                u64 src_max_bag, const PassDst* dst = nullptr, const vsrmc_shard_io* io = nullptr) {
   const Model& M = c->model.M;
   std::memset(&c->h, 0, sizeof(c->h));
   c->h.viol_fp = ~(u64)0;
@@ -1558,8 +1636,19 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
   if (n_parents > 0) {
     // an ordinary level into other buffers (the streamed level's sub-slices) runs the plain instantiation: the code of a stored level
     static const bool plain_normal = std::getenv("VSRMC_STREAM_MODES_KERNEL") == nullptr;
-    const bool use_plain = mode == MODE_NORMAL && plain_normal && c->plain_kernel && c->plain_blk == VSR_BLOCK;
+    const bool use_plain = !io && mode == MODE_NORMAL && plain_normal && c->plain_kernel && c->plain_blk == VSR_BLOCK;
     const FusedShape fs = fused_shape(c, src_max_bag, use_plain);
+    u32 cchunk = 0;
+    if (io) {
+      if (c->cand_idx_cap < (u64)c->opt.world * io->cand_cap) {   // per announced candidate: where it was written / what regenerates it
+        if (c->cand_idx) (void)hipFree(c->cand_idx);
+        c->cand_idx = nullptr;
+        c->cand_idx_cap = 0;
+        HIPCHK(hipMalloc((void**)&c->cand_idx, (u64)c->opt.world * io->cand_cap * 8));
+        c->cand_idx_cap = (u64)c->opt.world * io->cand_cap;
+      }
+      cchunk = (u32)std::max<u64>(16, std::min<u64>(512, io->cand_cap / (4 * (u64)c->num_cus * 2)));
+    }
     const int tile = fs.tile;
     const u64 ntiles = (n_parents + tile - 1) / tile;
     const u32 ccap = fs.ccap;
@@ -1582,11 +1671,12 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(ichunk_max, nx_cap / (4 * (u64)grid)));
     const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    const void* kern = use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
+    const void* kern = io ? c->fused_kernel : use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
     hipLaunchKernelGGL((ExpandKernel)kern, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
-                       c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, 1, nullptr, (u64)0, (u32)VSR_CAND_CAP,
+                       c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, io ? c->opt.world : 1,
+                       io ? io->cand_send : nullptr, io ? io->cand_cap : (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
-                       ichunk, wchunk, tile, ccap, nullptr, (u64)0, nullptr, (u32)0,
+                       ichunk, wchunk, tile, ccap, io ? c->filter : nullptr, io ? c->fmask : (u64)0, io ? c->cand_idx : nullptr, cchunk,
                        mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -1659,373 +1749,8 @@ int min_violator(vsrmc_checker* c, u64 fp_min, u64* key) {
 }
 }  // namespace
 
-// Two levels beyond the last materialised one.  Level L+1 becomes a VIRTUAL level: its fingerprints are claimed and its states'
-// invariants checked (MODE_INSERT), but no record is stored.  Then the newest level is expanded AGAIN, slice by slice: the
-// successors that won their slot (key == final meta word, exactly one per new state) are written to the otherwise idle next
-// buffer (MODE_REGEN) and immediately expanded in probe mode (MODE_PROBE, level L+2), after which the slice's records are
-// dropped.  Cost: the newest level is expanded twice; memory: none beyond one slice.  virt = level L+1, probe = level L+2.
-int32_t vsrmc_checker_probe2(vsrmc_checker* c, vsrmc_level_info* virt, vsrmc_level_info* probe) {
-  if (!c || !virt || !probe) return fail(VSRMC_E_ARG, "NULL argument");
-  if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
-  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
-  if (c->level + 2 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
-  HIPCHK(hipSetDevice(c->opt.device));
-  std::memset(virt, 0, sizeof(*virt));
-  std::memset(probe, 0, sizeof(*probe));
-  virt->viol_fp = virt->viol_index = probe->viol_fp = probe->viol_index = ~(u64)0;
-  c->probe_fp = 0;
-  c->probe_level = 0;
-  c->probe_extra_fp = 0;
-  const double t0 = now_s();
-  c->expand_ms = 0;
-  // ---- pass 1: the virtual level
-  int rc = expand_pass(c, c->words[c->cur], c->off[c->cur], c->n_frontier, 0, c->level + 1, MODE_INSERT, c->bag_known ? c->cur_max_bag : (u64)c->model.M.max_bag);
-  c->failed = 1;                                               // whatever happens next, the seen-set now holds a level that has no frontier:
-  c->failed_code = 0;                                          // stepping on is impossible
-  if (rc) return rc;
-  virt->level = c->level + 1;
-  virt->frontier = c->n_frontier;
-  virt->generated = c->h.generated;
-  virt->deadlocks = c->h.deadlocks;
-  virt->n_new = c->h.n_new;
-  virt->distinct = c->distinct + c->h.n_new;
-  virt->total_generated = c->total_generated + c->h.generated;
-  virt->probes = c->h.probes;
-  virt->max_bag = c->h.max_bag;
-  for (int a = 0; a < 16; a++) virt->act_generated[a] = c->h.act_generated[a];
-  virt->fp_xor = c->h.fp_xor;
-  virt->fp_sum = c->h.fp_sum;
-  virt->expand_ms = c->expand_ms;
-  virt->seconds = now_s() - t0;
-  const u64 gen1 = c->h.generated, virt_max_bag = c->h.max_bag;
-  if (c->h.viol_fp != ~(u64)0) {                               // a violation already in level L+1: one probed step
-    virt->viol_fp = c->h.viol_fp;
-    virt->viol_mask = (int32_t)c->h.viol_mask;
-    c->probe_fp = c->h.viol_fp;                                 // the virtual level's states are in the seen-set: walk from the violator itself
-    c->probe_level = c->level + 1;
-    c->probe_extra_fp = 0;
-    return 0;
-  }
-  // ---- pass 2: slices of the newest level -> their part of level L+1 -> probe of level L+2
-  const double t1 = now_s();
-  c->expand_ms = 0;
-  const int nxt = c->cur ^ 1;
-  const u64 g = std::max<u64>(1, (gen1 + c->n_frontier - 1) / std::max<u64>(1, c->n_frontier));   // successors per parent, rounded up
-  const u64 nx_cap = c->opt.frontier_states;
-  // a slice may not produce more than a quarter of the next buffers (index range and words), chunk slack included
-  u64 slice = std::min<u64>(nx_cap / (4 * g), c->words_cap(nxt) / (4 * g * (u64)c->lds_stride));
-  slice = std::max<u64>(128, slice & ~(u64)127);
-  u64 best_fp = ~(u64)0, gen2 = 0, dead2 = 0, seen_bad = 0, probes2 = 0, regen = 0;
-  u32 mask2 = 0;
-  for (u64 a = 0; a < c->n_frontier; a += slice) {
-    const u64 n = std::min<u64>(slice, c->n_frontier - a);
-    rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, c->level + 1, MODE_REGEN, c->bag_known ? c->cur_max_bag : (u64)c->model.M.max_bag);
-    if (rc) return rc;
-    const u64 part_n = c->h.n_new;                             // index range of this slice's part of level L+1
-    regen += c->h.rec_words;
-    rc = expand_pass(c, c->words[nxt], c->off[nxt], part_n, 0, c->level + 2, MODE_PROBE, virt_max_bag);
-    if (rc) return rc;
-    gen2 += c->h.generated;
-    dead2 += c->h.deadlocks;
-    probes2 += c->h.probes;
-    seen_bad += c->h.n_pending;
-    if (c->h.viol_fp != ~(u64)0) {
-      mask2 |= c->h.viol_mask;
-      if (c->h.viol_fp < best_fp) {
-        u64 k2 = ~(u64)0;
-        rc = min_violator(c, c->h.viol_fp, &k2);
-        if (rc) return rc;
-        if (k2 != ~(u64)0) {                                    // its parent is a state of the virtual level: in the seen-set, found by its fingerprint bits
-          int found = 0;
-          u64 pfp = 0, pmeta = 0;
-          rc = table_lookup(c, meta_pfp(k2), c->level + 1, 1, &found, &pfp, &pmeta);
-          if (rc) return rc;
-          if (found > 1) return fail(VSRMC_E_STATE, "ambiguous predecessor pointer: several states of the parent's level share the 45 fingerprint bits the violating successor keeps of its parent");
-          if (found) {
-            best_fp = c->h.viol_fp;
-            c->probe_fp = pfp;
-            c->probe_level = c->level + 1;
-            c->probe_extra_fp = c->h.viol_fp;
-          }
-        }
-      }
-    }
-  }
-  probe->level = c->level + 2;
-  probe->frontier = virt->n_new;
-  probe->generated = gen2;
-  probe->deadlocks = dead2;
-  probe->probes = probes2;
-  probe->pending = seen_bad;
-  probe->record_words = regen;
-  probe->distinct = virt->distinct;
-  probe->total_generated = virt->total_generated + gen2;
-  probe->expand_ms = c->expand_ms;
-  probe->seconds = now_s() - t1;
-  if (best_fp != ~(u64)0) {
-    probe->viol_fp = best_fp;
-    probe->viol_mask = (int32_t)mask2;
-  }
-  return 0;
-}
-
-// Three levels beyond the last materialised one: level L+1 is a VIRTUAL level, level L+2 is streamed through a scratch buffer
-// (inserted into the seen-set, never kept), level L+3 is probed.
-//   pass 1: level L expanded, MODE_INSERT                      -> level L+1 exists as seen-set entries (exact count, final keys)
-//   pass 2: for each slice of L:      MODE_REGEN into the next buffers            = that slice's part of level L+1
-//             for each sub-slice:     MODE_NORMAL into the scratch buffers        = new level-(L+2) states, inserted + written
-//                                     MODE_PROBE over the scratch buffers         = invariants of their successors (level L+3)
-// Level L+1 must be complete in the seen-set before the first level-(L+2) state is inserted (else a state of L+1 met first
-// as a successor of L+1 would be filed one level too deep).  Level L+2 is NOT complete while level L+3 is probed, and that
-// matters: the invariants read aux variables that are outside the VIEW (VSR.tla:102-104), so a successor with the fingerprint
-// of a level-(L+2) state that is not inserted yet can look violating although the search never visits it (TLC drops it as
-// seen).  The probe passes therefore only COLLECT violating successors (fingerprint, key); when level L+2 is complete the
-// ones that are states of a level < L+3 are dropped (k_table_seen) and the smallest remaining fingerprint is the violation.
-// Cost: level L is expanded twice, levels L+1 and L+2 once.  Slice sizes adapt to the fill of the buffers (first slice: worst-case sizing).  On the README
-// defect configuration this takes one MI355X from level 21 — the last level whose records fit the HBM next
-// to the seen-set — to the depth-24 violation without touching host memory.
-int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_level_info* virt2, vsrmc_level_info* probe) {
-  if (!c || !virt1 || !virt2 || !probe) return fail(VSRMC_E_ARG, "NULL argument");
-  if (c->opt.world > 1 || c->opt.exact_ties) return fail(VSRMC_E_STATE, "probe levels need an unsharded single-pass checker");
-  if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
-  if (c->level + 3 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
-  HIPCHK(hipSetDevice(c->opt.device));
-  std::memset(virt1, 0, sizeof(*virt1));
-  std::memset(virt2, 0, sizeof(*virt2));
-  std::memset(probe, 0, sizeof(*probe));
-  virt1->viol_fp = virt1->viol_index = virt2->viol_fp = virt2->viol_index = probe->viol_fp = probe->viol_index = ~(u64)0;
-  c->probe_fp = 0;
-  c->probe_level = 0;
-  c->probe_extra_fp = 0;
-  const Model& M = c->model.M;
-  const int L = c->level, nxt = c->cur ^ 1;
-  const u64 bagL = c->bag_known ? c->cur_max_bag : (u64)M.max_bag;
-  // ---- pass 1: virtual level L+1
-  double t0 = now_s();
-  c->expand_ms = 0;
-  int rc = expand_pass(c, c->words[c->cur], c->off[c->cur], c->n_frontier, 0, L + 1, MODE_INSERT, bagL);
-  c->failed = 1;                                               // the seen-set now holds levels that have no frontier: stepping on is impossible
-  c->failed_code = 0;
-  if (rc) return rc;
-  virt1->level = L + 1;
-  virt1->frontier = c->n_frontier;
-  virt1->generated = c->h.generated;
-  virt1->deadlocks = c->h.deadlocks;
-  virt1->n_new = c->h.n_new;
-  virt1->distinct = c->distinct + c->h.n_new;
-  virt1->total_generated = c->total_generated + c->h.generated;
-  virt1->probes = c->h.probes;
-  virt1->max_bag = c->h.max_bag;
-  for (int a = 0; a < 16; a++) virt1->act_generated[a] = c->h.act_generated[a];   // per action, like a stored level
-  virt1->fp_xor = c->h.fp_xor;
-  virt1->fp_sum = c->h.fp_sum;
-  virt1->expand_ms = c->expand_ms;
-  virt1->seconds = now_s() - t0;
-  const u64 gen1 = c->h.generated, bag1 = std::min<u64>(c->h.max_bag, (u64)M.max_bag);
-  if (c->h.viol_fp != ~(u64)0) {
-    virt1->viol_fp = c->h.viol_fp;
-    virt1->viol_mask = (int32_t)c->h.viol_mask;
-    c->probe_fp = c->h.viol_fp;
-    c->probe_level = L + 1;
-    return 0;
-  }
-  // ---- pass 2
-  t0 = now_s();
-  c->expand_ms = 0;
-  struct Scratch {
-    PassDst d;
-    ~Scratch() {
-      if (d.words) (void)hipFree(d.words);
-      if (d.off) (void)hipFree(d.off);
-      if (d.fp) (void)hipFree(d.fp);
-    }
-  } scratch;
-  PassDst& B = scratch.d;                                      // scratch buffers: a quarter of the next buffers' size
-  B.words_cap = std::max<u64>((u64)1 << 22, c->words_cap(nxt) / 4);
-  B.cap = std::max<u64>((u64)1 << 16, c->opt.frontier_states / 4);
-  hipError_t e = hipMalloc((void**)&B.words, B.words_cap * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&B.off, (B.cap + 1) * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&B.fp, B.cap * 8);
-  if (e != hipSuccess) return fail(VSRMC_E_HIP, std::string("hipMalloc of the probe3 scratch buffers: ") + hipGetErrorString(e));
-  // Slice sizes.  A target buffer loses up to a quarter to the blocks' unfinished chunks; states and words of a slice are
-  // budgeted at a third of it (1.5x headroom over the expectation).
-  //  * slices of level L: MODE_REGEN writes a state where its min-key parent sits — keys order by the parent's fingerprint,
-  //    so the new states spread evenly over the parents: (level-(L+1) states per valid parent, known exactly from pass 1) x
-  //    (average record of level L + 2 words);
-  //  * sub-slices of level L+1: MODE_NORMAL is first come, first served — early sub-slices find more new states per parent than
-  //    late ones, and the index range they come from is dense at its start (the holes of unfinished chunks sit at its end):
-  //    the first sub-slice is sized for the worst case (every generated successor new, of the largest size), later ones by
-  //    the largest per-position yield seen so far.
-  const u64 g1 = std::max<u64>(1, (gen1 + c->n_frontier - 1) / std::max<u64>(1, c->n_frontier));
-  auto worst_size = [&](u64 cap_n, u64 cap_w) {
-    const u64 sz = std::min<u64>(cap_n / (4 * g1), cap_w / (4 * g1 * (u64)c->lds_stride));
-    return std::max<u64>(128, sz & ~(u64)127);
-  };
-  auto sized = [&](u64 cap_n, u64 cap_w, double per_n, double per_w) {
-    const double sz = std::min((double)cap_n / (3.0 * std::max(per_n, 1e-3)), (double)cap_w / (3.0 * std::max(per_w, 1e-3)));
-    return std::max<u64>(128, (u64)std::min(sz, 1e15) & ~(u64)127);
-  };
-  const double nbar1 = (double)virt1->n_new / (double)std::max<u64>(1, c->n_valid);
-  const double wbar1 = (double)c->cur_w / (double)std::max<u64>(1, c->n_valid) + 2.0;
-  const u64 slice = std::max<u64>(worst_size(c->opt.frontier_states, c->words_cap(nxt)),
-                                  sized(c->opt.frontier_states, c->words_cap(nxt), nbar1, nbar1 * wbar1));
-  u64 sub = worst_size(B.cap, B.words_cap);
-  double yield_n = 0, yield_w = 0;
-  u64 n2 = 0, gen2 = 0, dead2 = 0, probes2 = 0, bag2 = 0, viol2 = ~(u64)0, words2 = 0, n_slices = 0, n_subs = 0;
-  u64 gen3 = 0, dead3 = 0, probes3 = 0, fx2 = 0, fs2 = 0, act2[16] = {0}, act3[16] = {0};
-  u64* d_sum = nullptr;
-  if (hipMalloc((void**)&d_sum, 24) != hipSuccess) return fail(VSRMC_E_HIP, "hipMalloc");
-  struct FreeSum { u64* p; ~FreeSum() { (void)hipFree(p); } } free_sum{d_sum};
-  std::vector<u64> bad;                                        // (fingerprint, key) of the violating successors the probe passes saw
-  u32 mask2 = 0, mask3 = 0;
-  double ms2 = 0, ms3 = 0;
-  for (u64 a = 0; a < c->n_frontier && !rc;) {
-    const u64 n = std::min<u64>(slice, c->n_frontier - a);
-    c->expand_ms = 0;
-    rc = expand_pass(c, c->words[c->cur], c->off[c->cur] + a, n, a, L + 1, MODE_REGEN, bagL);
-    if (rc) break;
-    ms2 += c->expand_ms;
-    a += n;
-    n_slices++;
-    const u64 part = c->h.n_new;                               // index range of this slice's part of level L+1 (holes included)
-    for (u64 b = 0; b < part && !rc;) {
-      const u64 nb = std::min<u64>(sub, part - b);
-      c->expand_ms = 0;
-      rc = expand_pass(c, c->words[nxt], c->off[nxt] + b, nb, b, L + 2, MODE_NORMAL, bag1, &B);
-      if (rc) break;
-      ms2 += c->expand_ms;
-      b += nb;
-      n_subs++;
-      const u64 part2 = c->h.n_new;
-      gen2 += c->h.generated;
-      for (int a = 0; a < 16; a++) act2[a] += c->h.act_generated[a];
-      dead2 += c->h.deadlocks;
-      probes2 += c->h.probes;
-      words2 += c->h.rec_words;
-      bag2 = std::max<u64>(bag2, c->h.max_bag);
-      if (c->h.ties) {
-        rc = fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables (SURVEY F2)");
-        break;
-      }
-      if (c->h.viol_fp != ~(u64)0) {
-        mask2 |= c->h.viol_mask;
-        viol2 = std::min<u64>(viol2, c->h.viol_fp);
-      }
-      if (part2) {
-        {   // checksums of the streamed level: the sub-slice's fingerprints sit in the scratch buffer until it is reused
-          u64 hsum[3] = {0, 0, 0};
-          if (hipMemsetAsync(d_sum, 0, 24, c->stream) != hipSuccess) { rc = fail(VSRMC_E_HIP, "probe3: hipMemsetAsync"); break; }
-          hipLaunchKernelGGL(k_level_checksum, dim3(1024), dim3(256), 0, c->stream, B.fp, part2, d_sum);
-          if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hsum, d_sum, 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-              hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(VSRMC_E_HIP, "probe3: k_level_checksum"); break; }
-          fx2 ^= hsum[0];
-          fs2 += hsum[1];
-        }
-        const u64 cnt = c->h.n_written;                          // records written = new level-(L+2) states of this sub-slice
-        n2 += cnt;
-        yield_n = std::max(yield_n, (double)cnt / (double)nb);
-        yield_w = std::max(yield_w, (double)c->h.rec_words / (double)nb);
-        sub = std::max<u64>(worst_size(B.cap, B.words_cap), sized(B.cap, B.words_cap, yield_n, yield_w));
-      }
-      if (viol2 != ~(u64)0 || part2 == 0) continue;            // a violation one level up: level L+2 is completed, nothing deeper is probed
-      c->expand_ms = 0;
-      rc = expand_pass(c, B.words, B.off, part2, 0, L + 3, MODE_PROBE, std::min<u64>(c->h.max_bag, (u64)M.max_bag));
-      if (rc) break;
-      ms3 += c->expand_ms;
-      gen3 += c->h.generated;
-      for (int a = 0; a < 16; a++) act3[a] += c->h.act_generated[a];
-      dead3 += c->h.deadlocks;
-      probes3 += c->h.probes;
-      if (c->h.n_pending) {
-        mask3 |= c->h.viol_mask;
-        if (c->h.n_pending > c->opt.pending_entries || bad.size() / 2 + c->h.n_pending > ((u64)1 << 24)) {
-          rc = fail(VSRMC_E_REP, "more violating successors in the probed level than the pending list holds (pending_entries)");
-          break;
-        }
-        const size_t at = bad.size();
-        bad.resize(at + 2 * c->h.n_pending);
-        HIPCHK(hipMemcpy(bad.data() + at, c->pending, 16 * c->h.n_pending, hipMemcpyDeviceToHost));
-      }
-    }
-  }
-  if (rc) return rc;
-  const double dt2 = now_s() - t0;
-  virt2->level = L + 2;
-  virt2->frontier = virt1->n_new;
-  virt2->generated = gen2;
-  for (int a = 0; a < 16; a++) virt2->act_generated[a] = act2[a];
-  virt2->deadlocks = dead2;
-  virt2->n_new = n2;
-  virt2->distinct = virt1->distinct + n2;
-  virt2->total_generated = virt1->total_generated + gen2;
-  virt2->probes = probes2;
-  virt2->max_bag = bag2;
-  virt2->fp_xor = fx2;
-  virt2->fp_sum = fs2;
-  virt2->record_words = words2;
-  virt2->pending = n_slices << 32 | n_subs;                    // (slices of level L) << 32 | sub-slices of level L+1
-  virt2->expand_ms = ms2;
-  virt2->seconds = dt2 * (ms2 / std::max(1e-9, ms2 + ms3));   // the two levels share the pass: split by kernel time
-  if (viol2 != ~(u64)0) {
-    virt2->viol_fp = viol2;
-    virt2->viol_mask = (int32_t)mask2;
-    c->probe_fp = viol2;
-    c->probe_level = L + 2;
-    c->probe_extra_fp = 0;
-    return 0;
-  }
-  probe->level = L + 3;
-  probe->frontier = n2;
-  probe->generated = gen3;
-  for (int a = 0; a < 16; a++) probe->act_generated[a] = act3[a];
-  probe->deadlocks = dead3;
-  probe->probes = probes3;
-  probe->distinct = virt2->distinct;
-  probe->total_generated = virt2->total_generated + gen3;
-  probe->expand_ms = ms3;
-  probe->seconds = dt2 - virt2->seconds;
-  // level L+2 is complete now: which of the collected successors are states of level L+3?
-  const u64 nbad = bad.size() / 2;
-  if (nbad) {
-    std::vector<std::pair<u64, u64>> pairs(nbad);
-    for (u64 i = 0; i < nbad; i++) pairs[i] = std::make_pair(bad[2 * i], bad[2 * i + 1]);
-    std::sort(pairs.begin(), pairs.end());                     // by fingerprint, then key
-    std::vector<u64> fps, flags;
-    for (u64 i = 0; i < nbad; i++)
-      if (i == 0 || pairs[i].first != pairs[i - 1].first) fps.push_back(pairs[i].first);
-    flags.assign(fps.size(), 0);
-    std::vector<uint8_t> seen8(fps.size(), 0);
-    rc = vsrmc_checker_seen_batch(c, fps.data(), (u64)fps.size(), L + 3, seen8.data());
-    if (rc) return rc;
-    for (size_t i = 0; i < fps.size(); i++) flags[i] = seen8[i];
-    u64 first = ~(u64)0, k3 = ~(u64)0;
-    size_t g = 0;                                              // group index = index into fps
-    for (u64 i = 0; i < nbad; i++) {
-      if (i && pairs[i].first != pairs[i - 1].first) g++;
-      if (flags[g]) continue;
-      probe->pending++;                                        // violating successors seen, duplicates included
-      if (first == ~(u64)0) {
-        first = pairs[i].first;                                // smallest fingerprint; of its entries the smallest key
-        k3 = pairs[i].second;
-      }
-    }
-    if (first != ~(u64)0) {
-      int found = 0;
-      u64 pfp = 0, pmeta = 0;                                  // its parent: the level-(L+2) state with these fingerprint bits, in the seen-set
-      rc = table_lookup(c, meta_pfp(k3), L + 2, 1, &found, &pfp, &pmeta);
-      if (rc) return rc;
-      if (found > 1) return fail(VSRMC_E_STATE, "ambiguous predecessor pointer: several states of the parent's level share the 45 fingerprint bits the violating successor keeps of its parent");
-      probe->viol_fp = first;
-      probe->viol_mask = (int32_t)mask3;
-      if (found) {
-        c->probe_fp = pfp;
-        c->probe_level = L + 2;
-        c->probe_extra_fp = first;
-      }
-    }
-  }
-  return 0;
-}
+// ---- levels beyond the record buffers: virtual / regenerated / streamed / probed levels, vsrmc_checker_deepen, _probe2, _probe3
+#include "vsr_deep.hpp"
 
 // Probe level: expand the newest level WITHOUT storing its successors — every successor that is not a state of an earlier
 // level gets its invariants checked, nothing is inserted into the seen-set, no frontier is written.  The search cannot
@@ -2127,6 +1852,7 @@ int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t ca
 int32_t vsrmc_checker_step(vsrmc_checker* c, vsrmc_level_info* info) {
   if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
+  if (c->deep) return fail(VSRMC_E_STATE, "levels beyond the record buffers exist in the seen-set (vsrmc_checker_deepen): the search goes on with vsrmc_checker_deepen / _advance");
   if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: drive the level with the vsrmc_shard_* phases");
   return step_local(c, info);
 }
@@ -2163,19 +1889,61 @@ int32_t vsrmc_shard_partition(vsrmc_checker* c, uint64_t* n_kept) {
   return 0;
 }
 
+// Will the next level fit the idle record buffer?  Level sizes of these models grow by a factor that FALLS from level to level once the
+// search is past its first few levels (tests/golden/oracle_levels_*.json: r(l+1) / r(l) is 0.92 .. 0.99 everywhere beyond level 10), so
+// the last level's factor bounds the next one's; records grow by at most one bag entry per level.  Small levels are bounded by the
+// successors generated per state instead.  A wrong "yes" ends in ERR_FRONTIER_FULL, a wrong "no" only costs a level of re-expansion.
+static bool next_level_fits(const vsrmc_checker* c) {
+  const u64 n = c->n_valid;
+  if (n == 0) return true;
+  double pred;
+  if (n < 32768 || c->hist_new[0] == 0) pred = (double)n * (double)std::max<u64>(2, c->g_last) * 1.25;
+  else pred = (double)n * std::min((double)c->g_last, (double)c->hist_new[1] / (double)c->hist_new[0] * 1.02);
+  const double wbar = (double)std::max<u64>(c->cur_rec_w, (u64)c->model.M.fixed * n) / (double)n + 1.0;
+  const int nxt = c->cur ^ 1;
+  const double blocks = 4.0 * c->num_cus;                        // every resident block leaves a partly used word and index chunk behind
+  const double cap_w = (double)c->words_cap(nxt), cap_n = (double)c->opt.frontier_states;
+  return pred * wbar + std::min(blocks * 262144.0, cap_w / 4) <= cap_w && pred * 1.09 + std::min(blocks * 8192.0, cap_n / 4) <= cap_n;
+}
+
+// One unit of progress of the automatic level scheme (no level numbers, no sizes from the caller): an ordinary BFS level while the
+// next one is predicted to fit the record buffers (*what = 1: a = that level), otherwise one pass of the deep search — the next level
+// inserted into the seen-set only, the one after it probed (*what = 2: a = the inserted level, b = the probed one, b->level == 0 when the
+// pass probed nothing).  a->n_new == 0: the search is exhausted.
+int32_t vsrmc_checker_advance(vsrmc_checker* c, vsrmc_level_info* a, vsrmc_level_info* b, int32_t* what) {
+  if (!c || !a || !b || !what) return fail(VSRMC_E_ARG, "NULL argument");
+  std::memset(b, 0, sizeof(*b));
+  b->viol_fp = b->viol_index = ~(u64)0;
+  if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: vsrmc_shard_loop_advance");
+  if (!c->deep && (c->opt.exact_ties || next_level_fits(c))) {
+    *what = 1;
+    return vsrmc_checker_step(c, a);
+  }
+  *what = 2;
+  return vsrmc_checker_deepen(c, a, b);
+}
+
+// ≙ ModelChecker.run: stop_reason 0 = exhausted, 1 = invariant violated (*last = the level it was found in; a probed level: see
+// vsrmc_checker_probe_trace), 2 = max_depth, 3 = max_seconds, 4 = the seen-set is 85 % full (the search is incomplete: depth reached
+// = last->level)
 int32_t vsrmc_check(vsrmc_checker* c, int32_t max_depth, double max_seconds, int32_t* stop_reason, vsrmc_level_info* last) {
   if (!c || !stop_reason || !last) return fail(VSRMC_E_ARG, "NULL argument");
   const double t0 = now_s();
   std::memset(last, 0, sizeof(*last));
   last->level = c->level;
   last->distinct = c->distinct;
+  vsrmc_level_info a, b;
   while (true) {
-    if (max_depth > 0 && c->level >= max_depth) { *stop_reason = 2; return 0; }
+    if (max_depth > 0 && c->level + c->deep >= max_depth) { *stop_reason = 2; return 0; }
     if (max_seconds > 0 && now_s() - t0 > max_seconds) { *stop_reason = 3; return 0; }
-    int rc = vsrmc_checker_step(c, last);
+    if ((double)(c->deep ? c->deep_distinct : c->distinct) > 0.85 * (double)(c->tmask + 1)) { *stop_reason = 4; return 0; }
+    int32_t what = 0;
+    int rc = vsrmc_checker_advance(c, &a, &b, &what);
     if (rc) return rc;
-    if (last->viol_mask) { *stop_reason = 1; return 0; }
-    if (last->n_new == 0) { *stop_reason = 0; return 0; }
+    *last = a;
+    if (a.viol_mask) { *stop_reason = 1; return 0; }
+    if (a.n_new == 0) { *stop_reason = 0; return 0; }
+    if (what == 2 && b.level && b.viol_mask) { *last = b; *stop_reason = 1; return 0; }
   }
 }
 
@@ -2368,6 +2136,7 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   if (!c || !path) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   if (c->opt.world > 1 && c->opt.exact_ties) return fail(VSRMC_E_STATE, "checkpoints of sharded exact-mode checkers are not supported");
+  if (c->deep) return fail(VSRMC_E_STATE, "the seen-set holds levels beyond the newest materialised one (vsrmc_checker_deepen): no checkpoint can describe that state");
   HIPCHK(hipSetDevice(c->opt.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   const Model& M = c->model.M;
@@ -2747,6 +2516,11 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
     if (c->off[b]) (void)hipFree(c->off[b]);
   }
   if (c->lvl_fp) (void)hipFree(c->lvl_fp);
+  for (PassDst& B : c->scratch) {
+    if (B.words) (void)hipFree(B.words);
+    if (B.off) (void)hipFree(B.off);
+    if (B.fp) (void)hipFree(B.fp);
+  }
   if (c->pending) (void)hipFree(c->pending);
   if (c->ctl) (void)hipFree(c->ctl);
   if (c->d_find) (void)hipFree(c->d_find);
