@@ -9,20 +9,25 @@ transfer-defect configuration (BASELINE.json configs[2]: ReplicaCount=3, ClientC
 VIEW + SYMMETRY on, INVARIANT AcknowledgedWriteNotLost; /root/reference/README.md:13-18).  One "step" = one complete run of the hot
 path: level-synchronous BFS from Init until the first invariant violation is found and its counter-example reconstructed —
 depth 24, 1 821 858 767 distinct states, 8.9e9 successors generated; the seen-set is cleared at the start of every step, HBM
-allocations are reused.  `value` = distinct states of the K timed runs / their wall time (barrier + torch.cuda.synchronize() on both
-sides), `time_to_first_violation_s` = one run.  The `config2` object beside it holds the same figures for BASELINE configs[1] (the
-shipped VSR.cfg constants: 28 levels, 319 228 361 distinct states) — the headline of rounds 1-2, and the headline again when the
-README configuration cannot run (less than ~250 GB of free HBM) or with --workload config2 / --no-config3.
+allocations are reused.  No level number and no buffer size comes from this file: the checker sizes itself from the free HBM and the
+automatic level scheme (ModelChecker.advance) stores a level while the next one is predicted to fit, then goes on through the seen-set
+alone.  `value` = distinct states of the K timed runs / their wall time (barrier + torch.cuda.synchronize() on both sides),
+`time_to_first_violation_s` = one run.  The `config2` object beside it holds the same figures for BASELINE configs[1] (the shipped
+VSR.cfg constants: 28 levels, 319 228 361 distinct states) — the headline of rounds 1-2, and the headline only with --workload config2 /
+--no-config3: a README leg that cannot run is an error of the bench (non-zero exit), not a reason to print another workload's number.
 Inputs are the model itself (deterministic, no data files): "synthetic" in the contract's sense.  Every run asserts every level's
 figures against the CPU oracle's fixtures (tests/golden/oracle_levels_config{2,3}.json); a wrong count aborts the bench.
 
-N > 1: the seen-set is sharded by the high fingerprint bits, one rank per GPU, successors routed to their owner with
-an all-to-all per level (vsr_tlaplus_amd/sharded.py); total work is fixed as N grows ("strong").
+N > 1: the SAME workload — the README defect configuration — with the seen-set sharded by the high fingerprint bits, one rank per GPU,
+successors routed to their owner with an all-to-all per level / pass (vsr_tlaplus_amd/sharded_bench.py over the C++ level loop); total
+work is fixed as N grows ("strong").  The automatic level scheme decides per run what is stored: at N >= 4 every level up to the
+violation, at N = 2 the last levels live in the two seen-sets only.
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (k_expand: algorithmic bytes / HIP-event time on the checker's
 stream; `traffic` = the committed PMC figure when it was measured on THIS build's kernel sources, else null), `cpu_baseline` = the
-CPU oracle (a port, not TLC) timed on this box's host cores on a bounded sample of the headline's configuration, and
-`fingerprint_collision_estimate` (TLC's n^2 / 2^65).
+CPU oracle (a port, not TLC) timed on this box's host cores on a bounded sample of the headline's configuration,
+`fingerprint_collision_estimate` (TLC's n^2 / 2^65) and `collision_audit` (the untimed verification runs repeated under a second member
+of the fingerprint family, vsrmc_model_set_fp_seed: every per-level count must equal the oracle fixture's under both).
 """
 import argparse
 import json
@@ -428,7 +433,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("VSR_BENCH_SHARDED"):   # VSR_BENCH_SHARDED=1: the N > 1 leg on one rank
         from vsr_tlaplus_amd import sharded_bench
-        return sharded_bench.main(args, CONFIG, EXPECT)
+        return sharded_bench.main(args, sys.modules[__name__])
     want_readme = args.workload in ("auto", "readme", "config3") and not args.no_config3
     want_c2 = args.workload in ("auto", "config2") and not args.no_config2
     c2 = rd = None

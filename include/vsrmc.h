@@ -419,6 +419,15 @@ void vsrmc_shard_loop_destroy(vsrmc_shard_loop* l);
 int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsrmc_level_info* local);
 /* ≙ vsrmc_check: stop_reason 0 exhausted, 1 invariant violated, 2 max_depth */
 int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t stop_on_violation, int32_t* stop_reason, vsrmc_level_info* last);
+/* vsrmc_checker_deepen / vsrmc_checker_advance for a sharded run (collective; figures over all ranks): levels beyond the ranks' record
+ * buffers live in the ranks' seen-sets only and are regenerated from the newest stored level; every pass of the descent is the
+ * protocol of a sharded level with other sources and targets (csrc/vsr_shard_loop.hpp).  advance: an ordinary sharded level while EVERY
+ * rank predicts that its part of the next one fits, else deepen.  vsrmc_shard_loop_run is the loop over advance (stop_reason 4: a
+ * rank's seen-set is 85 % full). */
+int32_t vsrmc_shard_loop_deepen(vsrmc_shard_loop* l, vsrmc_level_info* inserted, vsrmc_level_info* probed);
+int32_t vsrmc_shard_loop_advance(vsrmc_shard_loop* l, vsrmc_level_info* a, vsrmc_level_info* b, int32_t* what);
+/* the fingerprints of the counter-example of a violation a probe pass found (collective), Init first; *n = its length */
+int32_t vsrmc_shard_loop_probe_trace_fps(vsrmc_shard_loop* l, uint64_t* fps, int32_t cap, int32_t* n);
 int32_t vsrmc_shard_loop_status(vsrmc_shard_loop* l, int32_t* level, uint64_t* distinct, uint64_t* n_frontier, int32_t* replicated,
                                 uint64_t* viol_fp, int32_t* viol_mask, int32_t* viol_level, uint64_t* moved, uint64_t* bytes_sent);
 /* TLCTrace.getTrace across ranks (collective): fps[0 .. level) = fingerprints of the path Init -> the level-`level` state `fp`;

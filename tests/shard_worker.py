@@ -81,7 +81,10 @@ def main():
         if fp:
             walks.append(dict(rank=r, level=sc.level, fp="%016x" % fp, fps=["%016x" % f for f in sc.trace_fps(sc.level, fp)]))
     with open("%s.rank%d.json" % (out, rank), "w") as f:
-        json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks,
+        viol = None
+        if sc.violation is not None:
+            viol = dict(level=sc.violation["level"], fp="%016x" % sc.violation["fp"], mask=sc.violation["mask"])
+        json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks, violation=viol,
                        bytes_sent=sc.x.bytes_sent, moved=sc.moved, probe=probe, restored=restored), f)
     dist.barrier()
     dist.destroy_process_group()

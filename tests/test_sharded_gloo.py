@@ -279,3 +279,108 @@ print("OK", len(runs[0]))
 """ % ROOT)
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the automatic level scheme on a sharded run: levels beyond the ranks' record buffers (vsrmc_shard_loop_advance / _deepen)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_deep_world(world, params, inv_mask, max_depth, tmp_path, port, fw_log2=0, replicate_below=0):
+    out = str(tmp_path / ("deep_w%d" % world))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "shard_deep_worker.py")] + [str(x) for x in params] + \
+          [str(inv_mask), str(max_depth), out, str(fw_log2), str(replicate_below)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ranks = [json.load(open("%s.rank%d.json" % (out, k))) for k in range(world)]
+    # seconds / launches are the rank's own; act_generated[0] is not a count (a shader clock rides in that slot)
+    strip = lambda lv: {k: (v[1:] if k == "act_generated" else v) for k, v in lv.items() if k not in ("seconds", "launches")}   # noqa: E731
+    for r_ in ranks[1:]:                                                 # every figure is the level's, the same on every rank
+        assert ([strip(x) for x in r_["levels"]], r_["probed"], r_["violation"], r_["path"], r_["distinct"]) == \
+            ([strip(x) for x in ranks[0]["levels"]], ranks[0]["probed"], ranks[0]["violation"], ranks[0]["path"], ranks[0]["distinct"])
+    return ranks[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,rb", [(2, 0), (3, 300)])
+def test_sharded_deep_levels_against_the_oracle(tmp_path, world, rb):
+    """(3,1,{v1,v2},1) with AcknowledgedWritesExistOnMajority (violated at depth 19, 109 878 states) on 2 / 3 ranks with record buffers
+    of 2^17 words: a few sharded levels are stored, the rest live in the ranks' seen-sets only — virtual, regenerated (every rank's
+    candidates shown to their owners, the one carrying the slot's final key rebuilt by k_materialize), streamed and probed levels, each
+    held against the oracle: new states, successors in total and per action, deadlocks, largest bag, and for the levels that are never
+    stored the xor / sum of their fingerprints.  The violation is found by a probe pass; its counter-example replays in the oracle."""
+    from oracle import orc
+    params, inv = (3, 1, 2, 1), 2
+    got = run_deep_world(world, params, inv, 19, tmp_path, 29690 + world, fw_log2=17, replicate_below=rb)
+    P = orc.Params(*params, invariant_mask=inv)
+    ob = orc.Bfs(P)
+    kinds = [lv["kind"] for lv in got["levels"]]
+    assert "level" in kinds and kinds.count("deep") >= 5 and kinds == sorted(kinds, key=lambda k: k == "deep"), kinds
+    for lv in got["levels"]:
+        n = ob.step()
+        assert lv["level"] == ob.info["depth"]
+        assert (lv["n_new"], lv["generated"], lv["deadlocks"]) == (n, ob.info["generated"], ob.info["deadlocks"]), lv["level"]
+        if lv["kind"] == "deep":
+            fps = ob.level_fps(lv["level"])
+            assert lv["fp_xor"] == "%016x" % int(np.bitwise_xor.reduce(fps)), lv["level"]
+            assert lv["fp_sum"] == "%016x" % (int(fps.astype(object).sum()) & ((1 << 64) - 1)), lv["level"]
+    assert got["levels"][-1]["level"] == 18 and got["distinct"] == ob.info["distinct"] == 109878
+    ob.step()
+    words, off = ob.frontier()
+    viol = min(orc.fingerprint(P, words[int(off[i]): int(off[i + 1])])[0] for i in range(len(off) - 1)
+               if orc.invariants(P, words[int(off[i]): int(off[i + 1])]))
+    assert got["violation"] == dict(level=19, fp="%016x" % viol, mask=2, probed=True)
+    assert got["probed"]["generated"] == ob.info["generated"] and got["probed"]["deadlocks"] == ob.info["deadlocks"]
+    path = [int(f, 16) for f in got["path"]]
+    rec = orc.init_record(P)
+    assert len(path) == 19 and orc.fingerprint(P, rec)[0] == path[0]
+    for f in path[1:]:
+        nxt = [s for s in orc.successors(P, rec) if s["fp"] == f]
+        assert nxt, "a state of the counter-example is not a successor of its predecessor"
+        rec, bad = nxt[0]["words"], nxt[0]["inv"]
+    assert bad == 2
+
+
+@pytest.mark.gpu
+def test_readme_configuration_on_two_ranks(tmp_path, oracle_levels):
+    """BASELINE configs[2] (the reference README's defect configuration) through the sharded path at world 2, both ranks on this GPU with
+    half of its memory each (sizes from the free HBM, no level numbers): all 23 levels of the CPU oracle's fixture — the stored ones and
+    the ones that exist in the two seen-sets only — and the probe's violator 042ca5372e82d6fb at depth 24, with a 24-state path."""
+    g = oracle_levels["config3"]
+    p = g["params"]
+    got = run_deep_world(2, (p["R"], p["C"], p["n"], p["L"]), p["inv_mask"], 23, tmp_path, 29697)
+    assert len(got["levels"]) == 22 and "deep" in [lv["kind"] for lv in got["levels"]]
+    for lv, want in zip(got["levels"], g["levels"][1:]):
+        assert (lv["level"], lv["n_new"], lv["generated"], lv["deadlocks"], lv["max_bag"]) == \
+            (want["level"], want["new"], want["generated"], want["deadlocks"], want["max_bag"]), want["level"]
+        assert lv["act_generated"][1:16] == want["act_generated"][1:16], want["level"]
+        if lv["kind"] == "deep" and g["checksums"]:
+            assert (lv["fp_xor"], lv["fp_sum"]) == (want["fp_xor"], want["fp_sum"]), want["level"]
+    assert got["distinct"] == g["distinct"]
+    pr = g["probe"]
+    assert (got["probed"]["level"], got["probed"]["generated"], got["probed"]["deadlocks"], got["probed"]["viol_mask"]) == \
+        (pr["level"], pr["generated"], pr["deadlocks"], pr["viol_mask"])
+    assert got["violation"]["probed"] and got["violation"]["level"] == 24 and len(got["path"]) == 24
+    if g["checksums"]:
+        assert got["violation"]["fp"] == pr["viol_fp"] == "042ca5372e82d6fb"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["hip", "native", "hip-exact"])
+def test_violation_of_any_mask_on_a_remotely_owned_successor_is_reported(tmp_path, engine):
+    """Round-2 advice (high): a successor that is written speculatively by its generator and owned by another rank carries its
+    violated-invariant mask beside its state index (cand_pack) — two bits of it in round 2, which lost the masks 4 / 8 / 16 of the
+    analysis models.  No shipped cfg reaches such a violation, so the test hook VSRMC_TEST_FORCE_BAD=<fp>:<mask> makes one: a state of
+    level 8 that rank 0 generates and rank 1 owns fails the invariants 4 | 8 | 16.  The run must report exactly that state, at that
+    level, with the whole mask — through the Python loop, the C++ loop and the two-kernel (exact) scheme."""
+    params, depth = (3, 1, 2, 2), 9
+    ranks = run_world(engine, 2, params, depth, tmp_path, 29700, 0)
+    assert all(r["violation"] is None for r in ranks)
+    lvl8 = ranks[0]["levels"][7]
+    assert lvl8["level"] == 8 and not lvl8["replicated"]
+    owner = lambda fp: ((fp >> 40) & 0xFFFFFF) % 2                       # noqa: E731  (sharded.owner_of)
+    remote = [f for f in lvl8["fps"] if owner(int(f, 16)) == 1]            # generated (and stored) by rank 0, owned by rank 1
+    assert remote
+    target = remote[len(remote) // 2]
+    ranks = run_world(engine, 2, params, depth, tmp_path, 29701, 0, VSRMC_TEST_FORCE_BAD="%s:28" % target)
+    for r in ranks:
+        assert r["violation"] == dict(level=8, fp=target, mask=28), r["violation"]

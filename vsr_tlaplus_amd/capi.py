@@ -150,6 +150,9 @@ SYMBOLS = {
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]),
     "vsrmc_shard_loop_trace_fps": (C.c_int32, [V, C.c_int32, C.c_uint64, V]),
+    "vsrmc_shard_loop_deepen": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo)]),
+    "vsrmc_shard_loop_advance": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo), C.POINTER(C.c_int32)]),
+    "vsrmc_shard_loop_probe_trace_fps": (C.c_int32, [V, V, C.c_int32, C.POINTER(C.c_int32)]),
 }
 
 _lib = None

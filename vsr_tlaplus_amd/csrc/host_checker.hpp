@@ -1,0 +1,755 @@
+// host_checker.hpp — the checker handle (≙ ModelChecker + Worker.run): buffers, kernel selection, the phases of a BFS level, passes over arbitrary sources, trace walks (included by vsrmc.hip: one translation unit, the sections share its anonymous-namespace helpers).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------------------
+// checker
+// ---------------------------------------------------------------------------------------------------------------
+struct PassDst {            // where a pass writes (records, refs, fingerprints)
+  u64* words = nullptr;
+  u64 words_cap = 0;
+  u64* off = nullptr;
+  u64* fp = nullptr;
+  u64 cap = 0;
+};
+struct DeepLevelRec { u64 n_new = 0, n_local = 0, generated = 0, max_bag = 0, frontier = 0; };   // n_local: this rank's share (unsharded: all)   // a level that exists in the seen-set only (vsr_deep.hpp)
+struct vsrmc_checker {
+  vsrmc_model model;
+  vsrmc_options opt;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  Slot* table = nullptr;
+  u64 tmask = 0;
+  u64* words[2] = {nullptr, nullptr};
+  u64* off[2] = {nullptr, nullptr};
+  u64* lvl_fp = nullptr;
+  u64* pending = nullptr;
+  LevelCtl* ctl = nullptr;
+  u64* d_find = nullptr;
+  int cur = 0;
+  int level = 0;
+  u64 n_frontier = 0;
+  u64 distinct = 0, total_generated = 0;
+  int num_cus = 256;
+  int lds_stride = 65;
+  int failed = 0;
+  // TLCTrace: there is no separate log — a state's slot in the seen-set names its parent:
+  // 45 bits of its parent's fingerprint (meta word, vsr_model.hpp); traces are walked through the table (k_trace_walk)
+  // state of the level in flight (between the phases)
+  LevelCtl h;
+  double t_level0 = 0, expand_ms = 0, materialize_ms = 0;
+  u64 nx_n = 0, nx_w = 0;
+  u64 n_valid = 1;                       // states in the newest level (n_frontier is its index range, holes included)
+  u64 cur_w = 0;                         // words of the current frontier buffer in use (chunk slack included)
+  u64* rslot = nullptr;                  // sharded: slot of every received candidate
+  u64 rslot_cap = 0;
+  u64* filter = nullptr;                 // sharded single-pass levels: this rank's sent-filter (vsr_kernels.hpp, k_expand)
+  u64 fmask = 0;
+  u64* cand_idx = nullptr;               // ... and where each announced candidate was written (world x cand_cap)
+  u64 cand_idx_cap = 0;
+  bool level_fused = false;              // the level in flight is a single-pass level
+  int failed_code = 0;                   // device ERR_* that stopped the search (failed == 1)
+  // the single-pass kernel of this model (a specialised instantiation when there is one) and its launch shape
+  void* fused_kernel = nullptr;
+  void* plain_kernel = nullptr;          // the same without modes / sharding, when the configuration has one (ordinary unsharded levels)
+  void* modes_kernel = nullptr;          // the same without sharding (expand_pass: the passes of vsrmc_checker_probe / _probe2 / _probe3), or null
+  int plain_blk = VSR_BLOCK;             // threads per block of plain_kernel: 256, or 64 = one wave per block with a 16-record tile of its own
+  u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
+  bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
+  // vsrmc_checker_probe / _probe2: where the reported violator's counter-example is walked from — the fingerprint of the deepest
+  // state of the path that is IN the seen-set, its level, and the fingerprint of the one probed state beyond it (0: none)
+  u64 probe_fp = 0, probe_extra_fp = 0;
+  int probe_level = 0;
+  int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
+  bool saw_violation = false;            // a committed level held a violating state (the caller went on): probe passes apply every action
+  // levels beyond the record buffers (vsr_deep.hpp): `deep` levels above `level` are complete in the seen-set and have no frontier
+  int deep = 0;
+  std::vector<DeepLevelRec> deep_lv;     // [i] = level + 1 + i
+  u64 deep_g = 2;                        // successors generated per expanded state, rounded up, the largest any level showed (worst-case slice sizes)
+  u64 deep_distinct = 0, deep_generated = 0;
+  bool deep_regen_done = false;          // a descent has set taken bits in the levels beyond the base: cleared before the next one
+  std::vector<PassDst> scratch;          // scratch buffers of the descent, each a quarter of the one above down to a floor (allocated on first use)
+  u64 hist_new[2] = {0, 0};              // new states of the last two levels (growth estimate of vsrmc_checker_advance)
+  u64 g_last = 16, cur_rec_w = 0;        // successors generated per expanded state of the last level (rounded up, + 1); words of the newest level's records
+  u64 words_cap(int b) const { return (b == 1 && opt.frontier_words_b) ? opt.frontier_words_b : opt.frontier_words; }
+};
+
+namespace {
+typedef void (*ExpandKernel)(Model, const u64*, const u64*, u64, int, int, Slot*, u64, u64*, u64, LevelCtl*, int, int, u64*, u64, u32, u64*,
+                             u64, u64*, u64, u64*, u32, u32, int, u32, u64*, u64, u64*, u32, int, u64);
+// k_expand<true, SPEC>: the configurations of BASELINE.json (and their small neighbours used by the tests) have their own
+// instantiation with the model constants folded in; anything else runs the generic one.
+ExpandKernel exact_kernel_for(const Model& M) {               // two-kernel levels: k_expand<false, SPEC>
+  if (M.model_id == 1) return k_expand<false, 1000>;
+  if (M.model_id == 2) return k_expand<false, 2000>;
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 211: return k_expand<false, 211>;
+    case 312: return k_expand<false, 312>;
+    case 313: return k_expand<false, 313>;
+    case 512: return k_expand<false, 512>;
+    default: return k_expand<false, 0>;
+  }
+}
+typedef void (*MaterializeKernel)(Model, const u64*, const u64*, const u64*, u64, Slot*, u64*, u64, u64*, u64, u64*, LevelCtl*,
+                                  const uint8_t*, u64*, u64*, int, u32, u32, int, const u64*);
+MaterializeKernel materialize_kernel_for(const Model& M) {
+  if (M.model_id == 1) return k_materialize<1000>;
+  if (M.model_id == 2) return k_materialize<2000>;
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 211: return k_materialize<211>;
+    case 312: return k_materialize<312>;
+    case 313: return k_materialize<313>;
+    case 512: return k_materialize<512>;
+    default: return k_materialize<0>;
+  }
+}
+ExpandKernel plain_kernel_for(const Model& M, int blk) {      // unsharded ordinary levels: modes and sharding compiled out
+  if (blk != VSR_BLOCK) return nullptr;
+  if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true> : nullptr;   // the shipped VR_STATE_TRANSFER.cfg
+  if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302, true> : nullptr;   // the shipped VR_APP_STATE.cfg
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 312: return k_expand<true, 312, true>;
+    case 313: return k_expand<true, 313, true>;
+    case 512: return k_expand<true, 512, true>;
+    default: return nullptr;
+  }
+}
+ExpandKernel modes_kernel_for(const Model& M) {               // unsharded passes with a mode (probe / virtual / regenerated / streamed levels)
+  if (M.model_id != 0) return nullptr;
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 312: return k_expand<true, 312, 2>;
+    case 313: return k_expand<true, 313, 2>;
+    case 512: return k_expand<true, 512, 2>;
+    default: return nullptr;
+  }
+}
+ExpandKernel fused_kernel_for(const Model& M) {
+  if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302> : k_expand<true, 1000>;
+  if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302> : k_expand<true, 2000>;
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 211: return k_expand<true, 211>;
+    case 212: return k_expand<true, 212>;
+    case 311: return k_expand<true, 311>;
+    case 312: return k_expand<true, 312>;
+    case 313: return k_expand<true, 313>;
+    case 323: return k_expand<true, 323>;
+    case 412: return k_expand<true, 412>;
+    case 512: return k_expand<true, 512>;
+    default: return k_expand<true, 0>;
+  }
+}
+// Launch shape of the single-pass kernel for one launch.  The LDS slot of a record only has to hold the longest record of the
+// level that is being expanded (stride = fixed words + its largest bag, made odd: conflict-free columns), not the format's
+// worst case, so deep levels of small bags leave room for more resident blocks.  64-record tiles when that gives at least
+// three blocks per CU (registers and LDS, asked from the runtime), else 128-record tiles (R <= 3) at two.
+#ifndef VSR_CCAP64          // work-list entries of a 64-record tile, R <= 3 (24 per record; an overflow is ERR_FRONTIER_FULL, never silent)
+#define VSR_CCAP64 1536
+#endif
+struct FusedShape {
+  int blk;
+  int tile;
+  u32 ccap;
+  int stride;
+  size_t lds;
+  unsigned blocks_per_cu;
+};
+FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = false) {
+  const Model& M = c->model.M;
+  FusedShape f;
+  f.stride = (int)std::min<u64>((u64)c->lds_stride, (u64)((M.fixed + (int)std::min<u64>(max_bag_of_source, 255)) | 1));
+  const void* kernel = (plain && c->plain_kernel) ? c->plain_kernel : c->fused_kernel;
+  const int blk = (plain && c->plain_kernel) ? c->plain_blk : VSR_BLOCK;
+  auto occupancy = [&](int tile, u32 ccap, size_t* lds) {
+    *lds = (size_t)tile * f.stride * 8 + 2 * (size_t)ccap * 4;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, blk, *lds) != hipSuccess) nb = 0;
+    return nb;
+  };
+  f.blk = blk;
+  if (blk == 512) {
+    f.tile = 128;
+    f.ccap = 3072u;
+    f.blocks_per_cu = (unsigned)std::max(1, std::min(occupancy(128, f.ccap, &f.lds), 2));
+    return f;
+  }
+  if (blk == 64) {                                              // one wave, 16 records, 24 (R <= 3) or 32 work-list entries per record
+    f.tile = 16;
+    f.ccap = M.R <= 3 ? 384u : 512u;
+    f.blocks_per_cu = (unsigned)std::max(1, std::min(occupancy(16, f.ccap, &f.lds), 16));
+    return f;
+  }
+  size_t lds64 = 0, lds128 = 0;
+  const u32 ccap64 = M.R <= 3 ? (u32)VSR_CCAP64 : (u32)VSR_CAND_CAP;      // work-list entries per tile (24 resp. 32 per record)
+  const int occ64 = occupancy(64, ccap64, &lds64);
+  const int occ128 = M.R <= 3 ? occupancy(128, 1536u, &lds128) : 0;
+  if (M.R <= 3 && occ64 < 3 && occ128 >= 1) {
+    f.tile = 128; f.ccap = 1536u; f.lds = lds128; f.blocks_per_cu = (unsigned)std::min(occ128, 2);
+  } else {
+    f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, VSR_OCC));
+  }
+  if (const char* e = std::getenv("VSRMC_MAX_BPC"))            // diagnostic: fewer resident blocks per CU (occupancy sweeps)
+    f.blocks_per_cu = (unsigned)std::max(1, std::min<int>((int)f.blocks_per_cu, std::atoi(e)));
+  return f;
+}
+
+// Put the checker in its initial state (ModelChecker.doInit): empty seen-set, Init in frontier 0 and in the set.
+int checker_seed(vsrmc_checker* c) {
+  const Model& M = c->model.M;
+  c->saw_violation = false;
+  c->deep = 0;
+  c->deep_lv.clear();
+  c->deep_g = 2;
+  c->deep_distinct = c->deep_generated = 0;
+  c->deep_regen_done = false;
+  c->hist_new[0] = c->hist_new[1] = 0;
+  c->g_last = 16;
+  c->cur_rec_w = 0;
+  c->failed = 0;
+  c->failed_code = 0;
+  HIPCHK(hipSetDevice(c->opt.device));
+  hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
+  HIPCHK(hipGetLastError());
+  std::vector<u64> wire, dev(512);
+  init_record_wire(M, wire);
+  int len = wire_to_device(M, wire.data(), dev.data());
+  u64 H[6];
+  hash_full_host(M, (const u64*)dev.data(), H);   // pure arithmetic on the constant Init record (same code as the kernels)
+  for (int i = 0; i < M.np; i++) dev[M.h0 + i] = H[i];
+  u64 zero = (u64)len, init_fp = 0;                            // ref of record 0: offset 0, length len
+  u32 init_ak = 0;
+  canonical_fp(M, dev[0], &dev[M.h0], &init_fp, &init_ak);
+  // sharded: every rank starts with Init (replicated phase: the small early levels are explored by every rank on its own,
+  // vsrmc_shard_local_step); vsrmc_shard_partition then leaves each state with its owner
+  const bool mine = true;
+  if (c->filter) HIPCHK(hipMemsetAsync(c->filter, 0, (c->fmask + 1) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(LevelCtl), c->stream));
+  if (mine) {
+    HIPCHK(hipMemcpyAsync(c->words[0], dev.data(), len * 8, hipMemcpyDefault, c->stream));   // the buffer may be pinned host memory
+    HIPCHK(hipMemcpyAsync(c->off[0], &zero, 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, c->stream, M, c->words[0], c->table, c->tmask, c->lvl_fp, c->ctl);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->cur = 0;
+  c->level = 1;
+  c->n_frontier = mine ? 1 : 0;
+  c->n_valid = c->n_frontier;
+  c->cur_w = (u64)len;
+  c->distinct = mine ? 1 : 0;
+  c->total_generated = 0;
+  c->failed = 0;
+  c->cur_max_bag = 0;
+  c->bag_known = true;
+  c->failed_code = 0;
+  c->probe_fp = 0;
+  c->probe_level = 0;
+  c->probe_extra_fp = 0;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+void vsrmc_options_default(vsrmc_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->device = 0;
+  o->table_log2 = 26;
+  o->frontier_words = (uint64_t)1 << 27;
+  o->frontier_states = (uint64_t)1 << 22;
+  o->pending_entries = (uint64_t)1 << 23;
+  o->keep_trace = 1;
+  o->trace_entries = 0;
+  o->rank = 0;
+  o->world = 1;
+}
+
+// vsrmc_options with table_log2 == 0 and / or frontier_words == 0: sized from the free memory of the device.  Seen-set: the largest power
+// of two of 16-byte slots within 30 % of what is free (1.7e9 states at load 0.4 on an empty MI355X); sharded runs on ONE device (tests)
+// take their share.  Records: what is left after the seen-set, the index arrays (24 B per state index), the sent-filter and a reserve
+// for the scratch buffers of the deep search (vsr_deep.hpp: 1/4 + 1/16 + .. of one record buffer) and the exchange buffers of a sharded
+// run, in two equal buffers — the last two levels differ by the growth factor, but which of the two buffers holds the last one is not
+// known in advance; pending list: only the exact scheme needs one worth the name.
+static int autosize_options(vsrmc_options* o, const Model& M) {
+  if (o->table_log2 != 0 && o->frontier_words != 0) return 0;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipSetDevice(o->device));
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  const char* share_env = std::getenv("VSRMC_AUTOSIZE_SHARE");     // several checkers on one device (tests: ranks sharing a GPU): 1 / share each
+  const double share = share_env ? std::max(1.0, std::atof(share_env)) : 1.0;
+  double avail = ((double)free_b - 3.0e9) / share;                 // runtime, code objects, small allocations
+  if (avail < 256e6) return fail(VSRMC_E_HIP, "less than 256 MB of free device memory to size the checker from");
+  if (o->table_log2 == 0) {
+    int lg = 8;
+    while (lg < 36 && (double)((u64)1 << (lg + 1)) * 16.0 <= 0.30 * avail) lg++;
+    o->table_log2 = lg;
+  }
+  avail -= (double)((u64)1 << o->table_log2) * 16.0;
+  if (o->world > 1 && !o->exact_ties) avail -= (double)((u64)1 << (o->filter_log2 > 0 ? o->filter_log2 : o->table_log2)) * 8.0;
+  if (o->pending_entries == 0) o->pending_entries = o->exact_ties ? (u64)1 << 24 : (u64)1 << 16;
+  avail -= (double)o->pending_entries * 24.0;
+  if (o->frontier_words == 0) {
+    if (o->world > 1) avail *= 0.80;                               // candidate / verdict / rebalancing buffers of the level loop
+    // per record word: 8 B in each of two buffers, 1/24 state index (3 arrays of 8 B), a third of one buffer for the scratch buffers
+    const double per_word = 2.0 * 8.0 + 8.0 / 3.0 + 24.0 / 24.0;
+    const double words = avail / per_word;
+    if (words < 4096.0 * (M.fixed + M.max_bag)) return fail(VSRMC_E_HIP, "not enough free device memory for the record buffers");
+    o->frontier_words = (u64)words;
+    o->frontier_words_b = 0;
+    if (o->frontier_states == 0) o->frontier_states = std::max<u64>((u64)1 << 16, o->frontier_words / 24);
+  }
+  if (o->frontier_states == 0) o->frontier_states = std::max<u64>((u64)1 << 16, o->frontier_words / 24);
+  return 0;
+}
+
+int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o_in, vsrmc_checker** out) {
+  if (!m || !o_in || !out) return fail(VSRMC_E_ARG, "NULL argument");
+  vsrmc_options sized = *o_in;
+  {
+    const int rc0 = autosize_options(&sized, m->M);
+    if (rc0) return rc0;
+  }
+  const vsrmc_options* o = &sized;
+  if (o->table_log2 < 8 || o->table_log2 > 36 || o->frontier_states < 1 || o->frontier_words < 256 ||
+      o->pending_entries < 4 * (uint64_t)VSR_CAND_CAP)
+    return fail(VSRMC_E_ARG, "bad options");
+  if (o->world < 1 || o->world > 8 || o->rank < 0 || o->rank >= o->world) return fail(VSRMC_E_ARG, "bad rank / world (1..8 ranks)");
+  if (o->frontier_states > ((uint64_t)1 << 40)) return fail(VSRMC_E_ARG, "frontier_states > 2^40");   // origin word: parent index | ordinal << 40
+  // a block reserves frontier indices in chunks of at least VSR_CAND_CAP (one tile's successors) and clears the unused tail of its
+  // chunk: a frontier smaller than one chunk would be written past its end
+  if (o->frontier_states < (uint64_t)VSR_CAND_CAP) return fail(VSRMC_E_ARG, "frontier_states must be at least 2048 (one index chunk)");
+  int rc = check_device(o->device);
+  if (rc) return rc;
+  vsrmc_checker* c = new vsrmc_checker();
+  c->model = *m;
+  c->opt = *o;
+  const Model& M = c->model.M;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, o->device));
+  c->num_cus = prop.multiProcessorCount;
+  c->lds_stride = (M.fixed + M.max_bag) | 1;
+  HIPCHK(hipStreamCreate(&c->stream));
+  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+  u64 slots = (u64)1 << o->table_log2;
+  c->tmask = slots - 1;
+  hipError_t e = hipMalloc((void**)&c->table, slots * sizeof(Slot));
+  c->host_frontier = o->host_frontier & 3;
+  for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    // host_frontier: the records stay in pinned host memory and the kernels read / write them over PCIe (zero-copy); the
+    // refs, fingerprints, trace log and the seen-set stay in HBM.  For state spaces whose frontier outgrows the 288 GB.
+    if ((c->host_frontier >> b) & 1) e = hipHostMalloc((void**)&c->words[b], c->words_cap(b) * 8, hipHostMallocMapped | hipHostMallocPortable);
+    else e = hipMalloc((void**)&c->words[b], c->words_cap(b) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->off[b], (o->frontier_states + 1) * 8);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&c->lvl_fp, o->frontier_states * 8);
+  if (e == hipSuccess && o->world > 1 && !o->exact_ties) {
+    const int fl = o->filter_log2 > 0 ? o->filter_log2 : o->table_log2;
+    c->fmask = ((u64)1 << fl) - 1;
+    e = hipMalloc((void**)&c->filter, (c->fmask + 1) * 8);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&c->pending, o->pending_entries * 24);   // (slot, key, parent index) entries of the exact scheme
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ctl, sizeof(LevelCtl));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_find, 8);
+  if (e != hipSuccess) {
+    vsrmc_checker_destroy(c);
+    return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  c->fused_kernel = (void*)fused_kernel_for(M);
+  c->modes_kernel = (void*)modes_kernel_for(M);
+  {
+    // VSRMC_BLK=64 / 512 select the experimental block shapes of a -DVSRMC_EXPERIMENTAL_BLK=1 build (A/B runs); default 256
+    const char* e = std::getenv("VSRMC_BLK");
+    const int want = e ? std::atoi(e) : VSRMC_DEFAULT_BLK;
+    c->plain_blk = ((want == 64 || want == 512) && plain_kernel_for(M, want)) ? want : VSR_BLOCK;
+    c->plain_kernel = (void*)plain_kernel_for(M, c->plain_blk);
+  }
+  rc = checker_seed(c);
+  if (rc) { vsrmc_checker_destroy(c); return rc; }
+  *out = c;
+  return 0;
+}
+
+int32_t vsrmc_checker_options(const vsrmc_checker* c, vsrmc_options* out) {
+  if (!c || !out) return fail(VSRMC_E_ARG, "NULL argument");
+  *out = c->opt;
+  return 0;
+}
+
+int32_t vsrmc_checker_reset(vsrmc_checker* c) {
+  if (!c) return fail(VSRMC_E_ARG, "NULL argument");
+  return checker_seed(c);
+}
+
+}  // extern "C"
+
+namespace {
+
+// ---- the phases of one BFS level (shared by the single-GPU step and the sharded protocol) --------------------------
+int level_error(vsrmc_checker* c, const LevelCtl& h, int new_level) {
+  c->failed = 1;
+  c->failed_code = (int)h.err;
+  char buf[256];
+  std::snprintf(buf, sizeof(buf), "device error %u at frontier index %llu ordinal %llu (level %d)", h.err,
+                (unsigned long long)(h.err_info >> 16), (unsigned long long)(h.err_info & 0xFFFF), new_level);
+  std::string msg = buf;
+  if (h.err == ERR_EVAL_421) msg = "VSR.tla:421: record has no field 'commit' (ReceivePrepareMsg, ClientCount >= 2); " + msg;
+  return fail(h.err < ERR_REP_RANGE ? VSRMC_E_EVAL : VSRMC_E_REP, msg);
+}
+
+// phase 1: k_expand over the current frontier.  io == nullptr: unsharded.
+int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NORMAL) {
+  const Model& M = c->model.M;
+  HIPCHK(hipSetDevice(c->opt.device));
+  if (c->level + 1 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
+  c->t_level0 = now_s();
+  c->expand_ms = c->materialize_ms = 0;
+  std::memset(&c->h, 0, sizeof(c->h));
+  c->h.viol_fp = ~(u64)0;
+  HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
+  c->level_fused = !c->opt.exact_ties;
+  if (c->n_frontier > 0) {
+    // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
+    const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
+    // sharded: records arrive from other ranks (rebalancing), the local maximum says nothing -> the format's capacity
+    const bool use_plain = fused && !io && mode == MODE_NORMAL && c->plain_kernel;
+    const FusedShape fs = fused_shape(c, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, use_plain);
+    const int cdiv = std::max(1, VSR_BLOCK / fs.blk);            // one-wave blocks: four times the blocks, a quarter of the chunk sizes
+    const int tile = fused ? fs.tile : (M.R <= 3 ? 128 : 64);
+    const int stride = fused ? fs.stride : c->lds_stride;
+    u64 ntiles = (c->n_frontier + tile - 1) / tile;
+    // every block reserves pending-list room in chunks: the list must hold one chunk per block beyond the real entries
+    const u32 pchunk = c->opt.pending_entries >= ((u64)1 << 24) ? 8192u : (u32)VSR_CAND_CAP;
+    if (io && c->cand_idx_cap < (u64)c->opt.world * io->cand_cap) {   // per announced candidate: where it was written (fused) / its parent (exact)
+      if (c->cand_idx) (void)hipFree(c->cand_idx);
+      c->cand_idx = nullptr;
+      c->cand_idx_cap = 0;
+      HIPCHK(hipMalloc((void**)&c->cand_idx, (u64)c->opt.world * io->cand_cap * 8));
+      c->cand_idx_cap = (u64)c->opt.world * io->cand_cap;
+    }
+    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * 3);
+    if (!fused) grid = (unsigned)std::min<u64>(grid, std::max<u64>(1, c->opt.pending_entries / (4 * (u64)pchunk)));   // the pending list is only used by the two-kernel scheme
+    const u32 ccap = fused ? fs.ccap : (tile == 128 ? 1536u : (u32)VSR_CAND_CAP);   // 128-record tiles: two blocks per CU in LDS
+    size_t lds = (size_t)tile * stride * 8 + 2 * (size_t)ccap * 4;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    // fused single-pass mode (unsharded, not exact_ties): the lane that inserts a fingerprint writes the successor itself
+    const int nxt = c->cur ^ 1;
+    const u64 nx_cap = c->opt.frontier_states;
+    u32 ichunk = 0, wchunk = 0, cchunk = 0;
+    if (fused && io)   // candidate entries a block reserves per owner at a time: <= 1/4 of a bucket in total over all blocks
+      cchunk = (u32)std::max<u64>(16, std::min<u64>(512, io->cand_cap / (4 * (u64)c->num_cus * 2)));
+    if (fused) {
+      // persistent blocks (2 resident per CU: 225 VGPRs, 79 KB LDS): every block leaves one partly used index chunk and
+      // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
+      grid = (unsigned)std::min<u64>((u64)ntiles, (u64)c->num_cus * fs.blocks_per_cu);
+      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP / cdiv), c->words_cap(nxt) / (4 * 16384))));
+      // a tile's successors (at most ccap records of at most stride + 5 words each) must fit one word chunk, and every block
+      // may leave one partly used chunk behind: fewer blocks if the buffer is too small for that
+      // (a buffer too small even for one such chunk keeps going with what it has: the kernel refuses a tile that does not fit
+      // its chunk with ERR_FRONTIER_FULL instead of writing past it)
+      const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(stride + 5));
+      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, c->words_cap(nxt) / (4 * wmin)));
+      ichunk = (u32)std::max<u64>(VSR_CAND_CAP / cdiv, std::min<u64>(8192 / cdiv, nx_cap / (4 * (u64)grid)));
+      wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144 / cdiv, c->words_cap(nxt) / (4 * (u64)grid)));
+    }
+    if (fused)
+      hipLaunchKernelGGL((ExpandKernel)(use_plain ? c->plain_kernel : c->fused_kernel), dim3(grid),
+                         dim3(use_plain ? fs.blk : VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+                         c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
+                         stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
+                         c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, ichunk,
+                         wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk,
+                         mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), (u64)0);
+    else
+      hipLaunchKernelGGL(exact_kernel_for(M), dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+                         c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
+                         c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
+                         0, nullptr, 0, nullptr, 0, 0, tile, ccap, nullptr, 0, io ? c->cand_idx : nullptr, 0, 0, (u64)0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->n_frontier > 0) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->expand_ms = ms;
+  }
+  c->nx_n = c->nx_w = 0;
+  if (c->h.err) return level_error(c, c->h, c->level + 1);
+  if (!c->opt.exact_ties) {                                    // fused: the level is already materialised (sharded: speculatively)
+    c->nx_n = c->h.n_new;
+    c->nx_w = c->h.words_new;
+    if (c->h.ties) {
+      c->failed = 1;
+      return fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables "
+                                 "(SURVEY F2); the single-pass scheme cannot arbitrate: create the checker with "
+                                 "vsrmc_options.exact_ties = 1");
+    }
+  }
+  return 0;
+}
+
+// phase 2: k_materialize over a list of (slot-or-fp, key) entries into one target (next frontier or a peer's bucket)
+// (src_words / src_off: where the parents are read from — default: the current frontier; a slice of another buffer in the deep search)
+int phase_materialize(vsrmc_checker* c, const u64* entries, u64 n, const uint8_t* verdict, u64* t_words, u64 t_words_cap,
+                      u64* t_off, u64 t_cap, u64* t_fp, u64* cnt_n, u64* cnt_w, int entry_words, const u64* pidx_arr,
+                      const u64* src_words = nullptr, const u64* src_off = nullptr) {
+  if (n == 0) return 0;
+  if (!src_words) { src_words = c->words[c->cur]; src_off = c->off[c->cur]; }
+  const Model& M = c->model.M;
+  // persistent waves: each keeps private output chunks, so the grid is sized to what is resident (LDS: 5 waves / CU)
+  u64 grid64 = std::min<u64>((n + VSR_MAT_BLOCK - 1) / VSR_MAT_BLOCK, (u64)c->num_cus * 5);
+  const u64 min_wchunk = (u64)VSR_MAT_BLOCK * c->lds_stride;
+  grid64 = std::max<u64>(1, std::min<u64>(grid64, std::min<u64>(t_words_cap / (4 * min_wchunk), t_cap / (4 * 64))));
+  const u32 ichunk = (u32)std::min<u64>(1024, std::max<u64>(64, t_cap / (4 * grid64)));
+  const u32 wchunk = (u32)std::min<u64>(65536, std::max<u64>(min_wchunk, t_words_cap / (4 * grid64)));
+  unsigned grid = (unsigned)grid64;
+  size_t lds = (size_t)VSR_MAT_BLOCK * c->lds_stride * 8;
+  HIPCHK(hipEventRecord(c->ev[2], c->stream));
+  hipLaunchKernelGGL(materialize_kernel_for(M), dim3(grid), dim3(VSR_MAT_BLOCK), lds, c->stream, M, src_words, src_off, entries, n,
+                     c->table, t_words, t_words_cap, t_off, t_cap, t_fp, c->ctl, verdict, cnt_n, cnt_w, c->lds_stride, ichunk, wchunk,
+                     entry_words, pidx_arr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->ev[3], c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+  c->materialize_ms += ms;
+  return 0;
+}
+
+// materialise the local pending list straight into the next frontier (self bucket)
+int phase_materialize_local(vsrmc_checker* c) {
+  u64 n_pending = std::min<u64>(c->h.n_pending, c->opt.pending_entries);
+  const u64 nx_cap = c->opt.frontier_states;
+  const int nxt = c->cur ^ 1;
+  int rc = phase_materialize(c, c->pending, n_pending, nullptr, c->words[nxt], c->words_cap(nxt), c->off[nxt], nx_cap,
+                             c->lvl_fp, &c->ctl->n_new, &c->ctl->words_new, 3, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost));
+  if (c->h.err) return level_error(c, c->h, c->level + 1);
+  c->nx_n = c->h.n_new;
+  c->nx_w = c->h.words_new;
+  return 0;
+}
+
+// phase 3: the level is complete: swap the frontiers, fill in the local statistics
+int phase_commit(vsrmc_checker* c, vsrmc_level_info* info) {
+  std::memset(info, 0, sizeof(*info));
+  const LevelCtl& h = c->h;
+  info->frontier = c->n_frontier;
+  info->generated = h.generated;
+  info->deadlocks = h.deadlocks;
+  info->pending = h.n_pending;
+  info->probes = h.probes;
+  info->max_bag = h.max_bag;
+  for (int a = 0; a < 16; a++) info->act_generated[a] = h.act_generated[a];
+  for (int a = 0; a < 8; a++) info->phase_cycles[a] = h.phase_cycles[a];
+  info->viol_fp = ~(u64)0;
+  info->viol_index = ~(u64)0;
+  info->expand_ms = c->expand_ms;
+  info->materialize_ms = c->materialize_ms;
+  // nx_n is an index RANGE: waves allocate indices in chunks and publish unused ones as invalid refs (0)
+  u64 n_new = 0;
+  if (c->nx_n > 0 && c->opt.world == 1 && !c->opt.exact_ties) {
+    n_new = h.n_written;                                         // single-pass, unsharded: every record written is a new state
+  } else if (c->nx_n > 0) {
+    u64 zero = 0;
+    HIPCHK(hipMemcpyAsync(c->d_find, &zero, 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_count_valid, dim3(1024), dim3(256), 0, c->stream, c->off[c->cur ^ 1], c->nx_n, c->d_find);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&n_new, c->d_find, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  c->total_generated += h.generated;
+  info->n_new = n_new;
+  info->words_new = c->nx_w;
+  info->record_words = h.rec_words;
+  if (n_new > 0 || c->opt.world > 1) {   // sharded: levels stay aligned across ranks even when this shard got nothing
+    c->cur ^= 1;
+    c->level += 1;
+    c->distinct += n_new;
+    c->n_frontier = c->nx_n;
+    c->n_valid = n_new;
+    c->cur_w = c->nx_w;
+    c->cur_max_bag = h.max_bag;
+    c->bag_known = c->opt.world == 1;
+    c->hist_new[0] = c->hist_new[1];
+    c->hist_new[1] = n_new;
+    c->g_last = (h.generated + std::max<u64>(1, info->frontier) - 1) / std::max<u64>(1, info->frontier) + 1;
+    c->cur_rec_w = h.rec_words;
+  } else {
+    c->n_frontier = 0;
+    c->n_valid = 0;
+  }
+  if (h.viol_fp != ~(u64)0) {
+    info->viol_fp = h.viol_fp;
+    info->viol_mask = (int32_t)h.viol_mask;
+    c->saw_violation = true;
+  }
+  info->level = c->level;
+  info->distinct = c->distinct;
+  info->total_generated = c->total_generated;
+  info->seconds = now_s() - c->t_level0;
+  return 0;
+}
+
+int find_fp_newest(vsrmc_checker* c, u64 fp, u64* idx) {
+  *idx = ~(u64)0;
+  if (c->n_frontier == 0) return 0;
+  u64 big = ~(u64)0;
+  HIPCHK(hipMemcpy(c->d_find, &big, 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_find_fp, dim3((unsigned)((c->n_frontier + 255) / 256)), dim3(256), 0, c->stream, c->lvl_fp, c->n_frontier, fp,
+                     c->d_find);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(idx, c->d_find, 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int32_t step_local(vsrmc_checker* c, vsrmc_level_info* info) {
+  int rc = phase_expand(c, nullptr);
+  if (!rc && c->opt.exact_ties) rc = phase_materialize_local(c);
+  if (rc) {   // like a TLC evaluation error: the run aborts, the partial level is not committed
+    std::memset(info, 0, sizeof(*info));
+    info->level = c->level;
+    info->distinct = c->distinct;
+    info->error_code = (int32_t)c->h.err;
+    return rc;
+  }
+  rc = phase_commit(c, info);
+  if (rc) return rc;
+  if (info->viol_mask) return find_fp_newest(c, info->viol_fp, &info->viol_index);
+  return 0;
+}
+
+namespace {
+// One single-pass launch over an arbitrary source (a slice of the newest level, or the partial next frontier a MODE_REGEN
+// slice just wrote), unsharded.  Resets the level counters, returns them in c->h.  Destination = the next-frontier buffers.
+// io != nullptr: a pass of a sharded run (vsr_deep.hpp) — successors owned by other ranks are announced into io's buckets
+int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 n_parents, u64 p_offset, int level, int mode,
+                u64 src_max_bag, const PassDst* dst = nullptr, const vsrmc_shard_io* io = nullptr) {
+  const Model& M = c->model.M;
+  std::memset(&c->h, 0, sizeof(c->h));
+  c->h.viol_fp = ~(u64)0;
+  HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
+  if (n_parents > 0) {
+    // an ordinary level into other buffers (the streamed level's sub-slices) runs the plain instantiation: the code of a stored level
+    static const bool plain_normal = std::getenv("VSRMC_STREAM_MODES_KERNEL") == nullptr;
+    const bool use_plain = !io && mode == MODE_NORMAL && plain_normal && c->plain_kernel && c->plain_blk == VSR_BLOCK;
+    const FusedShape fs = fused_shape(c, src_max_bag, use_plain);
+    u32 cchunk = 0;
+    if (io) {
+      if (c->cand_idx_cap < (u64)c->opt.world * io->cand_cap) {   // per announced candidate: where it was written / what regenerates it
+        if (c->cand_idx) (void)hipFree(c->cand_idx);
+        c->cand_idx = nullptr;
+        c->cand_idx_cap = 0;
+        HIPCHK(hipMalloc((void**)&c->cand_idx, (u64)c->opt.world * io->cand_cap * 8));
+        c->cand_idx_cap = (u64)c->opt.world * io->cand_cap;
+      }
+      cchunk = (u32)std::max<u64>(16, std::min<u64>(512, io->cand_cap / (4 * (u64)c->num_cus * 2)));
+    }
+    const int tile = fs.tile;
+    const u64 ntiles = (n_parents + tile - 1) / tile;
+    const u32 ccap = fs.ccap;
+    const size_t lds = fs.lds;
+    const int nxt = c->cur ^ 1;
+    u64* const d_words = dst ? dst->words : c->words[nxt];
+    u64* const d_off = dst ? dst->off : c->off[nxt];
+    u64* const d_fp = dst ? dst->fp : c->lvl_fp;
+    const u64 d_wcap = dst ? dst->words_cap : c->words_cap(nxt);
+    const u64 nx_cap = dst ? dst->cap : c->opt.frontier_states;
+    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * fs.blocks_per_cu);
+    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), d_wcap / (4 * 16384))));
+    const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(fs.stride + 5));   // see phase_expand
+    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, d_wcap / (4 * wmin)));
+    // index chunks: a block leaves the unused tail of its last chunk behind as invalid refs, and the NEXT pass stages those holes like records.
+    // A whole level (2.6e8 states) loses 1-3 % to 8192-index chunks; a sub-slice of a streamed level (7e6 states from 1024 blocks) lost a third
+    // of its index range, and the probe pass over it 16 % of its time (VSRMC_ICHUNK=8192: the old size, for A/B runs).
+    static const u64 ichunk_small = std::getenv("VSRMC_ICHUNK") ? (u64)std::atoll(std::getenv("VSRMC_ICHUNK")) : 2048;
+    const u64 ichunk_max = (dst || mode == MODE_REGEN) ? std::max<u64>(VSR_CAND_CAP, ichunk_small) : 8192;
+    const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(ichunk_max, nx_cap / (4 * (u64)grid)));
+    const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    const void* kern = io ? c->fused_kernel : use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
+    hipLaunchKernelGGL((ExpandKernel)kern, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
+                       c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, io ? c->opt.world : 1,
+                       io ? io->cand_send : nullptr, io ? io->cand_cap : (u64)0, (u32)VSR_CAND_CAP,
+                       d_words, d_wcap, d_off, nx_cap, d_fp,
+                       ichunk, wchunk, tile, ccap, io ? c->filter : nullptr, io ? c->fmask : (u64)0, io ? c->cand_idx : nullptr, cchunk,
+                       mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (n_parents > 0) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->expand_ms += ms;
+  }
+  if (c->h.err) return level_error(c, c->h, level);
+  if (c->h.ties) {
+    c->failed = 1;
+    return fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables (SURVEY F2)");
+  }
+  return 0;
+}
+
+// one step of a trace walk through the seen-set (k_table_lookup): by_low_bits = 0: the slot of fingerprint `key`; 1: the slot of
+// the level-`level` state whose fingerprint ends in the 45 bits `key` (what a child's meta word knows of its parent)
+int table_lookup(vsrmc_checker* c, u64 key, int level, int by_low_bits, int* found, u64* fp, u64* meta) {   // *found = matching states
+  u64* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 24));
+  hipLaunchKernelGGL(k_table_lookup, dim3(1), dim3(64), 0, c->stream, c->table, c->tmask, key, level, by_low_bits, d);
+  u64 h[3] = {0, 0, 0};
+  const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+                  hipMemcpy(h, d, 24, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) return fail(VSRMC_E_HIP, "k_table_lookup failed");
+  *found = (int32_t)std::min<u64>(h[0], 0x7FFFFFFF);          // by_low_bits: the number of matching states (> 1: ambiguous)
+  *fp = h[1];
+  *meta = h[2];
+  return 0;
+}
+// TLCTrace.getTrace, backwards half: the fingerprints of the path Init -> the level-`level` state with fingerprint `fp`
+int walk_trace(vsrmc_checker* c, u64 fp, int level, std::vector<u64>* fps) {
+  if (level < 1) return fail(VSRMC_E_ARG, "no such level");
+  fps->assign((size_t)level + 1, 0);
+  u64* d_fps = nullptr;
+  HIPCHK(hipMalloc((void**)&d_fps, ((u64)level + 1) * 8));
+  bool ok = hipMemsetAsync(d_fps, 0, ((u64)level + 1) * 8, c->stream) == hipSuccess;
+  hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, c->stream, c->table, c->tmask, fp, level, d_fps);
+  ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+       hipMemcpy(fps->data(), d_fps, ((u64)level + 1) * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d_fps);
+  if (!ok) return fail(VSRMC_E_HIP, "k_trace_walk failed");
+  const u64 status = fps->back();
+  fps->pop_back();
+  if ((status & 0xFF) == 2) {
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "ambiguous predecessor pointer: %llu states of level %llu share the 45 fingerprint bits a successor keeps of its "
+                  "parent (expected about once in 2^45 / level size steps); the counter-example cannot be walked through the seen-set",
+                  (unsigned long long)(status >> 16), (unsigned long long)((status >> 8) & 0xFF));
+    return fail(VSRMC_E_STATE, buf);
+  }
+  if (status != 0 || (*fps)[0] == 0) return fail(VSRMC_E_STATE, "the seen-set holds no path from Init to this state at this level");
+  return 0;
+}
+
+// smallest-fingerprint violator of the (fp, key) list a PROBE / INSERT pass left in c->pending; among equal fps the smallest key
+int min_violator(vsrmc_checker* c, u64 fp_min, u64* key) {
+  *key = ~(u64)0;
+  const u64 n = std::min<u64>(c->h.n_pending, std::min<u64>(c->opt.pending_entries, (u64)1 << 20));
+  std::vector<u64> list(2 * n);
+  if (n) HIPCHK(hipMemcpy(list.data(), c->pending, 16 * n, hipMemcpyDeviceToHost));
+  for (u64 i = 0; i < n; i++)
+    if (list[2 * i] == fp_min && list[2 * i + 1] < *key) *key = list[2 * i + 1];
+  return 0;
+}
+}  // namespace
+
+}  // extern "C"

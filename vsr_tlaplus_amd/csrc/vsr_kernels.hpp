@@ -849,7 +849,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           claimed_now = claimed;
         }
         // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
-        const int bad = (check || do_write || (remote && mode == MODE_INSERT)) ? Ops::invariants(M, rec, D) : 0;
+        int bad = (check || do_write || (remote && mode == MODE_INSERT)) ? Ops::invariants(M, rec, D) : 0;
+        if constexpr (PLAIN == 0)                               // test hook (Model::test_bad_fp): compiled into the sharded / generic instantiation only
+          if (M.test_bad_mask && fp == M.test_bad_fp && (check || do_write || remote)) bad |= (int)M.test_bad_mask;
         if (mode == MODE_PROBE) {
           if (bad) {
             const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
@@ -1172,6 +1174,7 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
       bad = Ops::invariants(M, (const u64*)rec, D);
+      if (M.test_bad_mask && fp == M.test_bad_fp) bad |= (int)M.test_bad_mask;   // test hook (Model::test_bad_fp)
       nbag = hdr_nmsg(D.hdr);
       clen = M.fixed + nbag;
       if (clen > stride) clen = stride;                        // cannot happen: gen() raised ERR_REP_BAG in k_expand

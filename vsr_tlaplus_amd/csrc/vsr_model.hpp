@@ -69,6 +69,9 @@ struct Model {
   int m0;                // first message-bound ordinal = 4R + R*C*n
   u32 primtab;           // Primary(v) for v = 0..7, 3 bits each (a table: `%` by a run-time R costs ~20 instructions)
   u32 pitab[6];          // permutation i: pi[v] in bits 2v..2v+1
+  u64 test_bad_fp;       // TEST HOOK (VSRMC_TEST_FORCE_BAD=<hex fingerprint>:<mask>, read when a model is built): the state with this fingerprint
+  u32 test_bad_mask;     // fails the invariants of this mask — whatever they say — in the sharded and the two-kernel paths.  0 = off.  Lets a test
+  u32 test_pad_;         // put a violator of ANY mask on a rank that does not own it (the shipped cfgs reach no violation of masks 4 / 8 / 16).
   u64 fp_seed;           // xor-ed into every salt of the view hash: 0 = the function the fixtures were made with; any other value is an
                          // independent member of the same family (second-hash audit: counts must not depend on it, vsrmc_model_set_fp_seed)
 };

@@ -438,7 +438,9 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
   }
   // ---- 7. commit; one all-gather carries every figure of the level
   if (!rc) rc = vsrmc_shard_commit(c, local);
-  struct InfoRow { u64 n_new, generated, deadlocks, pending, viol_fp, err, viol_mask, max_bag, probes; } irow;
+  struct InfoRow { u64 n_new, generated, deadlocks, pending, viol_fp, err, viol_mask, max_bag, probes, record_words, act[16]; } irow;
+  for (int i = 0; i < 16; i++) irow.act[i] = local->act_generated[i];
+  irow.record_words = local->record_words;
   irow.n_new = local->n_new; irow.generated = local->generated; irow.deadlocks = local->deadlocks; irow.pending = local->pending;
   irow.viol_fp = local->viol_mask ? local->viol_fp : ~(u64)0; irow.err = rc ? (u64)(rc < 0 ? -rc : rc) : 0;
   irow.viol_mask = (u64)local->viol_mask; irow.max_bag = local->max_bag; irow.probes = local->probes;
@@ -450,6 +452,8 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
   for (const InfoRow& r : iall) {
     worst = std::max(worst, r.err);
     global->n_new += r.n_new; global->generated += r.generated; global->deadlocks += r.deadlocks; global->pending += r.pending; global->probes += r.probes;
+    global->record_words += r.record_words;
+    for (int i = 0; i < 16; i++) global->act_generated[i] += r.act[i];
     gviol = std::min(gviol, r.viol_fp);
     gbag = std::max(gbag, r.max_bag);
   }
@@ -474,14 +478,26 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
 }
 
 // vsrmc_check for a sharded run (collective): stop_reason 0 exhausted, 1 invariant violated, 2 max_depth
+int32_t vsrmc_shard_loop_advance(vsrmc_shard_loop* l, vsrmc_level_info* a, vsrmc_level_info* b, int32_t* what);
 int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t stop_on_violation, int32_t* stop_reason, vsrmc_level_info* last) {
   if (!l || !stop_reason || !last) return fail(VSRMC_E_ARG, "NULL argument");
-  vsrmc_level_info local;
+  vsrmc_level_info b;
   for (;;) {
-    if (max_depth > 0 && l->level >= max_depth) { *stop_reason = 2; return 0; }
-    const int rc = vsrmc_shard_loop_step(l, last, &local);
+    if (max_depth > 0 && l->level + l->deep >= max_depth) { *stop_reason = 2; return 0; }
+    // a seen-set that fills up: every rank asks, any rank's answer stops all (the all-gather inside advance needs every rank)
+    u64 full = (double)(l->c->deep ? l->c->deep_distinct : l->c->distinct) > 0.85 * (double)(l->c->tmask + 1) ? 1 : 0;
+    if (!l->replicated) {
+      u64 all[8] = {0};
+      const int rc0 = l->comm.allgather(l->comm.ctx, &full, all, 8);
+      if (rc0) return rc0 > 0 ? fail(VSRMC_E_HIP, "the caller's all-gather failed") : rc0;
+      for (int p = 0; p < l->world; p++) full = std::max(full, all[p]);
+    }
+    if (full) { *stop_reason = 4; return 0; }
+    int32_t what = 0;
+    const int rc = vsrmc_shard_loop_advance(l, last, &b, &what);
     if (rc) return rc;
     if (last->n_new == 0) { *stop_reason = 0; return 0; }
+    if (what == 2 && b.level && b.viol_mask && !last->viol_mask) *last = b;
     if (l->has_violation && stop_on_violation) { *stop_reason = 1; return 0; }
   }
 }

@@ -438,9 +438,12 @@ class HipShardEngine:
 
     def __init__(self, model, rank, world, device=0, table_log2=26, frontier_words=1 << 27, frontier_states=1 << 22,
                  pending_entries=1 << 23, cand_cap=1 << 22, rec_cap=1 << 21, rec_words_cap=1 << 26, keep_trace=True,
-                 trace_entries=0, exact_ties=False, filter_log2=0, recover=None):
+                 trace_entries=0, exact_ties=False, filter_log2=0, recover=None, native_only=False):
         """cand_cap: (fp, key) candidates per peer and level; rec_cap / rec_words_cap: records / words one rebalancing move
-        to one peer may carry.  recover: this rank's checkpoint file (save()), written by the same rank of the same world."""
+        to one peer may carry.  recover: this rank's checkpoint file (save()), written by the same rank of the same world.
+        table_log2 / frontier_words / frontier_states / pending_entries / cand_cap = 0: sized from the free memory of the device
+        (vsrmc_options with zeros; cand_cap: its share of the fifth the checker leaves for the exchange buffers).
+        native_only: the engine will run under the C++ level loop, which owns its exchange buffers — none are allocated here."""
         self.model, self.rank, self.world, self.device = model, rank, world, device
         if not torch.cuda.is_available():
             # libvsrmc.so and torch both bind libamdhip64.so.7 (ROCm's resp. torch's bundled copy); the first one loaded serves the
@@ -461,10 +464,17 @@ class HipShardEngine:
             check(capi.load().vsrmc_checker_load(model._h, C.byref(o), os.fsencode(recover), C.byref(self._h)))
         dev = torch.device("cuda", device)
         self.dev = dev
+        check(capi.load().vsrmc_checker_options(self._h, C.byref(o)))       # sizes left 0 were derived from the free device memory
+        self.options = o
+        if not cand_cap:
+            # 42 bytes per candidate and peer (16 sent + 16 received + 8 beside it + 2 verdict bytes); the checker's record memory is
+            # 19.7 bytes per frontier word and 4/5 of what the exchange buffers + records share: 3/4 of the remaining fifth
+            cand_cap = max(1 << 16, int(0.75 * 0.25 * 19.7 * int(o.frontier_words) / (42.0 * world)))
         self.cand_cap, self.rec_cap, self.rec_words_cap = cand_cap, rec_cap, rec_words_cap
-        self.cand_send = torch.zeros((world, cand_cap, 2), dtype=torch.int64, device=dev)
-        self.verdict_in = torch.zeros((world, cand_cap), dtype=torch.uint8, device=dev)
-        self.io = capi.ShardIO(self.cand_send.data_ptr(), cand_cap)
+        if not native_only:
+            self.cand_send = torch.zeros((world, cand_cap, 2), dtype=torch.int64, device=dev)
+            self.verdict_in = torch.zeros((world, cand_cap), dtype=torch.uint8, device=dev)
+            self.io = capi.ShardIO(self.cand_send.data_ptr(), cand_cap)
         self._export_bufs = []                                  # allocated on first use: rebalancing is rare
         self._cand_counts = [0] * world
         self._err_text = ""
@@ -787,15 +797,64 @@ class NativeShardedChecker:
             self.levels.append(out)
         return out
 
+    def _global_dict(self, info, local=None):
+        gd = info.as_dict()
+        out = dict(level=gd["level"], n_new=gd["n_new"], generated=gd["generated"], deadlocks=gd["deadlocks"], pending=gd["pending"],
+                   distinct=self.distinct, viol_fp=gd["viol_fp"] if gd["viol_mask"] else None, viol_mask=gd["viol_mask"], max_bag=gd["max_bag"],
+                   fp_xor=gd["fp_xor"], fp_sum=gd["fp_sum"], act_generated=gd["act_generated"], expand_ms=gd["expand_ms"],
+                   materialize_ms=gd["materialize_ms"], launches=gd["pending"], record_words=gd["record_words"], seconds=gd["seconds"])
+        if local is not None:
+            out["local"] = local
+        return out
+
+    def advance(self):
+        """One unit of progress of the automatic level scheme (vsrmc_shard_loop_advance, collective): an ordinary sharded level while
+        every rank predicts that its part of the next one fits, else one pass of the deep search (the next level inserted into the
+        ranks' seen-sets only, the one after it probed).  -> ("level", dict, None) | ("deep", inserted dict, probed dict or None);
+        figures over all ranks."""
+        a, b = capi.LevelInfo(), capi.LevelInfo()
+        what = C.c_int32()
+        rc = capi.load().vsrmc_shard_loop_advance(self._l, C.byref(a), C.byref(b), C.byref(what))
+        if rc != 0:
+            raise ShardError("level %d: %s" % (getattr(self, "depth", self.level) + 1, capi.load().vsrmc_last_error().decode()))
+        was_replicated = self.replicated
+        self._sync()
+        if what.value == 1:
+            self.depth = self.level
+            out = self._global_dict(a)
+            out["replicated"] = was_replicated
+            out["level"] = self.level
+            if out["n_new"]:
+                self.levels.append(out)
+            return "level", out, None
+        da, db = self._global_dict(a), self._global_dict(b)
+        self.depth = da["level"]
+        if self.violation is not None and "probed" not in self.violation:
+            self.violation["probed"] = bool(db["level"] and db["viol_mask"] and not da["viol_mask"])
+        return "deep", da, (db if db["level"] else None)
+
     def run(self, max_depth=None, stop_on_violation=True):
+        self.depth = getattr(self, "depth", self.level)
         while True:
-            if max_depth is not None and self.level >= max_depth:
+            if max_depth is not None and self.depth >= max_depth:
                 return "max-depth"
-            d = self.step()
+            kind, d, p = self.advance()
             if d["n_new"] == 0:
                 return "exhausted"
             if self.violation is not None and stop_on_violation:
                 return "violation"
+
+    def violation_trace_fps(self):
+        """fingerprints of the counter-example of the violation the run found, Init first (collective)"""
+        v = self.violation
+        if v.get("probed"):
+            out = np.zeros(v["level"] + 1, dtype=np.uint64)
+            n = C.c_int32()
+            rc = capi.load().vsrmc_shard_loop_probe_trace_fps(self._l, C.c_void_p(out.ctypes.data), len(out), C.byref(n))
+            if rc != 0:
+                raise ShardError("trace walk: %s" % capi.load().vsrmc_last_error().decode())
+            return [int(f) for f in out[: n.value]]
+        return self.trace_fps(v["level"], v["fp"])
 
     def trace_fps(self, level, fp):
         out = np.zeros(level, dtype=np.uint64)

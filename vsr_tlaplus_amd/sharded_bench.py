@@ -1,28 +1,34 @@
-"""bench.py's N > 1 leg: the same workload (config 2 to the first violation) with the seen-set sharded over N GPUs.
-One rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run), backend "nccl" (= RCCL over xGMI)."""
+"""bench.py's N > 1 leg: the README defect configuration (BASELINE configs[2]) with the seen-set sharded over N GPUs, through the
+automatic level scheme of the C++ level loop (csrc/vsr_shard_loop.hpp: vsrmc_shard_loop_advance).  One rank per GPU (RANK / LOCAL_RANK /
+WORLD_SIZE from torch.distributed.run), backend "nccl" (= RCCL over xGMI, called directly from the loop).
+
+Nothing here names a level or a size: every rank sizes its seen-set shard, record buffers and exchange buffers from the free memory of
+its GPU, stores a level while every rank predicts that its part of the next one fits, and goes on through the seen-sets alone
+(virtual / regenerated / streamed / probed levels) when one does not — at N >= 4 everything up to the violation is stored, at N = 2
+(and N = 1 under VSR_BENCH_SHARDED=1) the last levels are not.  Every level's figures over all ranks are asserted against the CPU oracle's
+fixture on every run.  `--workload config2` runs BASELINE configs[1] the same way."""
 import json
-import math
 import os
 import time
 
 import torch
 import torch.distributed as dist
 
-# per-level maxima of the workload (tests/golden/config2_violation.json): sizes every buffer
-MAX_NEW, MAX_GENERATED, MAX_WORDS, TOTAL = 80003390, 217755238, 3029987047, 319228361
 HBM_PEAK_GBS = 8000.0
 # levels with fewer new states than this are explored by every rank on its own (no collectives): a level of a million states
 # is under a millisecond of kernel time, less than the exchanges of one sharded level
 REPLICATE_BELOW = int(os.environ.get("VSR_BENCH_REPLICATE_BELOW", 1 << 20))
 
 
-def main(args, CONFIG, EXPECT):
+def main(args, bench):
     import vsr_tlaplus_amd as vt
     from vsr_tlaplus_amd import sharded
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("VSR_BENCH_BACKEND", "nccl")      # "gloo": functional check of this leg on a one-GPU box
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if backend != "nccl":                                       # (all ranks share device 0, buckets staged through the host)
         local_rank = 0
+        os.environ.setdefault("VSRMC_AUTOSIZE_SHARE", str(world_env))
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
         if backend == "nccl":
@@ -30,69 +36,84 @@ def main(args, CONFIG, EXPECT):
         else:
             dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    # slack 1.4: frontier imbalance between ranks (rebalancing tolerates 25 %) and the speculative successors that lose (≈ 5 %).
-    # On top of that every resident block of k_expand leaves one partly used index chunk (<= 8192 indices) and one word chunk
-    # (<= 262144 words) behind per level: up to 4 blocks per CU.
-    slack = 1.4
-    blocks = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
-    tail_idx, tail_words = blocks * 8192, blocks * 262144
-    per_rank = lambda x, extra=0: int(x / world * slack) + extra + (1 << 16)   # noqa: E731
-    per_pair = lambda x, extra=0: int(x / world / world * slack) + extra + (1 << 16)   # noqa: E731
-    m = vt.Model.from_constants(R=CONFIG["R"], C_=CONFIG["C"], n=CONFIG["n"], L=CONFIG["L"])
-    table_log2 = max(20, int(math.ceil(math.log2(4.4 * TOTAL / world))))
-    eng = sharded.HipShardEngine(
-        m, rank, world, device=local_rank, table_log2=table_log2, frontier_words=per_rank(MAX_WORDS, 2 * tail_words),
-        frontier_states=per_rank(MAX_NEW, 2 * tail_idx), pending_entries=1 << 16,   # single-pass levels: no pending list
-        cand_cap=per_pair(MAX_GENERATED), filter_log2=max(20, int(math.ceil(math.log2(2.0 * TOTAL / world)))),
-        # records stay with their generator; these two only bound one rebalancing move to one peer (early, small levels)
-        rec_cap=1 << 22, rec_words_cap=1 << 28,
-        keep_trace=True, trace_entries=per_rank(TOTAL, 16 * tail_idx))
-    x = sharded.Exchanger()
-    # the level loop: native (C++, csrc/vsr_shard_loop.hpp) over RCCL called directly — the default on "nccl" — or the Python loop over
-    # torch.distributed (VSR_BENCH_PYLOOP=1; always on "gloo" unless VSR_BENCH_NATIVE=1 asks for the native loop over gloo callbacks)
-    native = (backend == "nccl" and not os.environ.get("VSR_BENCH_PYLOOP")) or bool(os.environ.get("VSR_BENCH_NATIVE"))
-    comm = None
-    if native:
-        comm = sharded.RcclComm(local_rank) if backend == "nccl" else sharded.TorchHostComm()
-    S = dict(alg_bytes=0.0, launches=0, distinct=0, ttfv=[])
-    moved = [0]
-    sent = [0]
+    readme = args.workload != "config2"
+    cfg = bench.README if readme else bench.CONFIG
+    if readme:
+        E = bench.load_readme_expect()
+        want_levels = E["levels"]
+        expect = dict(distinct=1821858767, depth=24, viol_fp=E["viol_fp"], probe_generated=E["probe_generated"])
+    else:
+        want_levels = [dict(n_new=lv["new"], generated=lv["generated"], deadlocks=lv["deadlocks"], max_bag=lv["max_bag"], act_generated=lv["act_generated"])
+                       for lv in bench.EXPECT["levels"]]
+        expect = dict(distinct=bench.EXPECT["distinct"], depth=bench.EXPECT["depth"], viol_fp=bench.EXPECT["viol_fp"], probe_generated=None)
+    m = vt.Model.from_constants(R=cfg["R"], C_=cfg["C"], n=cfg["n"], L=cfg["L"])
+    t0 = time.perf_counter()
+    eng = sharded.HipShardEngine(m, rank, world, device=local_rank, table_log2=0, frontier_words=0, frontier_states=0, pending_entries=0, cand_cap=0,
+                                 rec_cap=1 << 22, rec_words_cap=1 << 28, native_only=True)
+    setup = time.perf_counter() - t0
+    comm = sharded.RcclComm(local_rank) if backend == "nccl" else sharded.TorchHostComm()
+    S = dict(alg_bytes=0.0, launches=0, distinct=0, ttfv=[], kernel_ms=0.0, stored_ms=0.0, deep_ms=0.0, stored_levels=0, passes=[], sent=0, moved=0)
 
     def one_run(record):
         eng.reset()
-        eng.kernel_ms = dict(expand=0.0, materialize=0.0)
-        if native:
-            sc = sharded.NativeShardedChecker(eng, comm, replicate_below=REPLICATE_BELOW)
-        else:
-            sc = sharded.ShardedChecker(eng, x, replicate_below=REPLICATE_BELOW)
+        sc = sharded.NativeShardedChecker(eng, comm, replicate_below=REPLICATE_BELOW)
+        sc.depth = sc.level
         t0 = time.perf_counter()
-        cur_words = (int(m.layout.fixed_words) + int(m.layout.permutations)) if sc.e.local_distinct() else 0
-        while True:
-            d = sc.step()
-            loc = d["local"]
-            if record and loc["frontier"]:
-                S["launches"] += 1
-                S["alg_bytes"] += 8.0 * cur_words + 8.0 * loc["generated"] + 8.0 * loc["n_new"] + 8.0 * loc["record_words"]
-            cur_words = loc["record_words"]
-            if d["n_new"] == 0 or sc.violation is not None:
-                break
-        if sc.violation is not None:                          # counter-example reconstructed = found
-            fps = sc.trace_fps(sc.violation["level"], sc.violation["fp"])
-            if rank == 0:
-                tr = sharded.replay_fps(m, fps, device=local_rank)
-                assert len(tr) == sc.violation["level"]
+        s_rec, n_prev = 8.0 * (int(m.layout.fixed_words) + int(m.layout.permutations)), 1
+        alg, kms, dms, launches, stored, passes, found = 0.0, 0.0, 0.0, 0, 0, [], None
+        while found is None:
+            kind, a, b = sc.advance()
+            assert a["n_new"], "the search is exhausted before the violation"
+            want = want_levels[a["level"] - 1]
+            assert (a["n_new"], a["generated"]) == (want["n_new"], want["generated"]), (a["level"], a["n_new"], a["generated"])
+            if want.get("deadlocks") is not None:
+                assert a["deadlocks"] == want["deadlocks"], a["level"]
+            if want.get("act_generated") is not None:
+                assert [int(x) for x in a["act_generated"][1:16]] == want["act_generated"][1:16], a["level"]
+            # algorithmic bytes of the whole job (every state read once and written once, 8 B per generated successor and per new key)
+            alg += s_rec * n_prev + 8.0 * a["generated"] + 8.0 * a["n_new"]
+            if kind == "level":
+                s_rec = 8.0 * a["record_words"] / a["n_new"] if a["record_words"] else s_rec
+                alg += s_rec * a["n_new"]
+                kms += a["expand_ms"]
+                launches += 1
+                stored = a["level"]
+                if a["viol_mask"]:
+                    found = a
+            else:
+                alg += s_rec * a["n_new"]
+                dms += a["expand_ms"] + a["materialize_ms"]
+                launches += a["launches"]
+                row = dict(level=a["level"], seconds=round(a["seconds"], 4), launches=a["launches"])
+                if a["viol_mask"]:
+                    found = a
+                elif b is not None:
+                    alg += s_rec * a["n_new"] + 8.0 * b["generated"]
+                    dms += b["expand_ms"]
+                    row.update(probed_level=b["level"], probe_seconds=round(b["seconds"], 4))
+                    if b["viol_mask"]:
+                        found = b
+                passes.append(row)
+            n_prev = a["n_new"]
+        fps = sc.violation_trace_fps()                          # counter-example reconstructed = found (collective walk through the shards)
+        if rank == 0:
+            tr = sharded.replay_fps(m, fps, device=local_rank)
+            assert len(tr) == expect["depth"]
         dt = time.perf_counter() - t0
-        assert sc.distinct == EXPECT["distinct"] and sc.level == EXPECT["depth"], (sc.distinct, sc.level)
-        assert sc.violation and (EXPECT["viol_fp"] is None or sc.violation["fp"] == EXPECT["viol_fp"])
-        moved[0] = sc.moved
-        sent[0] += sc.bytes_sent if native else 0
-        if native:
-            sc.close()
+        assert sc.distinct == expect["distinct"] and found["level"] == expect["depth"], (sc.distinct, found["level"])
+        assert expect["viol_fp"] is None or found["viol_fp"] == expect["viol_fp"]
+        assert expect["probe_generated"] is None or kind == "level" or b is None or not b["viol_mask"] or b["generated"] == expect["probe_generated"]
+        S["moved"] = sc.moved
+        S["sent"] += sc.bytes_sent
+        sc.close()
         if record:
             S["distinct"] += sc.distinct
             S["ttfv"].append(dt)
-            S["expand_ms"] = S.get("expand_ms", 0.0) + eng.kernel_ms["expand"]
-            S["mat_ms"] = S.get("mat_ms", 0.0) + eng.kernel_ms["materialize"]
+            S["alg_bytes"] += alg
+            S["stored_ms"] += kms
+            S["deep_ms"] += dms
+            S["launches"] += launches
+            S["stored_levels"], S["passes"] = stored, passes
 
     for _ in range(args.warmup):
         one_run(False)
@@ -109,27 +130,38 @@ def main(args, CONFIG, EXPECT):
     elapsed = float(t.item())
     if rank == 0:
         value = S["distinct"] / elapsed
-        avg_launch_s = S["expand_ms"] / 1e3 / max(1, S["launches"])
-        achieved = S["alg_bytes"] / max(1, S["launches"]) / max(avg_launch_s, 1e-12) / 1e9
-        print(json.dumps({
-            "metric": "distinct states/sec (whole node), VSR 3-replica", "value": round(value, 1), "unit": "distinct states/s",
+        kernel_ms = S["stored_ms"] + S["deep_ms"]                # rank 0's k_expand time (HIP events on the checker's stream)
+        avg_launch_s = kernel_ms / 1e3 / max(1, S["launches"])
+        achieved = S["alg_bytes"] / world / max(kernel_ms / 1e3, 1e-12) / 1e9   # per GPU: the job's algorithmic bytes / N over rank 0's kernel time
+        out = {
+            "metric": "distinct states/sec (whole node) + time-to-first-violation, VSR 3-replica", "value": round(value, 1), "unit": "distinct states/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 "
-                                   "(BASELINE configs[1] = shipped VSR.cfg), VIEW+SYMMETRY, to first violation: 28 levels, "
-                                   "319228361 distinct states", "parallelism": "seen-set sharded by fingerprint over %d ranks, "
-                                   "all-to-all of (fp, key) candidates per level (RCCL), levels below %d new states replicated"
-                                   % (world, REPLICATE_BELOW), "table_slots_log2_per_rank": table_log2,
-                       "level_loop": ("native C++ (csrc/vsr_shard_loop.hpp), " + ("direct RCCL: grouped ncclSend/ncclRecv" if backend == "nccl" else "gloo callbacks, host-staged"))
-                                     if native else "Python over torch.distributed (vsr_tlaplus_amd/sharded.py)"},
-            "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
-            "xgmi_bytes_sent_rank0_per_step": int((sent[0] if native else x.bytes_sent) / max(1, args.steps + args.warmup)),
-            "records_moved_by_rebalancing_rank0": moved[0],
-            "roofline": {"bound": "hbm", "kernel": "k_expand (rank 0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": S["launches"],
-                         "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3),
-                                                "k_apply_verdict": round(S["mat_ms"] / args.steps, 3)}},
-        }))
+            "config": {"workload": ("VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2,v3} StartViewOnTimerLimit=3 (the reference README's state-"
+                                    "transfer-defect configuration, README:13-18 = BASELINE configs[2]), VIEW+SYMMETRY, to the first violation at depth 24: "
+                                    "1821858767 distinct states" if readme else
+                                    "VSR.tla BFS, ReplicaCount=3 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 (BASELINE configs[1] = shipped VSR.cfg), "
+                                    "VIEW+SYMMETRY, to first violation: 28 levels, 319228361 distinct states"),
+                       "parallelism": "seen-set sharded by fingerprint over %d ranks, all-to-all of (fp, key) candidates per level / pass (RCCL), records "
+                                      "stay with their generator, levels below %d new states replicated; automatic level scheme: levels 1-%d stored, %d "
+                                      "pass(es) through the seen-sets alone" % (world, REPLICATE_BELOW, S["stored_levels"], len(S["passes"])),
+                       "sized_from_free_hbm": dict(table_slots_log2_per_rank=int(eng.options.table_log2), frontier_words_per_buffer=int(eng.options.frontier_words),
+                                                   candidates_per_peer=int(eng.cand_cap)),
+                       "level_loop": "native C++ (csrc/vsr_shard_loop.hpp), " + ("direct RCCL: grouped ncclSend/ncclRecv" if backend == "nccl" else "gloo callbacks, host-staged")},
+            "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4), "setup_s": round(setup, 2),
+            "xgmi_bytes_sent_rank0_per_step": int(S["sent"] / max(1, args.steps + args.warmup)),
+            "records_moved_by_rebalancing_rank0": S["moved"],
+            "deep_passes": S["passes"],
+            "roofline": {"bound": "hbm", "kernel": "k_expand (rank 0; the job's algorithmic bytes / N over rank 0's kernel time)", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "traffic_note": "PMC passes exist for the N = 1 line only (profiles/): no counter run on more than one GPU",
+                         "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": S["launches"] // max(1, args.steps),
+                         "kernel_ms_per_step": {"k_expand": round(kernel_ms / args.steps, 3), "k_expand_stored_levels": round(S["stored_ms"] / args.steps, 3),
+                                                "k_expand_deep_passes": round(S["deep_ms"] / args.steps, 3)}},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = bench.cpu_baseline(args.cpu_seconds, cfg)
+        print(json.dumps(out))
     dist.barrier()
+    eng.close()
     dist.destroy_process_group()
