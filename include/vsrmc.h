@@ -123,8 +123,12 @@ int32_t vsrmc_fingerprint_batch(const vsrmc_model* m, int32_t device, const uint
                                 uint64_t n, uint64_t* fps, uint32_t* auxkeys);
 
 /* ---- TLC's own fingerprint: tlc2.util.FP64 over Value.fingerPrint of the `view` value (VSR.tla:140-150) ------------
- * A characterisation mode (VSR.tla only): the seen-set never uses it.  Everything TLC-specific is recalled, not pinned — see
- * vsr_tlcfp.hpp.  With SYMMETRY the state fingerprinted is the permuted state TLC picks (TLCStateMut.fingerPrint: the smallest under
+ * A characterisation mode (VSR.tla only): the seen-set never uses it.  A TLC-STYLE FP64, not a parity-checked one: everything
+ * TLC-specific is recalled, not pinned — see vsr_tlcfp.hpp.  One recalled detail is known to be doubtful: a model value is serialised
+ * here as MODELVALUE + its index in cfg creation order, whereas ModelValue.fingerPrint may extend with the value's UniqueString token,
+ * which is assigned in interning order over ALL strings of the parsed spec (module names, operators, fields ...), not over the model
+ * values alone — if so, neither the FP64 values nor the min-permutation choice under SYMMETRY can be bit-equal to TLC's until a real
+ * run's token table is supplied (tools/tlc_handoff.sh is where that would be found out).  With SYMMETRY the state fingerprinted is the permuted state TLC picks (TLCStateMut.fingerPrint: the smallest under
  * Value.compareTo, variable by variable in declaration order).
  * vsrmc_tlc_fingerprint_batch: n wire records -> FP64s, computed on the GPU.
  * vsrmc_tlc_view_bytes: the byte stream the fingerprint of ONE wire record is taken over, under value permutation `permutation`

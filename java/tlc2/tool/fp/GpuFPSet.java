@@ -75,26 +75,35 @@ public class GpuFPSet extends FPSet {
                 final ArrayDeque<Req> batch = new ArrayDeque<Req>();
                 while (!queue.isEmpty() && batch.size() < BATCH && queue.peek().isPut == op) batch.add(queue.poll());
                 lock.unlock();
-                final int m = batch.size();
-                final long[] fps = new long[m];
-                final byte[] out = new byte[m];
-                int i = 0;
-                for (Req q : batch) fps[i++] = q.fp;
+                // Everything between this unlock and the re-lock below runs WITHOUT the lock, and whatever happens in it — a native
+                // failure, a RuntimeException / Error out of the JNI call, an OutOfMemoryError allocating the arrays — the batch must be
+                // marked done and `flushing` reset, or every other worker waits in awaitUninterruptibly() for ever.  The finally block
+                // re-locks first (so that the outer finally's unlock() is balanced), then hands every request of the batch its answer or
+                // the error.
+                byte[] out = null;
                 IOException err = null;
                 try {
+                    final int m = batch.size();
+                    final long[] fps = new long[m];
+                    out = new byte[m];
+                    int i = 0;
+                    for (Req q : batch) fps[i++] = q.fp;
                     final int rc = op ? putBlock0(handle, fps, out) : containsBlock0(handle, fps, out);
                     if (rc != 0) err = new IOException(lastError0());
+                } catch (Throwable t) {
+                    err = new IOException("GpuFPSet: the native batch call failed: " + t, t);
                 } finally {
                     lock.lock();
+                    int i = 0;
+                    for (Req q : batch) {
+                        q.present = err == null && out != null && out[i] != 0;
+                        i++;
+                        q.error = err;
+                        q.done = true;
+                    }
+                    flushing = false;
+                    flushed.signalAll();
                 }
-                i = 0;
-                for (Req q : batch) {
-                    q.present = out[i++] != 0;
-                    q.error = err;
-                    q.done = true;
-                }
-                flushing = false;
-                flushed.signalAll();
             }
         } finally {
             lock.unlock();

@@ -231,21 +231,25 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,native", [(4, False), (2, True)])
-def test_bench_sharded_leg_at_full_scale(world, native):
-    """`bench.py --gpus N` (the driver's scaling run) with N ranks sharing this GPU over gloo: the whole 319 M-state workload
-    with the buffer sizes the leg computes for that world size; bench asserts the distinct-state count, the depth, the
-    violating fingerprint and the trace replay itself.  native: the level loop in C++ (on a multi-GPU node it talks RCCL directly;
-    here its two collectives are gloo callbacks and the buckets are staged through the host)."""
+@pytest.mark.parametrize("world,workload", [(2, "readme"), (4, "config2")])
+def test_bench_sharded_leg_at_full_scale(world, workload):
+    """`bench.py --gpus N` (the driver's scaling run) with N ranks sharing this GPU over gloo — the level loop in C++ (on a multi-GPU
+    node it talks RCCL directly; here its two collectives are gloo callbacks and the buckets are staged through the host).  world 2:
+    the README defect configuration, the leg's default — every rank sizes itself from (its share of) the free HBM, the last levels live
+    in the seen-sets only; world 4: config 2 (319 M states) the same way.  bench asserts every level's figures, the distinct-state
+    count, the depth, the violating fingerprint and the trace replay itself."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29680 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
-                       env=dict(os.environ, OMP_NUM_THREADS="1", VSR_BENCH_BACKEND="gloo", **({"VSR_BENCH_NATIVE": "1"} if native else {})))
+           "--master-port", str(29680 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline"] + (["--workload", "config2"] if workload == "config2" else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1", VSR_BENCH_BACKEND="gloo"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["launches"] >= 27
-    assert out["config"]["level_loop"].startswith("native C++" if native else "Python")   # the C++ loop over gloo callbacks / the Python loop
+    assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["launches"] >= 20
+    assert out["config"]["level_loop"].startswith("native C++")
+    assert ("README" in out["config"]["workload"]) == (workload == "readme")
+    if workload == "readme":
+        assert len(out["deep_passes"]) >= 2 and out["deep_passes"][-1]["probed_level"] == 24
 
 
 @pytest.mark.gpu

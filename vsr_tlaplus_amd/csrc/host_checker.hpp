@@ -276,7 +276,8 @@ static int autosize_options(vsrmc_options* o, const Model& M) {
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   const char* share_env = std::getenv("VSRMC_AUTOSIZE_SHARE");     // several checkers on one device (tests: ranks sharing a GPU): 1 / share each
   const double share = share_env ? std::max(1.0, std::atof(share_env)) : 1.0;
-  double avail = ((double)free_b - 3.0e9) / share;                 // runtime, code objects, small allocations
+  double avail = ((double)free_b - 4.0e9) / share;                 // runtime, code objects, small allocations (a sharded run: make the
+                                                                   // communicator BEFORE the checker, so that its buffers are not counted as free)
   if (avail < 256e6) return fail(VSRMC_E_HIP, "less than 256 MB of free device memory to size the checker from");
   if (o->table_log2 == 0) {
     int lg = 8;

@@ -215,7 +215,15 @@ class StateEncoder {
         if (!integer(*v, 0, 0, n, &x)) return false;       // RestartEmptyLimit = 0
       } else if (n == "clients" || n == "replicas") {
         const long want = n == "clients" ? M.C : M.R;
-        if (v->kind != TVal::RANGE || v->i != 1 || v->j != want) return fail(n + " does not match the model's constants");
+        // TLC keeps 1..N an interval (the reference's trace: `clients |-> 1..1`); the same value enumerated ({1, 2, 3}) is accepted too
+        bool ok = v->kind == TVal::RANGE && v->i == 1 && v->j == want;
+        if (v->kind == TVal::SET && (long)v->items.size() == want) {
+          long seen = 0;
+          for (const TVal& e : v->items)
+            if (e.kind == TVal::INT && e.i >= 1 && e.i <= want) seen |= 1L << e.i;
+          ok = seen == ((1L << (want + 1)) - 2);
+        }
+        if (!ok) return fail(n + " does not match the model's constants");
       } else if (n == "aux_client_acked") {
         if (v->kind == TVal::SEQ && v->items.empty()) continue;
         if (v->kind != TVal::FCN) return fail("aux_client_acked must be a function");

@@ -13,6 +13,9 @@
 //       IntValue      INTVALUE(1) int                       BoolValue   BOOLVALUE(0) 't' / 'f'
 //       ModelValue    MODELVALUE(21) int index              (index = creation order = order of first appearance in the cfg: the Values, then
 //                                                            Normal, ViewChange, Recovering, RequestMsg, ..., RecoveryResponseMsg, Nil — VSR.cfg:6-24)
+//                     DOUBTFUL: ModelValue.fingerPrint may extend with the value's UniqueString TOKEN (val.fingerPrint -> FP64.Extend(fp, tok)),
+//                     assigned in interning order over all strings of the parsed spec, not over the model values alone; then these bytes — and
+//                     the min-permutation choice, which compares model values by this index — differ from TLC's (round-3 advice; unpinnable here)
 //       StringValue   STRINGVALUE(3) int length, chars
 //       RecordValue   FCNRCDVALUE(9) int #fields, then per field in normal order: the NAME as a string value, the value
 //       TupleValue    FCNRCDVALUE(9) int length, then per element: INTVALUE(1) int index (from 1), the element

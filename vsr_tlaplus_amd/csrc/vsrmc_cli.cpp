@@ -31,8 +31,10 @@ static void usage() {
       "                    python3 -m torch.distributed.run ... -m vsr_tlaplus_amd.sharded_cli with the other arguments;\n"
       "                    -tableLog2 / -frontierGiB are then PER RANK; see that module for -replicateBelow, -backend, -exactTies,\n"
       "                    -checkpoint PREFIX / -recover PREFIX (one file per rank), -probeAt N)\n"
-      "  -tableLog2 N      seen-set slots = 2^N x 16 B (default 28)\n"
-      "  -frontierGiB G    size of each of the two frontier buffers (default 8); -frontierBGiB G: the second one (levels 2, 4, ..)\n"
+      "  -tableLog2 N      seen-set slots = 2^N x 16 B; -frontierGiB G: size of each of the two record buffers (-frontierBGiB G: the second one).\n"
+      "                    Default for both: sized from the free memory of the device (the largest power of two of slots within 30 %% of it, the\n"
+      "                    rest in two equal record buffers).  Levels are stored while the next one is predicted to fit; beyond that the search goes\n"
+      "                    on through the seen-set alone (Virtual(L) / Probe(L+1) lines) until the seen-set is 85 %% full.\n"
       "  -simulate         random walks instead of BFS (TLC -simulate): -depth N (default 100) -walkers N (131072) -seed S -maxSeconds T\n"
       "  -validateTrace F  read a TLC trace (trace expression, or console \"State k:\" form) and check on the GPU that it is a\n"
       "                    behaviour of the model: Init, then one generated successor after the other; reports the invariants\n"
@@ -114,8 +116,8 @@ int main(int argc, char** argv) {
   unsigned sim_walkers = 1u << 17;
   unsigned long long sim_seed = 1;
   double sim_seconds = 60.0;
-  int max_depth = 1 << 30, device = 0, table_log2 = 28, probe2_at = 0, probe3_at = 0, host_mask = 0;
-  double frontier_gib = 8.0, frontier_b_gib = 0.0;
+  int max_depth = 1 << 30, device = 0, table_log2 = 0, probe2_at = 0, probe3_at = 0, host_mask = 0;   // 0 = sized from the free device memory
+  double frontier_gib = 0.0, frontier_b_gib = 0.0;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--help" || a == "-h" || a == "-help") { usage(); return 0; }
@@ -248,7 +250,7 @@ int main(int argc, char** argv) {
   o.host_frontier = host_frontier ? 3 : (host_mask & 3);
   o.frontier_words = (uint64_t)(frontier_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);
   o.frontier_words_b = (uint64_t)(frontier_b_gib * 1024.0 * 1024.0 * 1024.0 / 8.0);   // 0 = like the first
-  o.frontier_states = o.frontier_words / 24;
+  o.frontier_states = o.frontier_words / 24;                   // (0 with -frontierGiB 0: derived with the words)
   o.pending_entries = (uint64_t)1 << 20;   // single-pass levels keep no pending list (the buffer only collects violators of probe levels)
   // one entry per state plus the unused tails of the per-block index chunks (<= 4096 per block per level, 510 levels at most)
   o.trace_entries = ((uint64_t)1 << table_log2) / 2 + ((uint64_t)1 << 28);   // + chunk tails: <= 1024 blocks x 8192 indices x ~30 large levels
@@ -341,25 +343,33 @@ int main(int argc, char** argv) {
       }
       break;
     }
-    rc = vsrmc_checker_step(c, &info);
-    if (rc == VSRMC_E_REP && probe_last && std::strstr(vsrmc_last_error(), "device error 21") != nullptr) {
-      // the level does not fit: probe it (invariants only, nothing stored)
-      std::printf("Level %d does not fit the frontier buffers (%s); probing it without storing its states.\n", depth + 1, vsrmc_last_error());
-      vsrmc_level_info pi;
-      rc = vsrmc_checker_probe(c, &pi);
-      if (rc != 0) break;
-      double dtp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      std::printf("Probe(%d): %llu states generated from %llu states, %llu violating successors seen. (%.2f s)\n", pi.level,
-                  (unsigned long long)pi.generated, (unsigned long long)pi.frontier, (unsigned long long)pi.pending, dtp);
-      info.total_generated = pi.total_generated;
-      if (pi.viol_mask) {
-        probed_violation = true;
-        info.viol_mask = pi.viol_mask;
-        viol_level = (uint64_t)pi.level;
-      } else {
-        std::printf("No violation in level %d; the search is incomplete beyond it.\n", pi.level);
+    // the automatic level scheme: an ordinary level while the next one is predicted to fit the record buffers, else one more level through
+    // the seen-set alone (vsrmc_checker_deepen: inserted, counted and checked, its records regenerated when needed) and a probe of the one after
+    int32_t what = 0;
+    vsrmc_level_info probed;
+    rc = vsrmc_checker_advance(c, &info, &probed, &what);
+    if (rc != 0) break;
+    if (what == 2) {
+      for (int a2 = 1; a2 < 16; a2++) cov[a2] += info.act_generated[a2];
+      const double dtp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (dump) { std::printf("Level %d is not stored (it does not fit the record buffers): -dump ends at level %d.\n", info.level, depth); std::fclose(dump); dump = nullptr; }
+      if (info.n_new == 0) break;
+      depth = info.level;
+      std::printf("Virtual(%d): %llu states generated, %llu distinct states found, %llu states in the level (not stored; %llu launches). (%.2f s)\n", info.level,
+                  (unsigned long long)info.total_generated, (unsigned long long)info.distinct, (unsigned long long)info.n_new, (unsigned long long)info.pending, dtp);
+      if (info.viol_mask) { probed_violation = true; viol_level = (uint64_t)info.level; break; }
+      if (probed.level) {
+        std::printf("Probe(%d): %llu states generated from %llu states, %llu violating successors seen. (%.2f s)\n", probed.level,
+                    (unsigned long long)probed.generated, (unsigned long long)probed.frontier, (unsigned long long)probed.pending, dtp);
+        if (probed.viol_mask) {
+          probed_violation = true;
+          info.viol_mask = probed.viol_mask;
+          info.total_generated = probed.total_generated;
+          viol_level = (uint64_t)probed.level;
+          break;
+        }
       }
-      break;
+      continue;
     }
     if (rc != 0) break;
     for (int a2 = 1; a2 < 16; a2++) cov[a2] += info.act_generated[a2];

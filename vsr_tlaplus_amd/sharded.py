@@ -466,6 +466,8 @@ class HipShardEngine:
         self.dev = dev
         check(capi.load().vsrmc_checker_options(self._h, C.byref(o)))       # sizes left 0 were derived from the free device memory
         self.options = o
+        if not cand_cap and world == 1:
+            cand_cap = 1 << 16                                  # nobody to announce to
         if not cand_cap:
             # 42 bytes per candidate and peer (16 sent + 16 received + 8 beside it + 2 verdict bytes); the checker's record memory is
             # 19.7 bytes per frontier word and 4/5 of what the exchange buffers + records share: 3/4 of the remaining fifth

@@ -47,11 +47,12 @@ def main(args, bench):
                        for lv in bench.EXPECT["levels"]]
         expect = dict(distinct=bench.EXPECT["distinct"], depth=bench.EXPECT["depth"], viol_fp=bench.EXPECT["viol_fp"], probe_generated=None)
     m = vt.Model.from_constants(R=cfg["R"], C_=cfg["C"], n=cfg["n"], L=cfg["L"])
+    # the communicator first: RCCL's own device buffers must be there when the checker sizes itself from what is free
+    comm = sharded.RcclComm(local_rank) if backend == "nccl" else sharded.TorchHostComm()
     t0 = time.perf_counter()
     eng = sharded.HipShardEngine(m, rank, world, device=local_rank, table_log2=0, frontier_words=0, frontier_states=0, pending_entries=0, cand_cap=0,
                                  rec_cap=1 << 22, rec_words_cap=1 << 28, native_only=True)
     setup = time.perf_counter() - t0
-    comm = sharded.RcclComm(local_rank) if backend == "nccl" else sharded.TorchHostComm()
     S = dict(alg_bytes=0.0, launches=0, distinct=0, ttfv=[], kernel_ms=0.0, stored_ms=0.0, deep_ms=0.0, stored_levels=0, passes=[], sent=0, moved=0)
 
     def one_run(record):
