@@ -52,7 +52,6 @@ struct vsrmc_checker {
   void* fused_kernel = nullptr;
   void* plain_kernel = nullptr;          // the same without modes / sharding, when the configuration has one (ordinary unsharded levels)
   void* modes_kernel = nullptr;          // the same without sharding (expand_pass: the passes of vsrmc_checker_probe / _probe2 / _probe3), or null
-  int plain_blk = VSR_BLOCK;             // threads per block of plain_kernel: 256, or 64 = one wave per block with a 16-record tile of its own
   u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
   bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
   // vsrmc_checker_probe / _probe2: where the reported violator's counter-example is walked from — the fingerprint of the deepest
@@ -102,8 +101,7 @@ MaterializeKernel materialize_kernel_for(const Model& M) {
     default: return k_materialize<0>;
   }
 }
-ExpandKernel plain_kernel_for(const Model& M, int blk) {      // unsharded ordinary levels: modes and sharding compiled out
-  if (blk != VSR_BLOCK) return nullptr;
+ExpandKernel plain_kernel_for(const Model& M) {               // unsharded ordinary levels: modes and sharding compiled out
   if (M.model_id == 1) return (M.R == 3 && M.n == 2) ? k_expand<true, 1302, true> : nullptr;   // the shipped VR_STATE_TRANSFER.cfg
   if (M.model_id == 2) return (M.R == 3 && M.n == 2) ? k_expand<true, 2302, true> : nullptr;   // the shipped VR_APP_STATE.cfg
   switch (M.R * 100 + M.C * 10 + M.n) {
@@ -157,7 +155,7 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
   FusedShape f;
   f.stride = (int)std::min<u64>((u64)c->lds_stride, (u64)((M.fixed + (int)std::min<u64>(max_bag_of_source, 255)) | 1));
   const void* kernel = (plain && c->plain_kernel) ? c->plain_kernel : c->fused_kernel;
-  const int blk = (plain && c->plain_kernel) ? c->plain_blk : VSR_BLOCK;
+  const int blk = VSR_BLOCK;                                   // (one-wave and 512-thread blocks were measured and rejected: DESIGN.md §5, round 3)
   auto occupancy = [&](int tile, u32 ccap, size_t* lds) {
     *lds = (size_t)tile * f.stride * 8 + 2 * (size_t)ccap * 4;
     int nb = 0;
@@ -165,18 +163,6 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
     return nb;
   };
   f.blk = blk;
-  if (blk == 512) {
-    f.tile = 128;
-    f.ccap = 3072u;
-    f.blocks_per_cu = (unsigned)std::max(1, std::min(occupancy(128, f.ccap, &f.lds), 2));
-    return f;
-  }
-  if (blk == 64) {                                              // one wave, 16 records, 24 (R <= 3) or 32 work-list entries per record
-    f.tile = 16;
-    f.ccap = M.R <= 3 ? 384u : 512u;
-    f.blocks_per_cu = (unsigned)std::max(1, std::min(occupancy(16, f.ccap, &f.lds), 16));
-    return f;
-  }
   size_t lds64 = 0, lds128 = 0;
   const u32 ccap64 = M.R <= 3 ? (u32)VSR_CCAP64 : (u32)VSR_CAND_CAP;      // work-list entries per tile (24 resp. 32 per record)
   const int occ64 = occupancy(64, ccap64, &lds64);
@@ -356,13 +342,7 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o_in, vs
   }
   c->fused_kernel = (void*)fused_kernel_for(M);
   c->modes_kernel = (void*)modes_kernel_for(M);
-  {
-    // VSRMC_BLK=64 / 512 select the experimental block shapes of a -DVSRMC_EXPERIMENTAL_BLK=1 build (A/B runs); default 256
-    const char* e = std::getenv("VSRMC_BLK");
-    const int want = e ? std::atoi(e) : VSRMC_DEFAULT_BLK;
-    c->plain_blk = ((want == 64 || want == 512) && plain_kernel_for(M, want)) ? want : VSR_BLOCK;
-    c->plain_kernel = (void*)plain_kernel_for(M, c->plain_blk);
-  }
+  c->plain_kernel = (void*)plain_kernel_for(M);
   rc = checker_seed(c);
   if (rc) { vsrmc_checker_destroy(c); return rc; }
   *out = c;
@@ -413,7 +393,6 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     // sharded: records arrive from other ranks (rebalancing), the local maximum says nothing -> the format's capacity
     const bool use_plain = fused && !io && mode == MODE_NORMAL && c->plain_kernel;
     const FusedShape fs = fused_shape(c, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, use_plain);
-    const int cdiv = std::max(1, VSR_BLOCK / fs.blk);            // one-wave blocks: four times the blocks, a quarter of the chunk sizes
     const int tile = fused ? fs.tile : (M.R <= 3 ? 128 : 64);
     const int stride = fused ? fs.stride : c->lds_stride;
     u64 ntiles = (c->n_frontier + tile - 1) / tile;
@@ -441,19 +420,19 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
       // persistent blocks (2 resident per CU: 225 VGPRs, 79 KB LDS): every block leaves one partly used index chunk and
       // one word chunk behind per level, so fewer blocks = fewer unused slots in the next frontier
       grid = (unsigned)std::min<u64>((u64)ntiles, (u64)c->num_cus * fs.blocks_per_cu);
-      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP / cdiv), c->words_cap(nxt) / (4 * 16384))));
+      grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
       // a tile's successors (at most ccap records of at most stride + 5 words each) must fit one word chunk, and every block
       // may leave one partly used chunk behind: fewer blocks if the buffer is too small for that
       // (a buffer too small even for one such chunk keeps going with what it has: the kernel refuses a tile that does not fit
       // its chunk with ERR_FRONTIER_FULL instead of writing past it)
       const u64 wmin = std::max<u64>(16384, (u64)ccap * (u64)(stride + 5));
       grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, c->words_cap(nxt) / (4 * wmin)));
-      ichunk = (u32)std::max<u64>(VSR_CAND_CAP / cdiv, std::min<u64>(8192 / cdiv, nx_cap / (4 * (u64)grid)));
-      wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144 / cdiv, c->words_cap(nxt) / (4 * (u64)grid)));
+      ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
+      wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     }
     if (fused)
       hipLaunchKernelGGL((ExpandKernel)(use_plain ? c->plain_kernel : c->fused_kernel), dim3(grid),
-                         dim3(use_plain ? fs.blk : VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
+                         dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, ichunk,
@@ -640,7 +619,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
   if (n_parents > 0) {
     // an ordinary level into other buffers (the streamed level's sub-slices) runs the plain instantiation: the code of a stored level
     static const bool plain_normal = std::getenv("VSRMC_STREAM_MODES_KERNEL") == nullptr;
-    const bool use_plain = !io && mode == MODE_NORMAL && plain_normal && c->plain_kernel && c->plain_blk == VSR_BLOCK;
+    const bool use_plain = !io && mode == MODE_NORMAL && plain_normal && c->plain_kernel;
     const FusedShape fs = fused_shape(c, src_max_bag, use_plain);
     u32 cchunk = 0;
     if (io) {

@@ -373,11 +373,10 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
 // in the constants, still specific to the model): the constants of the model
 // become compile-time constants of this instantiation (every device function below is inlined), so loops over replicas,
 // clients, values and permutations unroll without predicates and strides fold into addresses.
-// BLK = threads per block: 256 (four waves share a tile of 64 or 128 records, block barriers between the phases) or 64 — one wave per
-// block with a tile of 16 records of its own: the same phases, but a barrier of a one-wave workgroup costs nothing, no wave waits
-// for the slowest wave of its tile, and the 16 waves of a CU drift apart so that their memory and issue phases interleave.
+// BLK = threads per block = 256: four waves share a tile of 64 (or 128) records, block barriers between the phases.  (One wave per block
+// with a 16-record tile of its own and 512-thread blocks were built and measured in round 3: 268 and 212 ms against 156 — DESIGN.md §5.)
 template <bool FUSED, int SPEC = 0, int PLAIN = 0, int BLK = VSR_BLOCK>
-// (hipcc turns the second bound into waves per SIMD as blocks * max(1, threads / 256): 4 = 128 VGPRs for either block size)
+// (hipcc turns the second bound into waves per SIMD as blocks * max(1, threads / 256): 4 = 128 VGPRs)
 __global__ void __launch_bounds__(BLK, (FUSED ? (SPEC ? VSR_OCC : 2) : 3) / (BLK > VSR_BLOCK ? BLK / VSR_BLOCK : 1))
 k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world_arg, u64* cand_send,

@@ -22,11 +22,7 @@
 #include "vras_parse.hpp"
 #include "vsr_kernels.hpp"
 
-// threads per block of the ordinary-level kernel (k_expand<.., PLAIN, BLK>): 64 = one wave per block with its own 16-record tiles
 #define VSRMC_FP_VERSION 2          // fingerprint function of this build; checkpoints of another version are refused
-#ifndef VSRMC_DEFAULT_BLK
-#define VSRMC_DEFAULT_BLK 256
-#endif
 
 using namespace vsr;
 
