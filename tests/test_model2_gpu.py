@@ -123,12 +123,10 @@ def test_model2_whole_workload_against_the_oracle(vt, oracle_levels):
     g = oracle_levels["model2"]
     p = g["params"]
     m = vt.Model.second_model(R=p["R"], n=p["n"], L=p["L"], invariant_mask=p["inv_mask"])
-    biggest = max(lv["new"] for lv in g["levels"])
-    mc = vt.ModelChecker(m, table_log2=max(20, int(np.ceil(np.log2(2.5 * g["distinct"])))),
-                         frontier_words=int(biggest * (m.layout.fixed_words + 1 + g["max_bag"]) * 1.1) + (1 << 29),
-                         frontier_states=int(biggest * 1.3) + (1 << 24), pending_entries=1 << 15, keep_trace=False)
+    mc = vt.ModelChecker.auto(m)                                 # sized from the free HBM; every level of the fixture fits the record buffers
     for lv in g["levels"][1:]:
-        d = mc.step()
+        kind, d, _ = mc.advance()
+        assert kind == "level"
         assert (d["level"], d["n_new"], d["generated"], d["deadlocks"], d["max_bag"], d["viol_mask"]) == \
             (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"], 0), lv["level"]
         assert [int(x) for x in d["act_generated"][1:16]] == lv["act_generated"][1:16], lv["level"]

@@ -23,10 +23,7 @@ def main():
             g = json.load(f)
         p = g["params"]
         m = make(R=p["R"], n=p["n"], L=p["L"], invariant_mask=p["inv_mask"])
-        biggest = max(lv["new"] for lv in g["levels"])
-        mc = vt.ModelChecker(m, table_log2=max(20, int(np.ceil(np.log2(2.5 * g["distinct"])))),
-                             frontier_words=int(biggest * (m.layout.fixed_words + 1 + g["max_bag"]) * 1.1) + (1 << 29),
-                             frontier_states=int(biggest * 1.3) + (1 << 24), pending_entries=1 << 15)
+        mc = vt.ModelChecker.auto(m)                             # sized from the free HBM
         best = None
         for _ in range(a.runs + 1):                              # the first run warms up
             mc.reset()

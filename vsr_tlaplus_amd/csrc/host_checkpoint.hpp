@@ -195,6 +195,7 @@ int32_t vsrmc_checker_lookup(vsrmc_checker* c, uint64_t key, int32_t level, int3
 int32_t vsrmc_checker_level_fps(vsrmc_checker* c, uint64_t* out, uint64_t cap, uint64_t* n) {
   if (!c || !n) return fail(VSRMC_E_ARG, "NULL argument");
   *n = c->n_valid;
+  if (c->deep_regen_done) return fail(VSRMC_E_STATE, "the fingerprint array of the newest stored level was reused by a descent of the deep search (vsrmc_checker_deepen): states are addressed by fingerprint from here on (vsrmc_checker_trace_fp, _lookup)");
   if (!out || cap < c->n_valid) return fail(VSRMC_E_ARG, "buffer too small");
   HIPCHK(hipSetDevice(c->opt.device));
   std::vector<u64> all(c->n_frontier);
@@ -211,6 +212,7 @@ int32_t vsrmc_checker_level_checksum(vsrmc_checker* c, uint64_t* fp_xor, uint64_
   if (!c || !fp_xor || !fp_sum || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
   *fp_xor = *fp_sum = *n_states = 0;
   if (c->n_frontier == 0) return 0;
+  if (c->deep_regen_done) return fail(VSRMC_E_STATE, "the fingerprint array of the newest stored level was reused by a descent of the deep search (vsrmc_checker_deepen): states are addressed by fingerprint from here on (vsrmc_checker_trace_fp, _lookup)");
   HIPCHK(hipSetDevice(c->opt.device));
   u64* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, 24));
@@ -397,6 +399,7 @@ int32_t vsrmc_checker_trace(vsrmc_checker* c, int32_t level, uint64_t index, uin
   if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
   if (level != c->level || index >= c->n_frontier)
     return fail(VSRMC_E_ARG, "no such state: states are addressed by index in the newest level only (older ones: vsrmc_checker_trace_fp)");
+  if (c->deep_regen_done) return fail(VSRMC_E_STATE, "the fingerprint array of the newest stored level was reused by a descent of the deep search (vsrmc_checker_deepen): states are addressed by fingerprint from here on (vsrmc_checker_trace_fp, _lookup)");
   HIPCHK(hipSetDevice(c->opt.device));
   u64 fp = 0;
   HIPCHK(hipMemcpy(&fp, c->lvl_fp + index, 8, hipMemcpyDeviceToHost));

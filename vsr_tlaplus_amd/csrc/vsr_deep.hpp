@@ -84,39 +84,56 @@ struct DeepRun {
   int probed_level() const { return last_regen + (insert ? 2 : 1); }
 };
 
-// scratch buffer k (k >= 1) of the descent: a quarter of the one above it (k = 0 = the idle frontier buffers); allocated on first use, kept
+// The scratch buffers of a descent: buffer 0 = the idle frontier buffers; buffers 1 .. count = what `count` more nesting levels write
+// into.  They share what is free on the device EQUALLY (at most a quarter of a record buffer each): a geometric series — a quarter of the one
+// above, round 3's rule for its one scratch buffer — starves the deepest levels of a long descent (eight levels down a buffer of 12e9 words
+// is 2e6 words: millions of launches of a few thousand states; the analysis model's run to depth 33 took 570 s that way).  Planned at the start
+// of a pass, when the buffers are empty; re-planned (freed and allocated anew) when a pass needs more levels than the plan has.
+int deep_plan_scratch(vsrmc_checker* c, int count) {
+  if (count <= 0 || (size_t)count <= c->scratch.size()) return 0;
+  if (count > 400) return fail(VSRMC_E_REP, "deep search: more than 400 nested levels");
+  for (PassDst& B : c->scratch) {
+    if (B.words) (void)hipFree(B.words);
+    if (B.off) (void)hipFree(B.off);
+    if (B.fp) (void)hipFree(B.fp);
+  }
+  c->scratch.clear();
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  const int nxt = c->cur ^ 1;
+  // per buffer: W words of records + W / 12 state indices (refs + fingerprints: 16 B each) = 9.33 B per word
+  const char* share_env = std::getenv("VSRMC_AUTOSIZE_SHARE");   // several checkers on one device (tests: ranks sharing a GPU)
+  const double share = share_env ? std::max(1.0, std::atof(share_env)) : 1.0;
+  const double budget = std::max(0.0, (double)free_b - 1.0e9) / share / (double)count;
+  u64 wcap = (u64)std::min((double)(c->words_cap(nxt) / 4), budget / 9.34);
+  wcap = std::max<u64>((u64)1 << 21, wcap);                        // floor: 16 MB of records (tiny spaces; a device without that much left fails below)
+  for (int k = 0; k < count; k++) {
+    PassDst B;
+    B.words_cap = wcap;
+    B.cap = std::max<u64>((u64)1 << 15, wcap / 12);
+    hipError_t e = hipMalloc((void**)&B.words, B.words_cap * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&B.off, (B.cap + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&B.fp, B.cap * 8);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      if (B.words) (void)hipFree(B.words);
+      if (B.off) (void)hipFree(B.off);
+      if (B.fp) (void)hipFree(B.fp);
+      return fail(VSRMC_E_HIP, std::string("hipMalloc of a deep-search scratch buffer: ") + hipGetErrorString(e));
+    }
+    c->scratch.push_back(B);
+  }
+  return 0;
+}
+
 int deep_buffer(vsrmc_checker* c, int k, PassDst* out) {
   const int nxt = c->cur ^ 1;
   if (k == 0) {
     out->words = c->words[nxt]; out->words_cap = c->words_cap(nxt); out->off = c->off[nxt]; out->fp = c->lvl_fp; out->cap = c->opt.frontier_states;
     return 0;
   }
-  if (k > 400) return fail(VSRMC_E_REP, "deep search: more than 400 nested levels");
-  if ((size_t)k > c->scratch.size()) c->scratch.resize((size_t)k);
-  PassDst& B = c->scratch[(size_t)k - 1];
-  if (!B.words) {
-    u64 wcap = c->words_cap(nxt), ncap = c->opt.frontier_states;
-    for (int i = 0; i < k && wcap > ((u64)1 << 21); i++) { wcap /= 4; ncap /= 4; }
-    wcap = std::max<u64>((u64)1 << (k <= 2 ? 22 : 21), wcap);        // floor: 16 MB of records, 32 768 states — nested deeper than the sizes shrink
-    ncap = std::max<u64>((u64)1 << (k <= 2 ? 16 : 15), ncap);       // only tiny spaces get (tests: 36 levels through the seen-set alone)
-    hipError_t e = hipErrorOutOfMemory;
-    for (int attempt = 0; attempt < 6 && e != hipSuccess; attempt++, wcap /= 2, ncap /= 2) {   // less free memory than a quarter: take what there is
-      if (wcap < ((u64)1 << 20) || ncap < ((u64)1 << 14)) break;
-      B.words_cap = wcap; B.cap = ncap;
-      e = hipMalloc((void**)&B.words, wcap * 8);
-      if (e == hipSuccess) e = hipMalloc((void**)&B.off, (ncap + 1) * 8);
-      if (e == hipSuccess) e = hipMalloc((void**)&B.fp, ncap * 8);
-      if (e != hipSuccess) {
-        (void)hipGetLastError();
-        if (B.words) (void)hipFree(B.words);
-        if (B.off) (void)hipFree(B.off);
-        if (B.fp) (void)hipFree(B.fp);
-        B = PassDst();
-      }
-    }
-    if (e != hipSuccess) return fail(VSRMC_E_HIP, std::string("hipMalloc of a deep-search scratch buffer: ") + hipGetErrorString(e));
-  }
-  *out = B;
+  if ((size_t)k > c->scratch.size()) return fail(VSRMC_E_REP, "deep search: a nesting level without a planned scratch buffer");
+  *out = c->scratch[(size_t)k - 1];
   return 0;
 }
 
@@ -352,7 +369,8 @@ int deep_pass(vsrmc_checker* c, int last_regen, bool insert, vsrmc_level_info* i
   HIPCHK(hipMalloc((void**)&R.d_sum, 24));
   struct FreeSum { u64* p; ~FreeSum() { (void)hipFree(p); } } free_sum{R.d_sum};
   if (insert) { c->deep_lv.resize((size_t)(last_regen + 1 - c->level)); c->deep_lv.back() = DeepLevel(); }
-  int rc = 0;
+  int rc = deep_plan_scratch(c, last_regen - c->level - (insert ? 0 : 1));   // buffer k takes what level base + k yields
+  if (rc) { c->failed = 1; return rc; }
   if (io) { u64 sync = 0; rc = io->any(io->ctx, &sync); }      // every rank has cleared its taken bits
   if (!rc) rc = deep_descend(R, c->words[c->cur], c->off[c->cur], c->n_frontier, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, c->level, 0);
   if (rc) { c->failed = 1; return rc; }
