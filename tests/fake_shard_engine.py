@@ -212,3 +212,114 @@ class FakeShardEngine:
 
     def level_fps(self):
         return np.array(sorted(f for f in self.fps if f is not None), dtype=np.uint64)
+
+    # ---- levels beyond the record buffers (the passes of csrc/vsr_deep.hpp, sharded: vsr_shard_loop.hpp's second half) ----------------
+    # mode: "insert" (virtual level: claimed, counted, checked, nothing kept), "regen" (the candidate whose key IS the slot's final
+    # meta word rebuilds the state, exactly once), "normal" (inserted and kept for the caller: a scratch buffer), and deep_probe.
+    TAKEN = 1
+
+    def deep_source(self):
+        """the newest stored level: [(record, fingerprint)]"""
+        return [(r, f) for r, f in zip(self.frontier, self.fps) if r is not None]
+
+    def deep_untake(self, min_level):
+        for fp, m in list(self.seen.items()):
+            if (m >> 55) >= min_level and (m & self.TAKEN):
+                self.seen[fp] = m & ~self.TAKEN
+
+    def _deep_claim_one(self, fp, key, level):
+        """first inserter wins; keys of later candidates of the same level are min-merged -> True if this call inserted fp"""
+        cur = self.seen.get(fp)
+        if cur is None:
+            self.seen[fp] = key
+            return True
+        if (cur >> 55) == level and key < cur:
+            self.seen[fp] = key
+        return False
+
+    def _deep_grant_one(self, fp, key):
+        """regenerated level: the candidate whose key is the slot's meta word takes it, once"""
+        if self.seen.get(fp) == key:
+            self.seen[fp] = key | self.TAKEN
+            return True
+        return False
+
+    def deep_expand(self, src, level, mode):
+        """src: [(record, fingerprint)] of level - 1 -> (per-owner (n, 2) candidate tensors, 0)"""
+        if not hasattr(self, "sent_filter"):
+            self.sent_filter = set()
+        self.d_mode, self.d_level = mode, level
+        self.d_out, self.d_sent, self.d_keep = [], [[] for _ in range(self.world)], [[] for _ in range(self.world)]
+        st = self.d_stats = dict(generated=0, deadlocks=0, n_new=0, viol_fp=U64_MAX, viol_mask=0, fx=0, fs=0)
+        for rec, pfp in src:
+            succ = orc.successors(self.P, rec)
+            st["generated"] += len(succ)
+            st["deadlocks"] += 0 if succ else 1
+            for k, s in enumerate(succ):
+                key = self._key(level, s["auxkey"], pfp, k)
+                o = self.owner_of(s["fp"], self.world)
+                if o == self.rank:
+                    if mode == "regen":
+                        if self._deep_grant_one(s["fp"], key):
+                            self.d_out.append((np.array(s["words"], dtype=np.uint64), s["fp"]))
+                    elif self._deep_claim_one(s["fp"], key, level):
+                        self._deep_count(s)
+                        if mode == "normal":
+                            self.d_out.append((np.array(s["words"], dtype=np.uint64), s["fp"]))
+                    continue
+                if mode != "regen":                              # the sent-filter: an exact repeat was announced (and claimed) before
+                    tag = (s["fp"], s["auxkey"])
+                    if tag in self.sent_filter:
+                        continue
+                    self.sent_filter.add(tag)
+                self.d_sent[o].append((s["fp"], key))
+                self.d_keep[o].append(s)                         # what the generator keeps beside the candidate
+        return [_i64([x for fk in self.d_sent[o] for x in fk]).reshape(-1, 2) for o in range(self.world)], 0
+
+    def _deep_count(self, s):
+        st = self.d_stats
+        st["n_new"] += 1
+        st["fx"] ^= s["fp"]
+        st["fs"] = (st["fs"] + s["fp"]) & U64_MAX
+        if s["inv"]:
+            st["viol_fp"] = min(st["viol_fp"], s["fp"])
+            st["viol_mask"] |= s["inv"]
+
+    def deep_claim(self, cands, level, mode):
+        vals = _u64(cands)
+        out = []
+        for i in range(len(vals) // 2):
+            fp, key = vals[2 * i], vals[2 * i + 1]
+            out.append(1 if (self._deep_grant_one(fp, key) if mode == "regen" else self._deep_claim_one(fp, key, level)) else 0)
+        return torch.tensor(out, dtype=torch.uint8), 0
+
+    def deep_apply(self, verdicts):
+        """the verdict bytes of the announced candidates -> (records this pass yields [(record, fp)], the pass's figures)"""
+        for o in range(self.world):
+            if o == self.rank or not self.d_sent[o]:
+                continue
+            v = [int(x) for x in verdicts[o].cpu()]
+            assert len(v) == len(self.d_sent[o])
+            for s, win in zip(self.d_keep[o], v):
+                if not win:
+                    continue
+                if self.d_mode != "regen":
+                    self._deep_count(s)
+                if self.d_mode != "insert":
+                    self.d_out.append((np.array(s["words"], dtype=np.uint64), s["fp"]))
+        return self.d_out, self.d_stats
+
+    def deep_probe(self, src, level):
+        """successors of `src` (states of level - 1) that violate an invariant and are not in THIS rank's seen-set below `level`"""
+        gen = dead = mask = 0
+        bad = []
+        for rec, pfp in src:
+            succ = orc.successors(self.P, rec)
+            gen += len(succ)
+            dead += 0 if succ else 1
+            for k, s in enumerate(succ):
+                if s["inv"] and not (s["fp"] in self.seen and (self.seen[s["fp"]] >> 55) < level):
+                    bad.append((s["fp"], self._key(level, s["auxkey"], pfp, k)))
+                    mask |= s["inv"]
+        return dict(generated=gen, deadlocks=dead, viol_mask=mask), bad
+

@@ -49,7 +49,7 @@ def main():
     levels = [dict(level=1, n_new=sc.distinct, generated=0, deadlocks=0, replicated=sc.replicated,
                    fps=["%016x" % int(f) for f in eng.level_fps()])]
     restored = False
-    while sc.level < max_depth:
+    while sc.level < max_depth and not (int(os.environ.get("SHARD_DEEP_AT", "0")) and sc.level == int(os.environ.get("SHARD_DEEP_AT", "0")) - 1):
         if chk_at and sc.level == chk_at and not restored:
             sc.save(out + ".chk")
             if hasattr(eng, "close"):
@@ -64,6 +64,27 @@ def main():
             break
         levels.append(dict(level=d["level"], n_new=d["n_new"], generated=d["generated"], deadlocks=d["deadlocks"],
                            replicated=sc.replicated, fps=["%016x" % int(f) for f in eng.level_fps()]))
+    deep = []
+    deep_at = int(os.environ.get("SHARD_DEEP_AT", "0"))          # the levels from here on live in the ranks' seen-sets only (ShardedChecker.deepen)
+    if deep_at and sc.level == deep_at - 1:
+        depth_now = sc.level
+        while depth_now < int(os.environ.get("SHARD_DEEP_TO", "99")) and sc.violation is None:
+            a, b = sc.deepen(slice_size=int(os.environ.get("SHARD_DEEP_SLICE", "48")))
+            if a["n_new"] == 0:
+                break
+            depth_now = a["level"]
+            deep.append(dict(level=a["level"], n_new=a["n_new"], generated=a["generated"], deadlocks=a["deadlocks"], fp_xor="%016x" % a["fp_xor"],
+                             fp_sum="%016x" % a["fp_sum"], probed=None if b is None else dict(level=b["level"], generated=b["generated"], deadlocks=b["deadlocks"],
+                                                                                              viol_fp=None if b["viol_fp"] is None else "%016x" % b["viol_fp"], viol_mask=b["viol_mask"])))
+        path = []
+        if sc.violation is not None:
+            path = ["%016x" % f for f in (sc.probe_trace_fps() if sc.violation.get("probed") else sc.trace_fps(sc.violation["level"], sc.violation["fp"]))]
+        viol = None if sc.violation is None else dict(level=sc.violation["level"], fp="%016x" % sc.violation["fp"], mask=sc.violation["mask"], probed=bool(sc.violation.get("probed")))
+        with open("%s.rank%d.json" % (out, rank), "w") as f:
+            json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=depth_now, levels=levels, deep=deep, violation=viol, path=path), f)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     probe = None
     if probe_at and sc.level == probe_at - 1:
         probe = sc.probe()

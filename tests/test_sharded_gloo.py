@@ -388,3 +388,67 @@ def test_violation_of_any_mask_on_a_remotely_owned_successor_is_reported(tmp_pat
     ranks = run_world(engine, 2, params, depth, tmp_path, 29701, 0, VSRMC_TEST_FORCE_BAD="%s:28" % target)
     for r in ranks:
         assert r["violation"] == dict(level=8, fp=target, mask=28), r["violation"]
+
+
+@pytest.mark.parametrize("world,rb,deep_at", [(2, 0, 8), (3, 200, 10)])
+def test_sharded_deep_protocol_on_the_cpu_stand_in(tmp_path, world, rb, deep_at):
+    """The protocol of the levels beyond the ranks' record buffers (virtual level: announce -> first inserter wins -> winners counted;
+    regenerated level: every candidate shown to its owner, the one whose key is the slot's final meta word rebuilds the state, exactly
+    once per descent; inserted level + probe with the candidates shown to their owners) as the Python loop runs it over the CPU stand-in
+    engine — the reference implementation of what csrc/vsr_shard_loop.hpp does over the HIP engine (`-m gpu`:
+    test_sharded_deep_levels_against_the_oracle).  (3,1,{v1,v2},1) with AcknowledgedWritesExistOnMajority: stored sharded levels up to
+    `deep_at` - 1, then through the seen-sets alone with slices of 48 states (every loop runs many times, the ranks run out of work at
+    different moments) to the violation at depth 19 — every level's size, successors, deadlocks and fingerprint checksums against the
+    single-process oracle; a 19-state path that replays."""
+    from oracle import orc
+    params, inv, depth = (3, 1, 2, 1), 2, 19
+    ranks = run_world("fake", world, params, depth, tmp_path, 29720 + world, rb, SHARD_INV_MASK=inv, SHARD_DEEP_AT=deep_at)
+    P = orc.Params(*params, invariant_mask=inv)
+    ob = orc.Bfs(P)
+    for _ in range(deep_at - 2):
+        ob.step()
+    assert all(r["deep"] == ranks[0]["deep"] and r["violation"] == ranks[0]["violation"] and r["path"] == ranks[0]["path"] for r in ranks)
+    got = ranks[0]
+    assert len(got["deep"]) == 18 - (deep_at - 1)
+    for lv in got["deep"]:
+        n = ob.step()
+        fps = ob.level_fps(lv["level"])
+        assert (lv["level"], lv["n_new"], lv["generated"], lv["deadlocks"]) == (ob.info["depth"], n, ob.info["generated"], ob.info["deadlocks"]), lv["level"]
+        assert lv["fp_xor"] == "%016x" % int(np.bitwise_xor.reduce(fps)) and lv["fp_sum"] == "%016x" % (int(fps.astype(object).sum()) & ((1 << 64) - 1))
+    assert got["distinct"] == ob.info["distinct"] == 109878
+    ob.step()
+    words, off = ob.frontier()
+    viol = min(orc.fingerprint(P, words[int(off[i]): int(off[i + 1])])[0] for i in range(len(off) - 1)
+               if orc.invariants(P, words[int(off[i]): int(off[i + 1])]))
+    assert got["violation"] == dict(level=19, fp="%016x" % viol, mask=2, probed=True)
+    last = got["deep"][-1]["probed"]
+    assert (last["level"], last["generated"], last["deadlocks"]) == (19, ob.info["generated"], ob.info["deadlocks"])
+    path = [int(f, 16) for f in got["path"]]
+    rec = orc.init_record(P)
+    assert len(path) == 19 and orc.fingerprint(P, rec)[0] == path[0]
+    for f in path[1:]:
+        nxt = [s for s in orc.successors(P, rec) if s["fp"] == f]
+        assert nxt, "a state of the counter-example is not a successor of its predecessor"
+        rec, bad = nxt[0]["words"], nxt[0]["inv"]
+    assert bad == 2
+
+
+def test_sharded_deep_protocol_readme_configuration_prefix_on_the_cpu_stand_in(tmp_path):
+    """the README defect configuration (3,1,{v1,v2,v3},3: six value permutations) at world 2: levels 2-5 stored, 6-9 through the seen-sets
+    alone, the probe of level 10 clean — each against the single-process oracle"""
+    from oracle import orc
+    params = (3, 1, 3, 3)
+    ranks = run_world("fake", 2, params, 9, tmp_path, 29731, 0, SHARD_DEEP_AT=6, SHARD_DEEP_TO=9, SHARD_DEEP_SLICE=64)
+    ob = orc.Bfs(orc.Params(*params))
+    for _ in range(4):
+        ob.step()
+    got = ranks[0]
+    assert ranks[1]["deep"] == got["deep"] and [lv["level"] for lv in got["deep"]] == [6, 7, 8, 9] and got["violation"] is None
+    for lv in got["deep"]:
+        n = ob.step()
+        fps = ob.level_fps(lv["level"])
+        assert (lv["n_new"], lv["generated"], lv["deadlocks"]) == (n, ob.info["generated"], ob.info["deadlocks"]), lv["level"]
+        assert lv["fp_xor"] == "%016x" % int(np.bitwise_xor.reduce(fps))
+    ob.step()
+    assert got["deep"][-1]["probed"] == dict(level=10, generated=ob.info["generated"], deadlocks=ob.info["deadlocks"], viol_fp=None, viol_mask=0)
+    assert got["distinct"] == ob.info["distinct"] - ob.info["n_new"] if "n_new" in ob.info else True

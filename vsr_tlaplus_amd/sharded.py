@@ -415,6 +415,126 @@ class ShardedChecker:
                              "the ranks (expected about once in 2^45 / level size steps)" % (max(len(answers), max(r[0] for r in rows)), what))
         return answers[0]                                       # same fingerprint: same slot content up to the `taken` bit; the smallest
 
+    # ---- levels beyond the record buffers: the protocol of csrc/vsr_shard_loop.hpp's second half, over an engine's deep_* phases ----
+    def _deep_pass(self, src, level, mode):
+        """one collective pass: expand `src` (states of level - 1), announce what other ranks own, claim / grant, verdicts back
+        -> (records the pass yields on this rank, its local figures)"""
+        e, x = self.e, self.x
+        cands, err = e.deep_expand(src, level, mode)
+        recv, gerr, cat = x.exchange(cands, err)
+        self._raise_if(gerr, "deep expand")
+        verdict, err = e.deep_claim(cat, level, mode)
+        back, pos = [], 0
+        for p in range(self.world):
+            back.append(verdict[pos: pos + recv[p].shape[0]])
+            pos += recv[p].shape[0]
+        # the answers: as many rows come back from p as candidates went to p — no count exchange needed
+        vrecv, _, _ = x.exchange(back, recv_counts=[int(c.shape[0]) for c in cands])
+        self._raise_if(max(x.allreduce([int(err)], dist.ReduceOp.MAX)), "deep claim")
+        return e.deep_apply(vrecv)
+
+    def _any(self, flag):
+        return bool(self.x.allreduce([1 if flag else 0], dist.ReduceOp.MAX)[0])
+
+    def deepen(self, slice_size=64):
+        """One more level beyond the ranks' record buffers (collective; the Python counterpart of vsrmc_shard_loop_deepen, for engines
+        with deep_* phases — the CPU stand-in of the tests; the product runs the C++ loop).  The first call makes level L+1 a virtual
+        level; every further call descends from the newest stored level: regenerates levels L+1 .. L+j-1 slice inside slice, inserts level
+        L+j and probes level L+j+1.  slice_size: source states per pass (small in the tests, so that every loop runs many times and the
+        ranks run out of work at different moments).  -> (inserted dict, probed dict or None), figures over all ranks."""
+        e, x = self.e, self.x
+        if not hasattr(self, "deep"):
+            self.deep, self._deep_base = 0, None
+        if self.replicated:
+            raise ShardError("the replicated phase stores its levels")
+        L = self.level
+        acc = dict(generated=0, deadlocks=0, n_new=0, viol_fp=U64_MAX, viol_mask=0, fx=0, fs=0)
+        prb = dict(generated=0, deadlocks=0, viol_mask=0)
+        bad = []
+
+        def add(st):
+            for k in ("generated", "deadlocks", "n_new"):
+                acc[k] += st[k]
+            acc["fx"] ^= st["fx"]
+            acc["fs"] = (acc["fs"] + st["fs"]) & U64_MAX
+            acc["viol_mask"] |= st["viol_mask"]
+            acc["viol_fp"] = min(acc["viol_fp"], st["viol_fp"])
+
+        def slices(src):
+            a = 0
+            while self._any(a < len(src)):
+                yield src[a: a + slice_size]
+                a += slice_size
+
+        target = L + self.deep + 1
+        if self.deep == 0:
+            for part in slices(e.deep_source()):
+                _, st = self._deep_pass(part, L + 1, "insert")
+                add(st)
+        else:
+            e.deep_untake(L + 1)
+            x.barrier()                                          # every rank has cleared its taken bits before the first announcement
+
+            def descend(src, lv):
+                for part in slices(src):
+                    if lv + 1 < target:
+                        out, _ = self._deep_pass(part, lv + 1, "regen")
+                        descend(out, lv + 1)
+                    else:
+                        out, st = self._deep_pass(part, lv + 1, "normal")
+                        add(st)
+                        info, pairs = e.deep_probe(out, lv + 2)
+                        for k in ("generated", "deadlocks"):
+                            prb[k] += info[k]
+                        prb["viol_mask"] |= info["viol_mask"]
+                        bad.extend(pairs)
+            descend(e.deep_source(), L)
+        rows = x.allgather([acc["generated"], acc["deadlocks"], acc["n_new"], acc["fx"] >> 32, acc["fx"] & 0xFFFFFFFF, acc["fs"] >> 32, acc["fs"] & 0xFFFFFFFF,
+                            acc["viol_fp"] >> 32, acc["viol_fp"] & 0xFFFFFFFF, acc["viol_mask"], prb["generated"], prb["deadlocks"], prb["viol_mask"]])
+        fx = fs = 0
+        for r in rows:
+            fx ^= (r[3] << 32) | r[4]
+            fs = (fs + ((r[5] << 32) | r[6])) & U64_MAX
+        viol = min((r[7] << 32) | r[8] for r in rows)
+        ins = dict(level=target, generated=sum(r[0] for r in rows), deadlocks=sum(r[1] for r in rows), n_new=sum(r[2] for r in rows), fp_xor=fx, fp_sum=fs,
+                   viol_fp=None if viol == U64_MAX else viol, viol_mask=0)
+        if ins["n_new"] == 0:
+            ins["level"] = target - 1
+            return ins, None
+        self.deep += 1
+        self.distinct += ins["n_new"]
+        if viol != U64_MAX:
+            for r in rows:
+                ins["viol_mask"] |= r[9]
+            if self.violation is None:
+                self.violation = dict(level=target, fp=viol, mask=ins["viol_mask"])
+            return ins, None
+        if target == L + 1:
+            return ins, None                                     # the first pass probes nothing
+        # the probe's candidates: shown to their owners, which drop what they have seen below the probed level
+        own = [[] for _ in range(self.world)]
+        for fp, key in bad:
+            own[owner_of(int(fp), self.world)].extend((int(fp), int(key)))
+        send = [torch.from_numpy(np.array(o, dtype=np.uint64).astype(np.int64).reshape(-1, 2)) for o in own]
+        _, gerr, cat = x.exchange(send, 0)
+        self._raise_if(gerr, "deep probe")
+        got = cat.cpu().numpy().astype(np.int64).view(np.uint64).reshape(-1, 2)
+        keep = got[~e.seen_before(got[:, 0], target + 1)] if len(got) else got
+        best = min(((int(f), int(k)) for f, k in keep), default=(U64_MAX, U64_MAX))
+        rows2 = x.allgather([best[0] >> 32, best[0] & 0xFFFFFFFF, best[1] >> 32, best[1] & 0xFFFFFFFF])
+        gbest = min(((r[0] << 32) | r[1], (r[2] << 32) | r[3]) for r in rows2)
+        probed = dict(level=target + 1, generated=sum(r[10] for r in rows), deadlocks=sum(r[11] for r in rows), viol_fp=None, viol_mask=0)
+        if gbest[0] != U64_MAX:
+            for r in rows:
+                probed["viol_mask"] |= r[12]
+            parent = self._agree(e.lookup((gbest[1] >> 1) & ((1 << 45) - 1), target, True), "parent")
+            if parent is None:
+                raise ShardError("deep probe: the parent of the violating successor %016x is in no shard" % gbest[0])
+            probed["viol_fp"] = gbest[0]
+            if self.violation is None:
+                self.violation = dict(level=target + 1, fp=gbest[0], mask=probed["viol_mask"], probed=True, parent_fp=parent[0])
+        return ins, probed
+
     def trace_fps(self, level, fp):
         """Walk the predecessor pointers — they live in the seen-set slots, i.e. on the owner of each state — from the level-`level`
         state with fingerprint `fp` back to Init; every rank must call this.  -> the fingerprints of the path, Init first
