@@ -81,6 +81,8 @@ struct DeepRun {
   std::vector<u64> bad;        // (fingerprint, key) of the violating successors the probe passes saw
   u64 launches = 0, n_slices = 0, n_subs = 0;
   u64* d_sum = nullptr;
+  int err = 0;                 // sharded: a failure of this rank's LOCAL work between two collectives (a probe pass, a checksum) — carried to the next
+                               // "any slice left?" exchange, where every rank learns of it and all of them leave together (nobody waits in a collective)
   int probed_level() const { return last_regen + (insert ? 2 : 1); }
 };
 
@@ -150,9 +152,15 @@ int deep_run_pass(DeepRun& R, const u64* sw, const u64* so, u64 n, u64 p_off, in
   return expand_pass(R.c, sw, so, n, p_off, level, mode, bag, dst);
 }
 bool deep_more(DeepRun& R, bool mine, int* rc) {               // does ANY rank have another slice?  (unsharded: this one)
-  u64 f = mine ? 1 : 0;
-  if (R.io) *rc = R.io->any(R.io->ctx, &f);
-  return f != 0;
+  u64 f = (mine ? 1 : 0) | (R.err ? 2 : 0);
+  if (R.io) *rc = R.io->any(R.io->ctx, &f);                     // the maximum over the ranks: >= 2 = some rank failed
+  if (!*rc && f >= 2) *rc = R.err ? R.err : fail(VSRMC_E_STATE, "deep pass: another rank failed between two exchanges");
+  return !*rc && (f & 1) != 0;
+}
+int deep_local_fail(DeepRun& R, int rc) {                      // unsharded: the error itself; sharded: remembered, the caller goes on to the next exchange
+  if (!R.io) return rc;
+  if (!R.err) R.err = rc;
+  return 0;
 }
 u64 deep_cand_bound(const DeepRun& R, u64 g1) {
   if (!R.io || R.io->world <= 1) return ~(u64)0;
@@ -164,17 +172,19 @@ int deep_probe(DeepRun& R, const PassDst& B, u64 n, int lv, u64 bag) {
   vsrmc_checker* c = R.c;
   if (!n) return 0;
   c->expand_ms = 0;
+  if (R.err) return 0;
   int rc = expand_pass(c, B.words, B.off, n, 0, lv + 1, MODE_PROBE, bag);
-  if (rc) return rc;
+  if (rc) return deep_local_fail(R, rc);
   R.launches++;
   deep_acc(&R.prb, c->h, c->expand_ms);
   if (c->h.n_pending) {
     R.mask_prb |= c->h.viol_mask;
     if (c->h.n_pending > c->opt.pending_entries || R.bad.size() / 2 + c->h.n_pending > ((u64)1 << 24))
-      return fail(VSRMC_E_REP, "more violating successors in the probed level than the pending list holds (pending_entries)");
+      return deep_local_fail(R, fail(VSRMC_E_REP, "more violating successors in the probed level than the pending list holds (pending_entries)"));
     const size_t at = R.bad.size();
     R.bad.resize(at + 2 * c->h.n_pending);
-    HIPCHK(hipMemcpy(R.bad.data() + at, c->pending, 16 * c->h.n_pending, hipMemcpyDeviceToHost));
+    if (hipMemcpy(R.bad.data() + at, c->pending, 16 * c->h.n_pending, hipMemcpyDeviceToHost) != hipSuccess)
+      return deep_local_fail(R, fail(VSRMC_E_HIP, "deep search: copy of the probe's candidates"));
   }
   return 0;
 }
@@ -230,11 +240,15 @@ int deep_descend(DeepRun& R, const u64* src_words, const u64* src_off, u64 n_idx
     const u64 bag_new = std::min<u64>(c->h.max_bag, (u64)M.max_bag);
     {   // checksums of the level: the sub-slice's fingerprints sit in the scratch buffer until it is reused
       u64 hsum[3] = {0, 0, 0};
-      if (hipMemsetAsync(R.d_sum, 0, 24, c->stream) != hipSuccess) return fail(VSRMC_E_HIP, "deep search: hipMemsetAsync");
-      hipLaunchKernelGGL(k_level_checksum, dim3(1024), dim3(256), 0, c->stream, B.fp, part, R.d_sum);
-      if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hsum, R.d_sum, 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-          hipStreamSynchronize(c->stream) != hipSuccess)
-        return fail(VSRMC_E_HIP, "deep search: k_level_checksum");
+      bool ok = hipMemsetAsync(R.d_sum, 0, 24, c->stream) == hipSuccess;
+      if (ok) hipLaunchKernelGGL(k_level_checksum, dim3(1024), dim3(256), 0, c->stream, B.fp, part, R.d_sum);
+      ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(hsum, R.d_sum, 24, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+           hipStreamSynchronize(c->stream) == hipSuccess;
+      if (!ok) {
+        rc = deep_local_fail(R, fail(VSRMC_E_HIP, "deep search: k_level_checksum"));
+        if (rc) return rc;
+        continue;
+      }
       R.ins.fp_xor ^= hsum[0];
       R.ins.fp_sum += hsum[1];
       R.ins.n_new += hsum[2];                                  // the states that stayed (a sharded pass has withdrawn the announced ones that lost)
@@ -370,6 +384,11 @@ int deep_pass(vsrmc_checker* c, int last_regen, bool insert, vsrmc_level_info* i
   struct FreeSum { u64* p; ~FreeSum() { (void)hipFree(p); } } free_sum{R.d_sum};
   if (insert) { c->deep_lv.resize((size_t)(last_regen + 1 - c->level)); c->deep_lv.back() = DeepLevel(); }
   int rc = deep_plan_scratch(c, last_regen - c->level - (insert ? 0 : 1));   // buffer k takes what level base + k yields
+  if (io) {                                                    // a rank that could not allocate takes the others with it, before any of them waits for it
+    u64 bad_plan = rc ? 1 : 0;
+    const int arc = io->any(io->ctx, &bad_plan);
+    if (!rc && (arc || bad_plan)) rc = arc ? arc : fail(VSRMC_E_HIP, "deep pass: another rank could not allocate its scratch buffers");
+  }
   if (rc) { c->failed = 1; return rc; }
   if (io) { u64 sync = 0; rc = io->any(io->ctx, &sync); }      // every rank has cleared its taken bits
   if (!rc) rc = deep_descend(R, c->words[c->cur], c->off[c->cur], c->n_frontier, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, c->level, 0);
