@@ -200,6 +200,12 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
                "-tableLog2", "20", "-frontierGiB", "0.05"] + list(extra)
         return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"))
 
+    # the default: no sizes on the command line — the C++ level loop, every rank sized from (its share of) the free HBM, automatic scheme
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29673",
+                        "-m", "vsr_tlaplus_amd.sharded_cli", "-config", _cfg(tmp_path, R=2, vals="v1, v2", L=2), "-noTLA", "-backend", "gloo", "-replicateBelow", "16"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert "Model checking completed. No error has been found." in r.stdout and "2073 distinct states found" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "C++ level loop" in r.stdout and "search is 27" in r.stdout and "[sharded]" in r.stdout
     r = run(_cfg(tmp_path, R=2, vals="v1", L=1), "-replicateBelow", "8")
     assert "Model checking completed. No error has been found." in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert "76 distinct states found" in r.stdout and "search is 14" in r.stdout and "[sharded]" in r.stdout

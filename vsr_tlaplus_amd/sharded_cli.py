@@ -9,8 +9,11 @@ TLC's exit code (0 = no error, 12 = safety violation, 11 = deadlock, 1 = failure
 
   -config FILE        TLC configuration (VSR.cfg grammar)              -noTLA   do not read / hash-check the .tla file
   -maxDepth N         stop after N BFS levels (Init = level 1)         -checkDeadlock   stop at the first terminal state
-  -tableLog2 N        seen-set slots PER RANK = 2^N x 16 B (default 26)
-  -frontierGiB G      size of each of the two frontier buffers PER RANK (default 2)
+  -tableLog2 N        seen-set slots PER RANK = 2^N x 16 B; -frontierGiB G: size of each of the two record buffers PER RANK.
+                      DEFAULT (neither given, no -checkpoint / -recover / -exactTies / -probeAt): the AUTOMATIC scheme over the C++ level
+                      loop — every rank sizes its seen-set shard, record and exchange buffers from the free memory of its GPU, levels are
+                      stored while every rank's part of the next one fits, then the search goes on through the seen-sets alone
+                      (Virtual(L) / Probe(L+1) lines).  With explicit sizes: the Python loop, stored levels only (2^26 slots, 2 GiB)
   -replicateBelow K   levels with fewer than K new states are explored by every rank on its own (default 2^20; 0 = never)
   -exactTies          two-kernel levels that arbitrate same-level VIEW ties like the oracle (default: single-pass levels)
   -backend nccl|gloo  (default nccl)                                   -json    one JSON object per level
@@ -35,7 +38,7 @@ INVARIANTS = ["AcknowledgedWriteNotLost", "AcknowledgedWritesExistOnMajority", "
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    opt = dict(cfg=None, tla=None, max_depth=1 << 30, table_log2=26, frontier_gib=2.0, replicate_below=1 << 20, exact=False,
+    opt = dict(cfg=None, tla=None, max_depth=1 << 30, table_log2=0, frontier_gib=0.0, replicate_below=1 << 20, exact=False,
                backend="nccl", json=False, no_tla=False, check_deadlock=False, checkpoint=None, checkpoint_minutes=30.0, recover=None,
                probe_at=0)
     i = 0
@@ -101,6 +104,10 @@ def main(argv=None):
         say("Error: %s" % e)
         return 1
     lay = m.layout
+    if not (opt["table_log2"] or opt["frontier_gib"] or opt["checkpoint"] or opt["recover"] or opt["exact"] or opt["probe_at"]):
+        return run_automatic(opt, m, rank, world, local_rank, say)
+    opt["table_log2"] = opt["table_log2"] or 26
+    opt["frontier_gib"] = opt["frontier_gib"] or 2.0
     words = int(opt["frontier_gib"] * (1 << 30) / 8)
     states = max(1 << 12, words // 24)
     def make_engine(recover=None):
@@ -191,6 +198,91 @@ def main(argv=None):
     depth = sc.level if last["n_new"] else sc.level - 1
     say("The depth of the complete state graph search is %d.\nFinished in %.3f s (%.3g distinct states/s) on %d rank(s)."
         % (depth, dt, sc.distinct / dt if dt > 0 else 0.0, world))
+    dist.barrier()
+    dist.destroy_process_group()
+    return code
+
+
+def run_automatic(opt, m, rank, world, local_rank, say):
+    """the default: the C++ level loop (direct RCCL, or gloo callbacks) through vsrmc_shard_loop_advance, sizes from the free memory"""
+    import vsr_tlaplus_amd as vt
+    from vsr_tlaplus_amd import sharded
+    lay = m.layout
+    if opt["backend"] != "nccl":
+        os.environ.setdefault("VSRMC_AUTOSIZE_SHARE", str(world))   # the ranks share device 0
+    try:
+        comm = sharded.RcclComm(local_rank) if opt["backend"] == "nccl" else sharded.TorchHostComm()   # before the checker sizes itself
+        eng = sharded.HipShardEngine(m, rank, world, device=local_rank, table_log2=0, frontier_words=0, frontier_states=0, pending_entries=0,
+                                     cand_cap=0, rec_cap=1 << 22, rec_words_cap=1 << 28, native_only=True)
+        sc = sharded.NativeShardedChecker(eng, comm, replicate_below=opt["replicate_below"])
+    except (sharded.ShardError, vt.VsrmcError, OSError) as e:
+        say("Error: %s" % e)
+        return 1
+    sc.depth = sc.level
+    say("vsrmc: %s lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), invariant mask %d; "
+        "%d rank(s), backend %s, C++ level loop; per rank: seen-set 2^%d slots, record buffers 2 x %.1f GiB, %d candidates per peer"
+        % (["VSR.tla", "VR_STATE_TRANSFER.tla", "VR_APP_STATE.tla"][lay.module], lay.replica_count, lay.client_count, lay.value_count,
+           lay.start_view_on_timer_limit, lay.permutations, lay.invariant_mask, world, opt["backend"], int(eng.options.table_log2),
+           int(eng.options.frontier_words) * 8 / (1 << 30), int(eng.cand_cap)))
+    say("Finished computing initial states: 1 distinct state generated.")
+    t0 = time.time()
+    total_generated, code, last, deadlocked, kind = 0, 0, dict(n_new=1, deadlocks=0), False, "level"
+    try:
+        while sc.depth < opt["max_depth"]:
+            kind, d, b = sc.advance()
+            last = d
+            total_generated += d["generated"]
+            dt = time.time() - t0
+            if opt["json"]:
+                say(json.dumps(dict(level=d["level"], kind=kind, generated=d["generated"], new=d["n_new"], distinct=d["distinct"], deadlocks=d["deadlocks"],
+                                    seconds=round(dt, 4))))
+            elif d["n_new"] and kind == "level":
+                say("Progress(%d): %d states generated, %d distinct states found, %d states left on queue. (%.2f s)%s"
+                    % (d["level"], total_generated, d["distinct"], d["n_new"], dt, "" if d.get("replicated") else "  [sharded]"))
+            elif d["n_new"]:
+                say("Virtual(%d): %d states generated, %d distinct states found, %d states in the level (not stored). (%.2f s)  [sharded]"
+                    % (d["level"], total_generated, d["distinct"], d["n_new"], dt))
+            if b is not None:
+                total_generated += b["generated"]
+                say("Probe(%d): %d states generated from the %d states of level %d. (%.2f s)" % (b["level"], b["generated"], d["n_new"], d["level"], dt))
+            if sc.violation is not None:
+                break
+            if opt["check_deadlock"] and d["deadlocks"]:
+                deadlocked = True
+                break
+            if d["n_new"] == 0:
+                break
+    except (sharded.ShardError, vt.VsrmcError) as e:
+        say("Error: %s" % e)
+        code = 1
+    dt = time.time() - t0
+    if code == 0 and sc.violation is not None:
+        v = sc.violation
+        path = sc.violation_trace_fps()                          # every rank takes part in the walk
+        if rank == 0:
+            tr = sharded.replay_fps(m, path, device=local_rank)
+            fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64), device=local_rank)
+            assert int(fps[0]) == v["fp"], "trace replay does not end in the violating state"
+            mask = int(v["mask"])
+            if v.get("probed"):     # the probe's mask is the union over every violating successor the ranks saw: ask the path's last state
+                mask = m.check_trace([rec for _, rec in tr], device=local_rank)["inv_mask_last"]
+            for bit, name in enumerate(INVARIANTS):
+                if (mask >> bit) & 1:
+                    print("Error: Invariant %s is violated." % name)
+            print("Error: The behavior up to this point is:")
+            for t, (action, rec) in enumerate(tr):
+                print("State %d: <%s>\n%s\n" % (t + 1, action, m.format_state(rec)))
+        code = 12
+    elif code == 0 and deadlocked:
+        say("Error: Deadlock reached (%d state(s) of level %d have no successor)." % (last["deadlocks"], sc.depth - 1))
+        code = 11
+    elif code == 0 and last["n_new"] == 0:
+        say("Model checking completed. No error has been found.")
+    say("%d states generated, %d distinct states found, %d states left on queue." % (total_generated, sc.distinct, last["n_new"]))
+    depth = sc.depth - (1 if (last["n_new"] == 0 and kind == "level") else 0)   # (an empty sharded level still advances the ranks' level counters)
+    say("The depth of the complete state graph search is %d.\nFinished in %.3f s (%.3g distinct states/s) on %d rank(s)."
+        % (depth, dt, sc.distinct / dt if dt > 0 else 0.0, world))
+    sc.close()
     dist.barrier()
     dist.destroy_process_group()
     return code
