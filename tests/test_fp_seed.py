@@ -7,8 +7,6 @@ under another, so any count that depends on the fingerprint function shows up as
 
 CPU part: the seeded oracle (fingerprints change, counts do not).  GPU part: the seeded HIP path equals the seeded oracle set by set
 on small spaces, and the whole config-2 workload has the fixture's per-level counts under other seeds."""
-import json
-import os
 
 import numpy as np
 import pytest

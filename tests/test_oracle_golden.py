@@ -1,7 +1,6 @@
 """The CPU oracle(s) against the reference's golden vector (tests/golden/state_transfer_trace.json, derived from
 /root/reference/state_transfer_violation_trace.txt by tests/golden/make_golden.py) and against each other."""
 import numpy as np
-import pytest
 
 from oracle import orc, pycodec, pyoracle as po
 

@@ -4,7 +4,6 @@ Held here against the ORACLE's successors: over whole small state spaces and the
 by an action outside the set leaves every replica's log and the acknowledged map untouched and has its parent's invariant verdict; the actions
 inside the set do change them (the set is not vacuous).  The GPU side of the claim is the probe fixtures: violating successors and smallest
 violating fingerprint of the probed levels equal the oracle's (tests/test_gpu_parity.py, bench.py)."""
-import numpy as np
 import pytest
 
 PROBE_ACTIONS = {"SendSV", "ExecuteOp", "ReceiveClientRequest", "SendGetState", "ReceiveSV", "ReceivePrepareMsg", "ReceiveGetState", "ReceiveNewState"}

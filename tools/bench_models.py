@@ -16,7 +16,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--runs", type=int, default=3)
     a = ap.parse_args()
-    import numpy as np
     import vsr_tlaplus_amd as vt
     for label, make in (("model2", vt.Model.second_model), ("model3", vt.Model.third_model)):
         with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_%s.json" % label)) as f:

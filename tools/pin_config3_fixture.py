@@ -5,7 +5,6 @@ came partly from GPU runs) in line — every level figure must EQUAL the oracle'
 fingerprint and the probe's generated count likewise.  Nothing is copied from the GPU to the oracle side."""
 import json
 import os
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
