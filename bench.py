@@ -360,6 +360,14 @@ def run_readme(args, dump_trace=None, seed=0):
     return elapsed, S
 
 
+def sector_granular(alg_bytes, key_accesses, kernel_s, distinct):
+    """SURVEY §8(d)'s second figure: the algorithmic bytes with every 8-byte key access (one per generated successor's probe, one per insert)
+    priced as the 64-byte sector it moves — 2 S + 64 g + 64 per distinct state — over the same kernel time."""
+    b = alg_bytes + 56.0 * key_accesses
+    achieved = b / max(kernel_s, 1e-12) / 1e9
+    return {"bytes_per_state": round(b / max(1.0, distinct), 1), "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5)}
+
+
 def readme_object(args, elapsed, S):
     """The README configuration's figures as JSON fields (the headline line, or the `readme` object when it is not the headline)."""
     k = args.steps
@@ -384,6 +392,7 @@ def readme_object(args, elapsed, S):
                   "traffic": tr["bytes_per_launch"], "traffic_source": tr["source"],
                   "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": launches, "alg_bytes_per_launch": round(alg_run / launches),
                   "B_alg_per_state": round(alg_run / distinct, 1),
+                  "sector_granular": sector_granular(alg_run, S["generated"] / k + distinct, kernel_ms / 1e3, distinct),
                   "kernel_ms_per_step": {"k_expand": round(kernel_ms, 3), "k_expand_materialised_levels": round(S["mat_ms"] / k, 3),
                                          "k_expand_deep_passes": round(S["deep_ms"] / k, 3)}},
         materialised=dict(levels=S["mat_levels"], distinct=S["n_mat"], seconds=round(S["mat_s"] / k, 4), states_per_s=round(S["n_mat"] / (S["mat_s"] / k), 1)),
@@ -407,6 +416,7 @@ def config2_object(args, elapsed, S):
                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr["bytes_per_launch"], "traffic_source": tr["source"],
                   "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": S["launches"] // args.steps,
                   "alg_bytes_per_launch": round(S["alg_bytes"] / max(1, S["launches"])), "B_alg_per_state": round(2 * s_bytes + 8 * g + 8, 1),
+                  "sector_granular": sector_granular(S["alg_bytes"], S["generated"] + S["distinct"], S["expand_ms"] / 1e3, S["distinct"]),
                   "kernel_ms_per_step": {"k_expand": round(S["expand_ms"] / args.steps, 3)}})
 
 
