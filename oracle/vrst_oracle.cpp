@@ -624,12 +624,14 @@ void set_fp_seed(u64 seed) { g_fp_seed = seed; }
 u64 fp_seed() { return g_fp_seed; }
 static u64 salt_word(int r, int k) { return fmix64(0xA0761D6478BD642FULL + (u64)(8 * r + k)); }
 
-Fp fingerprint(const Params& P, const State& s) {
+Fp fingerprint(const Params& P, const State& s) { return fingerprint_with_seed(P, s, g_fp_seed); }
+
+Fp fingerprint_with_seed(const Params& P, const State& s, u64 seed) {
   std::vector<u64> rec;
   encode(P, s, rec);
   u64 sum = 0;
-  for (int r = 1; r <= P.R; r++) sum += fmix64(rec[r] ^ (salt_word(r, 0) ^ g_fp_seed));
-  for (size_t j = fixed_words(P); j < rec.size(); j++) sum += fmix64(rec[j] ^ (SALT_MSG ^ g_fp_seed));
+  for (int r = 1; r <= P.R; r++) sum += fmix64(rec[r] ^ (salt_word(r, 0) ^ seed));
+  for (size_t j = fixed_words(P); j < rec.size(); j++) sum += fmix64(rec[j] ^ (SALT_MSG ^ seed));
   Fp f;
   f.fp = sum ? sum : 1;
   f.auxkey = (u32)s.aux_svc;

@@ -129,5 +129,8 @@ Fp fingerprint(const Params& P, const State& s);                           // VI
 u64 fmix64(u64 x);
 void set_fp_seed(u64 seed);   // second-hash audit: xor-ed into every salt (process-global; 0 = the fixtures' function)
 u64 fp_seed();
+// the same function under an explicit seed (the collision hunt of vsr_oracle_lean.cpp compares two members of the family in one run)
+#define ORACLE_HAS_SEEDED_FP 1
+Fp fingerprint_with_seed(const Params& P, const State& s, u64 seed);
 
 }  // namespace vrst_oracle

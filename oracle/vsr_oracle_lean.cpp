@@ -23,6 +23,15 @@
 //   {"probe_level": l, "generated": .., "deadlocks": .., "violating_successors": .., "viol_fp": "..", "viol_mask": ..}.
 // CLI: vsr_oracle_lean R C nValues L --base-level B --slots N [--probe-level P] [--max-depth D] [--threads T] [--inv-mask M]
 //                      [--no-symmetry] [--verify-fp-all | --verify-fp-every N]
+//
+// Collision hunt (oracles that declare fingerprint_with_seed: the second model's): --hunt-seed HEX [--hunt-slots N] keeps a second set, of the
+// fingerprints of every NEW state under another member of the function family.  A new state whose audit fingerprint is in that set already is a
+// 64-bit collision of the audit function between two states the run's own function tells apart: printed with its record
+//   {"fp_collision": true, "audit_seed": "..", "audit_fp": "..", "level": l, "fp": "..", "words": ["..", ..]}
+// and from then on every state the later passes meet again (levels >= the base level) is hashed under the audit seed too; those with that audit
+// fingerprint are printed as {"fp_collision_member": true, ..}: the other state of the pair, if it lives at or beyond the base level.
+// --dump-audit-fp HEX prints the members of a known audit fingerprint from the start (new states of every level).  The audit fingerprint's lowest
+// bit is forced to 1 (0 marks an empty slot of the set: 63 bits compared); --hunt-mask HEX shortens it further (tests: forced collisions).
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -30,6 +39,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -167,12 +177,73 @@ struct FastFp {
 };
 #endif
 
+// second-hash collision hunt (see the header)
+struct Hunt {
+  bool on = false;
+  u64 seed = 0, slots = 0, mask = ~(u64)0;   // mask: tests shorten the audit fingerprint to force collisions
+  std::atomic<u64>* keys = nullptr;
+  std::atomic<u64> dump_fp{0};   // audit fingerprint whose states are printed when met (0 = none yet)
+  std::atomic<u64> found{0};
+  std::mutex mu;
+  void alloc(u64 n) { slots = n; keys = (std::atomic<u64>*)map_zero(n * 8); }
+  u64 home(u64 f) const { return (u64)(((unsigned __int128)(f * 0x9E3779B97F4A7C15ULL) * slots) >> 64); }
+  bool put(u64 f) {              // true when f was in the set already
+    u64 i = home(f);
+    for (u64 probes = 0;; probes++) {
+      u64 cur = keys[i].load(std::memory_order_acquire);
+      if (cur == 0) {
+        u64 exp = 0;
+        if (keys[i].compare_exchange_strong(exp, f, std::memory_order_acq_rel)) return false;
+        cur = exp;
+      }
+      if (cur == f) return true;
+      if (++i == slots) i = 0;
+      if (probes > slots) throw RepError("audit set full");
+    }
+  }
+};
+
 struct Ctx {
   Params P;
   Table tab;
   u32 target = 0;        // the level whose states this pass inserts (or probes)
   bool probe = false;
+  Hunt hunt;
 };
+
+#ifdef ORACLE_HAS_SEEDED_FP
+void hunt_print(Ctx& c, const char* what, u64 audit_fp, u32 level, u64 fp, const u64* rec, size_t n) {
+  std::lock_guard<std::mutex> g(c.hunt.mu);
+  std::printf("{\"%s\": true, \"audit_seed\": \"%016llx\", \"audit_fp\": \"%016llx\", \"level\": %u, \"fp\": \"%016llx\", \"words\": [", what,
+              (unsigned long long)c.hunt.seed, (unsigned long long)audit_fp, level, (unsigned long long)fp);
+  for (size_t k = 0; k < n; k++) std::printf("\"%016llx\"%s", (unsigned long long)rec[k], k + 1 < n ? ", " : "");
+  std::printf("]}\n");
+  std::fflush(stdout);
+}
+// a state this run has just inserted as new
+inline void hunt_new(Ctx& c, const State& st, u64 fp, const u64* rec, size_t n) {
+  if (!c.hunt.on) return;
+  const u64 g = (fingerprint_with_seed(c.P, st, c.hunt.seed).fp & c.hunt.mask) | 1;   // (0 = empty slot)
+  const bool dup = c.hunt.keys ? c.hunt.put(g) : false;
+  if (dup) {
+    c.hunt.found.fetch_add(1);
+    u64 none = 0;
+    c.hunt.dump_fp.compare_exchange_strong(none, g);             // the first collision's members are printed from now on
+    hunt_print(c, "fp_collision", g, c.target, fp, rec, n);
+  } else if (g == c.hunt.dump_fp.load(std::memory_order_relaxed)) {
+    hunt_print(c, "fp_collision_member", g, c.target, fp, rec, n);
+  }
+}
+// a state of an earlier level that a pass meets again
+inline void hunt_revisit(Ctx& c, const State& st, u32 level, u64 fp, const u64* rec, size_t n) {
+  const u64 want = c.hunt.dump_fp.load(std::memory_order_relaxed);
+  if (!c.hunt.on || !want) return;
+  if (((fingerprint_with_seed(c.P, st, c.hunt.seed).fp & c.hunt.mask) | 1) == want) hunt_print(c, "fp_collision_member", want, level, fp, rec, n);
+}
+#else
+inline void hunt_new(Ctx&, const State&, u64, const u64*, size_t) {}
+inline void hunt_revisit(Ctx&, const State&, u32, u64, const u64*, size_t) {}
+#endif
 
 // insert-or-find of fingerprint f as a state of level ctx.target; returns true when this call inserted it
 inline bool insert_level(Ctx& c, const Fp& f, Stats& st) {
@@ -242,6 +313,7 @@ void descend(Ctx& c, const State& s, u32 d, Stats& st, std::vector<std::vector<S
         continue;
       }
       if (!insert_level(c, f, st)) continue;
+      hunt_new(c, sc.st, f.fp, rec.data(), rec.size());
       st.n_new++;
       st.fp_xor ^= f.fp;
       st.fp_sum += f.fp;
@@ -257,6 +329,7 @@ void descend(Ctx& c, const State& s, u32 d, Stats& st, std::vector<std::vector<S
     if (side_level(sv) != d + 1 || side_auxkey(sv) != f.auxkey) continue;   // an older state, or the loser of a VIEW tie
     const u64 bit = (u64)1 << (i & 63);
     if (c.tab.bits[i >> 6].fetch_or(bit, std::memory_order_acq_rel) & bit) continue;   // expanded already in this pass
+    hunt_revisit(c, sc.st, d + 1, f.fp, rec.data(), rec.size());
     descend(c, sc.st, d + 1, st, pool, ffp, rec);
   }
 }
@@ -284,7 +357,8 @@ int main(int argc, char** argv) {
   P.R = std::atoi(argv[1]); P.C = std::atoi(argv[2]); P.n = std::atoi(argv[3]); P.L = std::atoi(argv[4]);
   int T = (int)std::thread::hardware_concurrency();
   u32 base_level = 0, probe_level = 0, max_depth = 1u << 30;
-  u64 slots = 0, verify_every = 4096;
+  u64 slots = 0, verify_every = 4096, hunt_slots = 0;
+  bool hunt_set = false;
   for (int i = 5; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--threads" && i + 1 < argc) T = std::atoi(argv[++i]);
@@ -296,12 +370,28 @@ int main(int argc, char** argv) {
     else if (a == "--no-symmetry") P.symmetry = false;
     else if (a == "--verify-fp-all") verify_every = 1;
     else if (a == "--verify-fp-every" && i + 1 < argc) verify_every = std::strtoull(argv[++i], nullptr, 10);
+    else if (a == "--hunt-seed" && i + 1 < argc) { c.hunt.on = true; c.hunt.seed = std::strtoull(argv[++i], nullptr, 16); hunt_set = true; }
+    else if (a == "--hunt-slots" && i + 1 < argc) hunt_slots = std::strtoull(argv[++i], nullptr, 10);
+    else if (a == "--hunt-mask" && i + 1 < argc) c.hunt.mask = std::strtoull(argv[++i], nullptr, 16);
+    else if (a == "--dump-audit-fp" && i + 1 < argc) c.hunt.dump_fp.store(std::strtoull(argv[++i], nullptr, 16) | 1);
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
   if (T < 1) T = 1;
   if (!base_level || !slots) { std::fprintf(stderr, "--base-level and --slots are required\n"); return 2; }
   if (probe_level && probe_level <= base_level) { std::fprintf(stderr, "--probe-level must lie beyond the base level\n"); return 2; }
   c.tab.alloc(slots);
+  if (hunt_set || c.hunt.dump_fp.load()) {
+#ifdef ORACLE_HAS_SEEDED_FP
+    if (!hunt_set) { std::fprintf(stderr, "--dump-audit-fp needs --hunt-seed (the seed the fingerprint was computed under)\n"); return 2; }
+    if (c.hunt.seed == fp_seed()) { std::fprintf(stderr, "--hunt-seed equals the run's own seed (VSR_ORACLE_FP_SEED): nothing to compare\n"); return 2; }
+    if (hunt_slots) c.hunt.alloc(hunt_slots);                     // without a set: only --dump-audit-fp
+    else if (!c.hunt.dump_fp.load()) { std::fprintf(stderr, "--hunt-seed needs --hunt-slots N (or --dump-audit-fp)\n"); return 2; }
+#else
+    (void)hunt_slots;
+    std::fprintf(stderr, "this oracle has no fingerprint_with_seed: no collision hunt\n");
+    return 2;
+#endif
+  }
 
   auto run_threads = [&](auto&& fn) {
     std::vector<std::thread> th;
@@ -386,6 +476,8 @@ int main(int argc, char** argv) {
           for (u32 k = ch.first; k < ch.first + ch.count; k++) {
             State s = decode(P, &pc.words[pc.off[k]], nullptr);
             if (lean) {
+              if (c.hunt.on && c.hunt.dump_fp.load(std::memory_order_relaxed))
+                hunt_revisit(c, s, src_level, 0, &pc.words[pc.off[k]], (size_t)(pc.off[k + 1] - pc.off[k]));
               descend(c, s, src_level, st, pool, ffp, rec);
               continue;
             }
@@ -401,6 +493,7 @@ int main(int argc, char** argv) {
               encode(P, sc.st, rec);
               const Fp f = ffp(P, sc.st, rec.data(), rec.size());
               if (!insert_level(c, f, st)) continue;
+              hunt_new(c, sc.st, f.fp, rec.data(), rec.size());
               out.words.insert(out.words.end(), rec.begin(), rec.end());
               out.off.push_back(out.words.size());
               st.n_new++;
@@ -459,8 +552,9 @@ int main(int argc, char** argv) {
   const double dt = now_s() - t0;
   std::printf("{\"summary\": true, \"stop\": \"%s\", \"depth\": %u, \"distinct\": %llu, \"generated\": %llu, \"seconds\": %.3f, \"states_per_s\": %.1f, "
               "\"max_bag\": %zu, \"viol_mask\": %d, \"viol_fp\": \"%016llx\", \"error\": \"%s\", \"threads\": %d, \"fp_version\": %d, "
-              "\"base_level\": %u, \"slots\": %llu}\n",
+              "\"base_level\": %u, \"slots\": %llu, \"audit_collisions\": %llu}\n",
               why, depth, (unsigned long long)distinct, (unsigned long long)total_generated, dt, distinct / (dt > 0 ? dt : 1e-9), max_bag,
-              viol_mask, (unsigned long long)(viol_mask ? viol_fp : 0), error.c_str(), T, FP_VERSION, base_level, (unsigned long long)c.tab.slots);
+              viol_mask, (unsigned long long)(viol_mask ? viol_fp : 0), error.c_str(), T, FP_VERSION, base_level, (unsigned long long)c.tab.slots,
+              (unsigned long long)c.hunt.found.load());
   return 0;
 }

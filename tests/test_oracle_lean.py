@@ -57,3 +57,35 @@ def test_lean_violation_and_probe_pass():
     assert (probe["probe_level"], probe["viol_fp"], probe["viol_mask"]) == (depth, s["viol_fp"], 2) and probe["violating_successors"] >= 1
     assert probe["generated"] == want[-2]["generated"] and probe["deadlocks"] == want[-2]["deadlocks"]
     assert (got[-1]["stop"], got[-1]["depth"], got[-1]["viol_fp"]) == ("violation", depth, s["viol_fp"])
+
+
+def test_collision_hunt_on_a_shortened_audit_fingerprint():
+    # the second model's lean driver with a 12-bit audit fingerprint (--hunt-mask): collisions galore.  Every reported state must really have
+    # the audit fingerprint it is reported under (recomputed through the oracle's binding, seed = the audit seed), the members printed for the
+    # first collision are different states, and the hunt changes nothing in the level figures
+    import numpy as np
+    from oracle import orc2
+    exe = os.path.join(os.path.dirname(orc.BIN_MT), "vrst_oracle_lean")
+    args = [3, 1, 2, 2, "--base-level", 6, "--slots", 1 << 19, "--max-depth", 10, "--threads", 3, "--inv-mask", 14, "--no-symmetry"]
+    plain = _run(exe, args)
+    got = _run(exe, args + ["--hunt-seed", "5eed5eed5eed5eed", "--hunt-slots", 1 << 18, "--hunt-mask", "fff"])
+    levels = [g for g in got if "level" in g and "words" not in g]
+    assert [{k: g[k] for k in KEYS} for g in levels] == [{k: w[k] for k in KEYS} for w in plain[:-1]]
+    col = [g for g in got if g.get("fp_collision")]
+    mem = [g for g in got if g.get("fp_collision_member")]
+    assert got[-1]["audit_collisions"] == len(col) > 100 and mem
+    first = col[0]["audit_fp"]
+    assert {g["audit_fp"] for g in mem} == {first}
+    assert len({tuple(g["words"]) for g in mem}) >= 2
+    P = orc2.Params(3, 2, 2, invariant_mask=14)
+    orc2.set_fp_seed(0x5EED5EED5EED5EED)
+    try:
+        for g in col[:200] + mem:
+            rec = np.array([int(w, 16) for w in g["words"]], dtype=np.uint64)
+            assert (orc2.fingerprint(P, rec)[0] & 0xFFF) | 1 == int(g["audit_fp"], 16)
+        orc2.set_fp_seed(0)
+        for g in col[:200]:                                      # "fp" = the run's own fingerprint of the state (seed 0 here)
+            rec = np.array([int(w, 16) for w in g["words"]], dtype=np.uint64)
+            assert orc2.fingerprint(P, rec)[0] == int(g["fp"], 16)
+    finally:
+        orc2.set_fp_seed(0)
