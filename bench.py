@@ -26,7 +26,7 @@ violation, at N = 2 the last levels live in the two seen-sets only.
 Extra objects on the JSON line: `roofline` for the dominant kernel (k_expand: algorithmic bytes / HIP-event time on the checker's
 stream; `traffic` = the committed PMC figure when it was measured on THIS build's kernel sources, else null), `cpu_baseline` = the
 CPU oracle (a port, not TLC) timed on this box's host cores on a bounded sample of the headline's configuration,
-`fingerprint_collision_estimate` (TLC's n^2 / 2^65) and `collision_audit` (the untimed verification runs repeated under a second member
+`fingerprint_collision_estimate` (the birthday bound n^2 / 2^65 and TLC's d (g - d) / 2^64) and `collision_audit` (the untimed verification runs repeated under a second member
 of the fingerprint family, vsrmc_model_set_fp_seed: every per-level count must equal the oracle fixture's under both).
 """
 import argparse
@@ -422,7 +422,8 @@ def config2_object(args, elapsed, S):
 
 def collision_estimate(n):
     """TLC prints, at the end of every run, the probability that two distinct states shared a 64-bit fingerprint (a false merge drops
-    a state silently): its optimistic estimate n^2 / 2^65 for n distinct states (MC.out "calculated (optimistic)")."""
+    a state silently).  This is the birthday bound n^2 / 2^65 for n distinct states; TLC's own "calculated (optimistic)" figure,
+    d * (g - d) / 2^64 for d distinct of g generated states, is reported beside it."""
     return float(n) * float(n) / 2.0 ** 65
 
 
@@ -483,8 +484,12 @@ def main():
         if k_ not in ("workload", "value", "ms_per_step", "time_to_first_violation_s", "roofline"):
             out[k_] = v
     n_states = head.get("distinct", EXPECT["distinct"])
-    out["fingerprint_collision_estimate"] = {"n2_over_2_65": collision_estimate(n_states), "distinct": n_states,
-                                             "note": "TLC's optimistic estimate of a 64-bit fingerprint collision (a false merge would drop a state silently)"}
+    n_gen = head.get("generated", sum(lv["generated"] for lv in EXPECT["levels"]))
+    out["fingerprint_collision_estimate"] = {"n2_over_2_65": collision_estimate(n_states), "tlc_optimistic": float(n_states) * float(max(0, n_gen - n_states)) / 2.0 ** 64,
+                                             "distinct": n_states, "generated": n_gen,
+                                             "note": "expected number of 64-bit fingerprint collisions among the distinct states (birthday bound n^2 / 2^65) and TLC's own "
+                                                     "'calculated (optimistic)' figure d * (g - d) / 2^64 (every successor judged seen could be one; the CLI prints the same): "
+                                                     "a false merge would drop a state silently — what collision_audit (a second hash) is for"}
     if rd is not None and c2 is not None:
         c2["value"] = round(c2["value"], 1)
         c2["ms_per_step"] = round(c2["ms_per_step"], 3)
