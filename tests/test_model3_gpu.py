@@ -115,7 +115,7 @@ def test_model3_successors_state_by_state(vt, orc2):
 
 
 def test_model3_whole_workload_against_the_oracle(vt, oracle_levels):
-    """the shipped VR_APP_STATE.cfg as deep as the CPU oracle went (tests/golden/oracle_levels_model3.json: 28 levels, 1.9e9 states — levels 23-28 from the memory-lean driver)"""
+    """the shipped VR_APP_STATE.cfg as deep as the CPU oracle went (tests/golden/oracle_levels_model3.json: 29 levels, 2.5e9 states — levels 23-29 from the memory-lean driver)"""
     g = oracle_levels["model3"]
     p = g["params"]
     m = vt.Model.third_model(R=p["R"], n=p["n"], L=p["L"], invariant_mask=p["inv_mask"])
