@@ -187,7 +187,7 @@ typedef struct vsrmc_level_info {
   uint64_t viol_fp;              /* smallest fingerprint of a violating new state, ~0 if none */
   uint64_t viol_index;           /* its index in the next frontier */
   int32_t viol_mask;
-  int32_t reserved0;
+  int32_t reserved0;             /* vsrmc_checker_status: levels beyond `level` that exist in the seen-set only; 0 elsewhere */
   double seconds;                /* host wall time of the step */
   double expand_ms;              /* HIP-event time of k_expand (on the checker's stream) */
   double materialize_ms;         /* HIP-event time of k_materialize */
@@ -283,30 +283,50 @@ int32_t vsrmc_checker_probe3(vsrmc_checker* c, vsrmc_level_info* virt1, vsrmc_le
  * L+j+1 (probed->level).  The search rolls on past the memory horizon at about 2.2 x the expansions of a stored BFS until the
  * seen-set is full, a level comes back empty (inserted->n_new == 0: exhausted) or an invariant fails (viol_mask of whichever info;
  * vsrmc_checker_probe_trace reconstructs the counter-example).  inserted->pending = k_expand launches of the pass, ->materialize_ms =
- * kernel time spent regenerating, ->words_new = (slices of level L) << 32 | slices of the levels below it.  vsrmc_checker_step and
- * vsrmc_checker_save are refused from the first call on (the seen-set holds levels that have no frontier); vsrmc_checker_reset starts over. */
+ * kernel time spent regenerating, ->words_new = (slices of level L) << 32 | slices of the levels below it.  vsrmc_checker_step is
+ * refused from the first call on (the seen-set holds levels that have no frontier) until the search has been RE-BASED: when the levels shrink again
+ * (the analysis models after their peak) and the newest seen-set-only level and the one predicted after it fit the record buffers, vsrmc_checker_advance
+ * spends one descent on regenerating that level INTO the idle record buffer (*what = 3: a = the level, unchanged figures) and the rest of the run is
+ * ordinary stored levels.  vsrmc_checker_save works between any two calls; vsrmc_checker_reset starts over. */
 int32_t vsrmc_checker_deepen(vsrmc_checker* c, vsrmc_level_info* inserted, vsrmc_level_info* probed);
 /* One unit of progress of the AUTOMATIC level scheme — no level numbers and no sizes from the caller: an ordinary BFS level while
  * the next one is predicted to fit the idle record buffer (*what = 1, a = its info), otherwise vsrmc_checker_deepen (*what = 2,
- * a = the inserted level, b = the probed one or b->level == 0).  The prediction: a level grows by at most the factor the last one
+ * a = the inserted level, b = the probed one or b->level == 0; *what = 3: no new level, the deep search was re-based onto level a->level,
+ * see vsrmc_checker_deepen).  The prediction: a level grows by at most the factor the last one
  * grew by (the factor falls from level to level in these models, tests/golden/oracle_levels_*.json) and by at most one bag entry
  * per record.  vsrmc_check is the loop over this call; vsrmc_options with table_log2 = 0 / frontier_words = 0 / frontier_states = 0 /
  * pending_entries = 0 are sized from the free memory of the device. */
 int32_t vsrmc_checker_advance(vsrmc_checker* c, vsrmc_level_info* a, vsrmc_level_info* b, int32_t* what);
+/* No fatal mispredictions.  (i) A level vsrmc_checker_advance stored although it did not fit ("frontier full": the prediction above was wrong, or the
+ * caller's own vsrmc_checker_step ran out of buffer) is not lost: k_expand goes on claiming, counting and checking after the buffers are exhausted, so
+ * the seen-set holds the whole level — the NEXT vsrmc_checker_advance (or the same one) keeps it as a seen-set-only level (*what = 2, its figures and
+ * checksums exact) and the search rolls on.  (ii) The seen-set: *state = 0 there is room for the next level, 1 = it has just been re-hashed into a
+ * table of twice the slots (device memory permitting; vsrmc_checker_options shows the new table_log2), 2 = it is more than 85 % full and cannot grow:
+ * the search is incomplete at the depth reached.  vsrmc_check asks before every unit of progress; loops over vsrmc_checker_advance should too. */
+int32_t vsrmc_checker_room(vsrmc_checker* c, int32_t* state);
 /* the (fingerprint, key) pairs of the violating successors the last vsrmc_checker_probe saw and did not find in this checker's
  * seen-set (duplicates included; *n = their number; pairs == NULL asks for the number only).  Sharded runs show them to their owners. */
 int32_t vsrmc_checker_probe_candidates(vsrmc_checker* c, uint64_t* pairs, uint64_t cap_pairs, uint64_t* n);
+/* The distinct violating STATES of the level the last vsrmc_checker_probe / _deepen / _advance probed (unsharded checkers): the fingerprints,
+ * ascending, of the violating successors that are states of no earlier level — viol_fp of the probe's info is fps[0].  Lets a caller ask whether
+ * a KNOWN violating state (the last state of the reference's state_transfer_violation_trace.txt:556-577) is among the ones the search met, not
+ * only which one it reports.  fps == NULL asks for the number only. */
+int32_t vsrmc_checker_probe_violators(vsrmc_checker* c, uint64_t* fps, uint64_t cap, uint64_t* n);
 /* seen[i] = 1 if fps[i] is in this checker's seen-set as a state of a level below `level` (host arrays) */
 int32_t vsrmc_checker_seen_batch(vsrmc_checker* c, const uint64_t* fps, uint64_t n, int32_t level, uint8_t* seen);
 int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
                                   uint64_t cap_states, uint64_t* n_states);
 
 /* ≙ TLC's checkpoints (ModelChecker.checkpoint → FPSet.beginChkpt/commitChkpt, StateQueue and TLCTrace checkpoints; `-recover`):
- * one file holds the search between two levels — the occupied seen-set slots, the newest frontier, the trace log.  It is written
+ * one file holds the search between two levels — the occupied seen-set slots, the newest stored frontier, what the automatic level scheme
+ * has learnt and, once the search has gone beyond the record buffers (vsrmc_checker_deepen), the descriptors of the levels that exist in
+ * the seen-set only: a deep search is saved between two passes and recovered to make every later pass as the uninterrupted run would.  It is written
  * to <path>.tmp and renamed.  vsrmc_checker_load creates a checker with `o` (capacities and table size may differ from the
  * run that saved; the model constants may not) and continues where the checkpoint stopped.  Unsharded checkers only. */
 int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path);
-/* where the search stands (after create / reset / load / step): level, n_new = states of the newest level, distinct, total_generated */
+/* where the search stands (after create / reset / load / step / advance): level = the newest STORED level, n_new = its states, reserved0 = the
+ * number of levels beyond it that are complete in the seen-set only (depth = level + reserved0), frontier = states of the deepest complete
+ * level, distinct, total_generated (both over every complete level) */
 int32_t vsrmc_checker_status(vsrmc_checker* c, vsrmc_level_info* info);
 int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const char* path, vsrmc_checker** out);
 

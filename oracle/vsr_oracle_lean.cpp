@@ -22,7 +22,7 @@
 // Output: the JSON lines of vsr_oracle_mt (one per level, then a summary); the probe pass prints
 //   {"probe_level": l, "generated": .., "deadlocks": .., "violating_successors": .., "viol_fp": "..", "viol_mask": ..}.
 // CLI: vsr_oracle_lean R C nValues L --base-level B --slots N [--probe-level P] [--max-depth D] [--threads T] [--inv-mask M]
-//                      [--no-symmetry] [--verify-fp-all | --verify-fp-every N]
+//                      [--no-symmetry] [--assume-commit-number] [--verify-fp-all | --verify-fp-every N]
 //
 // Collision hunt (oracles that declare fingerprint_with_seed: the second model's): --hunt-seed HEX [--hunt-slots N] keeps a second set, of the
 // fingerprints of every NEW state under another member of the function family.  A new state whose audit fingerprint is in that set already is a
@@ -55,6 +55,13 @@ using namespace ORACLE_NS;
 namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// --assume-commit-number: only VSR.tla's restatement has the field (the driver is compiled once per restatement)
+template <typename T>
+auto set_assume(T& p, int) -> decltype(p.assume_commit_number = true, void()) { p.assume_commit_number = true; }
+template <typename T>
+void set_assume(T&, long) { std::fprintf(stderr, "--assume-commit-number: not an option of this model\n"); std::exit(2); }
+void set_assume_commit_number(Params& P) { set_assume(P, 0); }
 
 void* map_zero(u64 bytes) {
   void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -368,6 +375,7 @@ int main(int argc, char** argv) {
     else if (a == "--slots" && i + 1 < argc) slots = std::strtoull(argv[++i], nullptr, 10);
     else if (a == "--inv-mask" && i + 1 < argc) P.invariant_mask = std::atoi(argv[++i]);
     else if (a == "--no-symmetry") P.symmetry = false;
+    else if (a == "--assume-commit-number") set_assume_commit_number(P);   // policy for VSR.tla:421 (BASELINE configs[3]: ClientCount = 2)
     else if (a == "--verify-fp-all") verify_every = 1;
     else if (a == "--verify-fp-every" && i + 1 < argc) verify_every = std::strtoull(argv[++i], nullptr, 10);
     else if (a == "--hunt-seed" && i + 1 < argc) { c.hunt.on = true; c.hunt.seed = std::strtoull(argv[++i], nullptr, 16); hunt_set = true; }

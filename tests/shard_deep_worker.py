@@ -23,7 +23,7 @@ def main():
     os.environ.setdefault("VSRMC_AUTOSIZE_SHARE", str(world))   # the ranks share one device here
     import vsr_tlaplus_amd as vt
     from vsr_tlaplus_amd import sharded
-    m = vt.Model.from_constants(R=R, C_=C_, n=n, L=L, invariant_mask=inv_mask)
+    m = vt.Model.from_constants(R=R, C_=C_, n=n, L=L, invariant_mask=inv_mask, assume_commit_number=bool(int(os.environ.get("SHARD_ASSUME_COMMIT", "0"))))
     if fw_log2:
         eng = sharded.HipShardEngine(m, rank, world, device=0, table_log2=20, frontier_words=1 << fw_log2, frontier_states=1 << (fw_log2 - 5),
                                      pending_entries=1 << 16, cand_cap=1 << 17, rec_cap=1 << 15, rec_words_cap=1 << 20, filter_log2=16, native_only=True)

@@ -158,3 +158,193 @@ def test_probe2_and_probe3_are_steps_of_the_same_machinery():
     _same(v, want[9])
     assert (p["level"], p["generated"], p["deadlocks"], p["viol_mask"]) == (12, want[10]["generated"], want[10]["deadlocks"], 0)
     mc.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: no fatal mispredictions, re-basing, checkpoints of a deep search
+# ---------------------------------------------------------------------------------------------------------------------
+def _fixture(key):
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_levels_%s.json" % key)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("words_log2", [17, 19, 21])
+def test_a_level_that_overflows_its_record_buffer_is_kept_in_the_seen_set(words_log2):
+    """A wrong "it fits" is not fatal any more.  Config 2 with record buffers of 2^17 / 2^19 / 2^21 words, stepped BLINDLY (vsrmc_checker_step, no
+    prediction) until a level runs out of buffer: the step reports "frontier full" as it always did — and the next advance() adopts that very
+    level from the seen-set (k_expand went on claiming, counting and checking after the buffers were exhausted): its size, successors in total
+    and per action, deadlocks, largest bag and both fingerprint checksums are the oracle fixture's, and so is every level the search then
+    reaches through the seen-set alone."""
+    import vsr_tlaplus_amd as vt
+    g = _fixture("config2")
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=24, frontier_words=1 << words_log2, frontier_states=1 << (words_log2 - 4), pending_entries=1 << 16)
+    failed_at = None
+    for _ in range(20):
+        try:
+            d = mc.step()
+        except vt.VsrmcError as e:
+            assert "frontier" in str(e).lower() or "device error 21" in str(e), str(e)
+            failed_at = mc.level + 1
+            break
+        lv = g["levels"][d["level"] - 1]
+        assert (d["n_new"], d["generated"]) == (lv["new"], lv["generated"])
+    assert failed_at is not None and 8 <= failed_at <= 19, failed_at
+    kind, a, b = mc.advance()                                    # the overflowed level, adopted
+    assert kind == "deep" and b is None and a["level"] == failed_at
+    seen = 0
+    while True:
+        lv = g["levels"][a["level"] - 1]
+        assert (a["n_new"], a["generated"], a["deadlocks"], a["max_bag"]) == (lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"]), a["level"]
+        assert [int(x) for x in a["act_generated"][1:16]] == lv["act_generated"][1:16], a["level"]
+        assert ("%016x" % a["fp_xor"], "%016x" % a["fp_sum"]) == (lv["fp_xor"], lv["fp_sum"]), a["level"]
+        seen += 1
+        if seen == 4:
+            break
+        kind, a, b = mc.advance()
+        assert kind == "deep"
+    assert mc.depth == failed_at + 3 and mc.distinct == sum(x["new"] for x in g["levels"][: failed_at + 3])
+    mc.close()
+
+
+def test_overflow_inside_the_automatic_scheme_and_a_seen_set_that_grows():
+    """The whole loop with both mispredictions forced: a seen-set of 2^10 slots for a search of 109 878 states (it is re-hashed into twice the
+    slots again and again, never "incomplete" while the device has memory), record buffers the levels outgrow, to the violation of
+    AcknowledgedWritesExistOnMajority at depth 19 of (3,1,{v1,v2},1) — the oracle's level figures all the way, the oracle's violating
+    fingerprint, and a counter-example that still walks back to Init through the re-hashed table."""
+    import vsr_tlaplus_amd as vt
+    from oracle import orc
+    P = orc.Params(3, 1, 2, 1, invariant_mask=2)
+    want, ob = _oracle_levels(orc, P, 19)
+    words, off = ob.frontier()
+    viol = min(orc.fingerprint(P, words[int(off[i]): int(off[i + 1])])[0] for i in range(len(off) - 1)
+               if orc.invariants(P, words[int(off[i]): int(off[i + 1])]))
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=1, invariant_mask=2)
+    mc = vt.ModelChecker(m, table_log2=10, frontier_words=1 << 18, frontier_states=1 << 14, pending_entries=1 << 16)
+    grown = 0
+    while mc.violation is None:
+        st = mc.room()
+        assert st != 2, "the seen-set must grow, not give up, while the device has memory"
+        grown += st == 1
+        kind, a, b = mc.advance()
+        if a["viol_mask"]:
+            break
+        _same(a, want[a["level"] - 2]) if kind == "deep" else None
+        w = want[a["level"] - 2]
+        assert (a["n_new"], a["generated"], a["deadlocks"]) == (w["n_new"], w["generated"], w["deadlocks"]), a["level"]
+    assert grown >= 2 and int(mc.options.table_log2) >= 17, (grown, int(mc.options.table_log2))   # (one call may double the table more than once)
+    assert mc.violation["mask"] == 2 and mc.violation["fp"] == viol and mc.violation["level"] == 19
+    tr = mc.violation_trace()
+    assert len(tr) == 19 and np.array_equal(tr[0][1], orc.init_record(P))
+    rec = tr[0][1]
+    for act, w in tr[1:]:
+        f = orc.fingerprint(P, w)[0]
+        nxt = [s for s in orc.successors(P, rec) if s["fp"] == f]
+        assert nxt, act
+        rec = nxt[0]["words"]
+    mc.close()
+    # and the native loop: vsrmc_check on the same sizes
+    mc = vt.ModelChecker(m, table_log2=10, frontier_words=1 << 18, frontier_states=1 << 14, pending_entries=1 << 16)
+    assert mc.check() == "violation" and mc.violation["fp"] == viol and int(mc.options.table_log2) >= 17
+    mc.close()
+
+
+def test_rebasing_when_the_levels_shrink():
+    """(2,1,{v1,v2},2): 2 073 states in 40 levels that grow to level 14 and shrink from there.  Three stored levels, two passes through the
+    seen-set alone — then advance() finds that the newest seen-set-only level fits the idle record buffer, spends one descent on regenerating
+    it INTO that buffer (k_export packs the regenerated slices), and the rest of the run is ordinary stored levels again: every level against
+    the oracle to exhaustion, and the re-based level itself state by state (fingerprint set and records)."""
+    import vsr_tlaplus_amd as vt
+    from oracle import orc
+    P = orc.Params(2, 1, 2, 2)
+    want, _ = _oracle_levels(orc, P, 100)
+    m = vt.Model.from_constants(R=2, C_=1, n=2, L=2)
+    mc = vt.ModelChecker(m, table_log2=16, frontier_words=1 << 20, frontier_states=1 << 14, pending_entries=1 << 15)
+    for _ in range(3):
+        mc.step()
+    for k in (3, 4):
+        a, _b = mc.deepen()
+        _same(a, want[k])
+    assert mc.depth == 6 and mc.level == 4 and not mc.rebased
+    kinds = []
+    for w in want[5:]:
+        kind, a, b = mc.advance()
+        kinds.append(kind)
+        if w["n_new"] == 0:
+            assert a["n_new"] == 0
+            break
+        assert (a["level"], a["n_new"], a["generated"], a["deadlocks"]) == (w["level"], w["n_new"], w["generated"], w["deadlocks"]), w["level"]
+        if kind == "level":
+            x, s_, n = mc.level_checksum()
+            assert (x, s_, n) == (w["fp_xor"], w["fp_sum"], w["n_new"]), w["level"]
+    assert mc.rebased and mc.rebased[0]["level"] == 6 and mc.rebased[0]["n"] == want[4]["n_new"], mc.rebased
+    assert kinds and all(k == "level" for k in kinds), kinds       # stored levels from the re-based one on
+    assert mc.distinct == 2073
+    mc.close()
+    # the re-based level itself: regenerated into the record buffer = the oracle's level, fingerprints and records
+    mc = vt.ModelChecker(m, table_log2=16, frontier_words=1 << 20, frontier_states=1 << 14, pending_entries=1 << 15)
+    for _ in range(3):
+        mc.step()
+    mc.deepen()
+    mc.deepen()
+    ob = orc.Bfs(P)
+    for _ in range(5):
+        ob.step()
+    a, b, what = vt.capi.LevelInfo(), vt.capi.LevelInfo(), __import__("ctypes").c_int32()
+    vt.capi.check(vt.capi.load().vsrmc_checker_advance(mc._h, a, b, what))
+    assert what.value == 3 and a.level == 6 and a.n_new == want[4]["n_new"]
+    mc.level, mc.n_frontier, mc.depth = a.level, a.n_new, a.level
+    assert np.array_equal(mc.level_fps(), ob.level_fps(6))
+    words, off = mc.frontier()
+    got = sorted(orc.fingerprint(P, words[int(off[i]): int(off[i + 1])])[0] for i in range(len(off) - 1))
+    assert np.array_equal(np.array(got, dtype=np.uint64), ob.level_fps(6))
+    d = mc.step()                                                # and the search steps on from it the ordinary way
+    assert (d["level"], d["n_new"], d["generated"]) == (7, want[5]["n_new"], want[5]["generated"])
+    mc.close()
+
+
+def test_a_deep_search_is_checkpointed_and_recovered_in_another_process(tmp_path):
+    """a search that has gone beyond its record buffers is saved BETWEEN TWO PASSES (seen-set, base level, the descriptors of the
+    levels that exist in the seen-set only) by one process and recovered by another one, which reproduces every later level figure of the
+    uninterrupted run — the oracle's — to the violation at depth 19, with its counter-example."""
+    import subprocess
+    import sys
+    import os
+    import vsr_tlaplus_amd as vt
+    from oracle import orc
+    P = orc.Params(3, 1, 2, 1, invariant_mask=2)
+    want, ob = _oracle_levels(orc, P, 19)
+    words, off = ob.frontier()
+    viol = min(orc.fingerprint(P, words[int(off[i]): int(off[i + 1])])[0] for i in range(len(off) - 1)
+               if orc.invariants(P, words[int(off[i]): int(off[i + 1])]))
+    path = str(tmp_path / "deep.chk")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys; sys.path.insert(0, %r)\n"
+              "import vsr_tlaplus_amd as vt\n"
+              "m = vt.Model.from_constants(R=3, C_=1, n=2, L=1, invariant_mask=2)\n"
+              "mc = vt.ModelChecker(m, table_log2=20, frontier_words=1 << 21, frontier_states=1 << 15, pending_entries=1 << 16)\n"
+              "for _ in range(8): mc.step()\n"
+              "for _ in range(4): a, b = mc.deepen()\n"
+              "mc.save(%r)\n"
+              "print('SAVED', mc.level, mc.depth, mc.distinct)\n") % (root, path)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SAVED 9 13" in r.stdout, r.stdout + r.stderr
+    m = vt.Model.from_constants(R=3, C_=1, n=2, L=1, invariant_mask=2)
+    mc = vt.ModelChecker(m, table_log2=20, frontier_words=1 << 21, frontier_states=1 << 15, pending_entries=1 << 16, recover=path)
+    assert (mc.level, mc.depth) == (9, 13) and mc.distinct == sum(w["n_new"] for w in want[:12]) + 1
+    found = None
+    while found is None:
+        a, b = mc.deepen()
+        if a["viol_mask"]:
+            found = a
+            break
+        _same(a, want[a["level"] - 2])
+        if b is not None and b["viol_mask"]:
+            found = b
+    assert (found["level"], found["viol_mask"], found["viol_fp"]) == (19, 2, viol)
+    assert len(mc.probe_trace()) == 19
+    mc.close()
+    with pytest.raises(vt.VsrmcError):                           # another model's constants: refused as before
+        vt.ModelChecker(vt.Model.from_constants(R=3, C_=1, n=2, L=2), table_log2=20, frontier_words=1 << 21, frontier_states=1 << 15, recover=path)

@@ -277,11 +277,13 @@ def test_golden_level_checksums(vt, golden_counts):
         mc.close()
 
 
-@pytest.mark.parametrize("key,seed", [("config2", 0), ("config3", 0), ("config5", 0), ("config3", 0x5EED5EED5EED5EED), ("config5", 0x0123456789ABCDEF)])
-def test_whole_workload_against_the_oracle(vt, oracle_levels, key, seed):
+@pytest.mark.parametrize("key,seed", [("config2", 0), ("config3", 0), ("config5", 0), ("config3", 0x5EED5EED5EED5EED), ("config5", 0x0123456789ABCDEF),
+                                      ("config4", 0), ("config4", 0x5EED5EED5EED5EED)])
+def test_whole_workload_against_the_oracle(vt, oracle_levels, golden_trace, key, seed):
     """Every level the CPU oracle reached (tests/golden/oracle_levels_*.json, written by tools/make_oracle_levels.py and the memory-lean
     driver — config 2 = all 28 levels to its first violation, config 3 = the README configuration: 23 levels + the probe of level 24,
-    config 5: 14 levels): new states, successors generated in total and PER ACTION (VSR.tla:896-918 order), deadlocks, largest bag, and
+    config 5: 14 levels, config 4 = BASELINE configs[3] (3,2,{v1,v2,v3},3) under the documented policy for VSR.tla:421, `assume_commit_number` —
+    strict TLC semantics abort there, test_config4_strict_raises_the_tlc_evaluation_error): new states, successors generated in total and PER ACTION (VSR.tla:896-918 order), deadlocks, largest bag, and
     the xor / sum of the level's fingerprints, computed on the device.  Through the AUTOMATIC level scheme: no level number and no buffer
     size comes from this test — the checker sizes itself from the free HBM and ModelChecker.advance stores a level while the next one is
     predicted to fit, then goes on through the seen-set alone (virtual / streamed / probed levels, csrc/vsr_deep.hpp).
@@ -290,7 +292,8 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, key, seed):
         pytest.skip("no oracle fixture for %s yet" % key)
     g = oracle_levels[key]
     p = g["params"]
-    m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=p["n"], L=p["L"], symmetry=p["symmetry"], invariant_mask=p["inv_mask"])
+    m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=p["n"], L=p["L"], symmetry=p["symmetry"], invariant_mask=p["inv_mask"],
+                                assume_commit_number=bool(p.get("assume_commit_number")))
     if seed:
         m.set_fp_seed(seed)
     mc = vt.ModelChecker.auto(m)
@@ -322,6 +325,27 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, key, seed):
             assert "%016x" % probed["viol_fp"] == want["viol_fp"]
         tr = mc.violation_trace()
         assert len(tr) == want["level"]
+        # The reference's own vector against the BIG search (not only against the successor function): every state of
+        # /root/reference/state_transfer_violation_trace.txt (24 states, lines 1-578; tests/golden/state_transfer_trace.json) is looked up in the
+        # seen-set of this 1.8e9-state run.  State i of a behaviour is reachable in i - 1 steps, so the BFS must hold its VIEW at a level <= i
+        # (not necessarily == i: the first discoverer of a view may carry other aux variables); state 24 — never inserted: level 24
+        # is only probed — must be one of the violating states the probe collected.  A lost state, a false merge or a level that is too deep
+        # anywhere along the reference's path shows up here.
+        gp = golden_trace["params"]
+        assert (gp["R"], gp["C"], len(gp["values"]), gp["L"]) == (p["R"], p["C"], p["n"], p["L"])
+        recs = [np.array([int(w, 16) for w in st["words"]], dtype=np.uint64) for st in golden_trace["states"]]
+        gfps, _ = m.fingerprints(np.concatenate(recs), np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64))
+        if not seed:
+            assert ["%016x" % int(f) for f in gfps] == [st["fp"] for st in golden_trace["states"]]
+        assert len(recs) == want["level"]
+        for i, f in enumerate(gfps[:-1]):
+            hit = mc.lookup(int(f))
+            assert hit is not None, "state %d of the reference trace is not in the seen-set" % (i + 1)
+            assert hit[0] == int(f) and 1 <= hit[1] >> 55 <= i + 1, (i + 1, hit[1] >> 55)
+        assert mc.lookup(int(gfps[-1])) is None                                # level 24 was probed, not inserted
+        viol = mc.probe_violators()
+        assert viol and viol[0] == probed["viol_fp"] and viol == sorted(set(viol))
+        assert int(gfps[-1]) in viol, "the reference trace's violating state is not among the %d violating states the probe met" % len(viol)
     elif g["stop"] == "violation":
         assert mc.violation is not None and mc.violation["mask"] == g["viol_mask"]
         if sums:
@@ -419,6 +443,24 @@ def test_cli_runs_config1_to_completion(vt, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Model checking completed. No error has been found." in r.stdout
     assert "76 distinct states found" in r.stdout and "search is 14" in r.stdout
+    # round-4 advice: -recover with the DEFAULT sizes (table_log2 = 0, frontierGiB = 0: sized from the free device memory before the checkpoint
+    # is held against them) — this failed with "the options are too small for this checkpoint"
+    r = subprocess.run([cli, "-config", cfg, "-noTLA", "-recover", chk], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Recovered from" in r.stdout and "76 distinct states found" in r.stdout and "search is 14" in r.stdout
+
+
+def test_cli_audit_reruns_under_a_second_fingerprint_function(vt, tmp_path):
+    """`vsrmc -audit` (TLC: a rerun under another -fp N, as a product feature): the search, then the same search under another member of the
+    fingerprint family, per-level counts compared."""
+    import os
+    import subprocess
+    from test_host_cpu import _cfg
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr_tlaplus_amd", "vsrmc")
+    cfg = _cfg(tmp_path, R=2, vals="v1, v2", L=2)
+    r = subprocess.run([cli, "-config", cfg, "-noTLA", "-tableLog2", "16", "-frontierGiB", "0.01", "-audit"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "2073 distinct states found" in r.stdout and "Audit: 39 levels, every new / generated / deadlock count equal" in r.stdout, r.stdout
     r = subprocess.run([cli, "-config", cfg, "VSR.tla", "-noTLA", "-checkDeadlock", "-tableLog2", "16", "-frontierGiB", "0.01"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 11 and "Deadlock reached" in r.stdout          # stock TLC without -deadlock (SURVEY F4)

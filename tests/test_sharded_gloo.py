@@ -294,12 +294,12 @@ print("OK", len(runs[0]))
 # ---------------------------------------------------------------------------------------------------------------------
 # the automatic level scheme on a sharded run: levels beyond the ranks' record buffers (vsrmc_shard_loop_advance / _deepen)
 # ---------------------------------------------------------------------------------------------------------------------
-def run_deep_world(world, params, inv_mask, max_depth, tmp_path, port, fw_log2=0, replicate_below=0):
+def run_deep_world(world, params, inv_mask, max_depth, tmp_path, port, fw_log2=0, replicate_below=0, **env):
     out = str(tmp_path / ("deep_w%d" % world))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "shard_deep_worker.py")] + [str(x) for x in params] + \
           [str(inv_mask), str(max_depth), out, str(fw_log2), str(replicate_below)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, OMP_NUM_THREADS="1", **{k: str(v) for k, v in env.items()}))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     ranks = [json.load(open("%s.rank%d.json" % (out, k))) for k in range(world)]
     # seconds / launches are the rank's own; act_generated[0] is not a count (a shader clock rides in that slot)
@@ -375,6 +375,24 @@ def test_readme_configuration_on_two_ranks(tmp_path, oracle_levels):
 
 
 @pytest.mark.gpu
+def test_config4_on_two_ranks(tmp_path, oracle_levels):
+    """BASELINE configs[3] (3,2,{v1,v2,v3},3: two clients) under the documented policy for VSR.tla:421 (`assume_commit_number`; strict TLC
+    semantics abort at that line) through the sharded path at world 2, both ranks on this GPU: the first 14 levels of the CPU oracle's
+    fixture (tests/golden/oracle_levels_config4.json), every figure per level, on a configuration whose second client doubles the
+    ReceiveClientRequest bindings and exercises the client-table branch of ReceivePrepareMsg (VSR.tla:414-421) on both ranks."""
+    g = oracle_levels["config4"]
+    p = g["params"]
+    assert p.get("assume_commit_number")
+    got = run_deep_world(2, (p["R"], p["C"], p["n"], p["L"]), p["inv_mask"], 14, tmp_path, 29698, SHARD_ASSUME_COMMIT=1)
+    assert [lv["level"] for lv in got["levels"]] == list(range(2, 15)) and got["violation"] is None
+    for lv, want in zip(got["levels"], g["levels"][1:]):
+        assert (lv["level"], lv["n_new"], lv["generated"], lv["deadlocks"], lv["max_bag"]) == \
+            (want["level"], want["new"], want["generated"], want["deadlocks"], want["max_bag"]), want["level"]
+        assert lv["act_generated"][1:16] == want["act_generated"][1:16], want["level"]
+    assert got["distinct"] == sum(lv["new"] for lv in g["levels"][:14])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("engine", ["hip", "native", "hip-exact"])
 def test_violation_of_any_mask_on_a_remotely_owned_successor_is_reported(tmp_path, engine):
     """Round-2 advice (high): a successor that is written speculatively by its generator and owned by another rank carries its
@@ -391,7 +409,14 @@ def test_violation_of_any_mask_on_a_remotely_owned_successor_is_reported(tmp_pat
     remote = [f for f in lvl8["fps"] if owner(int(f, 16)) == 1]            # generated (and stored) by rank 0, owned by rank 1
     assert remote
     target = remote[len(remote) // 2]
-    ranks = run_world(engine, 2, params, depth, tmp_path, 29701, 0, VSRMC_TEST_FORCE_BAD="%s:28" % target)
+    # the hook lives in libvsrmc_hooks.so only (-DVSRMC_TEST_HOOKS, built beside the product library by vsr_tlaplus_amd/build.py); the product
+    # library ignores the variable: the same run through it reports nothing
+    hooks = os.path.join(ROOT, "vsr_tlaplus_amd", "libvsrmc_hooks.so")
+    assert os.path.exists(hooks), "build it: python vsr_tlaplus_amd/build.py"
+    if engine == "hip":
+        ranks = run_world(engine, 2, params, depth, tmp_path, 29702, 0, VSRMC_TEST_FORCE_BAD="%s:28" % target)
+        assert all(r["violation"] is None for r in ranks)
+    ranks = run_world(engine, 2, params, depth, tmp_path, 29701, 0, VSRMC_TEST_FORCE_BAD="%s:28" % target, VSRMC_LIB=hooks)
     for r in ranks:
         assert r["violation"] == dict(level=8, fp=target, mask=28), r["violation"]
 

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--inv-mask", type=int, default=0, help="default: the shipped cfg's invariants (model 1: 1, model 2: 14, model 3: 30)")
     ap.add_argument("--model", type=int, default=1, help="1 = VSR.tla (vsr_oracle_mt), 2 = analysis/03-state-transfer/VR_STATE_TRANSFER.tla (vrst_oracle_mt), 3 = analysis/04-application-state/VR_APP_STATE.tla (vras_oracle_mt)")
     ap.add_argument("--no-symmetry", action="store_true")
+    ap.add_argument("--assume-commit-number", action="store_true",
+                    help="policy for VSR.tla:421 (`m.commit`, a field PrepareMsg does not have: TLC aborts there when ClientCount >= 2): read m.commit_number instead")
     ap.add_argument("--label", default="")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -50,6 +52,8 @@ def main():
         cmd += ["--count-only-from", str(a.count_only_from)]
     if a.no_symmetry:
         cmd += ["--no-symmetry"]
+    if a.assume_commit_number:
+        cmd += ["--assume-commit-number"]
     t0 = time.time()
     levels = []
 
@@ -65,7 +69,8 @@ def main():
                    % (" ".join([os.path.basename(exe)] + cmd[1:]), summary.get("threads", a.threads or "all"), platform.processor() or platform.machine(),
                       os.cpu_count() or 0, time.time() - t0),
             label=a.label or "(%d,%d,%d values,%d)" % (a.R, a.C, a.n, a.L),
-            model=a.model, params=dict(R=a.R, C=a.C, n=a.n, L=a.L, symmetry=(not a.no_symmetry) and a.model == 1, inv_mask=a.inv_mask),
+            model=a.model, params=dict(R=a.R, C=a.C, n=a.n, L=a.L, symmetry=(not a.no_symmetry) and a.model == 1, inv_mask=a.inv_mask,
+                        **({"assume_commit_number": True} if a.assume_commit_number else {})),
             stop=summary.get("stop", "running"), depth=summary.get("depth", len(levels)),
             distinct=summary.get("distinct", sum(lv["new"] for lv in levels)),
             generated=summary.get("generated", sum(lv["generated"] for lv in levels)),

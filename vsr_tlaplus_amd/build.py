@@ -5,6 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvsrmc.so")
+LIB_HOOKS = os.path.join(HERE, "libvsrmc_hooks.so")     # the same sources with -DVSRMC_TEST_HOOKS: test hooks the product library does not contain
 CLI = os.path.join(HERE, "vsrmc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
@@ -27,6 +28,11 @@ def build(force=False, verbose=False):
     srcs = sources()
     if force or _newer(LIB, srcs):
         cmd = [HIPCC] + FLAGS + ["-shared", "-o", LIB, os.path.join(CSRC, "vsrmc.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    if force or _newer(LIB_HOOKS, srcs):
+        cmd = [HIPCC] + FLAGS + ["-DVSRMC_TEST_HOOKS", "-shared", "-o", LIB_HOOKS, os.path.join(CSRC, "vsrmc.hip")]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

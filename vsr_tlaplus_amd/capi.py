@@ -120,8 +120,10 @@ SYMBOLS = {
     "vsrmc_checker_deepen": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo)]),
     "vsrmc_checker_options": (C.c_int32, [V, C.POINTER(Options)]),
     "vsrmc_checker_advance": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo), C.POINTER(C.c_int32)]),
+    "vsrmc_checker_room": (C.c_int32, [V, C.POINTER(C.c_int32)]),
     "vsrmc_checker_probe_candidates": (C.c_int32, [V, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_seen_batch": (C.c_int32, [V, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
+    "vsrmc_checker_probe_violators": (C.c_int32, [V, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_probe_trace": (C.c_int32, [V, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_save": (C.c_int32, [V, C.c_char_p]),
     "vsrmc_checker_status": (C.c_int32, [V, C.POINTER(LevelInfo)]),

@@ -340,7 +340,8 @@ class ModelChecker:
             self.level, self.n_frontier, self.distinct = info.level, info.n_new, info.distinct
             self.levels = [dict(level=info.level, n_new=info.n_new, generated=0, deadlocks=0, recovered=True)]
             self.violation = None
-            self.depth = self.level
+            self.rebased = []
+            self.depth = self.level + info.reserved0               # a deep search: the levels beyond the stored one came along in the seen-set
         check(capi.load().vsrmc_checker_options(self._h, C.byref(o)))       # sizes left 0 were derived from the free device memory
 
     def save(self, path):
@@ -354,6 +355,7 @@ class ModelChecker:
         self.distinct = 1
         self.levels = [dict(level=1, n_new=1, generated=0, deadlocks=0)]
         self.violation = None
+        self.rebased = []
 
     def reset(self):
         """Back to Init with an empty seen-set; keeps the HBM allocations (a fresh TLC run on the same model)."""
@@ -379,8 +381,12 @@ class ModelChecker:
         info = capi.LevelInfo()
         check(capi.load().vsrmc_check(self._h, max_depth, max_seconds, C.byref(reason), C.byref(info)))
         d = info.as_dict()
-        self.level = self.depth = d["level"]                              # the deepest level that is complete (stored or in the seen-set only)
+        self.depth = d["level"]                                           # the deepest level that is complete (stored or in the seen-set only)
         self.distinct = d["distinct"]
+        st = capi.LevelInfo()
+        check(capi.load().vsrmc_checker_status(self._h, C.byref(st)))     # the newest STORED level: what level_fps / frontier / trace(index) address
+        self.level, self.n_frontier = st.level, st.n_new
+        check(capi.load().vsrmc_checker_options(self._h, C.byref(self.options)))   # (the seen-set may have grown)
         if reason.value == 1:
             self.violation = dict(level=d["level"], index=d["viol_index"], fp=d["viol_fp"], mask=d["viol_mask"],
                                   probed=d["viol_index"] == (1 << 64) - 1)
@@ -409,6 +415,10 @@ class ModelChecker:
         a, b = capi.LevelInfo(), capi.LevelInfo()
         what = C.c_int32()
         check(capi.load().vsrmc_checker_advance(self._h, C.byref(a), C.byref(b), C.byref(what)))
+        while what.value == 3:                       # re-based: the newest seen-set-only level became the stored base (no new level): go on
+            self.level, self.n_frontier = a.level, a.n_new
+            self.rebased.append(dict(level=a.level, n=a.n_new, seconds=a.seconds, launches=a.pending))
+            check(capi.load().vsrmc_checker_advance(self._h, C.byref(a), C.byref(b), C.byref(what)))
         if what.value == 1:
             d = a.as_dict()
             self.level, self.n_frontier, self.distinct = d["level"], d["n_new"], d["distinct"]
@@ -422,6 +432,15 @@ class ModelChecker:
         self.depth, self.distinct = da["level"], da["distinct"]
         return "deep", da, (db if db["level"] else None)
 
+    def room(self):
+        """The seen-set before the next advance(): 0 = room enough, 1 = just re-hashed into a table of twice the slots (self.options.table_log2 is
+        refreshed), 2 = more than 85 % full and no device memory to grow into: the search is incomplete at the depth reached."""
+        st = C.c_int32()
+        check(capi.load().vsrmc_checker_room(self._h, C.byref(st)))
+        if st.value == 1:
+            check(capi.load().vsrmc_checker_options(self._h, C.byref(self.options)))
+        return st.value
+
     def run(self, max_depth=None, max_seconds=None, stop_on_violation=True):
         """Worker.run until the queue is empty, an invariant is violated, or a bound is hit — the automatic level scheme: levels are
         stored while they fit the record buffers, the search goes on beyond them through the seen-set alone (deepen)."""
@@ -432,7 +451,7 @@ class ModelChecker:
                 return "max-depth"
             if max_seconds is not None and time.time() - t0 > max_seconds:
                 return "max-seconds"
-            if self.distinct > 0.85 * (1 << int(self.options.table_log2)):
+            if self.room() == 2:
                 return "seen-set-full"
             kind, d, p = self.advance()
             if d["n_new"] == 0:
@@ -560,6 +579,14 @@ class ModelChecker:
             if d["viol_mask"] and self.violation is None:
                 self.violation = dict(level=d["level"], index=None, fp=d["viol_fp"], mask=d["viol_mask"], probed=True)
         return tuple(out)
+
+    def probe_violators(self):
+        """fingerprints (ascending) of the distinct violating states of the level the last probe / deepen / advance call probed"""
+        n = C.c_uint64()
+        check(capi.load().vsrmc_checker_probe_violators(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), dtype=np.uint64)
+        check(capi.load().vsrmc_checker_probe_violators(self._h, _p(out), len(out), C.byref(n)))
+        return [int(x) for x in out[: n.value]]
 
     def probe_trace(self):
         """The counter-example of the violation probe() reported: [(action name, record)] from Init to the violator."""

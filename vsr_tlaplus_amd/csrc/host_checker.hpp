@@ -58,6 +58,7 @@ struct vsrmc_checker {
   // state of the path that is IN the seen-set, its level, and the fingerprint of the one probed state beyond it (0: none)
   u64 probe_fp = 0, probe_extra_fp = 0;
   int probe_level = 0;
+  std::vector<u64> probe_viol;           // the distinct violating STATES of the last probed level (fingerprints, ascending): vsrmc_checker_probe_violators
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
   bool saw_violation = false;            // a committed level held a violating state (the caller went on): probe passes apply every action
   // levels beyond the record buffers (vsr_deep.hpp): `deep` levels above `level` are complete in the seen-set and have no frontier
@@ -66,7 +67,10 @@ struct vsrmc_checker {
   u64 deep_g = 2;                        // successors generated per expanded state, rounded up, the largest any level showed (worst-case slice sizes)
   u64 deep_distinct = 0, deep_generated = 0;
   bool deep_regen_done = false;          // a descent has set taken bits in the levels beyond the base: cleared before the next one
+  bool rebase_off = false;               // a re-basing descent could not get its scratch buffers: not tried again (vsr_deep.hpp: deep_rebase)
   std::vector<PassDst> scratch;          // scratch buffers of the descent, each a quarter of the one above down to a floor (allocated on first use)
+  bool full_recoverable = false;         // the last vsrmc_checker_step stopped with "frontier full" and lost nothing but records: the level is complete in the
+                                         // seen-set and vsrmc_checker_advance keeps it as a seen-set-only level (host_search.hpp: adopt_overflowed_level)
   u64 hist_new[2] = {0, 0};              // new states of the last two levels (growth estimate of vsrmc_checker_advance)
   u64 g_last = 16, cur_rec_w = 0;        // successors generated per expanded state of the last level (rounded up, + 1); words of the newest level's records
   u64 words_cap(int b) const { return (b == 1 && opt.frontier_words_b) ? opt.frontier_words_b : opt.frontier_words; }
@@ -191,6 +195,7 @@ int checker_seed(vsrmc_checker* c) {
   c->cur_rec_w = 0;
   c->failed = 0;
   c->failed_code = 0;
+  c->full_recoverable = false;
   HIPCHK(hipSetDevice(c->opt.device));
   hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
   HIPCHK(hipGetLastError());
@@ -229,6 +234,7 @@ int checker_seed(vsrmc_checker* c) {
   c->probe_fp = 0;
   c->probe_level = 0;
   c->probe_extra_fp = 0;
+  c->probe_viol.clear();
   return 0;
 }
 }  // namespace
@@ -256,7 +262,11 @@ void vsrmc_options_default(vsrmc_options* o) {
 // run, in two equal buffers — the last two levels differ by the growth factor, but which of the two buffers holds the last one is not
 // known in advance; pending list: only the exact scheme needs one worth the name.
 static int autosize_options(vsrmc_options* o, const Model& M) {
-  if (o->table_log2 != 0 && o->frontier_words != 0) return 0;
+  if (o->table_log2 != 0 && o->frontier_words != 0) {               // both pinned: only the two small sizes can still be "auto"
+    if (o->pending_entries == 0) o->pending_entries = o->exact_ties ? (u64)1 << 24 : (u64)1 << 16;
+    if (o->frontier_states == 0) o->frontier_states = std::max<u64>((u64)1 << 16, o->frontier_words / 24);
+    return 0;
+  }
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipSetDevice(o->device));
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -454,6 +464,13 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     c->expand_ms = ms;
   }
   c->nx_n = c->nx_w = 0;
+  c->full_recoverable = false;
+  if (!c->h.err && c->h.full) {                                // the record buffers ran out (LevelCtl::full): reported as before ..
+    c->h.err = ERR_FRONTIER_FULL;
+    c->h.err_info = c->h.full_info << 16;
+    // .. but an unsharded ordinary level has lost nothing except the records: the automatic scheme goes on from the seen-set
+    c->full_recoverable = !io && mode == MODE_NORMAL && !c->opt.exact_ties && c->opt.world == 1 && c->h.ties == 0;
+  }
   if (c->h.err) return level_error(c, c->h, c->level + 1);
   if (!c->opt.exact_ties) {                                    // fused: the level is already materialised (sharded: speculatively)
     c->nx_n = c->h.n_new;
@@ -670,6 +687,10 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->expand_ms += ms;
+  }
+  if (!c->h.err && c->h.full) {                                // a pass into buffers that ran out (LevelCtl::full): an error here — the caller sized the slice
+    c->h.err = ERR_FRONTIER_FULL;
+    c->h.err_info = c->h.full_info << 16;
   }
   if (c->h.err) return level_error(c, c->h, level);
   if (c->h.ties) {

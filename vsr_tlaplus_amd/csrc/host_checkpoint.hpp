@@ -5,11 +5,18 @@ extern "C" {
 // ---- checkpoint / recover ≙ TLC's checkpoints (ModelChecker.checkpoint: FPSet.beginChkpt/commitChkpt, StateQueue, TLCTrace) ----
 namespace {
 struct ChkHeader {
-  char magic[8];                 // "VSRMCCK3" (1 = the format with a separate trace log and index-based meta words; 2 = without the module in the header)
+  char magic[8];                 // "VSRMCCK4" (1 = the format with a separate trace log and index-based meta words; 2 = without the module in the header;
+                                 // 3 = without the deep-search section: no checkpoint once a level existed in the seen-set only)
   int32_t consts[12];            // R, C, n, L, symmetry, inv_mask, assume_commit, np, module (model_id), words per replica, fixed words,
                                  // version of the fingerprint function: records and fingerprints mean nothing under another layout or hash
   int32_t level, shard;          // shard: 0 = unsharded, else world << 16 | rank (each rank writes and reads its own file)
   u64 n_frontier, n_valid, cur_w, distinct, total_generated, n_levels, table_entries, trace_entries;
+  // what the automatic level scheme has learnt (a recovered run then makes the decisions the uninterrupted one would)
+  u64 hist_new[2], g_last, cur_rec_w, cur_max_bag;
+  // the search beyond the record buffers (vsr_deep.hpp): `deep` levels above `level` are complete in the seen-set and have no frontier; their
+  // descriptors (DeepLevelRec: 5 words each) follow the header.  The frontier below is the BASE level every descent starts from.
+  u64 deep, deep_g, deep_distinct, deep_generated;
+  u64 cur_buf;                   // which of the two record buffers holds the frontier (level L lives in buffer (L - 1) mod 2 until a re-basing moves it)
 };
 bool dev_to_file(FILE* f, const void* d_ptr, u64 bytes, std::vector<char>& buf) {
   for (u64 pos = 0; pos < bytes; pos += buf.size()) {
@@ -33,7 +40,8 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   if (!c || !path) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   if (c->opt.world > 1 && c->opt.exact_ties) return fail(VSRMC_E_STATE, "checkpoints of sharded exact-mode checkers are not supported");
-  if (c->deep) return fail(VSRMC_E_STATE, "the seen-set holds levels beyond the newest materialised one (vsrmc_checker_deepen): no checkpoint can describe that state");
+  if (c->opt.world > 1 && c->deep) return fail(VSRMC_E_STATE, "a sharded search that has gone beyond its record buffers is not checkpointed (the level loop's own state — the run's totals, "
+                                                               "the ranks' shares of every seen-set-only level — lives outside this handle); unsharded checkers are");
   HIPCHK(hipSetDevice(c->opt.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   const Model& M = c->model.M;
@@ -42,7 +50,7 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   if (!f) return fail(VSRMC_E_CFG, "cannot write " + tmp);
   ChkHeader h;
   std::memset(&h, 0, sizeof(h));
-  std::memcpy(h.magic, "VSRMCCK3", 8);
+  std::memcpy(h.magic, "VSRMCCK4", 8);
   const int32_t consts[12] = {M.R, M.C, M.n, M.L, c->model.symmetry, M.inv_mask, M.assume_commit, M.np, M.model_id, M.wpr, M.fixed, fp_function_id(M)};
   std::memcpy(h.consts, consts, sizeof(consts));
   h.level = c->level;
@@ -54,6 +62,11 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   h.total_generated = c->total_generated;
   h.n_levels = (u64)c->level;
   h.trace_entries = 0;                                          // the predecessor pointers travel inside the seen-set slots
+  h.hist_new[0] = c->hist_new[0]; h.hist_new[1] = c->hist_new[1];
+  h.g_last = c->g_last; h.cur_rec_w = c->cur_rec_w; h.cur_max_bag = c->bag_known ? c->cur_max_bag : ~(u64)0;
+  h.cur_buf = (u64)c->cur;
+  h.deep = (u64)c->deep; h.deep_g = c->deep_g; h.deep_distinct = c->deep_distinct; h.deep_generated = c->deep_generated;
+  if ((size_t)c->deep != c->deep_lv.size()) return fail(VSRMC_E_STATE, "inconsistent deep-search state");
   std::vector<char> buf((size_t)64 << 20);
   bool ok = true;
   // the seen-set: occupied slots only, window by window (the export buffer holds one window)
@@ -67,6 +80,8 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
     return fail(VSRMC_E_HIP, "hipMalloc of the checkpoint export window failed");
   }
   ok = std::fwrite(&h, sizeof(h), 1, f) == 1;                   // rewritten at the end with table_entries
+  static_assert(sizeof(DeepLevelRec) == 40, "a deep-level descriptor is five words");
+  if (ok && c->deep) ok = std::fwrite(c->deep_lv.data(), sizeof(DeepLevelRec), (size_t)c->deep, f) == (size_t)c->deep;
   u64 total = 0;
   for (u64 first = 0; first < slots && ok; first += win) {
     u64 cnt = 0;
@@ -91,15 +106,26 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   return 0;
 }
 
-int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const char* path, vsrmc_checker** out) {
-  if (!m || !o || !path || !out) return fail(VSRMC_E_ARG, "NULL argument");
-  if (o->world > 1 && o->exact_ties) return fail(VSRMC_E_STATE, "checkpoints of sharded exact-mode checkers are not supported");
+int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o_in, const char* path, vsrmc_checker** out) {
+  if (!m || !o_in || !path || !out) return fail(VSRMC_E_ARG, "NULL argument");
+  if (o_in->world > 1 && o_in->exact_ties) return fail(VSRMC_E_STATE, "checkpoints of sharded exact-mode checkers are not supported");
+  // options with zeros (the CLI's and ModelChecker.auto()'s defaults) are sized from the free device memory FIRST: the checkpoint is held
+  // against the sizes the checker will really have, not against the zeros (round-4 advice: `vsrmc -recover ck` without explicit sizes failed)
+  vsrmc_options sized = *o_in;
+  {
+    const int rc0 = autosize_options(&sized, m->M);
+    if (rc0) return rc0;
+  }
+  const vsrmc_options* o = &sized;
   FILE* f = std::fopen(path, "rb");
   if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + path);
   ChkHeader h;
-  bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VSRMCCK3", 8) == 0;
+  bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "VSRMCCK4", 8) == 0;
   // header invariants (a truncated or foreign file must not become an inconsistent checker)
-  if (ok) ok = h.level >= 1 && h.level < 511 && (u64)h.level == h.n_levels && h.n_valid <= h.n_frontier && h.trace_entries == 0;
+  if (ok) ok = h.level >= 1 && h.level < 511 && (u64)h.level == h.n_levels && h.n_valid <= h.n_frontier && h.trace_entries == 0 &&
+               h.deep < 511 && (u64)h.level + h.deep < 511 && (h.deep == 0 || h.deep_distinct >= h.distinct) && h.cur_buf <= 1;
+  std::vector<DeepLevelRec> deep_lv((size_t)(ok ? h.deep : 0));
+  if (ok && h.deep) ok = std::fread(deep_lv.data(), sizeof(DeepLevelRec), (size_t)h.deep, f) == (size_t)h.deep;
   if (!ok) {
     std::fclose(f);
     return fail(VSRMC_E_CFG, std::string(path) + " is not a (consistent) vsrmc checkpoint");
@@ -114,8 +140,10 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
     std::fclose(f);
     return fail(VSRMC_E_CFG, "the checkpoint was written by another rank or for another world size");
   }
-  const int buf_of_level = (h.level - 1) & 1;                   // level L lives in record buffer (L - 1) mod 2, also after recovery
+  const int buf_of_level = (int)h.cur_buf;                      // the record buffer the frontier was in: its level keeps alternating from there
   const u64 cap_of_buf = (buf_of_level == 1 && o->frontier_words_b) ? o->frontier_words_b : o->frontier_words;
+  if (o_in->table_log2 == 0)                                    // a seen-set that had grown beyond the automatic size (vsrmc_checker_room)
+    while (sized.table_log2 < 36 && (double)h.table_entries > 0.6 * (double)((u64)1 << sized.table_log2)) sized.table_log2++;
   if (h.n_frontier > o->frontier_states || h.cur_w > cap_of_buf || 2 * h.table_entries > ((u64)1 << o->table_log2)) {
     std::fclose(f);
     return fail(VSRMC_E_ARG, "the options are too small for this checkpoint (frontier, table)");
@@ -160,6 +188,18 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
   c->cur_w = h.cur_w;
   c->distinct = h.distinct;
   c->total_generated = h.total_generated;
+  c->hist_new[0] = h.hist_new[0]; c->hist_new[1] = h.hist_new[1];
+  c->g_last = std::max<u64>(2, h.g_last); c->cur_rec_w = h.cur_rec_w;
+  if (h.cur_max_bag != ~(u64)0 && o->world == 1) { c->cur_max_bag = h.cur_max_bag; c->bag_known = true; }
+  if (h.deep) {                                                // the levels beyond the base: in the seen-set (restored above), described here
+    c->deep = (int)h.deep;
+    c->deep_lv = deep_lv;
+    c->deep_g = std::max<u64>(2, h.deep_g);
+    c->deep_distinct = h.deep_distinct;
+    c->deep_generated = h.deep_generated;
+    c->deep_regen_done = true;                                 // taken bits of earlier descents travelled with the slots: cleared before the next one;
+                                                               // the base level's lvl_fp array had been reused as scratch: states are addressed by fingerprint
+  }
   *out = c;
   return 0;
 }
@@ -167,10 +207,12 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o, const c
 int32_t vsrmc_checker_status(vsrmc_checker* c, vsrmc_level_info* info) {
   if (!c || !info) return fail(VSRMC_E_ARG, "NULL argument");
   std::memset(info, 0, sizeof(*info));
-  info->level = c->level;
+  info->level = c->level;                                      // the newest STORED level
   info->n_new = c->n_valid;
-  info->distinct = c->distinct;
-  info->total_generated = c->total_generated;
+  info->reserved0 = c->deep;                                   // levels beyond it that are complete in the seen-set only (vsrmc_checker_deepen)
+  info->frontier = c->deep ? c->deep_lv.back().n_new : c->n_valid;   // states of the deepest complete level
+  info->distinct = c->deep ? c->deep_distinct : c->distinct;
+  info->total_generated = c->deep ? c->deep_generated : c->total_generated;
   info->words_new = c->cur_w;
   info->viol_fp = ~(u64)0;
   info->viol_index = ~(u64)0;

@@ -13,17 +13,20 @@ struct vsrmc_model {
 
 namespace {
 
-// TEST HOOK: VSRMC_TEST_FORCE_BAD=<hex fingerprint>:<mask> makes the state with that fingerprint fail the invariants of <mask> in the
-// sharded and two-kernel paths (Model::test_bad_fp) — how tests/test_sharded_gloo.py puts a violator of masks 4 / 8 / 16 on a rank that
-// does not own it.  Unset (always, outside that test): no effect.
+// TEST HOOK, compiled only with -DVSRMC_TEST_HOOKS (vsr_tlaplus_amd/libvsrmc_hooks.so, which build.py makes beside the product library and only
+// tests/test_sharded_gloo.py loads): VSRMC_TEST_FORCE_BAD=<hex fingerprint>:<mask> makes the state with that fingerprint fail the invariants of
+// <mask> in the sharded and two-kernel paths (Model::test_bad_fp) — how a test puts a violator of masks 4 / 8 / 16 on a rank that does not
+// own it.  The product library reads no such variable and evaluates no such compare.
 void apply_test_hooks(Model& M) {
   M.test_bad_fp = 0;
   M.test_bad_mask = 0;
+#ifdef VSRMC_TEST_HOOKS
   if (const char* e = std::getenv("VSRMC_TEST_FORCE_BAD")) {
     char* end = nullptr;
     const u64 fp = std::strtoull(e, &end, 16);
     if (end && *end == ':') { M.test_bad_fp = fp; M.test_bad_mask = (u32)std::strtoul(end + 1, nullptr, 0) & 31u; }
   }
+#endif
 }
 
 int build_model(int R, int C, int n, int L, int restart, int symmetry, int inv_mask, int assume_commit, vsrmc_model* out) {
@@ -47,7 +50,7 @@ int build_model(int R, int C, int n, int L, int restart, int symmetry, int inv_m
     M.pitab[np++] = (u32)perms[i][0] | ((u32)perms[i][1] << 2) | ((u32)perms[i][2] << 4);
   }
   M.np = np;
-  M.fixed = M.h0 + M.np;
+  M.fixed = M.h0 + M.np + VSR_PAD_WORDS;
   M.assume_commit = assume_commit ? 1 : 0;
   M.inv_mask = inv_mask;
   // LDS stride of one staged record: 63 words (R <= 3) or 95 words (R >= 4: more replicas, larger bags); odd, so that the
@@ -79,7 +82,7 @@ int build_model2(int R, int n, int L, int no_progress_limit, int symmetry, int i
   M.h0 = 1 + R;
   M.np = 1;
   M.pitab[0] = 0x24u;                                            // the identity
-  M.fixed = M.h0 + 1;
+  M.fixed = M.h0 + 1 + VSR_PAD_WORDS;
   M.inv_mask = inv_mask;
   M.max_bag = 63 - M.fixed;
   M.m0 = 4 * R + R * n;
@@ -108,7 +111,7 @@ int build_model3(int R, int n, int L, int no_progress_limit, int symmetry, int i
   M.h0 = 1 + 2 * R;
   M.np = 1;
   M.pitab[0] = 0x24u;                                            // the identity
-  M.fixed = M.h0 + 1;
+  M.fixed = M.h0 + 1 + VSR_PAD_WORDS;
   M.inv_mask = inv_mask;
   M.max_bag = 63 - M.fixed;
   M.m0 = 4 * R + R * n;
@@ -129,7 +132,7 @@ std::string strip(const std::string& s) {
 int wire_to_device(const Model& M, const u64* wire, u64* dev) {
   int nmsg = hdr_nmsg(wire[0]);
   for (int k = 0; k < M.h0; k++) dev[k] = wire[k];
-  for (int i = 0; i < M.np; i++) dev[M.h0 + i] = 0;
+  for (int i = M.h0; i < M.fixed; i++) dev[i] = 0;
   for (int j = 0; j < nmsg; j++) dev[M.fixed + j] = wire[M.h0 + j];
   return M.fixed + nmsg;
 }

@@ -17,6 +17,7 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
   c->probe_fp = 0;
   c->probe_level = 0;
   c->probe_extra_fp = 0;
+  c->probe_viol.clear();
   int rc = phase_expand(c, nullptr, MODE_PROBE);
   if (rc) return rc;
   std::memset(info, 0, sizeof(*info));
@@ -41,6 +42,14 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
     u64 key = ~(u64)0;
     rc = min_violator(c, c->h.viol_fp, &key);
     if (rc) return rc;
+    if (c->opt.world <= 1) {                                    // every violating successor the kernel listed is a state of the probed level
+      const u64 n = std::min<u64>(c->h.n_pending, std::min<u64>(c->opt.pending_entries, (u64)1 << 20));
+      std::vector<u64> list(2 * n);
+      if (n) HIPCHK(hipMemcpy(list.data(), c->pending, 16 * n, hipMemcpyDeviceToHost));
+      for (u64 i = 0; i < n; i++) c->probe_viol.push_back(list[2 * i]);
+      std::sort(c->probe_viol.begin(), c->probe_viol.end());
+      c->probe_viol.erase(std::unique(c->probe_viol.begin(), c->probe_viol.end()), c->probe_viol.end());
+    }
     if (key != ~(u64)0 && c->opt.world <= 1) {                  // its parent: the newest level's state with these fingerprint bits
       int found = 0;
       u64 pfp = 0, pmeta = 0;
@@ -65,6 +74,15 @@ int32_t vsrmc_checker_probe_candidates(vsrmc_checker* c, uint64_t* pairs, uint64
   if (cap_pairs < c->h.n_pending) return fail(VSRMC_E_ARG, "buffer too small");
   HIPCHK(hipSetDevice(c->opt.device));
   HIPCHK(hipMemcpy(pairs, c->pending, 16 * c->h.n_pending, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int32_t vsrmc_checker_probe_violators(vsrmc_checker* c, uint64_t* fps, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return fail(VSRMC_E_ARG, "NULL argument");
+  *n = (u64)c->probe_viol.size();
+  if (!fps) return 0;                                           // fps == NULL: only the number is asked for
+  if (cap < *n) return fail(VSRMC_E_ARG, "buffer too small");
+  for (u64 i = 0; i < *n; i++) fps[i] = c->probe_viol[(size_t)i];
   return 0;
 }
 
@@ -157,18 +175,165 @@ static bool next_level_fits(const vsrmc_checker* c) {
   return pred * wbar + std::min(blocks * 262144.0, cap_w / 4) <= cap_w && pred * 1.09 + std::min(blocks * 8192.0, cap_n / 4) <= cap_n;
 }
 
+// ---- no fatal mispredictions (round 5) ---------------------------------------------------------------------------------------------------
+// (1) A stored level that ran out of record buffer.  k_expand keeps enumerating, hashing, claiming, counting and checking after the buffers are
+// exhausted (LevelCtl::full: only the records written from then on are garbage), so when vsrmc_checker_step comes back with "frontier full" the
+// seen-set holds the COMPLETE level L+1 with its final min-merged keys, and the control block holds its exact figures: it is what a MODE_INSERT pass
+// (the first pass of the deep search, vsr_deep.hpp) would have left, except for the two fingerprint checksums, which one pass over the seen-set
+// supplies (k_table_level_checksum).  The level is adopted as the first seen-set-only level and the search rolls on from the base it already has.
+static int adopt_overflowed_level(vsrmc_checker* c, vsrmc_level_info* ins) {
+  if (!c->failed || !c->full_recoverable || c->failed_code != ERR_FRONTIER_FULL || c->deep || c->opt.world > 1 || c->opt.exact_ties)
+    return fail(VSRMC_E_STATE, "no overflowed level to adopt");
+  HIPCHK(hipSetDevice(c->opt.device));
+  const LevelCtl& h = c->h;
+  u64* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 24));
+  u64 sums[3] = {0, 0, 0};
+  bool ok = hipMemsetAsync(d, 0, 24, c->stream) == hipSuccess;
+  hipLaunchKernelGGL(k_table_level_checksum, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1, c->level + 1, d);
+  ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+       hipMemcpy(sums, d, 24, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) return fail(VSRMC_E_HIP, "k_table_level_checksum failed");
+  if (sums[2] != h.n_written)                                   // every claim wrote (or tried to write) one record: the two counts are one number
+    return fail(VSRMC_E_STATE, "adopting an overflowed level: the seen-set holds " + std::to_string((unsigned long long)sums[2]) +
+                               " states of the level, the kernel claimed " + std::to_string((unsigned long long)h.n_written));
+  c->failed = 0;
+  c->failed_code = 0;
+  c->full_recoverable = false;
+  std::memset(ins, 0, sizeof(*ins));
+  ins->level = c->level + (sums[2] ? 1 : 0);
+  ins->frontier = c->n_valid;
+  ins->n_new = sums[2];
+  ins->generated = h.generated;
+  ins->deadlocks = h.deadlocks;
+  ins->probes = h.probes;
+  ins->max_bag = h.max_bag;
+  ins->fp_xor = sums[0];
+  ins->fp_sum = sums[1];
+  ins->pending = 1;                                             // k_expand launches of this "pass"
+  ins->expand_ms = c->expand_ms;
+  ins->seconds = now_s() - c->t_level0;
+  for (int a = 0; a < 16; a++) ins->act_generated[a] = h.act_generated[a];
+  ins->viol_fp = ins->viol_index = ~(u64)0;
+  c->probe_fp = 0; c->probe_level = 0; c->probe_extra_fp = 0;
+  if (sums[2] == 0) {                                           // (cannot overflow with nothing written; kept for symmetry with deep_first_pass)
+    ins->distinct = c->distinct;
+    ins->total_generated = c->total_generated + h.generated;
+    return 0;
+  }
+  c->deep = 1;
+  c->deep_lv.assign(1, DeepLevelRec());
+  DeepLevelRec& dl = c->deep_lv[0];
+  dl.n_new = dl.n_local = sums[2]; dl.generated = h.generated; dl.max_bag = h.max_bag; dl.frontier = c->n_valid;
+  c->deep_g = std::max<u64>(c->deep_g, (h.generated + c->n_valid - 1) / std::max<u64>(1, c->n_valid) + 1);
+  c->deep_distinct = c->distinct + sums[2];
+  c->deep_generated = c->total_generated + h.generated;
+  c->deep_regen_done = true;                                    // the idle buffers (and lvl_fp) hold the overflowed level's debris: states are addressed by fingerprint from here on
+  ins->distinct = c->deep_distinct;
+  ins->total_generated = c->deep_generated;
+  if (h.viol_fp != ~(u64)0) {
+    ins->viol_fp = h.viol_fp;
+    ins->viol_mask = (int32_t)h.viol_mask;
+    c->probe_fp = h.viol_fp;                                    // the violator is in the seen-set: the counter-example is walked from it
+    c->probe_level = c->level + 1;
+  }
+  return 0;
+}
+
+// (2) A seen-set that fills up while device memory is free: re-hashed into a table of twice the slots (the probe sequence depends on the size,
+// the content does not; predecessor pointers are fingerprint bits, not slot numbers).  0 = grown, 1 = cannot (no memory, or 2^36 slots reached).
+static int table_grow(vsrmc_checker* c) {
+  if (c->opt.table_log2 >= 36) return 1;
+  HIPCHK(hipSetDevice(c->opt.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const u64 old_slots = c->tmask + 1, new_slots = old_slots * 2;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  if ((double)free_b < (double)new_slots * sizeof(Slot) + 512e6) return 1;
+  Slot* nt = nullptr;
+  u32* d_err = nullptr;
+  if (hipMalloc((void**)&nt, new_slots * sizeof(Slot)) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  if (hipMalloc((void**)&d_err, 4) != hipSuccess || hipMemsetAsync(d_err, 0, 4, c->stream) != hipSuccess) {
+    (void)hipFree(nt);
+    if (d_err) (void)hipFree(d_err);
+    return fail(VSRMC_E_HIP, "table_grow: hipMalloc");
+  }
+  hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, nt, new_slots);
+  hipLaunchKernelGGL(k_table_rehash, dim3(4096), dim3(256), 0, c->stream, c->table, old_slots, nt, new_slots - 1, d_err);
+  u32 terr = 0;
+  const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+                  hipMemcpy(&terr, d_err, 4, hipMemcpyDeviceToHost) == hipSuccess && terr == 0;
+  (void)hipFree(d_err);
+  if (!ok) { (void)hipFree(nt); return fail(VSRMC_E_HIP, "table_grow: re-hash failed"); }
+  (void)hipFree(c->table);
+  c->table = nt;
+  c->tmask = new_slots - 1;
+  c->opt.table_log2 += 1;
+  return 0;
+}
+
+// how many new states the next unit of progress may insert, at most: the newest level times the successors a state generates — bounded by the growth the
+// run has shown once it is past its first levels (level sizes of these models grow by a falling factor: next_level_fits)
+static double predicted_new(const vsrmc_checker* c) {
+  const u64 n = c->deep ? c->deep_lv.back().n_new : c->n_valid;
+  const u64 g = c->deep ? c->deep_g : std::max<u64>(2, c->g_last);
+  double pred = (double)n * (double)g;
+  double grow = 0;
+  if (c->deep >= 2) grow = (double)c->deep_lv.back().n_new / (double)std::max<u64>(1, c->deep_lv[c->deep_lv.size() - 2].n_new);
+  else if (c->deep == 1) grow = (double)c->deep_lv.back().n_new / (double)std::max<u64>(1, c->n_valid);
+  else if (c->hist_new[0]) grow = (double)c->hist_new[1] / (double)c->hist_new[0];
+  if (n >= 32768 && grow > 0) pred = std::min(pred, (double)n * grow * 1.05);
+  return pred;
+}
+
+// The seen-set before the next unit of progress: *state = 0 room enough, 1 = it was re-hashed into a larger table (vsrmc_checker_options shows the new
+// table_log2), 2 = more than 85 % full and it cannot grow — the search is incomplete at the depth reached.  vsrmc_check, the CLI and
+// ModelChecker.run ask before every vsrmc_checker_advance.
+int32_t vsrmc_checker_room(vsrmc_checker* c, int32_t* state) {
+  if (!c || !state) return fail(VSRMC_E_ARG, "NULL argument");
+  *state = 0;
+  const double slots = (double)(c->tmask + 1);
+  const double have = (double)(c->deep ? c->deep_distinct : c->distinct);   // (a sharded checker: this rank's share of both)
+  const bool over = have > 0.85 * slots;
+  if (!over && have + predicted_new(c) <= 0.85 * slots) return 0;
+  if (c->opt.world > 1) { *state = over ? 2 : 0; return 0; }    // ranks grow nothing on their own: the level loop stops the run together
+  while (true) {
+    const int g = table_grow(c);
+    if (g < 0) return g;
+    if (g == 1) { *state = over ? 2 : (*state ? 1 : 0); return 0; }   // cannot grow: full only once the load itself is past 0.85
+    *state = 1;
+    const double s2 = (double)(c->tmask + 1);
+    if (have + predicted_new(c) <= 0.85 * s2) return 0;
+  }
+}
+
 // One unit of progress of the automatic level scheme (no level numbers, no sizes from the caller): an ordinary BFS level while the
 // next one is predicted to fit the record buffers (*what = 1: a = that level), otherwise one pass of the deep search — the next level
 // inserted into the seen-set only, the one after it probed (*what = 2: a = the inserted level, b = the probed one, b->level == 0 when the
-// pass probed nothing).  a->n_new == 0: the search is exhausted.
+// pass probed nothing; *what = 3: no new level — the deep search was RE-BASED, a = the level that is the stored base now, vsr_deep.hpp).
+// a->n_new == 0: the search is exhausted.
 int32_t vsrmc_checker_advance(vsrmc_checker* c, vsrmc_level_info* a, vsrmc_level_info* b, int32_t* what) {
   if (!c || !a || !b || !what) return fail(VSRMC_E_ARG, "NULL argument");
   std::memset(b, 0, sizeof(*b));
   b->viol_fp = b->viol_index = ~(u64)0;
   if (c->opt.world > 1) return fail(VSRMC_E_STATE, "sharded checker: vsrmc_shard_loop_advance");
+  if (c->failed && c->full_recoverable) {                       // a vsrmc_checker_step the caller made itself ran out of record buffer: go on from the seen-set
+    *what = 2;
+    return adopt_overflowed_level(c, a);
+  }
   if (!c->deep && (c->opt.exact_ties || next_level_fits(c))) {
     *what = 1;
-    return vsrmc_checker_step(c, a);
+    int rc = vsrmc_checker_step(c, a);
+    if (rc && c->failed && c->full_recoverable) {               // the prediction was wrong: the level is complete in the seen-set, its records are not (see above)
+      *what = 2;
+      rc = adopt_overflowed_level(c, a);
+    }
+    return rc;
+  }
+  if (rebase_pays(c)) {                                          // the newest seen-set-only level fits the idle record buffer: make it the stored base
+    const int rc = deep_rebase(c, a);
+    if (rc <= 0) { *what = 3; return rc; }                       // (1 = no memory for the scratch buffers: go on without re-basing)
   }
   *what = 2;
   return vsrmc_checker_deepen(c, a, b);
@@ -187,10 +352,14 @@ int32_t vsrmc_check(vsrmc_checker* c, int32_t max_depth, double max_seconds, int
   while (true) {
     if (max_depth > 0 && c->level + c->deep >= max_depth) { *stop_reason = 2; return 0; }
     if (max_seconds > 0 && now_s() - t0 > max_seconds) { *stop_reason = 3; return 0; }
-    if ((double)(c->deep ? c->deep_distinct : c->distinct) > 0.85 * (double)(c->tmask + 1)) { *stop_reason = 4; return 0; }
-    int32_t what = 0;
-    int rc = vsrmc_checker_advance(c, &a, &b, &what);
+    int32_t room = 0;
+    int rc = vsrmc_checker_room(c, &room);                       // grows the seen-set while the device has memory for a table of twice the size
     if (rc) return rc;
+    if (room == 2) { *stop_reason = 4; return 0; }
+    int32_t what = 0;
+    rc = vsrmc_checker_advance(c, &a, &b, &what);
+    if (rc) return rc;
+    if (what == 3) continue;                                     // re-based: no new level, the next unit of progress is an ordinary level again
     *last = a;
     if (a.viol_mask) { *stop_reason = 1; return 0; }
     if (a.n_new == 0) { *stop_reason = 0; return 0; }

@@ -81,6 +81,9 @@ struct DeepRun {
   std::vector<u64> bad;        // (fingerprint, key) of the violating successors the probe passes saw
   u64 launches = 0, n_slices = 0, n_subs = 0;
   u64* d_sum = nullptr;
+  bool rebase = false;         // deep_rebase: the regenerated slices of level last_regen are not probed but moved, packed, into the idle record buffer
+  u64* d_cnt = nullptr;        //   [0] records, [1] words moved so far (k_export's running cursors)
+  u32* d_err = nullptr;
   int err = 0;                 // sharded: a failure of this rank's LOCAL work between two collectives (a probe pass, a checksum) — carried to the next
                                // "any slice left?" exchange, where every rank learns of it and all of them leave together (nobody waits in a collective)
   int probed_level() const { return last_regen + (insert ? 2 : 1); }
@@ -189,6 +192,17 @@ int deep_probe(DeepRun& R, const PassDst& B, u64 n, int lv, u64 bag) {
   return 0;
 }
 
+// re-basing: the valid records of a regenerated slice of the target level, appended (packed: no holes, no chunk slack) to the idle record buffer
+int deep_export(DeepRun& R, const PassDst& B, u64 part) {
+  vsrmc_checker* c = R.c;
+  if (!part) return 0;
+  const int nxt = c->cur ^ 1;
+  hipLaunchKernelGGL(k_export, dim3((unsigned)((part + 63) / 64)), dim3(64), 0, c->stream, (const u64*)B.words, B.off, B.fp, (u64)0, part,
+                     c->words[nxt], c->words_cap(nxt), c->off[nxt], c->lvl_fp, c->opt.frontier_states, R.d_cnt, R.d_err);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return fail(VSRMC_E_HIP, "deep search: k_export (re-basing)");
+  return 0;
+}
+
 // `n_idx` indices (holes included) of level lv in (src_words, src_off); k = nesting depth = which buffer takes what this level yields
 int deep_descend(DeepRun& R, const u64* src_words, const u64* src_off, u64 n_idx, u64 src_bag, int lv, int k) {
   vsrmc_checker* c = R.c;
@@ -223,7 +237,7 @@ int deep_descend(DeepRun& R, const u64* src_words, const u64* src_off, u64 n_idx
     sl.observe(n, part, c->h.words_new);
     if (regen) {
       R.ins.materialize_ms += c->expand_ms;                    // time spent regenerating (reported beside the level's own expansion)
-      if (lv + 1 == R.last_regen && !R.insert) rc = deep_probe(R, B, part, lv + 1, out_bag);
+      if (lv + 1 == R.last_regen && !R.insert) rc = R.rebase ? deep_export(R, B, part) : deep_probe(R, B, part, lv + 1, out_bag);
       else rc = deep_descend(R, B.words, B.off, part, out_bag, lv + 1, k + 1);
       if (rc) return rc;
       continue;
@@ -283,6 +297,7 @@ int deep_resolve(DeepRun& R) {
     if (seen8[g]) continue;
     R.prb.pending++;                                           // violating successors seen, duplicates included
     if (first == ~(u64)0) { first = pairs[i].first; key = pairs[i].second; }
+    if (c->probe_viol.empty() || c->probe_viol.back() != pairs[i].first) c->probe_viol.push_back(pairs[i].first);   // (sorted: ascending, distinct)
   }
   if (first == ~(u64)0) return 0;
   int found = 0;
@@ -444,6 +459,93 @@ int deep_pass(vsrmc_checker* c, int last_regen, bool insert, vsrmc_level_info* i
   return 0;
 }
 
+// ---- re-basing (round 5) ----------------------------------------------------------------------------------------------------------------
+// Every pass of the deep search regenerates ALL the levels between the base and the one it inserts.  When the levels shrink again — the analysis
+// models after their peak: level 38 of VR_STATE_TRANSFER has 1.3e8 states against 7.2e8 at level 32 — the newest seen-set-only level fits the idle
+// record buffer, and one descent that regenerates it and KEEPS what it regenerates (k_export packs every slice into the idle buffer: no holes,
+// no chunk slack, so the slices of a hundred launches append without loss) makes it the new stored base: the rest of the run is ordinary stored
+// levels.  The 47-level runs of round 4 re-expanded levels 26 .. L in every pass; 196 of model 2's 333 s went into its last seven small levels.
+bool rebase_pays(const vsrmc_checker* c) {
+  if (!c->deep || c->failed || c->opt.world > 1 || c->opt.exact_ties || c->rebase_off) return false;
+  const DeepLevel& top = c->deep_lv.back();
+  if (top.n_new == 0) return false;
+  if (!(c->deep >= 2 || top.n_new <= c->n_valid)) return false;           // (a level that did not fit a moment ago: wait until the run has shown where it goes)
+  const Model& M = c->model.M;
+  const int nxt = c->cur ^ 1;
+  const double words = (double)top.n_new * (double)(M.fixed + (int)std::min<u64>(top.max_bag, (u64)M.max_bag));   // upper bound: every record with the level's largest bag
+  return words <= 0.8 * (double)c->words_cap(nxt) && (double)top.n_new <= 0.8 * (double)c->opt.frontier_states;
+}
+
+int deep_rebase(vsrmc_checker* c, vsrmc_level_info* out) {
+  const Model& M = c->model.M;
+  const int K = c->level + c->deep;
+  DeepRun R;
+  R.c = c; R.base = c->level; R.last_regen = K; R.insert = false; R.rebase = true;
+  std::memset(&R.ins, 0, sizeof(R.ins));
+  std::memset(&R.prb, 0, sizeof(R.prb));
+  R.ins.viol_fp = R.ins.viol_index = R.prb.viol_fp = R.prb.viol_index = ~(u64)0;
+  const double t0 = now_s();
+  // buffer 0 of an ordinary descent IS the idle record buffer: here it is the destination, so the levels base+1 .. K go through scratch buffers 1 .. deep
+  int rc = deep_plan_scratch(c, c->deep);
+  if (rc) { c->rebase_off = true; return 1; }                    // no memory for one more scratch buffer: the search goes on without re-basing
+  if (c->deep_regen_done) {
+    hipLaunchKernelGGL(k_table_untake, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1, c->level + 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  c->deep_regen_done = true;
+  HIPCHK(hipMalloc((void**)&R.d_cnt, 16));
+  struct FreeCnt { u64* p; u32* q; ~FreeCnt() { (void)hipFree(p); if (q) (void)hipFree(q); } } free_cnt{R.d_cnt, nullptr};
+  HIPCHK(hipMalloc((void**)&R.d_err, 4));
+  free_cnt.q = R.d_err;
+  HIPCHK(hipMemsetAsync(R.d_cnt, 0, 16, c->stream));
+  HIPCHK(hipMemsetAsync(R.d_err, 0, 4, c->stream));
+  rc = deep_descend(R, c->words[c->cur], c->off[c->cur], c->n_frontier, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, c->level, 1);
+  if (rc) { c->failed = 1; return rc; }
+  u64 cnt[2] = {0, 0};
+  u32 xerr = 0;
+  HIPCHK(hipMemcpy(cnt, R.d_cnt, 16, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&xerr, R.d_err, 4, hipMemcpyDeviceToHost));
+  const DeepLevel top = c->deep_lv.back();
+  if (xerr || cnt[0] != top.n_new) {                            // the level's size is known exactly: a descent that regenerates another number of states is a bug
+    c->failed = 1;
+    return fail(xerr ? VSRMC_E_REP : VSRMC_E_STATE, xerr ? std::string("re-basing: the idle record buffer is too small for the level after all")
+                : "re-basing: level " + std::to_string(K) + " has " + std::to_string((unsigned long long)top.n_new) + " states, the descent regenerated " +
+                  std::to_string((unsigned long long)cnt[0]));
+  }
+  const u64 below = c->deep >= 2 ? c->deep_lv[c->deep_lv.size() - 2].n_new : c->n_valid;
+  c->cur ^= 1;
+  c->level = K;
+  c->n_frontier = cnt[0];
+  c->n_valid = cnt[0];
+  c->cur_w = cnt[1];
+  c->cur_rec_w = cnt[1];
+  c->distinct = c->deep_distinct;
+  c->total_generated = c->deep_generated;
+  c->cur_max_bag = std::min<u64>(top.max_bag, (u64)M.max_bag);
+  c->bag_known = true;
+  c->hist_new[0] = below;
+  c->hist_new[1] = top.n_new;
+  c->g_last = (top.generated + std::max<u64>(1, top.frontier) - 1) / std::max<u64>(1, top.frontier) + 1;
+  c->deep = 0;
+  c->deep_lv.clear();
+  c->deep_regen_done = false;                                   // lvl_fp holds the new base level's fingerprints (k_export carried them along)
+  std::memset(out, 0, sizeof(*out));
+  out->level = K;
+  out->frontier = below;
+  out->n_new = top.n_new;
+  out->distinct = c->distinct;
+  out->total_generated = c->total_generated;
+  out->max_bag = top.max_bag;
+  out->words_new = cnt[1];
+  out->record_words = cnt[1];
+  out->pending = R.launches;
+  out->materialize_ms = R.ins.materialize_ms;
+  out->seconds = now_s() - t0;
+  out->viol_fp = out->viol_index = ~(u64)0;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -463,6 +565,7 @@ int32_t vsrmc_checker_deepen(vsrmc_checker* c, vsrmc_level_info* inserted, vsrmc
   c->probe_fp = 0;
   c->probe_level = 0;
   c->probe_extra_fp = 0;
+  c->probe_viol.clear();
   if (c->deep == 0) return deep_first_pass(c, inserted);
   return deep_pass(c, c->level + c->deep, true, inserted, probed);
 }

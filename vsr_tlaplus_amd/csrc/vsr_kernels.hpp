@@ -116,6 +116,13 @@ struct LevelCtl {   // device-resident counters of one BFS level
   u64 tile_cursor;         // k_expand: the next frontier tile no block has taken yet
   u64 n_written;           // fused mode: records written to the next frontier (unsharded: = new states; sharded: incl. speculative ones)
   u64 fp_xor, fp_sum;      // MODE_INSERT (virtual level): xor / sum of the fingerprints this pass inserted = the level's checksums (no lvl_fp array exists)
+  // single-pass levels: the next-frontier buffers ran out of index or word chunks.  NOT an `err`: every successor is still enumerated, hashed,
+  // claimed, counted and checked — only the records (and refs / lvl_fp entries) written after that moment are garbage — so the seen-set holds the
+  // complete level and the host can keep it as a seen-set-only level (host_search.hpp: adopt_overflowed_level) instead of failing.  `err` stays
+  // free for the errors that DO lose successors (work list too small, a tile refused, a candidate bucket full) or abort the run.
+  u32 full;
+  u32 full_pad_;
+  u64 full_info;
 };
 
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
@@ -155,6 +162,13 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO
 
 __device__ __forceinline__ void raise_error(LevelCtl* ctl, int code, u64 info) {
   if (atomicCAS(&ctl->err, 0u, (u32)code) == 0u) ctl->err_info = info;
+}
+
+__device__ __forceinline__ void raise_full(LevelCtl* ctl, u64 info) {   // called by one thread of a block; a plain flag, nothing is lost (see LevelCtl::full)
+  if (ctl->full == 0u) {
+    ctl->full_info = info;
+    ctl->full = 1u;
+  }
 }
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -360,7 +374,7 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
       M.np = 1;
     }
     M.h0 = 1 + SR * M.wpr;
-    M.fixed = M.h0 + M.np;
+    M.fixed = M.h0 + M.np + VSR_PAD_WORDS;
     // the permutation table in build_model's order (identity first): compile-time constants, so that permute_word's select
     // masks fold (np == 1 only ever looks at entry 0)
     M.pitab[0] = 0x24u;
@@ -718,7 +732,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         VSR_SYNC();
         if (tid == 0) {
           u64 nb = atomicAdd((unsigned long long*)&ctl->n_new, (unsigned long long)ichunk);
-          if (nb + ichunk > nx_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
+          if (nb + ichunk > nx_cap) { raise_full(ctl, nb); nb = 0; }     // keep writing inside the buffer; the records are discarded, the claims stand
           s_ich_base = nb;
           s_ich_used = 0;
         }
@@ -728,7 +742,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         VSR_SYNC();
         if (tid == 0) {
           u64 nb = atomicAdd((unsigned long long*)&ctl->words_new, (unsigned long long)wchunk);
-          if (nb + wchunk > nx_words_cap) { raise_error(ctl, ERR_FRONTIER_FULL, nb); nb = 0; }
+          if (nb + wchunk > nx_words_cap) { raise_full(ctl, nb); nb = 0; }
           // a tile whose successors cannot fit even a fresh chunk would run into the next block's chunk: the host sizes
           // wchunk >= ccap * (stride + 5) so that this cannot happen; refuse instead of corrupting records if it ever does
           if (s_wneed > wchunk) { raise_error(ctl, ERR_FRONTIER_FULL, p_base); s_skip = 1; }
@@ -849,8 +863,10 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
         // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
         int bad = (check || do_write || (remote && mode == MODE_INSERT)) ? Ops::invariants(M, rec, D) : 0;
-        if constexpr (PLAIN == 0)                               // test hook (Model::test_bad_fp): compiled into the sharded / generic instantiation only
+#ifdef VSRMC_TEST_HOOKS                                       // test hook (Model::test_bad_fp): only in the library built with -DVSRMC_TEST_HOOKS (libvsrmc_hooks.so)
+        if constexpr (PLAIN == 0)
           if (M.test_bad_mask && fp == M.test_bad_fp && (check || do_write || remote)) bad |= (int)M.test_bad_mask;
+#endif
         if (mode == MODE_PROBE) {
           if (bad) {
             const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
@@ -1173,7 +1189,9 @@ k_materialize(Model Marg, const u64* __restrict__ fr_words, const u64* __restric
       u32 ak;
       canonical_fp(M, D.hdr, Hc, &fp, &ak);
       bad = Ops::invariants(M, (const u64*)rec, D);
+#ifdef VSRMC_TEST_HOOKS
       if (M.test_bad_mask && fp == M.test_bad_fp) bad |= (int)M.test_bad_mask;   // test hook (Model::test_bad_fp)
+#endif
       nbag = hdr_nmsg(D.hdr);
       clen = M.fixed + nbag;
       if (clen > stride) clen = stride;                        // cannot happen: gen() raised ERR_REP_BAG in k_expand
@@ -1312,6 +1330,42 @@ __global__ void k_level_checksum(const u64* __restrict__ fps, u64 n, u64* out) {
     if (x) atomicXor((unsigned long long*)&out[0], (unsigned long long)x);
     if (s) atomicAdd((unsigned long long*)&out[1], (unsigned long long)s);
     if (c) atomicAdd((unsigned long long*)&out[2], (unsigned long long)c);
+  }
+}
+
+// xor / sum / count of the fingerprints of the states of ONE level, read from the seen-set itself (a level whose lvl_fp array does not exist or
+// is not to be trusted: a stored level that overflowed its record buffer and is kept as a seen-set-only level): out[0..2]
+__global__ void k_table_level_checksum(const Slot* __restrict__ table, u64 n_slots, int level, u64* out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  u64 x = 0, s = 0, c = 0;
+  for (; i < n_slots; i += stride) {
+    const u64 f = table[i].fp;
+    if (f != 0 && meta_level(table[i].meta) == level) { x ^= f; s += f; c++; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    x ^= __shfl_down(x, o);
+    s += __shfl_down(s, o);
+    c += __shfl_down(c, o);
+  }
+  if ((threadIdx.x & 63) == 0 && c) {
+    atomicXor((unsigned long long*)&out[0], (unsigned long long)x);
+    atomicAdd((unsigned long long*)&out[1], (unsigned long long)s);
+    atomicAdd((unsigned long long*)&out[2], (unsigned long long)c);
+  }
+}
+
+// re-insertion of every occupied slot into a table of another size (growth of the seen-set between two levels: host_search.hpp, table_grow)
+__global__ void k_table_rehash(const Slot* __restrict__ old_table, u64 n_old, Slot* table, u64 tmask, u32* err) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n_old; i += stride) {
+    const Slot s = old_table[i];
+    if (s.fp == 0) continue;
+    u32 np = 0;
+    const Probe p = probe_insert(table, tmask, s.fp, CntReg{&np});
+    if (p.full) { atomicExch(err, (u32)ERR_TABLE_FULL); continue; }
+    table[p.slot].meta = s.meta;                                 // every fingerprint occurs once in the old table: nobody else writes this slot
   }
 }
 

@@ -23,6 +23,13 @@
 #define VSR_HD inline
 #endif
 
+// EXPERIMENT KNOB (tools/ab_build.sh NAME "-DVSR_PAD_WORDS=6"): dead words between the H words and the bag of every device-layout record.
+// They are staged, copied to every successor and never looked at: the measured cost of S + 8 * VSR_PAD_WORDS bytes per state brackets what a
+// record SMALLER by as much would buy (the slope dT/dS of k_expand).  0 in the product.
+#ifndef VSR_PAD_WORDS
+#define VSR_PAD_WORDS 0
+#endif
+
 namespace vsr {
 
 typedef uint64_t u64;

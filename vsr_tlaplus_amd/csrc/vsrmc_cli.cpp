@@ -34,7 +34,8 @@ static void usage() {
       "  -tableLog2 N      seen-set slots = 2^N x 16 B; -frontierGiB G: size of each of the two record buffers (-frontierBGiB G: the second one).\n"
       "                    Default for both: sized from the free memory of the device (the largest power of two of slots within 30 %% of it, the\n"
       "                    rest in two equal record buffers).  Levels are stored while the next one is predicted to fit; beyond that the search goes\n"
-      "                    on through the seen-set alone (Virtual(L) / Probe(L+1) lines) until the seen-set is 85 %% full.\n"
+      "                    on through the seen-set alone (Virtual(L) / Probe(L+1) lines).  A seen-set that fills up is re-hashed into twice the\n"
+      "                    slots while the device has the memory; when it cannot grow and is 85 %% full the run ends \"incomplete at depth N\" (exit 4).\n"
       "  -simulate         random walks instead of BFS (TLC -simulate): -depth N (default 100) -walkers N (131072) -seed S -maxSeconds T\n"
       "  -validateTrace F  read a TLC trace (trace expression, or console \"State k:\" form) and check on the GPU that it is a\n"
       "                    behaviour of the model: Init, then one generated successor after the other; reports the invariants\n"
@@ -53,7 +54,11 @@ static void usage() {
       "                    state_transfer_violation_trace.txt); -validateTrace reads it back\n"
       "  -dump FILE        write every distinct state in the text form of `tlc2.TLC -dump` (State k: + /\\ var = value conjuncts), level by\n"
       "                    level; for cross-checking small configurations against a real TLC run (refused beyond -dumpMax states, 1e6)\n"
-      "  -checkpoint FILE  write a checkpoint between levels, at most every -checkpointMinutes M (default 30; 0 = after every level)\n"
+      "  -checkpoint FILE  write a checkpoint between levels (stored ones and Virtual(L) ones alike), at most every -checkpointMinutes M\n"
+      "                    (default 30; 0 = after every level)\n"
+      "  -audit            second-hash audit (TLC: a rerun under another -fp N): when the search has ended, run it again to the same depth under\n"
+      "                    another member of the fingerprint family and compare every level's new / generated / deadlock counts: a 64-bit\n"
+      "                    collision that hid a state under one function would have to repeat under the other (exit 13 if they differ)\n"
       "  -recover FILE     continue the search a checkpoint stopped at (same constants; buffer sizes may differ)\n"
       "  -noTLA            do not read / hash-check the .tla file (only the cfg)\n"
       "  -json             one JSON object per level on stdout instead of TLC-style progress lines\n");
@@ -111,7 +116,7 @@ int main(int argc, char** argv) {
   std::string cfg, tla, trace_file, chk_file, recover_file, dump_file, dump_trace_file;
   unsigned long long dump_max = 1000000ull, dumped = 0;
   double chk_minutes = 30.0;
-  bool check_deadlock = false, no_tla = false, json = false, simulate = false, host_frontier = false, probe_last = false, coverage = false;
+  bool check_deadlock = false, no_tla = false, json = false, simulate = false, host_frontier = false, probe_last = false, coverage = false, audit = false;
   int sim_depth = 100;
   unsigned sim_walkers = 1u << 17;
   unsigned long long sim_seed = 1;
@@ -150,6 +155,7 @@ int main(int argc, char** argv) {
     else if (a == "-maxSeconds" && i + 1 < argc) sim_seconds = std::atof(argv[++i]);
     else if (a == "-json") json = true;
     else if (a == "-coverage") coverage = true;
+    else if (a == "-audit") audit = true;
     else if (a == "-workers" && i + 1 < argc) ++i;   // accepted for command-line compatibility; the GPU is the worker pool
     else if (!a.empty() && a[0] != '-') tla = a;
     else { std::fprintf(stderr, "vsrmc: unknown option %s\n", a.c_str()); usage(); return 2; }
@@ -308,10 +314,18 @@ int main(int argc, char** argv) {
     return true;
   };
   if (dump && recover_file.empty() && !dump_level(1)) return 1;
-  bool violated = false, deadlocked = false, probed_violation = false;
+  bool violated = false, deadlocked = false, probed_violation = false, incomplete = false;
   unsigned long long cov[16] = {0};
   uint64_t viol_level = 0, viol_index = 0;
-  int depth = info.level;
+  int depth = info.level + info.reserved0;                        // (a recovered deep search: the levels beyond the stored one)
+  struct Row { int level; unsigned long long n_new, generated, deadlocks; };
+  std::vector<Row> rows;                                          // what -audit compares
+  auto checkpoint_now = [&](int level) {
+    if (chk_file.empty() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t_chk).count() < 60.0 * chk_minutes) return;
+    if (vsrmc_checker_save(c, chk_file.c_str()) != 0) std::printf("Warning: %s\n", vsrmc_last_error());
+    else std::printf("Checkpointing of run %s completed (level %d).\n", chk_file.c_str(), level);
+    t_chk = std::chrono::steady_clock::now();
+  };
   while (depth < max_depth) {
     if ((probe2_at > 0 && depth + 1 == probe2_at) || (probe3_at > 0 && depth + 1 == probe3_at)) {
       const int nv = probe3_at > 0 && depth + 1 == probe3_at ? 2 : 1;        // virtual levels before the probed one
@@ -345,20 +359,39 @@ int main(int argc, char** argv) {
     }
     // the automatic level scheme: an ordinary level while the next one is predicted to fit the record buffers, else one more level through
     // the seen-set alone (vsrmc_checker_deepen: inserted, counted and checked, its records regenerated when needed) and a probe of the one after
-    int32_t what = 0;
+    int32_t what = 0, room = 0;
     vsrmc_level_info probed;
+    rc = vsrmc_checker_room(c, &room);                            // grows the seen-set while the device has the memory
+    if (rc != 0) break;
+    if (room == 1 && !json) std::printf("The seen-set was re-hashed into twice the slots.\n");
+    if (room == 2) { incomplete = true; break; }
     rc = vsrmc_checker_advance(c, &info, &probed, &what);
     if (rc != 0) break;
+    if (what == 3) {                                              // no new level: the deep search was re-based (the levels shrink again)
+      if (!json) std::printf("Re-based(%d): %llu states regenerated into the record buffers (%llu launches, %.2f s); stored levels from here on.\n", info.level,
+                             (unsigned long long)info.n_new, (unsigned long long)info.pending, info.seconds);
+      continue;
+    }
     if (what == 2) {
       for (int a2 = 1; a2 < 16; a2++) cov[a2] += info.act_generated[a2];
       const double dtp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (dump) { std::printf("Level %d is not stored (it does not fit the record buffers): -dump ends at level %d.\n", info.level, depth); std::fclose(dump); dump = nullptr; }
       if (info.n_new == 0) break;
       depth = info.level;
+      rows.push_back(Row{info.level, (unsigned long long)info.n_new, (unsigned long long)info.generated, (unsigned long long)info.deadlocks});
+      if (json)
+        std::printf("{\"level\": %d, \"stored\": false, \"generated\": %llu, \"new\": %llu, \"distinct\": %llu, \"deadlocks\": %llu, \"launches\": %llu, \"seconds\": %.4f}\n",
+                    info.level, (unsigned long long)info.generated, (unsigned long long)info.n_new, (unsigned long long)info.distinct,
+                    (unsigned long long)info.deadlocks, (unsigned long long)info.pending, dtp);
+      else
       std::printf("Virtual(%d): %llu states generated, %llu distinct states found, %llu states in the level (not stored; %llu launches). (%.2f s)\n", info.level,
                   (unsigned long long)info.total_generated, (unsigned long long)info.distinct, (unsigned long long)info.n_new, (unsigned long long)info.pending, dtp);
       if (info.viol_mask) { probed_violation = true; viol_level = (uint64_t)info.level; break; }
       if (probed.level) {
+        if (json)
+          std::printf("{\"probed_level\": %d, \"generated\": %llu, \"from\": %llu, \"violating_successors\": %llu, \"seconds\": %.4f}\n", probed.level,
+                      (unsigned long long)probed.generated, (unsigned long long)probed.frontier, (unsigned long long)probed.pending, dtp);
+        else
         std::printf("Probe(%d): %llu states generated from %llu states, %llu violating successors seen. (%.2f s)\n", probed.level,
                     (unsigned long long)probed.generated, (unsigned long long)probed.frontier, (unsigned long long)probed.pending, dtp);
         if (probed.viol_mask) {
@@ -369,11 +402,13 @@ int main(int argc, char** argv) {
           break;
         }
       }
+      checkpoint_now(info.level);
       continue;
     }
     if (rc != 0) break;
     for (int a2 = 1; a2 < 16; a2++) cov[a2] += info.act_generated[a2];
     if (info.n_new) depth = info.level;
+    if (info.n_new) rows.push_back(Row{info.level, (unsigned long long)info.n_new, (unsigned long long)info.generated, (unsigned long long)info.deadlocks});
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (json)
       std::printf("{\"level\": %d, \"generated\": %llu, \"new\": %llu, \"distinct\": %llu, \"deadlocks\": %llu, \"seconds\": %.4f}\n",
@@ -386,12 +421,7 @@ int main(int argc, char** argv) {
     if (info.viol_mask) { violated = true; viol_level = (uint64_t)info.level; viol_index = info.viol_index; break; }
     if (check_deadlock && info.deadlocks) { deadlocked = true; break; }
     if (info.n_new == 0) break;
-    if (!chk_file.empty() &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_chk).count() >= 60.0 * chk_minutes) {
-      if (vsrmc_checker_save(c, chk_file.c_str()) != 0) std::printf("Warning: %s\n", vsrmc_last_error());
-      else std::printf("Checkpointing of run %s completed (level %d).\n", chk_file.c_str(), info.level);
-      t_chk = std::chrono::steady_clock::now();
-    }
+    checkpoint_now(info.level);
   }
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   int exit_code = 0;
@@ -430,6 +460,10 @@ int main(int argc, char** argv) {
   } else if (deadlocked) {
     std::printf("Error: Deadlock reached (%llu state(s) of level %d have no successor).\n", (unsigned long long)info.deadlocks, info.level - 1);
     exit_code = 11;
+  } else if (incomplete) {
+    std::printf("Model checking INCOMPLETE at depth %d: the seen-set is more than 85 %% full and the device has no memory for a larger one "
+                "(no error has been found up to that depth).\n", depth);
+    exit_code = 4;
   } else if (info.n_new == 0) {
     std::printf("Model checking completed. No error has been found.\n");
   }
@@ -450,7 +484,41 @@ int main(int argc, char** argv) {
     std::fclose(dump);
     std::printf("%llu states dumped to %s.\n", dumped, dump_file.c_str());
   }
-  vsrmc_checker_destroy(c);
+  if (audit && rc == 0 && recover_file.empty() && !rows.empty()) {
+    // the second-hash audit: the same search under another member of the fingerprint family, to the depth the first one reached; only the counts are compared
+    vsrmc_checker_destroy(c);
+    c = nullptr;
+    const uint64_t seed2 = 0x5EED5EED5EED5EEDull;
+    size_t k = 0, first_diff = (size_t)-1;
+    if (vsrmc_model_set_fp_seed(m, seed2) != 0 || vsrmc_checker_create(m, &o, &c) != 0) {
+      std::printf("Error: audit run: %s\n", vsrmc_last_error());
+      exit_code = exit_code ? exit_code : 1;
+    } else {
+      const int last = rows.back().level;
+      int rc2 = 0;
+      while (k < rows.size()) {
+        int32_t what = 0, room = 0;
+        vsrmc_level_info a, b;
+        if ((rc2 = vsrmc_checker_room(c, &room)) != 0 || room == 2) break;
+        if ((rc2 = vsrmc_checker_advance(c, &a, &b, &what)) != 0 || a.n_new == 0) break;
+        if (what == 3) continue;
+        const Row& r = rows[k];
+        if (first_diff == (size_t)-1 && (a.level != r.level || a.n_new != r.n_new || a.generated != r.generated || a.deadlocks != r.deadlocks)) first_diff = k;
+        k++;
+        if (a.level >= last) break;
+      }
+      if (rc2 != 0) { std::printf("Error: audit run: %s\n", vsrmc_last_error()); exit_code = exit_code ? exit_code : 1; }
+      else if (first_diff != (size_t)-1 || k != rows.size()) {
+        const size_t d = first_diff != (size_t)-1 ? first_diff : k;
+        std::printf("Audit: the per-level counts under fingerprint seed %016llx DIFFER from level %d on: a 64-bit fingerprint collision hid a state "
+                    "under one of the two functions (TLC: rerun with another -fp).\n", (unsigned long long)seed2, d < rows.size() ? rows[d].level : last);
+        exit_code = exit_code ? exit_code : 13;
+      } else {
+        std::printf("Audit: %zu levels, every new / generated / deadlock count equal under fingerprint seed %016llx.\n", rows.size(), (unsigned long long)seed2);
+      }
+    }
+  }
+  if (c) vsrmc_checker_destroy(c);
   vsrmc_model_destroy(m);
   return exit_code;
 }
