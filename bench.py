@@ -320,6 +320,23 @@ def run_readme(args, dump_trace=None, seed=0):
         assert seed or E["viol_fp"] is None or found["viol_fp"] == E["viol_fp"]
         fps, _ = m.fingerprints(tr[-1][1], np.array([0, len(tr[-1][1])], dtype=np.uint64))
         assert int(fps[0]) == found["viol_fp"]                               # the reconstructed path ends in the reported violator
+        if verify:
+            # the reference's own golden vector against THIS run's seen-set (tests/golden/state_transfer_trace.json = the 24 states of the reference's
+            # state_transfer_violation_trace.txt as packed words): state i must sit at a BFS level <= i, and its last state — level 24 is probed,
+            # not inserted — must be one of the violating states the probe collected
+            with open(os.path.join(ROOT, "tests", "golden", "state_transfer_trace.json")) as f:
+                gt = json.load(f)
+            recs = [np.array([int(w, 16) for w in st["words"]], dtype=np.uint64) for st in gt["states"]]
+            gfps, _ = m.fingerprints(np.concatenate(recs), np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64))
+            levels = []
+            for i, f_ in enumerate(gfps[:-1]):
+                hit = mc.lookup(int(f_))
+                assert hit is not None and 1 <= (hit[1] >> 55) <= i + 1, ("state %d of the reference trace" % (i + 1), hit)
+                levels.append(int(hit[1] >> 55))
+            viol = mc.probe_violators()
+            assert int(gfps[-1]) in viol and viol[0] == found["viol_fp"]
+            S["reference_trace"] = dict(states_found_in_seen_set=len(levels), at_their_own_depth=sum(1 for i, l in enumerate(levels) if l == i + 1),
+                                        last_state_among_probe_violators=True, distinct_violating_states_at_depth_24=len(viol))
         fx = E["fx"]
         if fx.get("fp_version") == FP_VERSION and fx.get("trace") and not seed:   # the counter-example is a function of the state space alone
             S["same_trace"] = [(a_, ["%016x" % int(w) for w in rec]) for a_, rec in tr] == [(t["action"], t["words"]) for t in fx["trace"]]
@@ -386,7 +403,8 @@ def readme_object(args, elapsed, S):
                  % S["mat_levels"],
         value=distinct * k / elapsed, ms_per_step=1e3 * elapsed / k, time_to_first_violation_s=round(sum(S["ttfv"]) / len(S["ttfv"]), 4),
         distinct=int(distinct), generated=int(S["generated"] / k), setup_s=round(S["setup_s"], 2), oracle_pinned_levels=S["oracle_levels"],
-        violation_pinned_by=S["probe_source"], trace_equals_fixture=S["same_trace"], sized_from_free_hbm=S["sizes"],
+        violation_pinned_by=S["probe_source"], trace_equals_fixture=S["same_trace"], reference_trace_in_this_run=S.get("reference_trace"),
+        sized_from_free_hbm=S["sizes"],
         roofline={"bound": "hbm", "kernel": "k_expand (all launches of a run: PLAIN instantiation for the stored levels and the sub-slices of a streamed level, mode-capable one for the virtual / regenerated / probed passes)",
                   "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                   "traffic": tr["bytes_per_launch"], "traffic_source": tr["source"],

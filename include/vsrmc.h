@@ -443,6 +443,10 @@ void vsrmc_shard_loop_destroy(vsrmc_shard_loop* l);
 int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsrmc_level_info* local);
 /* ≙ vsrmc_check: stop_reason 0 exhausted, 1 invariant violated, 2 max_depth */
 int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t stop_on_violation, int32_t* stop_reason, vsrmc_level_info* last);
+/* the seen-set shards before the next vsrmc_shard_loop_advance (collective once the run is sharded): *state = 0 room on every rank, 2 = some rank's shard
+ * is more than 85 % full — every rank learns it in the same call and all of them stop together ("incomplete at depth N"); loops over
+ * vsrmc_shard_loop_advance ask before every call, vsrmc_shard_loop_run does */
+int32_t vsrmc_shard_loop_room(vsrmc_shard_loop* l, int32_t* state);
 /* vsrmc_checker_deepen / vsrmc_checker_advance for a sharded run (collective; figures over all ranks): levels beyond the ranks' record
  * buffers live in the ranks' seen-sets only and are regenerated from the newest stored level; every pass of the descent is the
  * protocol of a sharded level with other sources and targets (csrc/vsr_shard_loop.hpp).  advance: an ordinary sharded level while EVERY

@@ -214,18 +214,31 @@ class FakeShardEngine:
         return np.array(sorted(f for f in self.fps if f is not None), dtype=np.uint64)
 
     # ---- levels beyond the record buffers (the passes of csrc/vsr_deep.hpp, sharded: vsr_shard_loop.hpp's second half) ----------------
-    # mode: "insert" (virtual level: claimed, counted, checked, nothing kept), "regen" (the candidate whose key IS the slot's final
-    # meta word rebuilds the state, exactly once), "normal" (inserted and kept for the caller: a scratch buffer), and deep_probe.
+    # mode: "insert" (virtual level: claimed, counted, checked, nothing kept), "normal" (inserted and kept for the caller: a scratch buffer);
+    # deep_regen (the rank rebuilds the states ITS candidates inserted — the winner set `won` — once per descent, asking nobody); deep_probe.
     TAKEN = 1
 
     def deep_source(self):
         """the newest stored level: [(record, fingerprint)]"""
         return [(r, f) for r, f in zip(self.frontier, self.fps) if r is not None]
 
-    def deep_untake(self, min_level):
-        for fp, m in list(self.seen.items()):
-            if (m >> 55) >= min_level and (m & self.TAKEN):
-                self.seen[fp] = m & ~self.TAKEN
+    def deep_new_descent(self):
+        """a new descent: every state of the winner set may be rebuilt once more (csrc: vsrmc_checker::wepoch)"""
+        self.epoch = getattr(self, "epoch", 0) + 1
+
+    def deep_regen(self, src, level):
+        """src: [(record, fingerprint)] of level - 1 on this rank -> the states of `level` this rank's candidates inserted (its winner set:
+        fingerprint -> [level, last descent]), each exactly once per descent, whichever of the rank's instances reaches it first.  The
+        level matters: a successor of a level-l state may be ANOTHER level-l state of the set.  No exchange."""
+        won = self.__dict__.setdefault("won", {})
+        out = []
+        for rec, _pfp in src:
+            for s in orc.successors(self.P, rec):
+                w = won.get(s["fp"])
+                if w is not None and w[0] == level and w[1] != self.epoch:
+                    w[1] = self.epoch
+                    out.append((np.array(s["words"], dtype=np.uint64), s["fp"]))
+        return out
 
     def _deep_claim_one(self, fp, key, level):
         """first inserter wins; keys of later candidates of the same level are min-merged -> True if this call inserted fp"""
@@ -235,13 +248,6 @@ class FakeShardEngine:
             return True
         if (cur >> 55) == level and key < cur:
             self.seen[fp] = key
-        return False
-
-    def _deep_grant_one(self, fp, key):
-        """regenerated level: the candidate whose key is the slot's meta word takes it, once"""
-        if self.seen.get(fp) == key:
-            self.seen[fp] = key | self.TAKEN
-            return True
         return False
 
     def deep_expand(self, src, level, mode):
@@ -259,24 +265,21 @@ class FakeShardEngine:
                 key = self._key(level, s["auxkey"], pfp, k)
                 o = self.owner_of(s["fp"], self.world)
                 if o == self.rank:
-                    if mode == "regen":
-                        if self._deep_grant_one(s["fp"], key):
-                            self.d_out.append((np.array(s["words"], dtype=np.uint64), s["fp"]))
-                    elif self._deep_claim_one(s["fp"], key, level):
+                    if self._deep_claim_one(s["fp"], key, level):
                         self._deep_count(s)
                         if mode == "normal":
                             self.d_out.append((np.array(s["words"], dtype=np.uint64), s["fp"]))
                     continue
-                if mode != "regen":                              # the sent-filter: an exact repeat was announced (and claimed) before
-                    tag = (s["fp"], s["auxkey"])
-                    if tag in self.sent_filter:
-                        continue
-                    self.sent_filter.add(tag)
+                tag = (s["fp"], s["auxkey"])                       # the sent-filter: an exact repeat was announced (and claimed) before
+                if tag in self.sent_filter:
+                    continue
+                self.sent_filter.add(tag)
                 self.d_sent[o].append((s["fp"], key))
                 self.d_keep[o].append(s)                         # what the generator keeps beside the candidate
         return [_i64([x for fk in self.d_sent[o] for x in fk]).reshape(-1, 2) for o in range(self.world)], 0
 
     def _deep_count(self, s):
+        self.__dict__.setdefault("won", {}).setdefault(s["fp"], [self.d_level, 0])   # this rank's candidate made the state: it regenerates it
         st = self.d_stats
         st["n_new"] += 1
         st["fx"] ^= s["fp"]
@@ -290,7 +293,7 @@ class FakeShardEngine:
         out = []
         for i in range(len(vals) // 2):
             fp, key = vals[2 * i], vals[2 * i + 1]
-            out.append(1 if (self._deep_grant_one(fp, key) if mode == "regen" else self._deep_claim_one(fp, key, level)) else 0)
+            out.append(1 if self._deep_claim_one(fp, key, level) else 0)
         return torch.tensor(out, dtype=torch.uint8), 0
 
     def deep_apply(self, verdicts):
@@ -303,8 +306,7 @@ class FakeShardEngine:
             for s, win in zip(self.d_keep[o], v):
                 if not win:
                     continue
-                if self.d_mode != "regen":
-                    self._deep_count(s)
+                self._deep_count(s)
                 if self.d_mode != "insert":
                     self.d_out.append((np.array(s["words"], dtype=np.uint64), s["fp"]))
         return self.d_out, self.d_stats

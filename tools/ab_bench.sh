@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 A/B runs on the GPU box: tools/r04_ab.sh "<lib name>[:ENV=VAL,...]" ...  -> per variant k_expand ms per run on config 2 (two rounds)
+# A/B runs on the GPU box: tools/ab_bench.sh "<lib name>[:ENV=VAL,...]" ...  -> per variant k_expand ms per run on config 2 (two rounds)
 # and, for names listed in README_VARIANTS, one README-configuration leg (bench.py asserts every level figure against the oracle fixture)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -26,7 +26,7 @@ import sys, json
 l = sys.stdin.readline()
 try:
     d = json.loads(l)
-    print('$name', 'README ms_per_step', d['ms_per_step'], 'kernel', d['roofline']['kernel_ms_per_step'], 'probe3', d['probe3'])
+    print('$name', 'README ms_per_step', d['ms_per_step'], 'kernel', d['roofline']['kernel_ms_per_step'], 'materialised', d.get('materialised'), 'deep_passes', d.get('deep_passes'))
 except Exception as e:
     print('$name', 'README FAILED', l[:200])"
   tail -2 gpurun_out/ab_readme_$name.err | cut -c1-300

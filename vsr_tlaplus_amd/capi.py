@@ -148,6 +148,7 @@ SYMBOLS = {
     "vsrmc_shard_loop_destroy": (None, [V]),
     "vsrmc_shard_loop_step": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo)]),
     "vsrmc_shard_loop_run": (C.c_int32, [V, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(LevelInfo)]),
+    "vsrmc_shard_loop_room": (C.c_int32, [V, C.POINTER(C.c_int32)]),
     "vsrmc_shard_loop_status": (C.c_int32, [V, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]),

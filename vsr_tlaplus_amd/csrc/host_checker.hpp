@@ -69,6 +69,10 @@ struct vsrmc_checker {
   bool deep_regen_done = false;          // a descent has set taken bits in the levels beyond the base: cleared before the next one
   bool rebase_off = false;               // a re-basing descent could not get its scratch buffers: not tried again (vsr_deep.hpp: deep_rebase)
   std::vector<PassDst> scratch;          // scratch buffers of the descent, each a quarter of the one above down to a floor (allocated on first use)
+  // sharded deep search: the generator-side winner set (vsr_kernels.hpp: WSet) — which deep-level states THIS rank's candidates inserted
+  WSet h_wset = {nullptr, nullptr, 0};
+  WSet* d_wset = nullptr;                // the same three words on the device (what the kernels are handed); nullptr until the first deep pass
+  u32 wepoch = 0;                        // the number of the descent in flight
   bool full_recoverable = false;         // the last vsrmc_checker_step stopped with "frontier full" and lost nothing but records: the level is complete in the
                                          // seen-set and vsrmc_checker_advance keeps it as a seen-set-only level (host_search.hpp: adopt_overflowed_level)
   u64 hist_new[2] = {0, 0};              // new states of the last two levels (growth estimate of vsrmc_checker_advance)
@@ -78,7 +82,7 @@ struct vsrmc_checker {
 
 namespace {
 typedef void (*ExpandKernel)(Model, const u64*, const u64*, u64, int, int, Slot*, u64, u64*, u64, LevelCtl*, int, int, u64*, u64, u32, u64*,
-                             u64, u64*, u64, u64*, u32, u32, int, u32, u64*, u64, u64*, u32, int, u64);
+                             u64, u64*, u64, u64*, u32, u32, int, u32, u64*, u64, u64*, u32, int, u64, const WSet*, u32);
 // k_expand<true, SPEC>: the configurations of BASELINE.json (and their small neighbours used by the tests) have their own
 // instantiation with the model constants folded in; anything else runs the generic one.
 ExpandKernel exact_kernel_for(const Model& M) {               // two-kernel levels: k_expand<false, SPEC>
@@ -181,6 +185,37 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
   return f;
 }
 
+// the winner set of a sharded deep search: allocated at the first pass beyond the record buffers, half as many slots as the seen-set (the memory
+// autosize_options set aside for it), emptied whenever the search starts over
+int wset_ensure(vsrmc_checker* c) {
+  if (c->d_wset) return 0;
+  u64 slots = std::max<u64>((u64)1 << 12, (c->tmask + 1) / 2);
+  while (true) {
+    hipError_t e = hipMalloc((void**)&c->h_wset.fp, slots * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->h_wset.epoch, slots * 4);
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    if (c->h_wset.fp) (void)hipFree(c->h_wset.fp);
+    c->h_wset.fp = nullptr;
+    if (slots <= ((u64)1 << 16)) return fail(VSRMC_E_HIP, "hipMalloc of the winner set of the sharded deep search failed");
+    slots /= 2;                                                  // (a crowded device: a smaller set; it raises ERR_TABLE_FULL when it runs full)
+  }
+  c->h_wset.mask = slots - 1;
+  HIPCHK(hipMemsetAsync(c->h_wset.fp, 0, slots * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->h_wset.epoch, 0, slots * 4, c->stream));
+  HIPCHK(hipMalloc((void**)&c->d_wset, sizeof(WSet)));
+  HIPCHK(hipMemcpyAsync(c->d_wset, &c->h_wset, sizeof(WSet), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->wepoch = 0;
+  return 0;
+}
+void wset_free(vsrmc_checker* c) {
+  if (c->h_wset.fp) (void)hipFree(c->h_wset.fp);
+  if (c->h_wset.epoch) (void)hipFree(c->h_wset.epoch);
+  if (c->d_wset) (void)hipFree(c->d_wset);
+  c->h_wset.fp = nullptr; c->h_wset.epoch = nullptr; c->h_wset.mask = 0; c->d_wset = nullptr; c->wepoch = 0;
+}
+
 // Put the checker in its initial state (ModelChecker.doInit): empty seen-set, Init in frontier 0 and in the set.
 int checker_seed(vsrmc_checker* c) {
   const Model& M = c->model.M;
@@ -197,6 +232,7 @@ int checker_seed(vsrmc_checker* c) {
   c->failed_code = 0;
   c->full_recoverable = false;
   HIPCHK(hipSetDevice(c->opt.device));
+  wset_free(c);                                                  // (a fresh search: the next sharded deep pass starts an empty one)
   hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
   HIPCHK(hipGetLastError());
   std::vector<u64> wire, dev(512);
@@ -282,6 +318,7 @@ static int autosize_options(vsrmc_options* o, const Model& M) {
   }
   avail -= (double)((u64)1 << o->table_log2) * 16.0;
   if (o->world > 1 && !o->exact_ties) avail -= (double)((u64)1 << (o->filter_log2 > 0 ? o->filter_log2 : o->table_log2)) * 8.0;
+  if (o->world > 1 && !o->exact_ties) avail -= (double)((u64)1 << o->table_log2) * 6.0;    // the winner set of the deep search: half the slots, 12 B each
   if (o->pending_entries == 0) o->pending_entries = o->exact_ties ? (u64)1 << 24 : (u64)1 << 16;
   avail -= (double)o->pending_entries * 24.0;
   if (o->frontier_words == 0) {
@@ -447,12 +484,12 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
                          stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, ichunk,
                          wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk,
-                         mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), (u64)0);
+                         mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), (u64)0, (const WSet*)nullptr, 0u);
     else
       hipLaunchKernelGGL(exact_kernel_for(M), dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          c->lds_stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, nullptr,
-                         0, nullptr, 0, nullptr, 0, 0, tile, ccap, nullptr, 0, io ? c->cand_idx : nullptr, 0, 0, (u64)0);
+                         0, nullptr, 0, nullptr, 0, 0, tile, ccap, nullptr, 0, io ? c->cand_idx : nullptr, 0, 0, (u64)0, (const WSet*)nullptr, 0u);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }
@@ -677,7 +714,8 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
                        io ? io->cand_send : nullptr, io ? io->cand_cap : (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
                        ichunk, wchunk, tile, ccap, io ? c->filter : nullptr, io ? c->fmask : (u64)0, io ? c->cand_idx : nullptr, cchunk,
-                       mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset);
+                       mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset,
+                       (const WSet*)(io ? c->d_wset : nullptr), c->wepoch);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }

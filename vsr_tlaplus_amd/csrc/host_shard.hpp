@@ -55,7 +55,7 @@ int32_t vsrmc_shard_materialize(vsrmc_checker* c, const vsrmc_shard_io* io, cons
       if (n == 0) continue;
       if (!d_verdict_in) return fail(VSRMC_E_ARG, "verdicts missing");
       hipLaunchKernelGGL(k_apply_verdict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, io->cand_send + 2 * (u64)o * io->cand_cap,
-                         c->cand_idx + (u64)o * io->cand_cap, d_verdict_in + (u64)o * io->cand_cap, n, c->off[nxt], c->lvl_fp, c->ctl);
+                         c->cand_idx + (u64)o * io->cand_cap, d_verdict_in + (u64)o * io->cand_cap, n, c->off[nxt], c->lvl_fp, c->ctl, (const WSet*)nullptr, 0);
       HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[3], c->stream));

@@ -364,7 +364,7 @@ int deep_first_pass(vsrmc_checker* c, vsrmc_level_info* ins, const DeepIo* io = 
   ins->level = c->level + (R.ins.n_new ? 1 : 0);               // like vsrmc_checker_step: an empty level leaves the depth where it was
   if (R.ins.n_new == 0) { c->deep = 0; c->deep_lv.clear(); }   // exhausted: nothing was inserted, the checker is where it was
   ins->pending = R.launches;                                   // k_expand launches of this pass
-  c->deep_distinct = c->distinct + R.ins.n_new;                // (sharded: c->distinct is this rank's share; the loop keeps the run's total)
+  c->deep_distinct = c->distinct + (io ? n_local : R.ins.n_new);   // sharded: this rank's share of both — what its own seen-set holds (the level loop keeps the run's total)
   c->deep_generated = c->total_generated + R.ins.generated;
   ins->distinct = c->deep_distinct;
   ins->total_generated = c->deep_generated;
@@ -389,18 +389,21 @@ int deep_pass(vsrmc_checker* c, int last_regen, bool insert, vsrmc_level_info* i
   std::memset(&R.prb, 0, sizeof(R.prb));
   R.ins.viol_fp = R.ins.viol_index = R.prb.viol_fp = R.prb.viol_index = ~(u64)0;
   const double t0 = now_s();
-  if (c->deep_regen_done) {                                    // the taken bits an earlier descent left in the levels beyond the base
+  if (io) {
+    c->wepoch++;                                               // sharded: a regenerating lane takes a state by raising its epoch in the rank's winner set — nothing to clear
+  } else if (c->deep_regen_done) {                             // the taken bits an earlier descent left in the levels beyond the base
     hipLaunchKernelGGL(k_table_untake, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1, c->level + 1);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));                   // (sharded: before any rank's first announcement can reach this table)
+    HIPCHK(hipStreamSynchronize(c->stream));
   }
   c->deep_regen_done = true;
-  HIPCHK(hipMalloc((void**)&R.d_sum, 24));
-  struct FreeSum { u64* p; ~FreeSum() { (void)hipFree(p); } } free_sum{R.d_sum};
+  int rc = 0;
+  if (hipMalloc((void**)&R.d_sum, 24) != hipSuccess) { (void)hipGetLastError(); R.d_sum = nullptr; rc = fail(VSRMC_E_HIP, "deep pass: hipMalloc of the checksum words"); }
+  struct FreeSum { u64* p; ~FreeSum() { if (p) (void)hipFree(p); } } free_sum{R.d_sum};
   if (insert) { c->deep_lv.resize((size_t)(last_regen + 1 - c->level)); c->deep_lv.back() = DeepLevel(); }
-  int rc = deep_plan_scratch(c, last_regen - c->level - (insert ? 0 : 1));   // buffer k takes what level base + k yields
+  if (!rc) rc = deep_plan_scratch(c, last_regen - c->level - (insert ? 0 : 1));   // buffer k takes what level base + k yields
   if (io) {                                                    // a rank that could not allocate takes the others with it, before any of them waits for it
-    u64 bad_plan = rc ? 1 : 0;
+    u64 bad_plan = rc ? 1 : 0;                                 // (round-4 advice: NO local failure of this prologue returns before this exchange)
     const int arc = io->any(io->ctx, &bad_plan);
     if (!rc && (arc || bad_plan)) rc = arc ? arc : fail(VSRMC_E_HIP, "deep pass: another rank could not allocate its scratch buffers");
   }
@@ -419,7 +422,7 @@ int deep_pass(vsrmc_checker* c, int last_regen, bool insert, vsrmc_level_info* i
     DeepLevel& d = c->deep_lv.back();
     d.n_new = R.ins.n_new; d.n_local = n_local; d.generated = R.ins.generated; d.max_bag = R.ins.max_bag; d.frontier = below.n_new;
     c->deep_g = std::max<u64>(c->deep_g, (R.ins.generated + below.n_new - 1) / std::max<u64>(1, below.n_new) + 1);
-    c->deep_distinct += R.ins.n_new;
+    c->deep_distinct += io ? n_local : R.ins.n_new;            // (sharded: the rank's share, see deep_first_pass)
     c->deep_generated += R.ins.generated;
     *ins = R.ins;
     ins->level = last_regen + (R.ins.n_new ? 1 : 0);            // like vsrmc_checker_step: an empty level leaves the depth where it was

@@ -171,6 +171,48 @@ __device__ __forceinline__ void raise_full(LevelCtl* ctl, u64 info) {   // calle
   }
 }
 
+// ---- the generator-side winner set of a SHARDED deep search (round 5) -------------------------------------------------------------------------
+// Records stay with the rank that generated them, so a level that exists in the seen-sets only has to be REGENERATED by its generators.  Rounds 3-4
+// asked the OWNER every time: every candidate of every regenerating pass crossed the fabric with its key, the owner granted the one whose key is the
+// slot's final meta word, a verdict byte came back (45.6 GB per rank and step on the README configuration at world 2).  But the generator has been
+// told once already which of its candidates made a state: the verdict of the pass that INSERTED the level (first inserter wins, k_claim_batch_fused;
+// the lane's own compare-and-swap for the states it owns).  It keeps those fingerprints here — an open-addressing set of its own, 12 B per slot —
+// and a regenerating pass asks this set instead of the owner: no announcement, no exchange, no seen-set access.  A slot knows its state's LEVEL
+// (a successor of a level-l state may be another level-l state of the set, which must not be rebuilt as a member of level l+1), and `epoch` makes
+// the take exactly-once per descent (two instances of one rank can yield the same state): the first lane to raise a slot's epoch to the descent's
+// rebuilds the state; nothing is cleared between descents.
+struct WSet {
+  u64* fp;          // 0 = empty
+  u32* epoch;       // level(9) << 23 | the last descent that regenerated the state (23 bits)
+  u64 mask;         // slots - 1
+};
+__device__ __forceinline__ u64 wset_home(u64 fp, u64 mask) { return (fp >> 13) & mask; }   // (other bits than the seen-set's index: fp & tmask)
+__device__ __forceinline__ bool wset_insert(const WSet* w, u64 fp, int level) {            // false: the set is full.  (A state is inserted once in a
+  const u64 mask = w->mask;                                                                // run — by the one candidate that made it — and never while
+  u64 i = wset_home(fp, mask);                                                             // a regenerating pass reads the set: different launches.)
+  for (u64 step = 0; step <= mask && step < 65536; step++, i = (i + 1) & mask) {
+    const u64 cur = atomicCAS((unsigned long long*)&w->fp[i], 0ull, (unsigned long long)fp);
+    if (cur == 0) { w->epoch[i] = (u32)level << 23; return true; }
+    if (cur == fp) return true;
+  }
+  return false;
+}
+// is fp a level-`level` state of mine, and am I the first of this descent to ask?
+__device__ __forceinline__ bool wset_take(const WSet* w, u64 fp, int level, u32 epoch) {
+  const u64 mask = w->mask;
+  u64 i = wset_home(fp, mask);
+  for (u64 step = 0; step <= mask && step < 65536; step++, i = (i + 1) & mask) {
+    const u64 cur = w->fp[i];
+    if (cur == fp) {
+      if ((w->epoch[i] >> 23) != (u32)level) return false;
+      const u32 mine = ((u32)level << 23) | (epoch & 0x7FFFFFu);
+      return atomicMax(&w->epoch[i], mine) < mine;
+    }
+    if (cur == 0) return false;
+  }
+  return false;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 __device__ __forceinline__ u64 readlane64(u64 v, int l) {
@@ -410,7 +452,10 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
          //   MODE_REGEN   re-expansion of (a slice of) the same parents after a MODE_INSERT pass: the successor whose key IS
          //                the slot's final meta word — exactly one per new state — is written to the next frontier
          // violators of PROBE / INSERT go to the `pending` list as (fp, key) pairs (n_pending counts them).
-         int mode_arg, u64 p_offset /* index of parent 0 of this launch in its level (slices) */) {
+         int mode_arg, u64 p_offset /* index of parent 0 of this launch in its level (slices) */,
+         // sharded deep search (world > 1, a pass beyond the record buffers): the rank's winner set — MODE_INSERT / MODE_NORMAL record the states this
+         // rank's own lanes insert, MODE_REGEN rebuilds exactly the states the set holds, once per descent (wepoch), and announces nothing
+         const WSet* wset, u32 wepoch) {
   // PLAIN: the unsharded, ordinary level — the probe / virtual-level modes and the sharded branches are compiled out (11 % less
   // code: the specialised kernel then fits the 64-KB instruction cache with room to spare)
   // PLAIN == 2: unsharded with the modes (the probe / virtual / regenerated / streamed passes of vsrmc_checker_probe*): only the
@@ -843,9 +888,15 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             u64* fs = filter + ((fp >> 6) & fmask);
             if (__hip_atomic_load(fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) continue;
             __hip_atomic_store(fs, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            remote = true;
+            do_write = mode == MODE_NORMAL;                     // a virtual level: announced, not written (vsr_deep.hpp, sharded)
+          } else if (wset) {
+            do_write = wset_take(wset, fp, level, wepoch);      // regenerated level: this rank rebuilds what ITS candidates inserted — nobody is asked
+          } else {
+            remote = true;                                      // (no winner set: the owner grants the regeneration, rounds 3-4)
           }
-          remote = true;
-          do_write = mode == MODE_NORMAL;                       // virtual / regenerated levels: announced, not written (vsr_deep.hpp, sharded)
+        } else if (mode == MODE_REGEN && PLAIN == 0 && wset) {
+          do_write = wset_take(wset, fp, level, wepoch);        // the same rule for the states this rank owns itself: no seen-set access in a sharded regeneration
         } else if (mode == MODE_REGEN) {
           u64 m = META_EMPTY;
           u64 slot_i = 0;
@@ -860,6 +911,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           }
           do_write = claimed;
           claimed_now = claimed;
+          if (PLAIN == 0 && wset && claimed && !wset_insert(wset, fp, level)) raise_error(ctl, ERR_TABLE_FULL, fp);   // a state this rank's own lane made
         }
         // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
         int bad = (check || do_write || (remote && mode == MODE_INSERT)) ? Ops::invariants(M, rec, D) : 0;
@@ -1438,7 +1490,7 @@ __global__ void k_claim_batch_fused(Slot* table, u64 tmask, const u64* __restric
 // written speculatively at state index cand_idx[i] (bits 56..63: violated-invariant mask); losers are withdrawn (invalid
 // ref, exactly like an unused index), winners that violate an invariant are reported now.
 __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __restrict__ cand_idx, const uint8_t* __restrict__ verdict,
-                                u64 n, u64* nx_off, u64* lvl_fp, LevelCtl* ctl) {
+                                u64 n, u64* nx_off, u64* lvl_fp, LevelCtl* ctl, const WSet* wset /* deep passes: the winners are remembered */, int level) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 fp = entries[2 * i];
@@ -1446,6 +1498,7 @@ __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __re
   const u64 e = cand_idx[i];
   const u64 idx = cand_index(e);
   if (verdict[i]) {
+    if (wset && !wset_insert(wset, fp, level)) raise_error(ctl, ERR_TABLE_FULL, fp);
     const u32 bad = cand_bad(e);
     if (bad) {
       atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
@@ -1457,29 +1510,18 @@ __global__ void k_apply_verdict(const u64* __restrict__ entries, const u64* __re
   }
 }
 __device__ __forceinline__ u64 find_exact(const Slot* table, u64 tmask, u64 fp);
-// The same two roles for the levels of a sharded run that exist in the seen-set only (vsr_deep.hpp).
-// k_regen_verdict, owner side of a regenerated level: of all the copies of a state the ranks re-generate, the one whose key IS the slot's
-// final meta word materialises it — taken with a compare-and-swap, so that two instances carrying the same 64 bits yield one state.
-__global__ void k_regen_verdict(Slot* table, u64 tmask, const u64* __restrict__ entries, u64 n, uint8_t* verdict) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 fp = entries[2 * i], key = entries[2 * i + 1];
-  uint8_t v = 0;
-  if (fp != 0) {
-    const u64 slot = find_exact(table, tmask, fp);
-    if (slot != ~(u64)0 && table[slot].meta == key)
-      v = atomicCAS((unsigned long long*)&table[slot].meta, (unsigned long long)key, (unsigned long long)(key | META_TAKEN)) == key ? 1 : 0;
-  }
-  verdict[i] = v;
-}
+// The generator's side of the levels of a sharded run that exist in the seen-sets only (vsr_deep.hpp).  (Rounds 3-4 had an owner side for the
+// regenerated levels too — k_regen_verdict granted the candidate whose key is the slot's final meta word; since round 5 a rank regenerates what
+// its winner set holds and asks nobody: WSet, above.)
 // k_count_verdict, generator side of a virtual level: nothing was written, so the winners among the announced successors are only
 // counted — new states, checksums of their fingerprints, largest bag (cand_idx: bag size | violated-invariant mask << 56), violators.
 __global__ void k_count_verdict(const u64* __restrict__ entries, const u64* __restrict__ cand_idx, const uint8_t* __restrict__ verdict, u64 n,
-                                u64* pending, u64 pending_cap, LevelCtl* ctl) {
+                                u64* pending, u64 pending_cap, LevelCtl* ctl, const WSet* wset, int level) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 cnt = 0, fx = 0, fs = 0, bag = 0;
   if (i < n && entries[2 * i] != 0 && verdict[i]) {
     const u64 fp = entries[2 * i], e = cand_idx[i];
+    if (wset && !wset_insert(wset, fp, level)) raise_error(ctl, ERR_TABLE_FULL, fp);
     cnt = 1; fx = fp; fs = fp; bag = cand_index(e);
     const u32 bad = cand_bad(e);
     if (bad) {

@@ -479,20 +479,32 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
 
 // vsrmc_check for a sharded run (collective): stop_reason 0 exhausted, 1 invariant violated, 2 max_depth
 int32_t vsrmc_shard_loop_advance(vsrmc_shard_loop* l, vsrmc_level_info* a, vsrmc_level_info* b, int32_t* what);
+// The seen-sets before the next unit of progress (collective once the run is sharded): *state = 0 room on every rank, 2 = some rank's shard is more than
+// 85 % full — every rank learns it in the same call, so that all of them stop together with "incomplete at depth N" instead of one of them running
+// into ERR_TABLE_FULL inside a collective.  (A shard does not grow: the ranks of a node share no spare memory to re-hash into.)
+int32_t vsrmc_shard_loop_room(vsrmc_shard_loop* l, int32_t* state) {
+  if (!l || !state) return fail(VSRMC_E_ARG, "NULL argument");
+  u64 full = (double)(l->c->deep ? l->c->deep_distinct : l->c->distinct) > 0.85 * (double)(l->c->tmask + 1) ? 1 : 0;
+  if (!l->replicated) {
+    u64 all[8] = {0};
+    const int rc0 = l->comm.allgather(l->comm.ctx, &full, all, 8);
+    if (rc0) return rc0 > 0 ? fail(VSRMC_E_HIP, "the caller's all-gather failed") : rc0;
+    for (int p = 0; p < l->world; p++) full = std::max(full, all[p]);
+  }
+  *state = full ? 2 : 0;
+  return 0;
+}
+
 int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t stop_on_violation, int32_t* stop_reason, vsrmc_level_info* last) {
   if (!l || !stop_reason || !last) return fail(VSRMC_E_ARG, "NULL argument");
   vsrmc_level_info b;
   for (;;) {
     if (max_depth > 0 && l->level + l->deep >= max_depth) { *stop_reason = 2; return 0; }
     // a seen-set that fills up: every rank asks, any rank's answer stops all (the all-gather inside advance needs every rank)
-    u64 full = (double)(l->c->deep ? l->c->deep_distinct : l->c->distinct) > 0.85 * (double)(l->c->tmask + 1) ? 1 : 0;
-    if (!l->replicated) {
-      u64 all[8] = {0};
-      const int rc0 = l->comm.allgather(l->comm.ctx, &full, all, 8);
-      if (rc0) return rc0 > 0 ? fail(VSRMC_E_HIP, "the caller's all-gather failed") : rc0;
-      for (int p = 0; p < l->world; p++) full = std::max(full, all[p]);
-    }
-    if (full) { *stop_reason = 4; return 0; }
+    int32_t room = 0;
+    const int rc0 = vsrmc_shard_loop_room(l, &room);
+    if (rc0) return rc0;
+    if (room == 2) { *stop_reason = 4; return 0; }
     int32_t what = 0;
     const int rc = vsrmc_shard_loop_advance(l, last, &b, &what);
     if (rc) return rc;
@@ -562,12 +574,13 @@ int32_t vsrmc_shard_loop_trace_fps(vsrmc_shard_loop* l, int32_t level, uint64_t 
 }  // extern "C"
 
 // ================================================================================================================================
-// Levels beyond the record buffers on a sharded run (vsr_deep.hpp with the collective hooks).  Every pass of the descent is the
-// protocol of a sharded level with other sources / targets: k_expand over a slice announces the successors other ranks own (virtual
-// level: through the sent-filter, nothing written; regenerated level: every candidate, with the instance that can rebuild it; inserted
-// level: through the filter, written speculatively into the scratch buffer), the owners claim (k_claim_batch_fused) or, for a
-// regenerated level, grant the one candidate whose key is the slot's final meta word (k_regen_verdict), and the verdict bytes come
-// back: winners are counted (k_count_verdict), rebuilt from their parents (k_materialize) or kept (k_apply_verdict withdraws the rest).
+// Levels beyond the record buffers on a sharded run (vsr_deep.hpp with the collective hooks).  A pass that INSERTS a level is the protocol of a
+// sharded level with other sources / targets: k_expand over a slice announces the successors other ranks own through the sent-filter (virtual
+// level: nothing written; inserted level: written speculatively into the scratch buffer), the owners claim (k_claim_batch_fused: first inserter
+// wins), the verdict bytes come back, and the winners are counted (k_count_verdict) or kept (k_apply_verdict withdraws the rest) — and remembered
+// in the rank's winner set (vsr_kernels.hpp: WSet) together with the states the rank's own lanes inserted.  A pass that REGENERATES a level is
+// local: the rank rebuilds what its winner set holds, once per descent, and nothing crosses the fabric (rounds 3-4 asked the owners about every
+// candidate of every regenerating pass).
 // Loops run as long as ANY rank has a slice left; a rank that has run out takes part in the others' exchanges with empty buckets.
 // ================================================================================================================================
 namespace {
@@ -590,7 +603,19 @@ int loop_deep_pass(void* ctx, const u64* sw, const u64* so, u64 n, u64 p_off, in
   vsrmc_shard_io io;
   io.cand_send = l->cand_send;
   io.cand_cap = l->cand_cap;
-  int rc = expand_pass(c, sw, so, n, p_off, level, mode, bag, dst, &io);
+  int rc = wset_ensure(c);                                     // the rank's winner set (vsr_kernels.hpp: WSet), allocated at the first deep pass
+  if (!rc) rc = expand_pass(c, sw, so, n, p_off, level, mode, bag, dst, &io);
+  if (mode == MODE_REGEN) {
+    // A regenerated level costs NO exchange (round 5): every rank rebuilds the states its own candidates inserted — it has kept their fingerprints
+    // since the verdict of the pass that inserted them — and k_expand has written them already.  The ranks only tell each other that they are done
+    // (nobody goes on alone).  Rounds 3-4: every candidate to its owner, a verdict byte back, k_materialize for the winners.
+    u64 e0 = rc ? (u64)(rc < 0 ? -rc : rc) : 0, eall0[8] = {0};
+    const int crc0 = loop_allgather(l, &e0, eall0, 8);
+    if (crc0) return crc0;
+    for (int p = 0; p < w; p++)
+      if (eall0[p] && !rc) rc = fail(VSRMC_E_STATE, "deep pass (level " + std::to_string(level) + "), regeneration: error " + std::to_string((long long)eall0[p]) + " on another rank");
+    return rc;
+  }
   struct CountRow { u64 cnt[8]; u64 err; } mine;
   std::memset(&mine, 0, sizeof(mine));
   for (int p = 0; p < w; p++) mine.cnt[p] = (p == me || rc) ? 0 : std::min<u64>(c->h.cand_cnt[p], l->cand_cap);
@@ -613,8 +638,7 @@ int loop_deep_pass(void* ctx, const u64* sw, const u64* so, u64 n, u64 p_off, in
   // the owner's side: claim (virtual / inserted level) or grant the regeneration (the candidate that carries the slot's final key)
   if (!rc && n_recv) {
     const unsigned grid = (unsigned)((n_recv + 255) / 256);
-    if (mode == MODE_REGEN) hipLaunchKernelGGL(k_regen_verdict, dim3(grid), dim3(256), 0, c->stream, c->table, c->tmask, l->cand_recv, n_recv, l->verdict_out);
-    else hipLaunchKernelGGL(k_claim_batch_fused, dim3(grid), dim3(256), 0, c->stream, c->table, c->tmask, l->cand_recv, n_recv, level, l->verdict_out, c->ctl);
+    hipLaunchKernelGGL(k_claim_batch_fused, dim3(grid), dim3(256), 0, c->stream, c->table, c->tmask, l->cand_recv, n_recv, level, l->verdict_out, c->ctl);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(VSRMC_E_HIP, "deep pass: claim kernel");
   }
   {
@@ -628,15 +652,12 @@ int loop_deep_pass(void* ctx, const u64* sw, const u64* so, u64 n, u64 p_off, in
     const u64* ent = l->cand_send + 2 * (u64)o * l->cand_cap;
     const u64* cidx = c->cand_idx + (u64)o * l->cand_cap;
     const uint8_t* ver = l->verdict_in + (u64)o * l->cand_cap;
-    if (mode == MODE_REGEN) {
-      rc = phase_materialize(c, ent, k, ver, dst->words, dst->words_cap, dst->off, dst->cap, dst->fp, &c->ctl->n_new, &c->ctl->words_new, 2, cidx, sw, so);
-    } else {
-      if (mode == MODE_INSERT)
-        hipLaunchKernelGGL(k_count_verdict, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, ent, cidx, ver, k, c->pending, c->opt.pending_entries, c->ctl);
-      else
-        hipLaunchKernelGGL(k_apply_verdict, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, ent, cidx, ver, k, dst->off, dst->fp, c->ctl);
-      if (hipGetLastError() != hipSuccess) rc = fail(VSRMC_E_HIP, "deep pass: verdict kernel");
-    }
+    // the winners are counted (virtual level) or kept (inserted level) — and REMEMBERED in the rank's winner set: they are what it regenerates later
+    if (mode == MODE_INSERT)
+      hipLaunchKernelGGL(k_count_verdict, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, ent, cidx, ver, k, c->pending, c->opt.pending_entries, c->ctl, (const WSet*)c->d_wset, level);
+    else
+      hipLaunchKernelGGL(k_apply_verdict, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, ent, cidx, ver, k, dst->off, dst->fp, c->ctl, (const WSet*)c->d_wset, level);
+    if (hipGetLastError() != hipSuccess) rc = fail(VSRMC_E_HIP, "deep pass: verdict kernel");
   }
   if (!rc && (hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
     rc = fail(VSRMC_E_HIP, "deep pass: control block");

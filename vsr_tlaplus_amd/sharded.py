@@ -472,14 +472,14 @@ class ShardedChecker:
                 _, st = self._deep_pass(part, L + 1, "insert")
                 add(st)
         else:
-            e.deep_untake(L + 1)
-            x.barrier()                                          # every rank has cleared its taken bits before the first announcement
+            e.deep_new_descent()                                 # (nothing to clear, nobody to wait for: a regeneration is local)
 
             def descend(src, lv):
                 for part in slices(src):
                     if lv + 1 < target:
-                        out, _ = self._deep_pass(part, lv + 1, "regen")
-                        descend(out, lv + 1)
+                        # a regenerated level: the rank rebuilds the states ITS candidates inserted (its winner set), once per descent — no
+                        # announcement, no exchange (rounds 3-4 asked the owners about every candidate of every regenerating pass)
+                        descend(e.deep_regen(part, lv + 1), lv + 1)
                     else:
                         out, st = self._deep_pass(part, lv + 1, "normal")
                         add(st)
@@ -955,11 +955,21 @@ class NativeShardedChecker:
             self.violation["probed"] = bool(db["level"] and db["viol_mask"] and not da["viol_mask"])
         return "deep", da, (db if db["level"] else None)
 
+    def room(self):
+        """the seen-set shards before the next advance() (collective): 0 = room on every rank, 2 = some rank's shard is more than 85 % full"""
+        st = C.c_int32()
+        rc = capi.load().vsrmc_shard_loop_room(self._l, C.byref(st))
+        if rc != 0:
+            raise ShardError("seen-set check: %s" % capi.load().vsrmc_last_error().decode())
+        return st.value
+
     def run(self, max_depth=None, stop_on_violation=True):
         self.depth = getattr(self, "depth", self.level)
         while True:
             if max_depth is not None and self.depth >= max_depth:
                 return "max-depth"
+            if self.room() == 2:
+                return "seen-set-full"
             kind, d, p = self.advance()
             if d["n_new"] == 0:
                 return "exhausted"

@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0
+XGMI_LINK_GBS = 153.0        # one xGMI link of an MI355X, one direction (7 links per GPU: a fully connected 8-GPU node gives every pair its own)
 # levels with fewer new states than this are explored by every rank on its own (no collectives): a level of a million states
 # is under a millisecond of kernel time, less than the exchanges of one sharded level
 REPLICATE_BELOW = int(os.environ.get("VSR_BENCH_REPLICATE_BELOW", 1 << 20))
@@ -151,6 +152,15 @@ def main(args, bench):
                        "level_loop": "native C++ (csrc/vsr_shard_loop.hpp), " + ("direct RCCL: grouped ncclSend/ncclRecv" if backend == "nccl" else "gloo callbacks, host-staged")},
             "time_to_first_violation_s": round(sum(S["ttfv"]) / len(S["ttfv"]), 4), "setup_s": round(setup, 2),
             "xgmi_bytes_sent_rank0_per_step": int(S["sent"] / max(1, args.steps + args.warmup)),
+            # the exchange priced against the fabric BEFORE any multi-GPU run exists: rank 0's bytes spread over the links to its N - 1 peers at link
+            # peak, beside rank 0's kernel time for the same step — which of the two bounds a step (they do not overlap yet: DESIGN.md §7)
+            "exchange": (lambda b, ks: {"xgmi_bytes_sent_rank0_per_step": int(b), "links_used": max(1, min(world - 1, 7)), "link_peak_GBs": XGMI_LINK_GBS,
+                                        "xgmi_s_at_link_peak": round(b / (XGMI_LINK_GBS * 1e9 * max(1, min(world - 1, 7))), 4),
+                                        "kernel_s_per_step": round(ks, 4),
+                                        "bound_by": "kernel" if ks >= b / (XGMI_LINK_GBS * 1e9 * max(1, min(world - 1, 7))) else "exchange",
+                                        "note": "a regenerated level costs no exchange since round 5 (generator-side winner set): what is left are the (fp, key) "
+                                                "announcements of the levels that are inserted, their verdict bytes and the small all-gathers"})(
+                S["sent"] / max(1, args.steps + args.warmup), kernel_ms / 1e3 / max(1, args.steps)),
             "records_moved_by_rebalancing_rank0": S["moved"],
             "deep_passes": S["passes"],
             "roofline": {"bound": "hbm", "kernel": "k_expand (rank 0; the job's algorithmic bytes / N over rank 0's kernel time)", "achieved": round(achieved, 2),

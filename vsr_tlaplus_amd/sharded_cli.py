@@ -226,9 +226,12 @@ def run_automatic(opt, m, rank, world, local_rank, say):
            int(eng.options.frontier_words) * 8 / (1 << 30), int(eng.cand_cap)))
     say("Finished computing initial states: 1 distinct state generated.")
     t0 = time.time()
-    total_generated, code, last, deadlocked, kind = 0, 0, dict(n_new=1, deadlocks=0), False, "level"
+    total_generated, code, last, deadlocked, kind, incomplete = 0, 0, dict(n_new=1, deadlocks=0), False, "level", False
     try:
         while sc.depth < opt["max_depth"]:
+            if sc.room() == 2:                                   # (collective: every rank stops here together)
+                incomplete = True
+                break
             kind, d, b = sc.advance()
             last = d
             total_generated += d["generated"]
@@ -276,6 +279,9 @@ def run_automatic(opt, m, rank, world, local_rank, say):
     elif code == 0 and deadlocked:
         say("Error: Deadlock reached (%d state(s) of level %d have no successor)." % (last["deadlocks"], sc.depth - 1))
         code = 11
+    elif code == 0 and incomplete:
+        say("Model checking INCOMPLETE at depth %d: a rank's seen-set shard is more than 85 %% full (no error has been found up to that depth)." % sc.depth)
+        code = 4
     elif code == 0 and last["n_new"] == 0:
         say("Model checking completed. No error has been found.")
     say("%d states generated, %d distinct states found, %d states left on queue." % (total_generated, sc.distinct, last["n_new"]))
