@@ -445,6 +445,58 @@ def collision_estimate(n):
     return float(n) * float(n) / 2.0 ** 65
 
 
+def run_config4(args):
+    """BASELINE configs[3] (ReplicaCount=3, ClientCount=2, Values={v1,v2,v3}, StartViewOnTimerLimit=3) under the documented policy for VSR.tla:421
+    (`assume_commit_number`: strict TLC semantics abort at that line after 5 states, tests/test_gpu_parity.py) as deep as the CPU oracle's fixture
+    goes (tests/golden/oracle_levels_config4.json): one verified run (every level figure, per-action counts, fingerprint checksums), then the
+    timed ones.  No violation within that depth; the object is a rate, not a time-to-violation.  -> JSON fields"""
+    import torch
+    import vsr_tlaplus_amd as vt
+    torch.cuda.set_device(0)
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_config4.json")) as f:
+        g = json.load(f)
+    p = g["params"]
+    m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=p["n"], L=p["L"], symmetry=p["symmetry"], invariant_mask=p["inv_mask"], assume_commit_number=True)
+    mc = vt.ModelChecker.auto(m, device=0)
+    last = g["levels"][-1]["level"]
+    sums = g.get("fp_version") == FP_VERSION
+
+    def one_run(verify):
+        mc.reset()
+        t0 = time.perf_counter()
+        kms, stored = 0.0, 1
+        while mc.depth < last:
+            kind, a, b = mc.advance()
+            lv = g["levels"][a["level"] - 1]
+            assert (a["n_new"], a["generated"], a["deadlocks"], a["max_bag"], a["viol_mask"]) == (lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"], 0), a["level"]
+            kms += a["expand_ms"] + a["materialize_ms"] + (b["expand_ms"] if b is not None else 0.0)
+            stored += kind == "level"
+            if verify:
+                assert [int(x) for x in a["act_generated"][1:16]] == lv["act_generated"][1:16], a["level"]
+                x, s_ = (mc.level_checksum()[:2]) if kind == "level" else (a["fp_xor"], a["fp_sum"])
+                assert not sums or ("%016x" % x, "%016x" % s_) == (lv["fp_xor"], lv["fp_sum"]), a["level"]
+        assert mc.distinct == g["distinct"] and mc.violation is None
+        return time.perf_counter() - t0, kms, stored
+
+    try:
+        if not args.no_verify:
+            one_run(True)
+        k = max(1, min(args.steps, 3))
+        one_run(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rows = [one_run(False) for _ in range(k)]
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:
+        mc.close()
+    return dict(workload="VSR.tla BFS, ReplicaCount=3 ClientCount=2 Values={v1,v2,v3} StartViewOnTimerLimit=3 (BASELINE configs[3]) under the documented policy "
+                         "assume_commit_number for VSR.tla:421 (strict TLC semantics abort there), VIEW+SYMMETRY, the %d levels the CPU oracle's fixture holds: "
+                         "%d distinct states, no violation; every level asserted" % (last, g["distinct"]),
+                value=round(g["distinct"] * k / elapsed, 1), unit="distinct states/s", steps=k, ms_per_step=round(1e3 * elapsed / k, 3), depth=last,
+                distinct=g["distinct"], oracle_pinned_levels=len(g["levels"]), stored_levels=rows[-1][2], k_expand_ms_per_step=round(sum(r[1] for r in rows) / k, 3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -455,6 +507,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed verification runs (profiling: one run = the kernel launches of one BFS)")
     ap.add_argument("--no-config3", action="store_true", help="skip the README configuration (takes the whole HBM): config 2 is the headline")
     ap.add_argument("--no-config2", action="store_true", help="skip the config-2 object")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 object (BASELINE configs[3] under assume_commit_number)")
     ap.add_argument("--workload", choices=["auto", "readme", "config3", "config2"], default="auto",
                     help="auto (default): the README defect configuration (BASELINE configs[2], fits one MI355X) is the headline and config 2 "
                          "(BASELINE configs[1]) an object beside it; readme / config3: only the former; config2: only the latter")
@@ -465,7 +518,7 @@ def main():
         return sharded_bench.main(args, sys.modules[__name__])
     want_readme = args.workload in ("auto", "readme", "config3") and not args.no_config3
     want_c2 = args.workload in ("auto", "config2") and not args.no_config2
-    c2 = rd = None
+    c2 = rd = c4 = None
     audit = None
     if want_c2:
         elapsed, S, _ = run_single(args)
@@ -475,6 +528,8 @@ def main():
         # number under the headline: the exception propagates and the exit code is not 0
         elapsed, S = run_readme(args, os.environ.get("VSR_BENCH_DUMP_TRACE"))
         rd = readme_object(args, elapsed, S)
+    if args.workload == "auto" and not args.no_config4 and not args.no_config3:
+        c4 = run_config4(args)
     if not args.no_verify:
         # second-hash audit: the untimed verification runs once more under another member of the fingerprint family — every per-level count
         # (new states, generated, deadlocks, largest bag, per action) is asserted against the same oracle fixtures inside the runs
@@ -512,6 +567,8 @@ def main():
         c2["value"] = round(c2["value"], 1)
         c2["ms_per_step"] = round(c2["ms_per_step"], 3)
         out["config2"] = c2
+    if c4 is not None:
+        out["config4"] = c4
     out["collision_audit"] = audit
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, cfg)
