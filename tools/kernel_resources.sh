@@ -15,7 +15,7 @@ for b in blocks:
     m = re.search(r'\.name:\s+(\S+)', b)
     if not m or '$FILTER' not in m.group(1): continue
     g = lambda k: (re.search(r'\.' + k + r':\s+(\d+)', b) or [None, '?'])[1]
-    print(m.group(1)[:110], 'vgpr', g('vgpr_count'), 'agpr', g('agpr_count'), 'sgpr', g('sgpr_count'), 'spill_v', g('vgpr_spill_count'), 'scratch', g('private_segment_fixed_size'), 'lds', g('group_segment_fixed_size'))
+    print(m.group(1)[:110], 'vgpr', g('vgpr_count'), 'agpr', g('agpr_count'), 'sgpr', g('sgpr_count'), 'spill_v', g('vgpr_spill_count'), 'spill_s', g('sgpr_spill_count'), 'scratch', g('private_segment_fixed_size'), 'lds', g('group_segment_fixed_size'))
 "
 /opt/rocm/lib/llvm/bin/llvm-readelf -s co.o | awk -v f="$FILTER" '$4=="FUNC" && index($8,f) {print $3, $8}' | sort -k2 | cut -c1-130
 rm -rf $T

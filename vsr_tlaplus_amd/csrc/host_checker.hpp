@@ -73,6 +73,7 @@ struct vsrmc_checker {
   WSet h_wset = {nullptr, nullptr, 0};
   WSet* d_wset = nullptr;                // the same three words on the device (what the kernels are handed); nullptr until the first deep pass
   u32 wepoch = 0;                        // the number of the descent in flight
+  bool wset_used = false, wset_dirty = false;   // this search has put states into the set / a reset came after that: emptied before the next use
   bool full_recoverable = false;         // the last vsrmc_checker_step stopped with "frontier full" and lost nothing but records: the level is complete in the
                                          // seen-set and vsrmc_checker_advance keeps it as a seen-set-only level (host_search.hpp: adopt_overflowed_level)
   u64 hist_new[2] = {0, 0};              // new states of the last two levels (growth estimate of vsrmc_checker_advance)
@@ -188,7 +189,16 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
 // the winner set of a sharded deep search: allocated at the first pass beyond the record buffers, half as many slots as the seen-set (the memory
 // autosize_options set aside for it), emptied whenever the search starts over
 int wset_ensure(vsrmc_checker* c) {
-  if (c->d_wset) return 0;
+  if (c->opt.world <= 1) return 0;                              // one rank owns and generates everything: the seen-set's own taken bits do (vsr_deep.hpp)
+  if (c->d_wset) {
+    if (c->wset_dirty) {                                         // a search that started over (vsrmc_checker_reset): the set is emptied, the allocation kept
+      HIPCHK(hipMemsetAsync(c->h_wset.fp, 0, (c->h_wset.mask + 1) * 8, c->stream));
+      HIPCHK(hipMemsetAsync(c->h_wset.epoch, 0, (c->h_wset.mask + 1) * 4, c->stream));
+      c->wset_dirty = false;
+      c->wepoch = 0;
+    }
+    return 0;
+  }
   u64 slots = std::max<u64>((u64)1 << 12, (c->tmask + 1) / 2);
   while (true) {
     hipError_t e = hipMalloc((void**)&c->h_wset.fp, slots * 8);
@@ -207,6 +217,7 @@ int wset_ensure(vsrmc_checker* c) {
   HIPCHK(hipMemcpyAsync(c->d_wset, &c->h_wset, sizeof(WSet), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->wepoch = 0;
+  c->wset_dirty = false;
   return 0;
 }
 void wset_free(vsrmc_checker* c) {
@@ -232,7 +243,8 @@ int checker_seed(vsrmc_checker* c) {
   c->failed_code = 0;
   c->full_recoverable = false;
   HIPCHK(hipSetDevice(c->opt.device));
-  wset_free(c);                                                  // (a fresh search: the next sharded deep pass starts an empty one)
+  if (c->d_wset && c->wset_used) c->wset_dirty = true;           // (a fresh search: the next sharded deep pass empties the winner set before it uses it)
+  c->wset_used = false;
   hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
   HIPCHK(hipGetLastError());
   std::vector<u64> wire, dev(512);
@@ -438,7 +450,8 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
     const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
     // sharded: records arrive from other ranks (rebalancing), the local maximum says nothing -> the format's capacity
-    const bool use_plain = fused && !io && mode == MODE_NORMAL && c->plain_kernel;
+    // (a "sharded" run of ONE rank owns every fingerprint: nothing is ever remote, and the instantiation without the sharded branches does the level)
+    const bool use_plain = fused && (!io || c->opt.world == 1) && mode == MODE_NORMAL && c->plain_kernel;
     const FusedShape fs = fused_shape(c, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, use_plain);
     const int tile = fused ? fs.tile : (M.R <= 3 ? 128 : 64);
     const int stride = fused ? fs.stride : c->lds_stride;
@@ -673,7 +686,8 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
   if (n_parents > 0) {
     // an ordinary level into other buffers (the streamed level's sub-slices) runs the plain instantiation: the code of a stored level
     static const bool plain_normal = std::getenv("VSRMC_STREAM_MODES_KERNEL") == nullptr;
-    const bool use_plain = !io && mode == MODE_NORMAL && plain_normal && c->plain_kernel;
+    const bool one_rank = !io || c->opt.world == 1;                // (world 1 through the level loop: nothing is remote — the unsharded instantiations)
+    const bool use_plain = one_rank && mode == MODE_NORMAL && plain_normal && c->plain_kernel;
     const FusedShape fs = fused_shape(c, src_max_bag, use_plain);
     u32 cchunk = 0;
     if (io) {
@@ -708,14 +722,14 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(ichunk_max, nx_cap / (4 * (u64)grid)));
     const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    const void* kern = io ? c->fused_kernel : use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
+    const void* kern = !one_rank ? c->fused_kernel : use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
     hipLaunchKernelGGL((ExpandKernel)kern, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, io ? c->opt.world : 1,
                        io ? io->cand_send : nullptr, io ? io->cand_cap : (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
                        ichunk, wchunk, tile, ccap, io ? c->filter : nullptr, io ? c->fmask : (u64)0, io ? c->cand_idx : nullptr, cchunk,
                        mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset,
-                       (const WSet*)(io ? c->d_wset : nullptr), c->wepoch);
+                       (const WSet*)((io && c->opt.world > 1) ? c->d_wset : nullptr), c->wepoch);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
   }

@@ -389,7 +389,7 @@ int deep_pass(vsrmc_checker* c, int last_regen, bool insert, vsrmc_level_info* i
   std::memset(&R.prb, 0, sizeof(R.prb));
   R.ins.viol_fp = R.ins.viol_index = R.prb.viol_fp = R.prb.viol_index = ~(u64)0;
   const double t0 = now_s();
-  if (io) {
+  if (io && c->opt.world > 1) {
     c->wepoch++;                                               // sharded: a regenerating lane takes a state by raising its epoch in the rank's winner set — nothing to clear
   } else if (c->deep_regen_done) {                             // the taken bits an earlier descent left in the levels beyond the base
     hipLaunchKernelGGL(k_table_untake, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1, c->level + 1);

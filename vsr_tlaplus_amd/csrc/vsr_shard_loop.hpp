@@ -603,7 +603,8 @@ int loop_deep_pass(void* ctx, const u64* sw, const u64* so, u64 n, u64 p_off, in
   vsrmc_shard_io io;
   io.cand_send = l->cand_send;
   io.cand_cap = l->cand_cap;
-  int rc = wset_ensure(c);                                     // the rank's winner set (vsr_kernels.hpp: WSet), allocated at the first deep pass
+  int rc = wset_ensure(c);                                     // the rank's winner set (vsr_kernels.hpp: WSet), allocated at the first deep pass (world > 1)
+  if (!rc && c->d_wset) c->wset_used = true;
   if (!rc) rc = expand_pass(c, sw, so, n, p_off, level, mode, bag, dst, &io);
   if (mode == MODE_REGEN) {
     // A regenerated level costs NO exchange (round 5): every rank rebuilds the states its own candidates inserted — it has kept their fingerprints
