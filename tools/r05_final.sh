@@ -16,3 +16,5 @@ tail -c 400 gpurun_out/r05_sharded_world2_gloo_bench.json
 python tools/make_cfg.py gpurun_out/README.cfg 3 1 "v1, v2, v3" 3
 vsr_tlaplus_amd/vsrmc -config gpurun_out/README.cfg -noTLA -audit > gpurun_out/r05_cli_readme_audit.log 2>&1
 grep -v "|->" gpurun_out/r05_cli_readme_audit.log | grep -v "^$" | head -60
+timeout 1200 python tools/run_models_deep.py --max-seconds 900 > gpurun_out/r05_models_exhausted_two_seeds.jsonl 2> gpurun_out/r05_models.err
+cut -c1-420 gpurun_out/r05_models_exhausted_two_seeds.jsonl; tail -n 2 gpurun_out/r05_models.err

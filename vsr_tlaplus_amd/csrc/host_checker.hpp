@@ -10,6 +10,8 @@ struct PassDst {            // where a pass writes (records, refs, fingerprints)
   u64* off = nullptr;
   u64* fp = nullptr;
   u64 cap = 0;
+  bool own_words = true;    // scratch buffers of the deep search: false = `words` is a piece of the idle record buffer (nothing to free)
+  bool own_index = true;    //                                      false = `off` / `fp` are the idle frontier's own arrays
 };
 struct DeepLevelRec { u64 n_new = 0, n_local = 0, generated = 0, max_bag = 0, frontier = 0; };   // n_local: this rank's share (unsharded: all)   // a level that exists in the seen-set only (vsr_deep.hpp)
 struct vsrmc_checker {
@@ -68,7 +70,10 @@ struct vsrmc_checker {
   u64 deep_distinct = 0, deep_generated = 0;
   bool deep_regen_done = false;          // a descent has set taken bits in the levels beyond the base: cleared before the next one
   bool rebase_off = false;               // a re-basing descent could not get its scratch buffers: not tried again (vsr_deep.hpp: deep_rebase)
-  std::vector<PassDst> scratch;          // scratch buffers of the descent, each a quarter of the one above down to a floor (allocated on first use)
+  std::vector<PassDst> scratch;          // scratch buffers 1 .. of the descent (vsr_deep.hpp: deep_plan_scratch; planned at the start of a pass)
+  PassDst scratch0;                      // buffer 0 of the descent when the plan CARVES the idle record buffer (words == nullptr: buffer 0 is that whole buffer)
+  bool scratch_carved = false;
+  u64 scratch_front = 0;                 // a re-basing plan: the first words of the idle record buffer are the descent's destination, not scratch
   // sharded deep search: the generator-side winner set (vsr_kernels.hpp: WSet) — which deep-level states THIS rank's candidates inserted
   WSet h_wset = {nullptr, nullptr, 0};
   WSet* d_wset = nullptr;                // the same three words on the device (what the kernels are handed); nullptr until the first deep pass

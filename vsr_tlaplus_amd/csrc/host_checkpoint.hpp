@@ -459,9 +459,9 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
   }
   if (c->lvl_fp) (void)hipFree(c->lvl_fp);
   for (PassDst& B : c->scratch) {
-    if (B.words) (void)hipFree(B.words);
-    if (B.off) (void)hipFree(B.off);
-    if (B.fp) (void)hipFree(B.fp);
+    if (B.words && B.own_words) (void)hipFree(B.words);
+    if (B.off && B.own_index) (void)hipFree(B.off);
+    if (B.fp && B.own_index) (void)hipFree(B.fp);
   }
   if (c->pending) (void)hipFree(c->pending);
   if (c->ctl) (void)hipFree(c->ctl);

@@ -89,51 +89,92 @@ struct DeepRun {
   int probed_level() const { return last_regen + (insert ? 2 : 1); }
 };
 
-// The scratch buffers of a descent: buffer 0 = the idle frontier buffers; buffers 1 .. count = what `count` more nesting levels write
-// into.  They share what is free on the device EQUALLY (at most a quarter of a record buffer each): a geometric series — a quarter of the one
-// above, round 3's rule for its one scratch buffer — starves the deepest levels of a long descent (eight levels down a buffer of 12e9 words
-// is 2e6 words: millions of launches of a few thousand states; the analysis model's run to depth 33 took 570 s that way).  Planned at the start
-// of a pass, when the buffers are empty; re-planned (freed and allocated anew) when a pass needs more levels than the plan has.
-int deep_plan_scratch(vsrmc_checker* c, int count) {
-  if (count <= 0 || (size_t)count <= c->scratch.size()) return 0;
-  if (count > 400) return fail(VSRMC_E_REP, "deep search: more than 400 nested levels");
+// The scratch buffers of a descent: buffer k takes what nesting level k yields (k = 0: the slices of level base + 1, ..).  Every state of every
+// regenerated level passes through its buffer once per descent, so the launches of a descent number about sum_k (level size / buffer k's capacity):
+// EQUAL buffers minimise that (a geometric series — round 3's rule — starves the deepest levels of a long descent: the analysis model's run to
+// depth 33 took 570 s that way).  Rounds 3-4: buffer 0 = the WHOLE idle record buffer, buffers 1 .. count = equal shares of what is free on the device
+// (the reserve autosize_options leaves: a third of a record buffer) — at twelve nested levels 59 GB for buffer 0 and 1.4 GB for each of the others.
+// Round 5: the idle record buffer and the reserve are ONE pool, cut into count + 1 equal buffers (the first ones pieces of the idle record buffer,
+// the rest — and every piece's index arrays — allocated from the reserve) whenever that lowers the sum above.  Planned at the start of a pass,
+// when the buffers are empty; re-planned (freed and allocated anew) when a pass needs more levels than the plan has, or the other kind of plan:
+// a re-basing descent (deep_rebase) writes the new base level INTO the front of the idle record buffer (`front` words, known exactly), uses no
+// buffer 0, and cuts its buffers 1 .. count out of what lies behind that front and the reserve.
+void deep_free_scratch(vsrmc_checker* c) {
   for (PassDst& B : c->scratch) {
-    if (B.words) (void)hipFree(B.words);
-    if (B.off) (void)hipFree(B.off);
-    if (B.fp) (void)hipFree(B.fp);
+    if (B.words && B.own_words) (void)hipFree(B.words);
+    if (B.off && B.own_index) (void)hipFree(B.off);
+    if (B.fp && B.own_index) (void)hipFree(B.fp);
   }
   c->scratch.clear();
+  c->scratch0 = PassDst();
+  c->scratch_carved = false;
+  c->scratch_front = 0;
+}
+
+int deep_plan_scratch(vsrmc_checker* c, int count, bool carve = true, u64 front = 0) {
+  if (count < 0) count = 0;
+  if (count > 400) return fail(VSRMC_E_REP, "deep search: more than 400 nested levels");
+  const int nxt = c->cur ^ 1;
+  if ((c->host_frontier >> nxt) & 1) carve = false;              // (records in pinned host memory: scratch stays on the device)
+  front = (front + 63) & ~(u64)63;
+  if ((size_t)count <= c->scratch.size() && c->scratch_front == front && (c->scratch_carved == carve || (count == 0 && !carve))) return 0;
+  deep_free_scratch(c);
+  if (count == 0) return 0;                                       // one level below the base: buffer 0 (the idle record buffer) is all a pass needs
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  const int nxt = c->cur ^ 1;
-  // per buffer: W words of records + W / 12 state indices (refs + fingerprints: 16 B each) = 9.33 B per word
   const char* share_env = std::getenv("VSRMC_AUTOSIZE_SHARE");   // several checkers on one device (tests: ranks sharing a GPU)
   const double share = share_env ? std::max(1.0, std::atof(share_env)) : 1.0;
-  const double budget = std::max(0.0, (double)free_b - 1.0e9) / share / (double)count;
-  u64 wcap = (u64)std::min((double)(c->words_cap(nxt) / 4), budget / 9.34);
-  wcap = std::max<u64>((u64)1 << 21, wcap);                        // floor: 16 MB of records (tiny spaces; a device without that much left fails below)
-  for (int k = 0; k < count; k++) {
+  const double reserve = std::max(0.0, (double)free_b - 1.0e9) / share;   // bytes
+  if (front >= c->words_cap(nxt)) carve = false;
+  const double idle_w = (double)(c->words_cap(nxt) - (carve ? front : 0));   // what of the idle record buffer the plan may cut up
+  const int with0 = front ? 0 : 1;                               // a plan with a front has no buffer 0 (the front IS the pass's destination)
+  // per buffer from the reserve: W words of records + W / 12 state indices (refs + fingerprints: 16 B each) = 9.34 B per word; a piece of the idle
+  // record buffer only needs its index arrays there: 1.34 B per word
+  const u64 floor_w = (u64)1 << 21;                              // 16 MB of records (tiny spaces; a device without that much left fails below)
+  const double w_old = std::max((double)floor_w, std::min(idle_w / 4.0, reserve / (double)count / 9.34));   // rounds 3-4: buffers 1 .. count
+  const double cost_old = (with0 ? 1.0 / idle_w : 0.0) + (double)count / w_old;
+  int best_n = 0;
+  double best_s = 0;
+  if (carve)
+    for (int n_idle = 1; n_idle <= count + with0; n_idle++) {
+      const double from_res = (double)(count + with0 - n_idle) * 9.34 + (double)(n_idle - with0) * 1.34;
+      const double s = std::min(idle_w / (double)n_idle, from_res > 0 ? reserve / from_res : 1e30);
+      if (s > best_s) { best_s = s; best_n = n_idle; }
+    }
+  const bool carved = carve && best_n >= 1 + with0 && best_s >= (double)floor_w && (double)(count + with0) / best_s < cost_old;
+  const u64 wcap = carved ? (u64)best_s & ~(u64)63 : (u64)w_old;
+  auto alloc_index = [&](PassDst& B) -> bool {
+    B.cap = std::max<u64>((u64)1 << 15, B.words_cap / 12);
+    return hipMalloc((void**)&B.off, (B.cap + 1) * 8) == hipSuccess && hipMalloc((void**)&B.fp, B.cap * 8) == hipSuccess;
+  };
+  bool ok = true;
+  if (carved && with0) {
+    c->scratch0.words = c->words[nxt]; c->scratch0.words_cap = wcap; c->scratch0.own_words = false;
+    c->scratch0.off = c->off[nxt]; c->scratch0.fp = c->lvl_fp; c->scratch0.own_index = false;
+    c->scratch0.cap = std::min<u64>(c->opt.frontier_states, std::max<u64>((u64)1 << 15, wcap / 12));
+  }
+  for (int k = 1; k <= count && ok; k++) {
     PassDst B;
     B.words_cap = wcap;
-    B.cap = std::max<u64>((u64)1 << 15, wcap / 12);
-    hipError_t e = hipMalloc((void**)&B.words, B.words_cap * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&B.off, (B.cap + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&B.fp, B.cap * 8);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      if (B.words) (void)hipFree(B.words);
-      if (B.off) (void)hipFree(B.off);
-      if (B.fp) (void)hipFree(B.fp);
-      return fail(VSRMC_E_HIP, std::string("hipMalloc of a deep-search scratch buffer: ") + hipGetErrorString(e));
-    }
-    c->scratch.push_back(B);
+    if (carved && k - 1 + with0 < best_n) { B.words = c->words[nxt] + front + (u64)(k - 1 + with0) * wcap; B.own_words = false; }   // piece k - 1 + with0 behind the front
+    else ok = hipMalloc((void**)&B.words, B.words_cap * 8) == hipSuccess;
+    ok = ok && alloc_index(B);
+    c->scratch.push_back(B);                                     // (pushed even when an allocation failed: deep_free_scratch releases what it holds)
   }
+  if (!ok) {
+    (void)hipGetLastError();
+    deep_free_scratch(c);
+    return fail(VSRMC_E_HIP, "hipMalloc of a deep-search scratch buffer failed");
+  }
+  c->scratch_carved = carve;
+  c->scratch_front = front;
   return 0;
 }
 
 int deep_buffer(vsrmc_checker* c, int k, PassDst* out) {
   const int nxt = c->cur ^ 1;
   if (k == 0) {
+    if (c->scratch0.words) { *out = c->scratch0; return 0; }     // a piece of the idle record buffer (the plan carved it)
     out->words = c->words[nxt]; out->words_cap = c->words_cap(nxt); out->off = c->off[nxt]; out->fp = c->lvl_fp; out->cap = c->opt.frontier_states;
     return 0;
   }
@@ -198,7 +239,7 @@ int deep_export(DeepRun& R, const PassDst& B, u64 part) {
   if (!part) return 0;
   const int nxt = c->cur ^ 1;
   hipLaunchKernelGGL(k_export, dim3((unsigned)((part + 63) / 64)), dim3(64), 0, c->stream, (const u64*)B.words, B.off, B.fp, (u64)0, part,
-                     c->words[nxt], c->words_cap(nxt), c->off[nxt], c->lvl_fp, c->opt.frontier_states, R.d_cnt, R.d_err);
+                     c->words[nxt], c->scratch_front ? c->scratch_front : c->words_cap(nxt), c->off[nxt], c->lvl_fp, c->opt.frontier_states, R.d_cnt, R.d_err);   // (never past the front: scratch lies behind it)
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return fail(VSRMC_E_HIP, "deep search: k_export (re-basing)");
   return 0;
 }
@@ -489,7 +530,10 @@ int deep_rebase(vsrmc_checker* c, vsrmc_level_info* out) {
   R.ins.viol_fp = R.ins.viol_index = R.prb.viol_fp = R.prb.viol_index = ~(u64)0;
   const double t0 = now_s();
   // buffer 0 of an ordinary descent IS the idle record buffer: here it is the destination, so the levels base+1 .. K go through scratch buffers 1 .. deep
-  int rc = deep_plan_scratch(c, c->deep);
+  // the new base level goes to the FRONT of the idle record buffer, packed: at most n x (fixed + largest bag) words (rebase_pays holds that under 80 % of
+  // the buffer); the descent's buffers 1 .. deep are cut from what lies behind it and from the reserve
+  const u64 front_w = c->deep_lv.back().n_new * (u64)(M.fixed + (int)std::min<u64>(c->deep_lv.back().max_bag, (u64)M.max_bag));
+  int rc = deep_plan_scratch(c, c->deep, true, front_w);
   if (rc) { c->rebase_off = true; return 1; }                    // no memory for one more scratch buffer: the search goes on without re-basing
   if (c->deep_regen_done) {
     hipLaunchKernelGGL(k_table_untake, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1, c->level + 1);
