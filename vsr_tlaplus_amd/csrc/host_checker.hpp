@@ -54,6 +54,7 @@ struct vsrmc_checker {
   void* fused_kernel = nullptr;
   void* plain_kernel = nullptr;          // the same without modes / sharding, when the configuration has one (ordinary unsharded levels)
   void* modes_kernel = nullptr;          // the same without sharding (expand_pass: the passes of vsrmc_checker_probe / _probe2 / _probe3), or null
+  void* regen_bits_kernel = nullptr, *insert_kernel = nullptr;   // ... with ONE mode compiled in (k_expand: PLAIN == 3 / 4), or null
   u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
   bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
   // vsrmc_checker_probe / _probe2: where the reported violator's counter-example is walked from — the fingerprint of the deepest
@@ -79,6 +80,9 @@ struct vsrmc_checker {
   WSet* d_wset = nullptr;                // the same three words on the device (what the kernels are handed); nullptr until the first deep pass
   u32 wepoch = 0;                        // the number of the descent in flight
   bool wset_used = false, wset_dirty = false;   // this search has put states into the set / a reset came after that: emptied before the next use
+  // unsharded deep search: which (parent, ordinal) instance of the stored base inserted each state of the first seen-set-only level (vsr_deep.hpp)
+  u32* claim_bits = nullptr;
+  u64 claim_w = 0, claim_parents = 0;    // words per parent; parents covered (= the base level's index range)
   bool full_recoverable = false;         // the last vsrmc_checker_step stopped with "frontier full" and lost nothing but records: the level is complete in the
                                          // seen-set and vsrmc_checker_advance keeps it as a seen-set-only level (host_search.hpp: adopt_overflowed_level)
   u64 hist_new[2] = {0, 0};              // new states of the last two levels (growth estimate of vsrmc_checker_advance)
@@ -131,6 +135,16 @@ ExpandKernel modes_kernel_for(const Model& M) {               // unsharded passe
     case 312: return k_expand<true, 312, 2>;
     case 313: return k_expand<true, 313, 2>;
     case 512: return k_expand<true, 512, 2>;
+    default: return nullptr;
+  }
+}
+// one mode compiled in (k_expand: PLAIN == 3 / 4): which = MODE_REGEN (by the claim bitmap) or MODE_INSERT
+ExpandKernel one_mode_kernel_for(const Model& M, int which) {
+  if (M.model_id != 0) return nullptr;
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 312: return which == MODE_REGEN ? k_expand<true, 312, 3> : k_expand<true, 312, 4>;
+    case 313: return which == MODE_REGEN ? k_expand<true, 313, 3> : k_expand<true, 313, 4>;
+    case 512: return which == MODE_REGEN ? k_expand<true, 512, 3> : k_expand<true, 512, 4>;
     default: return nullptr;
   }
 }
@@ -191,6 +205,16 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
   return f;
 }
 
+// The seen-set's memory.  EXPERIMENT KNOB (environment, read per allocation): VSRMC_TABLE_MEM=uncached | finegrained allocates it with
+// hipExtMallocWithFlags(hipDeviceMallocUncached | hipDeviceMallocFinegrained) — every probe misses the caches anyway (the table is 100 x the L2 + Infinity
+// Cache), and a cached 16-byte probe drags a 128-byte line through the fabric; unset = hipMalloc (the product's default).
+hipError_t table_alloc(Slot** out, u64 slots) {
+  const char* e = std::getenv("VSRMC_TABLE_MEM");
+  if (e && std::strcmp(e, "uncached") == 0) return hipExtMallocWithFlags((void**)out, slots * sizeof(Slot), hipDeviceMallocUncached);
+  if (e && std::strcmp(e, "finegrained") == 0) return hipExtMallocWithFlags((void**)out, slots * sizeof(Slot), hipDeviceMallocFinegrained);
+  return hipMalloc((void**)out, slots * sizeof(Slot));
+}
+
 // the winner set of a sharded deep search: allocated at the first pass beyond the record buffers, half as many slots as the seen-set (the memory
 // autosize_options set aside for it), emptied whenever the search starts over
 int wset_ensure(vsrmc_checker* c) {
@@ -248,6 +272,7 @@ int checker_seed(vsrmc_checker* c) {
   c->failed_code = 0;
   c->full_recoverable = false;
   HIPCHK(hipSetDevice(c->opt.device));
+  if (c->claim_bits) { (void)hipFree(c->claim_bits); c->claim_bits = nullptr; c->claim_w = c->claim_parents = 0; }
   if (c->d_wset && c->wset_used) c->wset_dirty = true;           // (a fresh search: the next sharded deep pass empties the winner set before it uses it)
   c->wset_used = false;
   hipLaunchKernelGGL(k_table_init, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1);
@@ -382,7 +407,7 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o_in, vs
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
   u64 slots = (u64)1 << o->table_log2;
   c->tmask = slots - 1;
-  hipError_t e = hipMalloc((void**)&c->table, slots * sizeof(Slot));
+  hipError_t e = table_alloc(&c->table, slots);
   c->host_frontier = o->host_frontier & 3;
   for (int b = 0; b < 2 && e == hipSuccess; b++) {
     // host_frontier: the records stay in pinned host memory and the kernels read / write them over PCIe (zero-copy); the
@@ -407,6 +432,10 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o_in, vs
   c->fused_kernel = (void*)fused_kernel_for(M);
   c->modes_kernel = (void*)modes_kernel_for(M);
   c->plain_kernel = (void*)plain_kernel_for(M);
+  if (!std::getenv("VSRMC_NO_MODE_KERNELS")) {                   // (A/B knob: the run-time-switched instantiation for every pass, as in rounds 3-4)
+    c->regen_bits_kernel = (void*)one_mode_kernel_for(M, MODE_REGEN);
+    c->insert_kernel = (void*)one_mode_kernel_for(M, MODE_INSERT);
+  }
   rc = checker_seed(c);
   if (rc) { vsrmc_checker_destroy(c); return rc; }
   *out = c;
@@ -683,7 +712,8 @@ namespace {
 // slice just wrote), unsharded.  Resets the level counters, returns them in c->h.  Destination = the next-frontier buffers.
 // io != nullptr: a pass of a sharded run (vsr_deep.hpp) — successors owned by other ranks are announced into io's buckets
 int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 n_parents, u64 p_offset, int level, int mode,
-                u64 src_max_bag, const PassDst* dst = nullptr, const vsrmc_shard_io* io = nullptr) {
+                u64 src_max_bag, const PassDst* dst = nullptr, const vsrmc_shard_io* io = nullptr,
+                u32* claim_bits = nullptr, u64 claim_w = 0 /* unsharded MODE_INSERT / MODE_REGEN over the stored base: the claim bitmap (vsr_deep.hpp) */) {
   const Model& M = c->model.M;
   std::memset(&c->h, 0, sizeof(c->h));
   c->h.viol_fp = ~(u64)0;
@@ -728,11 +758,16 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     const void* kern = !one_rank ? c->fused_kernel : use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
+    if (one_rank && !use_plain) {                                // a pass that knows its mode: the instantiation with only that mode in it, when the configuration has one
+      if (mode == MODE_REGEN && claim_bits && c->regen_bits_kernel && claim_w <= 2 * (u64)(VSR_BLOCK / fs.tile)) kern = c->regen_bits_kernel;   // (two bitmap words per thread)
+      else if (mode == MODE_INSERT && c->insert_kernel) kern = c->insert_kernel;
+    }
+    if (claim_bits && kern != c->regen_bits_kernel && kern != c->insert_kernel) { claim_bits = nullptr; claim_w = 0; }   // (only those two know the bitmap)
     hipLaunchKernelGGL((ExpandKernel)kern, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, io ? c->opt.world : 1,
                        io ? io->cand_send : nullptr, io ? io->cand_cap : (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
-                       ichunk, wchunk, tile, ccap, io ? c->filter : nullptr, io ? c->fmask : (u64)0, io ? c->cand_idx : nullptr, cchunk,
+                       ichunk, wchunk, tile, ccap, io ? c->filter : (u64*)claim_bits, io ? c->fmask : claim_w, io ? c->cand_idx : nullptr, cchunk,
                        mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset,
                        (const WSet*)((io && c->opt.world > 1) ? c->d_wset : nullptr), c->wepoch);
     HIPCHK(hipGetLastError());

@@ -470,6 +470,7 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
   if (c->filter) (void)hipFree(c->filter);
   if (c->cand_idx) (void)hipFree(c->cand_idx);
   wset_free(c);
+  if (c->claim_bits) (void)hipFree(c->claim_bits);
   for (int i = 0; i < 4; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);

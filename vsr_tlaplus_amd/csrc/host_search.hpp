@@ -224,6 +224,7 @@ static int adopt_overflowed_level(vsrmc_checker* c, vsrmc_level_info* ins) {
   }
   c->deep = 1;
   c->deep_lv.assign(1, DeepLevelRec());
+  if (c->claim_bits) { (void)hipFree(c->claim_bits); c->claim_bits = nullptr; c->claim_w = c->claim_parents = 0; }   // (an ordinary level leaves no claim bitmap)
   DeepLevelRec& dl = c->deep_lv[0];
   dl.n_new = dl.n_local = sums[2]; dl.generated = h.generated; dl.max_bag = h.max_bag; dl.frontier = c->n_valid;
   c->deep_g = std::max<u64>(c->deep_g, (h.generated + c->n_valid - 1) / std::max<u64>(1, c->n_valid) + 1);
@@ -248,12 +249,13 @@ static int table_grow(vsrmc_checker* c) {
   HIPCHK(hipSetDevice(c->opt.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   const u64 old_slots = c->tmask + 1, new_slots = old_slots * 2;
+  deep_free_scratch(c);                                         // the deep search's scratch buffers are empty between two passes: the next pass plans them anew
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   if ((double)free_b < (double)new_slots * sizeof(Slot) + 512e6) return 1;
   Slot* nt = nullptr;
   u32* d_err = nullptr;
-  if (hipMalloc((void**)&nt, new_slots * sizeof(Slot)) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  if (table_alloc(&nt, new_slots) != hipSuccess) { (void)hipGetLastError(); return 1; }
   if (hipMalloc((void**)&d_err, 4) != hipSuccess || hipMemsetAsync(d_err, 0, 4, c->stream) != hipSuccess) {
     (void)hipFree(nt);
     if (d_err) (void)hipFree(d_err);

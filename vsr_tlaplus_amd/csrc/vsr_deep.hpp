@@ -193,7 +193,27 @@ void deep_acc(vsrmc_level_info* t, const LevelCtl& h, double ms) {
 
 int deep_run_pass(DeepRun& R, const u64* sw, const u64* so, u64 n, u64 p_off, int level, int mode, u64 bag, const PassDst* dst) {
   if (R.io) return R.io->pass(R.io->ctx, sw, so, n, p_off, level, mode, bag, dst);
-  return expand_pass(R.c, sw, so, n, p_off, level, mode, bag, dst);
+  // the claim bitmap of the first seen-set-only level: written by the pass that inserts it, read by every pass that regenerates it (both expand the stored base)
+  const bool first = level == R.base + 1 && R.c->claim_bits && (mode == MODE_INSERT || mode == MODE_REGEN) && p_off + n <= R.c->claim_parents;
+  return expand_pass(R.c, sw, so, n, p_off, level, mode, bag, dst, nullptr, first ? R.c->claim_bits : nullptr, first ? R.c->claim_w : 0);
+}
+
+// One bit per (parent of the base level, ordinal): 4 x ceil(ordinals / 32) bytes per parent (README: 20 B x 2.6e8 parents = 5 GB), from the reserve.
+// No memory for it: the regenerating passes keep asking the seen-set (MODE_REGEN's other rule).
+void deep_claim_bits_alloc(vsrmc_checker* c, u64 src_max_bag) {
+  if (c->claim_bits) { (void)hipFree(c->claim_bits); c->claim_bits = nullptr; }
+  c->claim_w = c->claim_parents = 0;
+  if (c->opt.world > 1 || !c->regen_bits_kernel || !c->insert_kernel || std::getenv("VSRMC_NO_CLAIM_BITS")) return;   // (two instantiations of k_expand know the bitmap)
+  const Model& M = c->model.M;
+  const u64 ords = (u64)M.m0 + std::min<u64>(src_max_bag, (u64)M.max_bag) * (u64)(M.R + 1) + 1;
+  const u64 w = (ords + 31) / 32, bytes = c->n_frontier * w * 4;
+  if (w > 8) return;                                             // (k_expand<.., 3> reads two words per thread, four threads per record at 64-record tiles)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)bytes > 0.4 * (double)free_b) return;
+  if (hipMalloc((void**)&c->claim_bits, std::max<u64>(bytes, 4)) != hipSuccess) { (void)hipGetLastError(); c->claim_bits = nullptr; return; }
+  if (hipMemsetAsync(c->claim_bits, 0, std::max<u64>(bytes, 4), c->stream) != hipSuccess) { (void)hipFree(c->claim_bits); c->claim_bits = nullptr; return; }
+  c->claim_w = w;
+  c->claim_parents = c->n_frontier;
 }
 bool deep_more(DeepRun& R, bool mine, int* rc) {               // does ANY rank have another slice?  (unsharded: this one)
   u64 f = (mine ? 1 : 0) | (R.err ? 2 : 0);
@@ -375,6 +395,7 @@ int deep_first_pass(vsrmc_checker* c, vsrmc_level_info* ins, const DeepIo* io = 
   c->deep = 1;
   c->deep_lv.assign(1, DeepLevel());
   const u64 cb = deep_cand_bound(R, std::max<u64>(c->deep_g, c->g_last));
+  if (!io) deep_claim_bits_alloc(c, bagL);
   int rc = 0;
   for (u64 a = 0; deep_more(R, a < c->n_frontier, &rc);) {
     if (rc) break;
@@ -576,6 +597,7 @@ int deep_rebase(vsrmc_checker* c, vsrmc_level_info* out) {
   c->g_last = (top.generated + std::max<u64>(1, top.frontier) - 1) / std::max<u64>(1, top.frontier) + 1;
   c->deep = 0;
   c->deep_lv.clear();
+  if (c->claim_bits) { (void)hipFree(c->claim_bits); c->claim_bits = nullptr; c->claim_w = c->claim_parents = 0; }   // (it described the old base's successors)
   c->deep_regen_done = false;                                   // lvl_fp holds the new base level's fingerprints (k_export carried them along)
   std::memset(out, 0, sizeof(*out));
   out->level = K;

@@ -460,7 +460,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   // code: the specialised kernel then fits the 64-KB instruction cache with room to spare)
   // PLAIN == 2: unsharded with the modes (the probe / virtual / regenerated / streamed passes of vsrmc_checker_probe*): only the
   // sharded branches are compiled out — the mode-capable kernel of the README configuration then fits the 64-KB instruction cache
-  const int mode = PLAIN == 1 ? (int)MODE_NORMAL : (mode_arg & 0xFF);
+  // PLAIN == 3 / 4 (round 5): unsharded with ONE mode compiled in — 3 = MODE_REGEN by the claim bitmap (no guards and no seen-set code at all), 4 =
+  // MODE_INSERT (a virtual level: no successor write; leaves the claim bitmap).  The mode-capable instantiation carries every mode behind a run-time switch
+  // and pays for it in registers (its README build spills 27 VGPRs; one more branch took that to 93, and every pass 10 % with it): a pass that knows its mode
+  // runs leaner code.  (A probe-only instantiation was built too and lost to the run-time-switched one — 88 spilled VGPRs: DESIGN.md §8.5.)
+  const int mode = PLAIN == 1 ? (int)MODE_NORMAL : PLAIN == 3 ? (int)MODE_REGEN : PLAIN == 4 ? (int)MODE_INSERT : (mode_arg & 0xFF);
   // MODE_NO_FOOTPRINT: the probe pass applies every action — the caller has seen a violating state among the parents' levels (a search that
   // went on after a reported violation), and a violating parent hands its verdict to successors of actions outside the footprint
   const bool no_footprint = PLAIN != 1 && (mode_arg & MODE_NO_FOOTPRINT) != 0;
@@ -531,6 +535,19 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     if (tile_i >= ntiles) break;
     const u64 p_base = tile_i * (u64)tile;
     const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
+    // PLAIN == 3 (regeneration by the claim bitmap): the bitmap IS the list of enabled instances that matter — the (parent, ordinal) pairs whose lane
+    // made a state when the level was inserted.  The words of this thread's record (thread g of the record's G threads takes words g and g + G; the host
+    // offers the bitmap only when 2 G words cover a parent) are fetched now, so that their latency hides behind the staging loads.
+    u32 cbits[2] = {0u, 0u};
+    if constexpr (PLAIN == 3) {
+      const int pm = tid & (tile - 1), gg = tid >> tshift, GG = BLK >> tshift;
+      if (pm < np_tile) {
+        const u32* row = (const u32*)filter + (p_offset + p_base + (u64)pm) * fmask;
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+          if ((u64)(gg + q * GG) < fmask) cbits[q] = row[gg + q * GG];
+      }
+    }
 
     // ---- stage the tile.  Frontier refs are (word offset << 8 | length): one coalesced load of 64 refs, then 16 lanes per
     // record / 16 records per pass, all 16 loads of a thread issued before the first LDS store (one HBM latency per tile)
@@ -624,6 +641,31 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           s_alive[p] = 1;
         };
         const int G = BLK >> tshift, g = tid >> tshift;     // threads per record, this thread's rank among them
+        if constexpr (PLAIN == 3) {
+          // no guards, no bag scans: every set bit is an instance that was enabled (and made a state) when the level was inserted; only its action id has
+          // to be found again — by the ordinal's range, or, for a message-bound one, by the one slot's own guard (which also names the action)
+          if (mine_valid) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              u32 bits = cbits[q];
+              while (bits) {
+                const int b = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const int ord = 32 * (g + q * G) + b;
+                int kind;
+                if (ord < M.m0) {
+                  kind = ord < M.R ? A_TimerSendSVC : ord < 2 * M.R ? A_SendDVC : ord < 3 * M.R ? A_SendSV : ord < 4 * M.R ? A_ExecuteOp : A_ReceiveClientRequest;
+                } else {
+                  const int q2 = ord - M.m0, j = q2 / (M.R + 1), k2 = q2 - j * (M.R + 1);
+                  int kind0 = 0;
+                  (void)Ops::guard(M, rec_mine, M.m0 + j, &kind0);
+                  kind = k2 == 0 ? kind0 : Ops::other_kind(kind0);
+                }
+                emit(kind, p_mine, ord);
+              }
+            }
+          }
+        } else {
         u64 lut[6] = {0, 0, 0, 0, 0, 0};
         if (mine_valid) {
 #pragma unroll
@@ -681,6 +723,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             VSR_SYNC();
           }
         }
+        }   // (PLAIN != 3)
       } else
       {
       // four independent guard evaluations per trip
@@ -897,6 +940,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           }
         } else if (mode == MODE_REGEN && PLAIN == 0 && wset) {
           do_write = wset_take(wset, fp, level, wepoch);        // the same rule for the states this rank owns itself: no seen-set access in a sharded regeneration
+        } else if (PLAIN == 3) {
+          // The first seen-set-only level, unsharded (round 5): the pass that INSERTED it left one bit per (parent, ordinal) whose lane made a state
+          // (`filter` / `fmask` carry the bitmap and its words per parent here — an unsharded pass has no sent-filter).  That instance rebuilds the
+          // state: no seen-set access at all, exactly once by construction (a state has one inserting lane).
+          do_write = (((const u32*)filter)[(p_offset + p_base + (u64)p) * fmask + ((u32)ord >> 5)] >> ((u32)ord & 31u)) & 1u;
         } else if (mode == MODE_REGEN) {
           u64 m = META_EMPTY;
           u64 slot_i = 0;
@@ -912,6 +960,8 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           do_write = claimed;
           claimed_now = claimed;
           if (PLAIN == 0 && wset && claimed && !wset_insert(wset, fp, level)) raise_error(ctl, ERR_TABLE_FULL, fp);   // a state this rank's own lane made
+          if (PLAIN == 4 && filter && claimed)   // unsharded virtual level: remember WHICH instance made the state (see PLAIN == 3 above)
+            atomicOr(&((u32*)filter)[(p_offset + p_base + (u64)p) * fmask + ((u32)ord >> 5)], 1u << ((u32)ord & 31u));
         }
         // the ONE evaluation of the invariants (three inlined copies pushed the mode-capable kernels out of the instruction cache)
         int bad = (check || do_write || (remote && mode == MODE_INSERT)) ? Ops::invariants(M, rec, D) : 0;
