@@ -758,6 +758,10 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     const void* kern = !one_rank ? c->fused_kernel : use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
+    // the claim bitmap of the first seen-set-only level (vsr_deep.hpp): written by the pass that inserts it, read by every pass that regenerates it — both
+    // expand the stored base (level c->level), slice by slice, p_offset = the slice's first parent
+    if (!claim_bits && c->claim_bits && one_rank && level == c->level + 1 && (mode == MODE_INSERT || mode == MODE_REGEN) &&
+        p_offset + n_parents <= c->claim_parents) { claim_bits = c->claim_bits; claim_w = c->claim_w; }
     if (one_rank && !use_plain) {                                // a pass that knows its mode: the instantiation with only that mode in it, when the configuration has one
       if (mode == MODE_REGEN && claim_bits && c->regen_bits_kernel && claim_w <= 2 * (u64)(VSR_BLOCK / fs.tile)) kern = c->regen_bits_kernel;   // (two bitmap words per thread)
       else if (mode == MODE_INSERT && c->insert_kernel) kern = c->insert_kernel;
@@ -767,7 +771,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, io ? c->opt.world : 1,
                        io ? io->cand_send : nullptr, io ? io->cand_cap : (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
-                       ichunk, wchunk, tile, ccap, io ? c->filter : (u64*)claim_bits, io ? c->fmask : claim_w, io ? c->cand_idx : nullptr, cchunk,
+                       ichunk, wchunk, tile, ccap, !one_rank ? c->filter : (u64*)claim_bits, !one_rank ? c->fmask : claim_w, io ? c->cand_idx : nullptr, cchunk,
                        mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset,
                        (const WSet*)((io && c->opt.world > 1) ? c->d_wset : nullptr), c->wepoch);
     HIPCHK(hipGetLastError());

@@ -193,9 +193,7 @@ void deep_acc(vsrmc_level_info* t, const LevelCtl& h, double ms) {
 
 int deep_run_pass(DeepRun& R, const u64* sw, const u64* so, u64 n, u64 p_off, int level, int mode, u64 bag, const PassDst* dst) {
   if (R.io) return R.io->pass(R.io->ctx, sw, so, n, p_off, level, mode, bag, dst);
-  // the claim bitmap of the first seen-set-only level: written by the pass that inserts it, read by every pass that regenerates it (both expand the stored base)
-  const bool first = level == R.base + 1 && R.c->claim_bits && (mode == MODE_INSERT || mode == MODE_REGEN) && p_off + n <= R.c->claim_parents;
-  return expand_pass(R.c, sw, so, n, p_off, level, mode, bag, dst, nullptr, first ? R.c->claim_bits : nullptr, first ? R.c->claim_w : 0);
+  return expand_pass(R.c, sw, so, n, p_off, level, mode, bag, dst);   // (expand_pass finds the claim bitmap of the first seen-set-only level by itself)
 }
 
 // One bit per (parent of the base level, ordinal): 4 x ceil(ordinals / 32) bytes per parent (README: 20 B x 2.6e8 parents = 5 GB), from the reserve.
@@ -289,7 +287,7 @@ int deep_descend(DeepRun& R, const u64* src_words, const u64* src_off, u64 n_idx
     if (rc) return rc;
     const u64 n = a < n_idx ? std::min<u64>(sl.next(), n_idx - a) : 0;   // (a rank that has run out still takes part in the others' exchanges)
     c->expand_ms = 0;
-    rc = deep_run_pass(R, src_words, src_off + a, n, R.io ? 0 : a, lv + 1, regen ? MODE_REGEN : MODE_NORMAL, src_bag, &B);
+    rc = deep_run_pass(R, src_words, src_off + a, n, (R.io && c->opt.world > 1) ? 0 : a, lv + 1, regen ? MODE_REGEN : MODE_NORMAL, src_bag, &B);
     if (rc) return rc;
     if (n) R.launches++;
     a += n;
@@ -395,13 +393,13 @@ int deep_first_pass(vsrmc_checker* c, vsrmc_level_info* ins, const DeepIo* io = 
   c->deep = 1;
   c->deep_lv.assign(1, DeepLevel());
   const u64 cb = deep_cand_bound(R, std::max<u64>(c->deep_g, c->g_last));
-  if (!io) deep_claim_bits_alloc(c, bagL);
+  if (!io || c->opt.world == 1) deep_claim_bits_alloc(c, bagL);   // (one rank through the level loop: nothing is remote, the unsharded mechanism applies)
   int rc = 0;
   for (u64 a = 0; deep_more(R, a < c->n_frontier, &rc);) {
     if (rc) break;
     const u64 n = a < c->n_frontier ? std::min<u64>(cb, c->n_frontier - a) : 0;
     c->expand_ms = 0;
-    rc = deep_run_pass(R, c->words[c->cur], c->off[c->cur] + a, n, io ? 0 : a, c->level + 1, MODE_INSERT, bagL, nullptr);
+    rc = deep_run_pass(R, c->words[c->cur], c->off[c->cur] + a, n, (io && c->opt.world > 1) ? 0 : a, c->level + 1, MODE_INSERT, bagL, nullptr);
     if (rc) break;
     a += n;
     if (n) R.launches++;
