@@ -247,3 +247,18 @@ def test_make_cfg_tool_writes_a_cfg_the_loader_accepts(vt, tmp_path):
     lay = vt.Model.load(str(out)).layout
     assert (lay.replica_count, lay.client_count, lay.value_count, lay.start_view_on_timer_limit) == (3, 1, 3, 3)
     assert lay.symmetry == 1 and lay.permutations == 6 and lay.invariant_mask == 1
+
+
+def test_test_hooks_live_in_the_hooks_library_only(vt):
+    """Round-4 review (hygiene): the test hook VSRMC_TEST_FORCE_BAD is compiled only with -DVSRMC_TEST_HOOKS — into libvsrmc_hooks.so, which
+    vsr_tlaplus_amd/build.py makes beside the product library and only tests/test_sharded_gloo.py loads.  The product library does not even contain
+    the variable's name; both export the same C ABI."""
+    from vsr_tlaplus_amd import capi
+    here = os.path.dirname(capi.LIB_PATH)
+    prod = open(os.path.join(here, "libvsrmc.so"), "rb").read()
+    hooks = open(os.path.join(here, "libvsrmc_hooks.so"), "rb").read()
+    assert b"VSRMC_TEST_FORCE_BAD" not in prod
+    assert b"VSRMC_TEST_FORCE_BAD" in hooks
+    lib = C.CDLL(os.path.join(here, "libvsrmc_hooks.so"))
+    for name in capi.SYMBOLS:
+        assert hasattr(lib, name), name
