@@ -314,8 +314,8 @@ def run_deep_world(world, params, inv_mask, max_depth, tmp_path, port, fw_log2=0
 @pytest.mark.parametrize("world,rb", [(2, 0), (3, 300)])
 def test_sharded_deep_levels_against_the_oracle(tmp_path, world, rb):
     """(3,1,{v1,v2},1) with AcknowledgedWritesExistOnMajority (violated at depth 19, 109 878 states) on 2 / 3 ranks with record buffers
-    of 2^17 words: a few sharded levels are stored, the rest live in the ranks' seen-sets only — virtual, regenerated (every rank's
-    candidates shown to their owners, the one carrying the slot's final key rebuilt by k_materialize), streamed and probed levels, each
+    of 2^17 words: a few sharded levels are stored, the rest live in the ranks' seen-sets only — virtual, regenerated (every rank rebuilds the
+    states ITS candidates inserted — its winner set — once per descent, asking nobody: round 5), streamed and probed levels, each
     held against the oracle: new states, successors in total and per action, deadlocks, largest bag, and for the levels that are never
     stored the xor / sum of their fingerprints.  The violation is found by a probe pass; its counter-example replays in the oracle."""
     from oracle import orc
@@ -424,8 +424,8 @@ def test_violation_of_any_mask_on_a_remotely_owned_successor_is_reported(tmp_pat
 @pytest.mark.parametrize("world,rb,deep_at", [(2, 0, 8), (3, 200, 10)])
 def test_sharded_deep_protocol_on_the_cpu_stand_in(tmp_path, world, rb, deep_at):
     """The protocol of the levels beyond the ranks' record buffers (virtual level: announce -> first inserter wins -> winners counted;
-    regenerated level: every candidate shown to its owner, the one whose key is the slot's final meta word rebuilds the state, exactly
-    once per descent; inserted level + probe with the candidates shown to their owners) as the Python loop runs it over the CPU stand-in
+    regenerated level: local — a rank rebuilds the states of that level its own candidates inserted (winner set: fingerprint -> level, last
+    descent), exactly once per descent, no exchange; inserted level + probe with the candidates shown to their owners) as the Python loop runs it over the CPU stand-in
     engine — the reference implementation of what csrc/vsr_shard_loop.hpp does over the HIP engine (`-m gpu`:
     test_sharded_deep_levels_against_the_oracle).  (3,1,{v1,v2},1) with AcknowledgedWritesExistOnMajority: stored sharded levels up to
     `deep_at` - 1, then through the seen-sets alone with slices of 48 states (every loop runs many times, the ranks run out of work at

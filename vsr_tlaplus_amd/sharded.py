@@ -417,7 +417,7 @@ class ShardedChecker:
 
     # ---- levels beyond the record buffers: the protocol of csrc/vsr_shard_loop.hpp's second half, over an engine's deep_* phases ----
     def _deep_pass(self, src, level, mode):
-        """one collective pass: expand `src` (states of level - 1), announce what other ranks own, claim / grant, verdicts back
+        """one collective pass that INSERTS a level: expand `src` (states of level - 1), announce what other ranks own, claim, verdicts back
         -> (records the pass yields on this rank, its local figures)"""
         e, x = self.e, self.x
         cands, err = e.deep_expand(src, level, mode)
