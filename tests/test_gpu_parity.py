@@ -301,10 +301,17 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, golden_trace, key,
     assert mc.level_checksum()[2] == 1
     last = g["levels"][-1]["level"]
     kinds, probed = [], None
+    # a level where THIS seed's fingerprint function is known to merge two distinct states (a 64-bit collision of that function, confirmed by the CPU
+    # oracle run under the same seed: the fixture's "other_seeds"): the count both sides then see under it
+    known = g.get("other_seeds", {}).get(hex(seed), {}).get("levels", {}) if seed else {}
+    short = 0
     while mc.depth < last and mc.violation is None:
         kind, d, b = mc.advance()
         kinds.append(kind)
-        lv = g["levels"][d["level"] - 1]
+        lv = dict(g["levels"][d["level"] - 1])
+        if str(lv["level"]) in known:
+            short += lv["new"] - known[str(lv["level"])]["new"]
+            lv.update(known[str(lv["level"])])
         assert (d["level"], d["n_new"], d["generated"], d["deadlocks"], d["max_bag"]) == (lv["level"], lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"]), lv["level"]
         assert [int(x) for x in d["act_generated"][1:16]] == lv["act_generated"][1:16], lv["level"]
         if kind == "level":
@@ -315,7 +322,7 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, golden_trace, key,
         if sums:
             assert ("%016x" % x, "%016x" % s_) == (lv["fp_xor"], lv["fp_sum"]), lv["level"]
         probed = b
-    assert mc.distinct == g["distinct"]
+    assert mc.distinct == g["distinct"] - short
     assert kinds == sorted(kinds, key=lambda k: k == "deep")                 # stored levels first, then the seen-set alone: one switch
     want = g.get("probe")
     if want:                                                                  # the README configuration: the probe of level 24 finds the violation
