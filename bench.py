@@ -335,8 +335,17 @@ def run_readme(args, dump_trace=None, seed=0):
                 levels.append(int(hit[1] >> 55))
             viol = mc.probe_violators()
             assert int(gfps[-1]) in viol and viol[0] == found["viol_fp"]
+            # the path THIS search took to the reference's last state (vsrmc_checker_trace_to_violator) beside the reference's own 23 steps
+            path = mc.trace_to_violator(int(gfps[-1]))
+            pfps, _ = m.fingerprints(np.concatenate([r for _a, r in path]), np.cumsum([0] + [len(r) for _a, r in path]).astype(np.uint64))
+            ref_actions, my_actions = [st["action"] for st in gt["states"]], [a_ for a_, _r in path]
+            assert len(path) == len(ref_actions) == 24 and int(pfps[-1]) == int(gfps[-1])
             S["reference_trace"] = dict(states_found_in_seen_set=len(levels), at_their_own_depth=sum(1 for i, l in enumerate(levels) if l == i + 1),
-                                        last_state_among_probe_violators=True, distinct_violating_states_at_depth_24=len(viol))
+                                        last_state_among_probe_violators=True, distinct_violating_states_at_depth_24=len(viol),
+                                        same_action_sequence_as_reference=my_actions == ref_actions,
+                                        states_shared_with_reference=sum(1 for a_, b_ in zip(pfps, gfps) if int(a_) == int(b_)),
+                                        same_action_multiset_as_reference=sorted(my_actions) == sorted(ref_actions),
+                                        actions_to_the_reference_last_state=my_actions[1:], reference_actions=ref_actions[1:])
         fx = E["fx"]
         if fx.get("fp_version") == FP_VERSION and fx.get("trace") and not seed:   # the counter-example is a function of the state space alone
             S["same_trace"] = [(a_, ["%016x" % int(w) for w in rec]) for a_, rec in tr] == [(t["action"], t["words"]) for t in fx["trace"]]

@@ -316,6 +316,12 @@ int32_t vsrmc_checker_probe_violators(vsrmc_checker* c, uint64_t* fps, uint64_t 
 int32_t vsrmc_checker_seen_batch(vsrmc_checker* c, const uint64_t* fps, uint64_t n, int32_t level, uint8_t* seen);
 int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
                                   uint64_t cap_states, uint64_t* n_states);
+/* ≙ TLCTrace.getTrace for a violating state of the CALLER's choice: the counter-example that ends in `fp`, one of vsrmc_checker_probe_violators (unsharded
+ * checkers).  vsrmc_checker_probe_trace walks to the violator with the smallest fingerprint; the reference's own counter-example
+ * (state_transfer_violation_trace.txt:555-577) ends in another violating state of the same level — this call prints the path the search took to THAT state,
+ * so that the two action sequences can be laid side by side.  Same layout as vsrmc_checker_trace. */
+int32_t vsrmc_checker_trace_to_violator(vsrmc_checker* c, uint64_t fp, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
+                                        uint64_t cap_states, uint64_t* n_states);
 
 /* ≙ TLC's checkpoints (ModelChecker.checkpoint → FPSet.beginChkpt/commitChkpt, StateQueue and TLCTrace checkpoints; `-recover`):
  * one file holds the search between two levels — the occupied seen-set slots, the newest stored frontier, what the automatic level scheme

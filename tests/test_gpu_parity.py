@@ -353,6 +353,21 @@ def test_whole_workload_against_the_oracle(vt, oracle_levels, golden_trace, key,
         viol = mc.probe_violators()
         assert viol and viol[0] == probed["viol_fp"] and viol == sorted(set(viol))
         assert int(gfps[-1]) in viol, "the reference trace's violating state is not among the %d violating states the probe met" % len(viol)
+        # ... and the path the search took to THAT state (vsrmc_checker_trace_to_violator; the reported counter-example ends in viol[0]): 24 states from Init,
+        # every step a step of the model (the replay re-executes it on the device), the last one the reference's last state.  Whether the action
+        # sequence is the reference's own is a property of the predecessor rule (smallest key wins), reported by bench.py, not asserted.
+        for f_end in (int(gfps[-1]), viol[0]):
+            path = mc.trace_to_violator(f_end)
+            assert len(path) == want["level"] and path[0][0] == "Initial predicate"
+            lens = np.cumsum([0] + [len(r) for _a, r in path]).astype(np.uint64)
+            pf, _ = m.fingerprints(np.concatenate([r for _a, r in path]), lens)
+            assert int(pf[-1]) == f_end and int(pf[0]) == int(gfps[0])
+            for i, f in enumerate(pf[:-1]):
+                hit = mc.lookup(int(f))
+                assert hit is not None and hit[1] >> 55 == i + 1                # the walked path sits at its own depths
+        assert [(a, [int(w) for w in r]) for a, r in mc.trace_to_violator(viol[0])] == [(a, [int(w) for w in r]) for a, r in tr]
+        with pytest.raises(vt.VsrmcError):
+            mc.trace_to_violator(int(gfps[-1]) ^ 1)                             # not a violating state of the probed level
     elif g["stop"] == "violation":
         assert mc.violation is not None and mc.violation["mask"] == g["viol_mask"]
         if sums:

@@ -120,6 +120,27 @@ def test_sharded_level_loop_matches_single_process_oracle(tmp_path, world, param
             assert max(last) <= 1.6 * sum(last) / world                 # and the frontier stays balanced
 
 
+@pytest.mark.parametrize("params,max_depth,rb", [((3, 1, 2, 2), 9, 200), ((3, 1, 3, 3), 8, 100)])
+def test_eight_ranks_on_the_cpu_stand_in(tmp_path, params, max_depth, rb):
+    """The target world size (BASELINE: 8 x MI355X) rehearsed on the CPU stand-in: prefixes of config 2 and of the README defect configuration on EIGHT
+    ranks — the replicated small levels, the partition at the first level with >= rb new states, eight-way owner buckets (owner_of(fp, 8)), the
+    all-to-all-v over eight peers, bulk rebalancing, the collective trace walks — per-level fingerprint sets, successor and deadlock counts against the
+    single-process oracle.  (Rounds 2-5 never ran the collectives beyond world 4.)"""
+    from vsr_tlaplus_amd.sharded import owner_of
+    ranks = run_world("fake", 8, params, max_depth, tmp_path, 29740 + params[2], rb)
+    check_against_oracle(ranks, params, max_depth)
+    replay_walks_with_oracle(ranks, params)
+    assert all(r["walks"] == ranks[0]["walks"] for r in ranks) and len(ranks[0]["walks"]) == 8
+    flags = [lv["replicated"] for lv in ranks[0]["levels"]]
+    assert flags[0] and not flags[-1] and flags == sorted(flags, reverse=True)         # one switch, early
+    assert sum(r["bytes_sent"] for r in ranks) > 0 and all(r["bytes_sent"] > 0 for r in ranks)
+    last = [len(r["levels"][-1]["fps"]) for r in ranks]
+    assert min(last) > 0 and max(last) <= 1.6 * sum(last) / 8                         # every rank holds work, the frontier is balanced
+    # the owner function spreads the last level's fingerprints over all eight shards
+    owners = [owner_of(int(f, 16), 8) for r in ranks for f in r["levels"][-1]["fps"]]
+    assert sorted(set(owners)) == list(range(8))
+
+
 @pytest.mark.parametrize("world,rb", [(2, 0), (3, 500)])
 def test_sharded_checkpoint_and_probe_level(tmp_path, world, rb):
     """(3,1,{v1,v2},1) with AcknowledgedWritesExistOnMajority: 146 935 states, violated at depth 19.  The run is checkpointed after
@@ -421,7 +442,7 @@ def test_violation_of_any_mask_on_a_remotely_owned_successor_is_reported(tmp_pat
         assert r["violation"] == dict(level=8, fp=target, mask=28), r["violation"]
 
 
-@pytest.mark.parametrize("world,rb,deep_at", [(2, 0, 8), (3, 200, 10)])
+@pytest.mark.parametrize("world,rb,deep_at", [(2, 0, 8), (3, 200, 10), (8, 200, 11)])
 def test_sharded_deep_protocol_on_the_cpu_stand_in(tmp_path, world, rb, deep_at):
     """The protocol of the levels beyond the ranks' record buffers (virtual level: announce -> first inserter wins -> winners counted;
     regenerated level: local — a rank rebuilds the states of that level its own candidates inserted (winner set: fingerprint -> level, last

@@ -1,6 +1,8 @@
 """Builds libvsrmc.so (HIP, gfx950) and the `vsrmc` CLI in-tree with hipcc.  No GPU is needed to build."""
 import os
+import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -24,19 +26,41 @@ def sources():
     return out
 
 
+def _snapshot():
+    """hipcc maps the files it compiles for minutes: the sources are compiled from a private copy, so that an edit meanwhile cannot end the build with a
+    bus error or produce a mixture of two states."""
+    snap = tempfile.mkdtemp(prefix="vsrmc_build.")
+    shutil.copytree(CSRC, os.path.join(snap, "vsr_tlaplus_amd", "csrc"))
+    os.makedirs(os.path.join(snap, "include"))
+    shutil.copy(os.path.join(os.path.dirname(HERE), "include", "vsrmc.h"), os.path.join(snap, "include", "vsrmc.h"))
+    return snap, os.path.join(snap, "vsr_tlaplus_amd", "csrc")
+
+
 def build(force=False, verbose=False):
     srcs = sources()
-    if force or _newer(LIB, srcs):
-        cmd = [HIPCC] + FLAGS + ["-shared", "-o", LIB, os.path.join(CSRC, "vsrmc.hip")]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-    if force or _newer(LIB_HOOKS, srcs):
-        cmd = [HIPCC] + FLAGS + ["-DVSRMC_TEST_HOOKS", "-shared", "-o", LIB_HOOKS, os.path.join(CSRC, "vsrmc.hip")]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+    need_lib = force or _newer(LIB, srcs)
+    need_hooks = force or _newer(LIB_HOOKS, srcs)
     cli_src = os.path.join(CSRC, "vsrmc_cli.cpp")
+    if need_lib or need_hooks:
+        t_start = max(os.path.getmtime(s) for s in srcs)
+        snap, csrc = _snapshot()
+        try:
+            procs = []
+            for need, lib, extra in ((need_lib, LIB, []), (need_hooks, LIB_HOOKS, ["-DVSRMC_TEST_HOOKS"])):
+                if not need:
+                    continue
+                cmd = [HIPCC] + FLAGS + extra + ["-shared", "-o", lib + ".tmp", os.path.join(csrc, "vsrmc.hip")]
+                if verbose:
+                    print(" ".join(cmd))
+                procs.append((lib, cmd, subprocess.Popen(cmd)))             # the two libraries side by side
+            for lib, cmd, p in procs:
+                if p.wait() != 0:
+                    raise subprocess.CalledProcessError(p.returncode, cmd)
+            for lib, _cmd, _p in procs:
+                os.replace(lib + ".tmp", lib)
+                os.utime(lib, (t_start + 1, t_start + 1))                     # as old as the snapshot: an edit made DURING the build makes the library stale again
+        finally:
+            shutil.rmtree(snap, ignore_errors=True)
     if os.path.exists(cli_src) and (force or _newer(CLI, srcs + [LIB])):
         cmd = [HIPCC, "-O2", "-std=c++17", "-o", CLI, cli_src, "-L" + HERE, "-lvsrmc", "-Wl,-rpath,$ORIGIN"]
         if verbose:

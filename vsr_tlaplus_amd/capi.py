@@ -125,6 +125,7 @@ SYMBOLS = {
     "vsrmc_checker_seen_batch": (C.c_int32, [V, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "vsrmc_checker_probe_violators": (C.c_int32, [V, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_probe_trace": (C.c_int32, [V, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_trace_to_violator": (C.c_int32, [V, C.c_uint64, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_save": (C.c_int32, [V, C.c_char_p]),
     "vsrmc_checker_status": (C.c_int32, [V, C.POINTER(LevelInfo)]),
     "vsrmc_checker_load": (C.c_int32, [V, C.POINTER(Options), C.c_char_p, C.POINTER(V)]),

@@ -600,6 +600,19 @@ class ModelChecker:
         check(capi.load().vsrmc_checker_probe_trace(self._h, _p(words), cap_w, _p(off), _p(acts), len(off), C.byref(n)))
         return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(n.value)]
 
+    def trace_to_violator(self, fp):
+        """The counter-example that ends in the violating state `fp` of the last probed level (one of probe_violators()), as the search reached it:
+        [(action name, record)] from Init.  probe_trace() is this for probe_violators()[0]."""
+        lay = self.model.layout
+        n_max = max(self.level, self.depth) + 3
+        cap_w = (n_max + 1) * int(lay.max_record_words)
+        words = np.zeros(cap_w, dtype=np.uint64)
+        off = np.zeros(n_max + 2, dtype=np.uint64)
+        acts = np.zeros(n_max + 2, dtype=np.int32)
+        n = C.c_uint64()
+        check(capi.load().vsrmc_checker_trace_to_violator(self._h, int(fp), _p(words), cap_w, _p(off), _p(acts), len(off), C.byref(n)))
+        return [(ACTION_NAMES[acts[t]], words[int(off[t]): int(off[t + 1])].copy()) for t in range(n.value)]
+
     def close(self):
         if self._h:
             capi.load().vsrmc_checker_destroy(self._h)

@@ -62,6 +62,8 @@ struct vsrmc_checker {
   u64 probe_fp = 0, probe_extra_fp = 0;
   int probe_level = 0;
   std::vector<u64> probe_viol;           // the distinct violating STATES of the last probed level (fingerprints, ascending): vsrmc_checker_probe_violators
+  std::vector<u64> probe_viol_key;       // ... and, beside each, the smallest key among its copies (it names the state's parent): vsrmc_checker_trace_to_violator
+  int probe_viol_level = 0;              // the probed level they belong to
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
   bool saw_violation = false;            // a committed level held a violating state (the caller went on): probe passes apply every action
   // levels beyond the record buffers (vsr_deep.hpp): `deep` levels above `level` are complete in the seen-set and have no frontier
@@ -74,6 +76,7 @@ struct vsrmc_checker {
   std::vector<PassDst> scratch;          // scratch buffers 1 .. of the descent (vsr_deep.hpp: deep_plan_scratch; planned at the start of a pass)
   PassDst scratch0;                      // buffer 0 of the descent when the plan CARVES the idle record buffer (words == nullptr: buffer 0 is that whole buffer)
   bool scratch_carved = false;
+  int scratch_buf = -1;                  // which record buffer (0 / 1) the plan's carved pieces point into: a plan made while the other buffer was idle is stale
   u64 scratch_front = 0;                 // a re-basing plan: the first words of the idle record buffer are the descent's destination, not scratch
   // sharded deep search: the generator-side winner set (vsr_kernels.hpp: WSet) — which deep-level states THIS rank's candidates inserted
   WSet h_wset = {nullptr, nullptr, 0};
@@ -83,6 +86,8 @@ struct vsrmc_checker {
   // unsharded deep search: which (parent, ordinal) instance of the stored base inserted each state of the first seen-set-only level (vsr_deep.hpp)
   u32* claim_bits = nullptr;
   u64 claim_w = 0, claim_parents = 0;    // words per parent; parents covered (= the base level's index range)
+  LevelCtl full_h;                       // ... the control block of THAT step (c->h is rewritten by every later pass, lookup or trace helper), its kernel time and start
+  double full_ms = 0, full_t0 = 0;
   bool full_recoverable = false;         // the last vsrmc_checker_step stopped with "frontier full" and lost nothing but records: the level is complete in the
                                          // seen-set and vsrmc_checker_advance keeps it as a seen-set-only level (host_search.hpp: adopt_overflowed_level)
   u64 hist_new[2] = {0, 0};              // new states of the last two levels (growth estimate of vsrmc_checker_advance)
@@ -229,6 +234,7 @@ int wset_ensure(vsrmc_checker* c) {
     return 0;
   }
   u64 slots = std::max<u64>((u64)1 << 12, (c->tmask + 1) / 2);
+  if (const char* e = std::getenv("VSRMC_WSET_LOG2")) slots = (u64)1 << std::max(8, std::min(36, std::atoi(e)));   // (tests: a small set that has to grow, wset_grow)
   while (true) {
     hipError_t e = hipMalloc((void**)&c->h_wset.fp, slots * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&c->h_wset.epoch, slots * 4);
@@ -249,6 +255,44 @@ int wset_ensure(vsrmc_checker* c) {
   c->wset_dirty = false;
   return 0;
 }
+// states in the winner set: what this rank's candidates inserted into the levels beyond the base (DeepLevelRec::n_local of each)
+u64 wset_count(const vsrmc_checker* c) {
+  u64 n = 0;
+  for (const DeepLevelRec& d : c->deep_lv) n += d.n_local;
+  return n;
+}
+// The set has half the slots of the seen-set shard at first (what autosize_options set aside), but must hold about the rank's share of every level beyond
+// the base — nearly the whole shard once the search is deep — and its probes give up after 65 536 steps: it is re-hashed into twice the slots between two
+// passes while the device has the memory (round-5 advice; vsrmc_shard_loop_room stops the run cleanly when it cannot grow).  0 = grown, 1 = no memory.
+int wset_grow(vsrmc_checker* c) {
+  if (!c->d_wset) return 1;
+  const u64 old_slots = c->h_wset.mask + 1, slots = old_slots * 2;
+  u64* nfp = nullptr;
+  u32* nep = nullptr;
+  u32* d_err = nullptr;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)slots * 12.0 + 1.0e9 > (double)free_b) return 1;   // (the scratch plan of the next descent needs its share too)
+  bool ok = hipMalloc((void**)&nfp, slots * 8) == hipSuccess && hipMalloc((void**)&nep, slots * 4) == hipSuccess && hipMalloc((void**)&d_err, 4) == hipSuccess;
+  ok = ok && hipMemsetAsync(nfp, 0, slots * 8, c->stream) == hipSuccess && hipMemsetAsync(nep, 0, slots * 4, c->stream) == hipSuccess &&
+       hipMemsetAsync(d_err, 0, 4, c->stream) == hipSuccess;
+  u32 err = 0;
+  if (ok) {
+    hipLaunchKernelGGL(k_wset_rehash, dim3(4096), dim3(256), 0, c->stream, (const u64*)c->h_wset.fp, (const u32*)c->h_wset.epoch, old_slots, nfp, nep, slots - 1, d_err);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess && err == 0;
+  }
+  if (d_err) (void)hipFree(d_err);
+  if (!ok) {
+    (void)hipGetLastError();
+    if (nfp) (void)hipFree(nfp);
+    if (nep) (void)hipFree(nep);
+    return 1;
+  }
+  (void)hipFree(c->h_wset.fp);
+  (void)hipFree(c->h_wset.epoch);
+  c->h_wset.fp = nfp; c->h_wset.epoch = nep; c->h_wset.mask = slots - 1;
+  if (hipMemcpy(c->d_wset, &c->h_wset, sizeof(WSet), hipMemcpyHostToDevice) != hipSuccess) return fail(VSRMC_E_HIP, "winner set: descriptor copy");
+  return 0;
+}
 void wset_free(vsrmc_checker* c) {
   if (c->h_wset.fp) (void)hipFree(c->h_wset.fp);
   if (c->h_wset.epoch) (void)hipFree(c->h_wset.epoch);
@@ -256,9 +300,14 @@ void wset_free(vsrmc_checker* c) {
   c->h_wset.fp = nullptr; c->h_wset.epoch = nullptr; c->h_wset.mask = 0; c->d_wset = nullptr; c->wepoch = 0;
 }
 
+void deep_free_scratch(vsrmc_checker* c);                       // (vsr_deep.hpp)
+
 // Put the checker in its initial state (ModelChecker.doInit): empty seen-set, Init in frontier 0 and in the set.
 int checker_seed(vsrmc_checker* c) {
   const Model& M = c->model.M;
+  // the scratch plan of a deep search points into whichever record buffer was idle when it was made: a search that starts over starts without one
+  deep_free_scratch(c);
+  c->rebase_off = false;
   c->saw_violation = false;
   c->deep = 0;
   c->deep_lv.clear();
@@ -313,6 +362,8 @@ int checker_seed(vsrmc_checker* c) {
   c->probe_level = 0;
   c->probe_extra_fp = 0;
   c->probe_viol.clear();
+  c->probe_viol_key.clear();
+  c->probe_viol_level = 0;
   return 0;
 }
 }  // namespace
@@ -554,6 +605,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     c->h.err_info = c->h.full_info << 16;
     // .. but an unsharded ordinary level has lost nothing except the records: the automatic scheme goes on from the seen-set
     c->full_recoverable = !io && mode == MODE_NORMAL && !c->opt.exact_ties && c->opt.world == 1 && c->h.ties == 0;
+    if (c->full_recoverable) { c->full_h = c->h; c->full_ms = c->expand_ms; c->full_t0 = c->t_level0; }
   }
   if (c->h.err) return level_error(c, c->h, c->level + 1);
   if (!c->opt.exact_ties) {                                    // fused: the level is already materialised (sharded: speculatively)

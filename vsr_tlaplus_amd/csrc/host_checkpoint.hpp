@@ -109,14 +109,6 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
 int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o_in, const char* path, vsrmc_checker** out) {
   if (!m || !o_in || !path || !out) return fail(VSRMC_E_ARG, "NULL argument");
   if (o_in->world > 1 && o_in->exact_ties) return fail(VSRMC_E_STATE, "checkpoints of sharded exact-mode checkers are not supported");
-  // options with zeros (the CLI's and ModelChecker.auto()'s defaults) are sized from the free device memory FIRST: the checkpoint is held
-  // against the sizes the checker will really have, not against the zeros (round-4 advice: `vsrmc -recover ck` without explicit sizes failed)
-  vsrmc_options sized = *o_in;
-  {
-    const int rc0 = autosize_options(&sized, m->M);
-    if (rc0) return rc0;
-  }
-  const vsrmc_options* o = &sized;
   FILE* f = std::fopen(path, "rb");
   if (!f) return fail(VSRMC_E_CFG, std::string("cannot read ") + path);
   ChkHeader h;
@@ -126,10 +118,33 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o_in, cons
                h.deep < 511 && (u64)h.level + h.deep < 511 && (h.deep == 0 || h.deep_distinct >= h.distinct) && h.cur_buf <= 1;
   std::vector<DeepLevelRec> deep_lv((size_t)(ok ? h.deep : 0));
   if (ok && h.deep) ok = std::fread(deep_lv.data(), sizeof(DeepLevelRec), (size_t)h.deep, f) == (size_t)h.deep;
+  if (ok && h.deep) {                                           // the descriptors against the header: every level non-empty, this handle's shares add up to its total
+    u64 sum_local = 0;
+    for (const DeepLevelRec& d : deep_lv) { ok = ok && d.n_new > 0 && d.n_local <= d.n_new; sum_local += d.n_local; }
+    ok = ok && sum_local == h.deep_distinct - h.distinct;
+  }
   if (!ok) {
     std::fclose(f);
     return fail(VSRMC_E_CFG, std::string(path) + " is not a (consistent) vsrmc checkpoint");
   }
+  // options with zeros (the CLI's and ModelChecker.auto()'s defaults) are sized from the free device memory FIRST: the checkpoint is held
+  // against the sizes the checker will really have, not against the zeros (round-4 advice: `vsrmc -recover ck` without explicit sizes failed).
+  // A seen-set that had grown beyond the automatic size (vsrmc_checker_room) is sized from the checkpoint BEFORE the record buffers are sized from
+  // what is left (round-5 advice: the table was bumped after the buffers had taken the memory it needs).
+  vsrmc_options sized = *o_in;
+  if (o_in->table_log2 == 0) {
+    vsrmc_options probe = *o_in;
+    const int rc0 = autosize_options(&probe, m->M);
+    if (rc0) { std::fclose(f); return rc0; }
+    int lg = (int)probe.table_log2;
+    while (lg < 36 && (double)h.table_entries > 0.6 * (double)((u64)1 << lg)) lg++;
+    if (lg != (int)probe.table_log2) sized.table_log2 = lg;     // (pinned: autosize_options takes it off the memory it shares out)
+  }
+  {
+    const int rc0 = autosize_options(&sized, m->M);
+    if (rc0) { std::fclose(f); return rc0; }
+  }
+  const vsrmc_options* o = &sized;
   const Model& M = m->M;
   const int32_t consts[12] = {M.R, M.C, M.n, M.L, m->symmetry, M.inv_mask, M.assume_commit, M.np, M.model_id, M.wpr, M.fixed, fp_function_id(M)};
   if (std::memcmp(h.consts, consts, sizeof(consts)) != 0) {
@@ -142,8 +157,6 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o_in, cons
   }
   const int buf_of_level = (int)h.cur_buf;                      // the record buffer the frontier was in: its level keeps alternating from there
   const u64 cap_of_buf = (buf_of_level == 1 && o->frontier_words_b) ? o->frontier_words_b : o->frontier_words;
-  if (o_in->table_log2 == 0)                                    // a seen-set that had grown beyond the automatic size (vsrmc_checker_room)
-    while (sized.table_log2 < 36 && (double)h.table_entries > 0.6 * (double)((u64)1 << sized.table_log2)) sized.table_log2++;
   if (h.n_frontier > o->frontier_states || h.cur_w > cap_of_buf || 2 * h.table_entries > ((u64)1 << o->table_log2)) {
     std::fclose(f);
     return fail(VSRMC_E_ARG, "the options are too small for this checkpoint (frontier, table)");

@@ -18,6 +18,8 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
   c->probe_level = 0;
   c->probe_extra_fp = 0;
   c->probe_viol.clear();
+  c->probe_viol_key.clear();
+  c->probe_viol_level = 0;
   int rc = phase_expand(c, nullptr, MODE_PROBE);
   if (rc) return rc;
   std::memset(info, 0, sizeof(*info));
@@ -46,9 +48,12 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
       const u64 n = std::min<u64>(c->h.n_pending, std::min<u64>(c->opt.pending_entries, (u64)1 << 20));
       std::vector<u64> list(2 * n);
       if (n) HIPCHK(hipMemcpy(list.data(), c->pending, 16 * n, hipMemcpyDeviceToHost));
-      for (u64 i = 0; i < n; i++) c->probe_viol.push_back(list[2 * i]);
-      std::sort(c->probe_viol.begin(), c->probe_viol.end());
-      c->probe_viol.erase(std::unique(c->probe_viol.begin(), c->probe_viol.end()), c->probe_viol.end());
+      std::vector<std::pair<u64, u64>> pr(n);
+      for (u64 i = 0; i < n; i++) pr[i] = std::make_pair(list[2 * i], list[2 * i + 1]);
+      std::sort(pr.begin(), pr.end());                            // by fingerprint, then key: the first entry of a fingerprint carries its smallest key
+      for (u64 i = 0; i < n; i++)
+        if (i == 0 || pr[i].first != pr[i - 1].first) { c->probe_viol.push_back(pr[i].first); c->probe_viol_key.push_back(pr[i].second); }
+      c->probe_viol_level = c->level + 1;
     }
     if (key != ~(u64)0 && c->opt.world <= 1) {                  // its parent: the newest level's state with these fingerprint bits
       int found = 0;
@@ -115,6 +120,31 @@ int32_t vsrmc_checker_probe_trace(vsrmc_checker* c, uint64_t* words, uint64_t ca
   int rc = walk_trace(c, c->probe_fp, c->probe_level, &fps);    // Init .. the deepest state of the path that is in the seen-set
   if (rc) return rc;
   if (c->probe_extra_fp) fps.push_back(c->probe_extra_fp);      // ... and the probed state beyond it
+  return vsrmc_model_replay_fps(&c->model, c->opt.device, fps.data(), (int32_t)fps.size(), words, cap_words, off, actions, cap_states, n_states);
+}
+
+// TLCTrace.getTrace for a violating state of the caller's choice: the probe collects EVERY violating successor (vsrmc_checker_probe_violators) and reports the
+// one with the smallest fingerprint; the reference's own counter-example (state_transfer_violation_trace.txt:555-577) ends in another one of them.  The path:
+// Init .. the violator's parent — the state of the level below whose fingerprint ends in the 45 bits the smallest key among the violator's copies carries,
+// the same rule that names every state's predecessor in the seen-set — then the violator itself.
+int32_t vsrmc_checker_trace_to_violator(vsrmc_checker* c, uint64_t fp, uint64_t* words, uint64_t cap_words, uint64_t* off, int32_t* actions,
+                                        uint64_t cap_states, uint64_t* n_states) {
+  if (!c || !words || !off || !actions || !n_states) return fail(VSRMC_E_ARG, "NULL argument");
+  const auto it = std::lower_bound(c->probe_viol.begin(), c->probe_viol.end(), (u64)fp);
+  if (it == c->probe_viol.end() || *it != fp || c->probe_viol_key.size() != c->probe_viol.size() || c->probe_viol_level < 2)
+    return fail(VSRMC_E_STATE, "not a violating state of the last probed level (vsrmc_checker_probe_violators lists them)");
+  const u64 key = c->probe_viol_key[(size_t)(it - c->probe_viol.begin())];
+  HIPCHK(hipSetDevice(c->opt.device));
+  int found = 0;
+  u64 pfp = 0, pmeta = 0;
+  int rc = table_lookup(c, meta_pfp(key), c->probe_viol_level - 1, 1, &found, &pfp, &pmeta);
+  if (rc) return rc;
+  if (found > 1) return fail(VSRMC_E_STATE, "ambiguous predecessor pointer: several states of the parent's level share the 45 fingerprint bits the violating successor keeps of its parent");
+  if (!found) return fail(VSRMC_E_STATE, "the parent of this violating state is not in the seen-set");
+  std::vector<u64> fps;
+  rc = walk_trace(c, pfp, c->probe_viol_level - 1, &fps);
+  if (rc) return rc;
+  fps.push_back((u64)fp);
   return vsrmc_model_replay_fps(&c->model, c->opt.device, fps.data(), (int32_t)fps.size(), words, cap_words, off, actions, cap_states, n_states);
 }
 
@@ -185,7 +215,7 @@ static int adopt_overflowed_level(vsrmc_checker* c, vsrmc_level_info* ins) {
   if (!c->failed || !c->full_recoverable || c->failed_code != ERR_FRONTIER_FULL || c->deep || c->opt.world > 1 || c->opt.exact_ties)
     return fail(VSRMC_E_STATE, "no overflowed level to adopt");
   HIPCHK(hipSetDevice(c->opt.device));
-  const LevelCtl& h = c->h;
+  const LevelCtl h = c->full_h;                                 // the overflowed step's own control block (snapshot: c->h may have been rewritten since)
   u64* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, 24));
   u64 sums[3] = {0, 0, 0};
@@ -212,8 +242,8 @@ static int adopt_overflowed_level(vsrmc_checker* c, vsrmc_level_info* ins) {
   ins->fp_xor = sums[0];
   ins->fp_sum = sums[1];
   ins->pending = 1;                                             // k_expand launches of this "pass"
-  ins->expand_ms = c->expand_ms;
-  ins->seconds = now_s() - c->t_level0;
+  ins->expand_ms = c->full_ms;
+  ins->seconds = now_s() - c->full_t0;
   for (int a = 0; a < 16; a++) ins->act_generated[a] = h.act_generated[a];
   ins->viol_fp = ins->viol_index = ~(u64)0;
   c->probe_fp = 0; c->probe_level = 0; c->probe_extra_fp = 0;

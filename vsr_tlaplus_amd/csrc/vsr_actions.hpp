@@ -670,7 +670,7 @@ template <int K>
 VSR_HD void hash_word_delta(const Model& M, u64 w_old, u64 w_new, int r, u64& dinv, u64* d) {
   if (w_old == w_new) return;
   constexpr u64 m01 = K == 0 ? (u64)0 : K == 1 ? LOGB_REP1 : LOGB_REPK;
-  const u64 s = salt_word<K>(r) ^ M.fp_seed;
+  const u64 s = salt_seeded<K>(M.fp_seed, r);
   if (K == 0 || !(word_has_values(w_old, m01) | word_has_values(w_new, m01))) {
     dinv += fmix64(w_new ^ s) - fmix64(w_old ^ s);
     return;

@@ -108,6 +108,7 @@ void deep_free_scratch(vsrmc_checker* c) {
   c->scratch.clear();
   c->scratch0 = PassDst();
   c->scratch_carved = false;
+  c->scratch_buf = -1;
   c->scratch_front = 0;
 }
 
@@ -117,7 +118,10 @@ int deep_plan_scratch(vsrmc_checker* c, int count, bool carve = true, u64 front 
   const int nxt = c->cur ^ 1;
   if ((c->host_frontier >> nxt) & 1) carve = false;              // (records in pinned host memory: scratch stays on the device)
   front = (front + 63) & ~(u64)63;
-  if ((size_t)count <= c->scratch.size() && c->scratch_front == front && (c->scratch_carved == carve || (count == 0 && !carve))) return 0;
+  // (a carved plan holds raw pointers into the record buffer that was idle when it was made: after a swap — a re-basing, a reset, a manual deepen at
+  // another level — those pieces alias the frontier the descent reads, so such a plan is never reused)
+  const bool same_buf = !c->scratch_carved || c->scratch_buf == nxt;
+  if ((size_t)count <= c->scratch.size() && c->scratch_front == front && same_buf && (c->scratch_carved == carve || (count == 0 && !carve))) return 0;
   deep_free_scratch(c);
   if (count == 0) return 0;                                       // one level below the base: buffer 0 (the idle record buffer) is all a pass needs
   size_t free_b = 0, total_b = 0;
@@ -167,6 +171,7 @@ int deep_plan_scratch(vsrmc_checker* c, int count, bool carve = true, u64 front 
     return fail(VSRMC_E_HIP, "hipMalloc of a deep-search scratch buffer failed");
   }
   c->scratch_carved = carve;
+  c->scratch_buf = nxt;
   c->scratch_front = front;
   return 0;
 }
@@ -356,8 +361,12 @@ int deep_resolve(DeepRun& R) {
     if (seen8[g]) continue;
     R.prb.pending++;                                           // violating successors seen, duplicates included
     if (first == ~(u64)0) { first = pairs[i].first; key = pairs[i].second; }
-    if (c->probe_viol.empty() || c->probe_viol.back() != pairs[i].first) c->probe_viol.push_back(pairs[i].first);   // (sorted: ascending, distinct)
+    if (c->probe_viol.empty() || c->probe_viol.back() != pairs[i].first) {   // (sorted: ascending, distinct; the first copy of a fingerprint carries its smallest key)
+      c->probe_viol.push_back(pairs[i].first);
+      c->probe_viol_key.push_back(pairs[i].second);
+    }
   }
+  c->probe_viol_level = plevel;
   if (first == ~(u64)0) return 0;
   int found = 0;
   u64 pfp = 0, pmeta = 0;
@@ -554,18 +563,19 @@ int deep_rebase(vsrmc_checker* c, vsrmc_level_info* out) {
   const u64 front_w = c->deep_lv.back().n_new * (u64)(M.fixed + (int)std::min<u64>(c->deep_lv.back().max_bag, (u64)M.max_bag));
   int rc = deep_plan_scratch(c, c->deep, true, front_w);
   if (rc) { c->rebase_off = true; return 1; }                    // no memory for one more scratch buffer: the search goes on without re-basing
+  // (nothing has changed yet: a failure of these small allocations is not fatal either — the search goes on with ordinary descents, as above)
+  struct FreeCnt { u64* p; u32* q; ~FreeCnt() { if (p) (void)hipFree(p); if (q) (void)hipFree(q); } } free_cnt{nullptr, nullptr};
+  if (hipMalloc((void**)&R.d_cnt, 16) != hipSuccess) { (void)hipGetLastError(); R.d_cnt = nullptr; c->rebase_off = true; return 1; }
+  free_cnt.p = R.d_cnt;
+  if (hipMalloc((void**)&R.d_err, 4) != hipSuccess) { (void)hipGetLastError(); R.d_err = nullptr; c->rebase_off = true; return 1; }
+  free_cnt.q = R.d_err;
+  if (hipMemsetAsync(R.d_cnt, 0, 16, c->stream) != hipSuccess || hipMemsetAsync(R.d_err, 0, 4, c->stream) != hipSuccess) { (void)hipGetLastError(); c->rebase_off = true; return 1; }
   if (c->deep_regen_done) {
     hipLaunchKernelGGL(k_table_untake, dim3(4096), dim3(256), 0, c->stream, c->table, c->tmask + 1, c->level + 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   c->deep_regen_done = true;
-  HIPCHK(hipMalloc((void**)&R.d_cnt, 16));
-  struct FreeCnt { u64* p; u32* q; ~FreeCnt() { (void)hipFree(p); if (q) (void)hipFree(q); } } free_cnt{R.d_cnt, nullptr};
-  HIPCHK(hipMalloc((void**)&R.d_err, 4));
-  free_cnt.q = R.d_err;
-  HIPCHK(hipMemsetAsync(R.d_cnt, 0, 16, c->stream));
-  HIPCHK(hipMemsetAsync(R.d_err, 0, 4, c->stream));
   rc = deep_descend(R, c->words[c->cur], c->off[c->cur], c->n_frontier, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, c->level, 1);
   if (rc) { c->failed = 1; return rc; }
   u64 cnt[2] = {0, 0};
@@ -633,6 +643,8 @@ int32_t vsrmc_checker_deepen(vsrmc_checker* c, vsrmc_level_info* inserted, vsrmc
   c->probe_level = 0;
   c->probe_extra_fp = 0;
   c->probe_viol.clear();
+  c->probe_viol_key.clear();
+  c->probe_viol_level = 0;
   if (c->deep == 0) return deep_first_pass(c, inserted);
   return deep_pass(c, c->level + c->deep, true, inserted, probed);
 }

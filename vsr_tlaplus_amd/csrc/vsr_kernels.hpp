@@ -148,7 +148,36 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO
 // new state.  Nothing in k_expand hands data from wave to wave through global memory inside a launch (the waves of a block talk
 // through LDS, blocks through atomics), so the barriers only have to order LDS: wait for the wave's LDS operations, then s_barrier.
 // The stores keep draining underneath the next tile's staging loads.
-#define VSR_SYNC() __syncthreads()
+// -DVSR_WAVE_DIAG=1 (diagnostic build, tools/wave_diag.py): every wave of k_expand adds up the shader clocks it spends INSIDE the block barriers; the epilogue
+// reports, per wave index 0..3, the barrier time in phase_cycles[0..3] and the wave's whole residency in phase_cycles[4..7] (instead of the phase split).
+// =2: only the barrier that closes the apply loop (the wait for the block's slowest wave of the apply phase) is counted.
+#ifndef VSR_WAVE_DIAG
+#define VSR_WAVE_DIAG 0
+#endif
+#ifndef VSR_TAKE
+#define VSR_TAKE 0
+#endif
+#ifndef VSR_SPEC_CAS
+#define VSR_SPEC_CAS 0
+#endif
+#ifndef VSR_DIRECT_REFS     // EXPERIMENT: every thread fetches the refs of the four records it stages itself (no barrier between the ref load and the record loads)
+#define VSR_DIRECT_REFS 0
+#endif
+#ifndef VSR_NO_TAIL_SYNC    // EXPERIMENT: no barrier at the bottom of the tile loop (what follows the apply-closing barrier touches LDS words of wave 0 only)
+#define VSR_NO_TAIL_SYNC 0
+#endif
+#ifndef VSR_ROUND_REV       // EXPERIMENT: the second round of the apply loop runs on the block's LAST waves (wave 0 carries the serial sections already)
+#define VSR_ROUND_REV 0
+#endif
+// =3: wave 1's waits per barrier GROUP (0 top / bottom of the tile loop, 1 after the ref load, 2 after staging, 3 after the work-list fill + parent fingerprints,
+// 4 inside the enumeration, 5 after it, 6 sort / reservations, 7 the barrier that closes the apply loop) in phase_cycles[0..7], its residency in act_generated[0].
+#if VSR_WAVE_DIAG == 3
+#define VSR_SYNC_G(g) do { const u64 b0_ = __builtin_readcyclecounter(); __syncthreads(); if (tid == 64) s_wd[g] += __builtin_readcyclecounter() - b0_; } while (0)
+#elif VSR_WAVE_DIAG
+#define VSR_SYNC_G(g) do { const u64 b0_ = __builtin_readcyclecounter(); __syncthreads(); if (VSR_WAVE_DIAG == 1 || (g) == 7) wd_wait += __builtin_readcyclecounter() - b0_; } while (0)
+#else
+#define VSR_SYNC_G(g) __syncthreads()
+#endif
 // seen-set probes read the home slot (16 B) first and the rest of its 64-byte line only when that slot holds another fingerprint
 // successor write: parent words copied eight per trip (four LDS reads in flight) instead of two
 // intra-tile duplicate filter in LDS ahead of the seen-set probes of k_expand (single-pass levels)
@@ -262,6 +291,22 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, CNT
   Probe r;
   r.slot = 0; r.meta = META_EMPTY; r.claimed = false; r.reload = false; r.full = false;
   u64 i = fp & mask;
+#if VSR_SPEC_CAS
+  // EXPERIMENT: the compare-and-swap of the home slot is issued TOGETHER with its 16-byte load (a new state then costs one memory round trip, not two
+  // dependent ones); an occupied slot makes the atomic a no-op that returns what the slot holds
+  {
+    const u64 old = atomicCAS((unsigned long long*)&table[i].fp, 0ull, (unsigned long long)fp);
+    const u64x2 sk = *(const u64x2*)&table[i];
+    nprobe.home();
+    if (old == 0) { r.slot = i; r.claimed = true; return r; }
+    if (old == fp) {
+      r.slot = i;
+      if (sk.x == fp) r.meta = sk.y; else r.reload = true;
+      return r;
+    }
+    i = (i + 1) & mask;
+  }
+#else
   {
     const u64x2 sk = *(const u64x2*)&table[i];
     nprobe.home();
@@ -277,6 +322,7 @@ __device__ __forceinline__ Probe probe_insert(Slot* table, u64 mask, u64 fp, CNT
     }
     i = (i + 1) & mask;
   }
+#endif
   for (u32 lines = 0; lines < 2048; lines++) {
     const u64 lb = i & ~(u64)3;
     const u64x2* lp = (const u64x2*)&table[lb];
@@ -499,6 +545,12 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   constexpr u64 CS_NONE = ((u64)1 << 40) - 1;                   // chunk base of "no chunk yet"
 
   const int tid = threadIdx.x, lane = tid & 63;
+#if VSR_WAVE_DIAG
+  u64 wd_wait = 0;
+  const u64 wd_t0 = __builtin_readcyclecounter();
+  __shared__ unsigned long long s_wd[8];
+  if (tid < 8) s_wd[tid] = 0;
+#endif
   const u64 ntiles = (n_parents + tile - 1) / tile;
   const int tshift = 31 - __clz(tile);                           // tile is a power of two
   if (tid < 32) s_acc[tid] = 0;
@@ -510,7 +562,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     s_ich_base = 0; s_ich_used = ichunk; s_wch_base = 0; s_wch_used = wchunk;
   }
   if (tid < 8) s_cstate[tid] = (CS_NONE << 24) | cchunk;
-  VSR_SYNC();
+  VSR_SYNC_G(0);
 
   // blockIdx -> tiles: the persistent blocks draw tiles from an atomic counter (ctl->tile_cursor, zeroed by the host with the other
   // level counters).  Tile costs are uneven and correlated along the frontier (successors per record, bag sizes), so the static
@@ -520,21 +572,41 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   // min-merged predecessor keys do not depend on it.
   __shared__ u64 s_tile_cur;
   u64 my_next = 0;
+#if VSR_TAKE
+  // EXPERIMENT (-DVSR_TAKE=<candidates>): the apply loop runs in rounds of BLK lanes and a tile of 64 records yields 320 (config 2) .. 416 (README)
+  // instances: the second round is a quarter / two thirds full and three waves wait for the one that runs it.  Here a tile is as many RECORDS as are
+  // expected to yield VSR_TAKE instances (smoothed instances per record of the block's own tiles); the cursor counts records, not tiles.
+  __shared__ u32 s_tile_n;
+  u32 my_take = (u32)tile, my_n = 0, avg_q8 = 0;                // thread 0: records to draw next time / drawn with my_next / instances per record x 256
+  if (tid == 0) { my_n = my_take; my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)my_take); }
+#else
   if (tid == 0) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+#endif
   for (;;) {
     if (tid == 0) {
       s_tile_cur = my_next;
+#if VSR_TAKE
+      s_tile_n = my_n;
+      if (my_next < n_parents) { my_n = my_take; my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)my_take); }
+#else
       if (my_next < ntiles) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+#endif
     }
     const u64 t_0 = VSR_CLK();
     if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; s_nsurv = 0; }
     if (tid < tile) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
-    VSR_SYNC();
+    VSR_SYNC_G(0);
     const u64 tile_i = s_tile_cur;
+#if VSR_TAKE
+    if (tile_i >= n_parents) break;
+    const u64 p_base = tile_i;
+    const int np_tile = (int)((n_parents - p_base) < (u64)s_tile_n ? (n_parents - p_base) : (u64)s_tile_n);
+#else
     if (tile_i >= ntiles) break;
     const u64 p_base = tile_i * (u64)tile;
     const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
+#endif
     // PLAIN == 3 (regeneration by the claim bitmap): the bitmap IS the list of enabled instances that matter — the (parent, ordinal) pairs whose lane
     // made a state when the level was inserted.  The words of this thread's record (thread g of the record's G threads takes words g and g + G; the host
     // offers the bitmap only when 2 G words cover a parent) are fetched now, so that their latency hides behind the staging loads.
@@ -557,15 +629,29 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
       if ((int)(ref & 255) > stride) raise_error(ctl, ERR_INTERNAL, (p_base + (u64)tid) << 16);   // LDS slots sized for shorter records
     }
-    VSR_SYNC();
+#if !VSR_DIRECT_REFS
+    VSR_SYNC_G(1);
+#endif
     constexpr int SG = BLK / 16;                                 // records staged per pass (16 lanes each)
     for (int half = 0; half < tile; half += 4 * SG)
       for (int wbase = 0; wbase < stride; wbase += 64) {      // records longer than 64 words (R >= 4): a second window
         u64 v[4][4];
+#if VSR_DIRECT_REFS
+        u64 refq[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int p = half + (tid >> 4) + SG * q;
+          refq[q] = p < np_tile ? fr_off[p_base + (u64)p] : 0;
+        }
+#endif
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int p = half + (tid >> 4) + SG * q;
+#if VSR_DIRECT_REFS
+          const u64 ref = refq[q];
+#else
           const u64 ref = p < np_tile ? s_ref[p] : 0;
+#endif
           const u64 off = ref >> 8;
           const int len = (int)(ref & 255) < stride ? (int)(ref & 255) : stride;
 #pragma unroll
@@ -577,7 +663,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int p = half + (tid >> 4) + SG * q;
+#if VSR_DIRECT_REFS
+          const int len = (int)(refq[q] & 255) < stride ? (int)(refq[q] & 255) : stride;
+#else
           const int len = p < np_tile ? ((int)(s_ref[p] & 255) < stride ? (int)(s_ref[p] & 255) : stride) : 0;
+#endif
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int k = wbase + (tid & 15) + 16 * j;
@@ -585,7 +675,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           }
         }
       }
-    VSR_SYNC();
+    VSR_SYNC_G(2);
     if (tid < np_tile && s_ref[tid] != 0) {                     // the parent's own fingerprint, from the view hashes it carries
       const u64* r0 = s_rec + tid * stride;
       u64 pf;
@@ -621,7 +711,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       const u32 PRIV = (ccap - (u32)BLK) / BLK;               // 5 at ccap 1536, 7 at 2048
       const u32 shared0 = PRIV * BLK;
       for (u32 k = tid; k < ccap; k += BLK) s_cand[k] = ~0u;
-      VSR_SYNC();
+      VSR_SYNC_G(3);
       u32 nmine = 0;
       bool alive = false;
       if constexpr (SPEC / 1000 == 0) {
@@ -704,7 +794,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
               if (pass) s_surv[base + (u32)__popcll(bal & (((u64)1 << lane) - 1))] = (u16)((p_mine << 8) | j);
             }
           }
-          VSR_SYNC();
+          VSR_SYNC_G(4);
           const u32 nsurv = s_nsurv;
           for (u32 i = tid; i < nsurv; i += BLK) {
             const int p = s_surv[i] >> 8, j = s_surv[i] & 255;
@@ -718,9 +808,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             }
           }
           if (j1 < maxbag) {                                      // another batch: the list is reused
-            VSR_SYNC();
+            VSR_SYNC_G(4);
             if (tid == 0) s_nsurv = 0;
-            VSR_SYNC();
+            VSR_SYNC_G(4);
           }
         }
         }   // (PLAIN != 3)
@@ -762,7 +852,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       if (alive) s_alive[p_mine] = 1;
       }
     }
-    VSR_SYNC();
+    VSR_SYNC_G(5);
     if (tid < np_tile && s_alive[tid] == 0 && s_ref[tid] != 0) atomicAdd(&s_dead, 1u);   // ref 0 = unused index (see k_materialize)
     // ---- counting sort of the work list by action id: the lanes of a wave then run the same action (no divergence between
     // the 15 action bodies, only inside one)
@@ -794,10 +884,18 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
       }
       s_ncand = acc > ccap ? ccap : acc;
+#if VSR_TAKE
+      {
+        const u32 q8 = (acc << 8) / (u32)np_tile;
+        avg_q8 = avg_q8 ? (3u * avg_q8 + q8) >> 2 : q8;
+        const u32 want = avg_q8 ? ((u32)VSR_TAKE << 8) / avg_q8 : (u32)tile;
+        my_take = want < 8u ? 8u : want > (u32)tile ? (u32)tile : want;
+      }
+#endif
       if (fused) s_wneed = s_ncand * (u32)(M.fixed + (int)s_maxbag + 5);   // upper bound of the successors' total length
     }
     const u64 t_2 = VSR_CLK();
-    VSR_SYNC();
+    VSR_SYNC_G(6);
     const u32 ncand = s_ncand;
     for (u32 c = tid; c < ccap; c += BLK) {
       const u32 code = s_cand[c];
@@ -805,7 +903,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       const u32 pos = atomicAdd(&s_kbase[code >> 18], 1u);
       if (pos < ccap) s_cand2[pos] = code;
     }
-    VSR_SYNC();
+    VSR_SYNC_G(6);
 
     const u64 t_3 = VSR_CLK();
     if (fused && (mode == MODE_NORMAL || mode == MODE_REGEN)) {
@@ -817,17 +915,17 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           nx_off[base + k] = 0;
           lvl_fp[base + k] = 0;
         }
-        VSR_SYNC();
+        VSR_SYNC_G(6);
         if (tid == 0) {
           u64 nb = atomicAdd((unsigned long long*)&ctl->n_new, (unsigned long long)ichunk);
           if (nb + ichunk > nx_cap) { raise_full(ctl, nb); nb = 0; }     // keep writing inside the buffer; the records are discarded, the claims stand
           s_ich_base = nb;
           s_ich_used = 0;
         }
-        VSR_SYNC();
+        VSR_SYNC_G(6);
       }
       if (s_wch_used + s_wneed > wchunk) {                      // records do not straddle chunks: the remainder is skipped
-        VSR_SYNC();
+        VSR_SYNC_G(6);
         if (tid == 0) {
           u64 nb = atomicAdd((unsigned long long*)&ctl->words_new, (unsigned long long)wchunk);
           if (nb + wchunk > nx_words_cap) { raise_full(ctl, nb); nb = 0; }
@@ -837,7 +935,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           s_wch_base = nb;
           s_wch_used = 0;
         }
-        VSR_SYNC();
+        VSR_SYNC_G(6);
       }
       if (tid == 0) { s_tile_ibase = s_ich_used; s_tile_wbase = s_wch_used; s_tile_icur = 0; s_tile_wcur = 0; }
     } else
@@ -846,7 +944,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       const u32 used = s_chunk_used;
       const u64 base = s_chunk_base;
       for (u32 k = used + tid; k < pchunk && used < pchunk; k += BLK) pending[3 * (base + k) + 1] = ~(u64)0;
-      VSR_SYNC();
+      VSR_SYNC_G(6);
       if (tid == 0) {
         u64 nb = atomicAdd((unsigned long long*)&ctl->n_pending, (unsigned long long)pchunk);
         if (nb + pchunk > pending_cap) {
@@ -856,18 +954,24 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         s_chunk_base = nb;
         s_chunk_used = 0;
       }
-      VSR_SYNC();
+      VSR_SYNC_G(6);
     }
     const u32 ncand_apply = s_skip ? 0u : ((PLAIN != 1 && FUSED && VSR_PROBE_FOOTPRINT) ? s_napply : ncand);                // s_skip: the tile was refused (see the word-chunk reservation)
     constexpr bool dd_on = false;
     if (tid == 0) { s_tile_base = s_chunk_used; s_tile_cursor = 0; }
-    VSR_SYNC();
+    VSR_SYNC_G(6);
     // ---- apply + fingerprint + seen-set claim: one lane per enabled instance
     // (no per-lane statistics: a lane runs this body once per tile, so every loop-carried register is a register of the body's peak — words
     // written come from the tile's word cursor, the largest bag / the virtual level's checksums go to LDS when a state is new, probes are counted
     // as one per candidate plus an LDS atomic per slot beyond the home slot)
     const CntLds my_probes{&s_acc[2]};
+#if VSR_ROUND_REV
+    for (u32 c0 = 0; c0 < ncand_apply; c0 += BLK) {
+      const u32 c = c0 + (((c0 / BLK) & 1u) ? (u32)(BLK - 1 - tid) : (u32)tid);
+      if (c >= ncand_apply) continue;
+#else
     for (u32 c = tid; c < ncand_apply; c += BLK) {
+#endif
       const u32 code = s_cand2[c];
       const int p = (int)((code >> 11) & 127), ord = (int)(code & 2047);
       const u64* rec = s_rec + p * stride;
@@ -1108,7 +1212,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
     }
     const u64 t_4 = VSR_CLK();
-    VSR_SYNC();
+    VSR_SYNC_G(7);
     if (tid == 0) {
       if (fused) {
         s_ich_used += s_tile_icur;
@@ -1129,7 +1233,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       s_acc[7] += t_5 - t_4;
     }
     if (tid < 16) s_acc[16 + tid] += s_kcount[tid];
-    VSR_SYNC();
+#if !VSR_NO_TAIL_SYNC
+    VSR_SYNC_G(0);
+#endif
   }
   // ---- block epilogue: invalidate the unused tail of the chunk, flush the accumulators
   {
@@ -1141,7 +1247,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         lvl_fp[base + k] = 0;
       }
       if (world > 1) {
-        VSR_SYNC();
+        VSR_SYNC_G(0);
         for (int o = 0; o < world; o++) {
           const u64 st = s_cstate[o];
           const u64 base = st >> 24;
@@ -1173,10 +1279,23 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       if (s_acc[1]) atomicAdd((unsigned long long*)&ctl->deadlocks, s_acc[1]);
       if (s_acc[2]) atomicAdd((unsigned long long*)&ctl->probes, s_acc[2]);
     }
+#if VSR_WAVE_DIAG == 3
+    if (tid == 64) {
+      for (int g = 0; g < 8; g++) atomicAdd((unsigned long long*)&ctl->phase_cycles[g], s_wd[g]);
+      atomicAdd((unsigned long long*)&ctl->act_generated[0], (unsigned long long)(__builtin_readcyclecounter() - wd_t0));
+    }
+    (void)wd_wait;
+#elif VSR_WAVE_DIAG
+    if (lane == 0 && (tid >> 6) < 4) {
+      atomicAdd((unsigned long long*)&ctl->phase_cycles[tid >> 6], (unsigned long long)wd_wait);
+      atomicAdd((unsigned long long*)&ctl->phase_cycles[4 + (tid >> 6)], (unsigned long long)(__builtin_readcyclecounter() - wd_t0));
+    }
+#else
     if (tid >= 3 && tid < 8 && s_acc[tid]) atomicAdd((unsigned long long*)&ctl->phase_cycles[tid - 3], s_acc[tid]);
     // wave 0's clock inside the apply loop: gen, hash, probe (into phase_cycles[5..7]), successor write (act_generated[0])
     if (tid >= 10 && tid < 13 && s_acc[tid]) atomicAdd((unsigned long long*)&ctl->phase_cycles[tid - 5], s_acc[tid]);
     if (tid == 13 && s_acc[13]) atomicAdd((unsigned long long*)&ctl->act_generated[0], s_acc[13]);
+#endif
     if (tid >= 16 && tid < 32 && s_acc[tid]) atomicAdd((unsigned long long*)&ctl->act_generated[tid - 16], s_acc[tid]);
   }
 }
@@ -1468,6 +1587,21 @@ __global__ void k_table_rehash(const Slot* __restrict__ old_table, u64 n_old, Sl
     const Probe p = probe_insert(table, tmask, s.fp, CntReg{&np});
     if (p.full) { atomicExch(err, (u32)ERR_TABLE_FULL); continue; }
     table[p.slot].meta = s.meta;                                 // every fingerprint occurs once in the old table: nobody else writes this slot
+  }
+}
+
+// the same for the generator-side winner set of a sharded deep search (host_checker.hpp: wset_grow): every fingerprint occurs once, its epoch word travels with it
+__global__ void k_wset_rehash(const u64* __restrict__ old_fp, const u32* __restrict__ old_epoch, u64 n_old, u64* fp, u32* epoch, u64 mask, u32* err) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n_old; i += stride) {
+    const u64 f = old_fp[i];
+    if (f == 0) continue;
+    u64 j = wset_home(f, mask);
+    bool done = false;
+    for (u64 step = 0; step <= mask && step < 65536 && !done; step++, j = (j + 1) & mask)
+      if (atomicCAS((unsigned long long*)&fp[j], 0ull, (unsigned long long)f) == 0) { epoch[j] = old_epoch[i]; done = true; }
+    if (!done) atomicExch(err, (u32)ERR_TABLE_FULL);
   }
 }
 

@@ -116,6 +116,22 @@ VSR_HD u64 salt_word(int r) {
   return r == 1 ? s1 : r == 2 ? s2 : r == 3 ? s3 : r == 4 ? s4 : s5;
 }
 
+#ifndef VSR_SALT_PIN
+#define VSR_SALT_PIN 1
+#endif
+// salt(position) ^ fp_seed.  The salt is a literal chosen by r; fp_seed is a kernel argument.  Written as one expression the optimiser turned the choice into a
+// switch over r whose arms are `literal ^ fp_seed` — loop-invariant, so hoisted out of the tile loop, nine 64-bit values (README configuration) held in VGPRs,
+// spilled, and RELOADED FROM SCRATCH in the middle of every successor's hash chain (three dependent scratch loads per successor; the review's "34 spilled
+// VGPRs").  The empty asm pins the chosen literal in a VGPR pair before the seed is xor-ed in: nothing invariant is left to hoist.
+template <int K>
+VSR_HD u64 salt_seeded(u64 fp_seed, int r) {
+  u64 sr = salt_word<K>(r);
+#if defined(__HIP_DEVICE_COMPILE__) && VSR_SALT_PIN
+  asm volatile("" : "+v"(sr));
+#endif
+  return sr ^ fp_seed;
+}
+
 // ---- header -------------------------------------------------------------------------------------------------
 VSR_HD int hdr_nmsg(u64 h) { return (int)(h & 0xFF); }
 VSR_HD int hdr_aux_svc(u64 h) { return (int)((h >> 8) & 7); }
@@ -213,7 +229,7 @@ VSR_HD bool word_has_values(u64 w, u64 m01) { return ((w | (w >> 1) | (w >> 2)) 
 // hash term of word K of replica r's block under permutation pt
 template <int K>
 VSR_HD u64 hash_rep_word(const Model& M, u64 w, int r, u32 pt) {
-  return fmix64(permute_word(w, K == 0 ? (u64)0 : K == 1 ? LOGB_REP1 : LOGB_REPK, pt) ^ (salt_word<K>(r) ^ M.fp_seed));
+  return fmix64(permute_word(w, K == 0 ? (u64)0 : K == 1 ? LOGB_REP1 : LOGB_REPK, pt) ^ salt_seeded<K>(M.fp_seed, r));
 }
 template <typename PTR>
 VSR_HD u64 hash_rep_block(const Model& M, PTR b, int r, u32 pt) {

@@ -485,6 +485,14 @@ int32_t vsrmc_shard_loop_advance(vsrmc_shard_loop* l, vsrmc_level_info* a, vsrmc
 int32_t vsrmc_shard_loop_room(vsrmc_shard_loop* l, int32_t* state) {
   if (!l || !state) return fail(VSRMC_E_ARG, "NULL argument");
   u64 full = (double)(l->c->deep ? l->c->deep_distinct : l->c->distinct) > 0.85 * (double)(l->c->tmask + 1) ? 1 : 0;
+  // the winner set of the deep search (round-5 advice): it fills with the rank's share of every level beyond the base, long before the seen-set shard does —
+  // grown between two passes while the device has the memory, else the run stops here, cleanly, instead of ERR_TABLE_FULL inside a pass
+  if (l->c->d_wset && l->c->deep) {
+    const u64 held = wset_count(l->c);
+    const u64 next = l->c->deep_lv.empty() ? 0 : 2 * l->c->deep_lv.back().n_local;   // the next level's share: growth below 2 from level to level
+    while ((double)(held + next) > 0.6 * (double)(l->c->h_wset.mask + 1) && wset_grow(l->c) == 0) {}
+    if ((double)(held + next) > 0.7 * (double)(l->c->h_wset.mask + 1)) full = 1;
+  }
   if (!l->replicated) {
     u64 all[8] = {0};
     const int rc0 = l->comm.allgather(l->comm.ctx, &full, all, 8);
