@@ -277,6 +277,8 @@ def run_readme(args, dump_trace=None, seed=0):
         t0 = time.perf_counter()
         cur_words = int(m.layout.fixed_words) + int(m.layout.permutations)
         alg, gen, kms, dms, launches, t_mat, n_mat, mat_levels = 0.0, 0, 0.0, 0.0, 0, 0.0, 0, 0
+        # the same kernel time and algorithmic bytes once more, per KIND of pass (= per instantiation of k_expand): [ms, bytes, launches]
+        split = {k_: [0.0, 0.0, 0] for k_ in ("stored", "virtual", "regenerate", "insert_beyond", "probe")}
         s_rec, n_prev = 8.0 * cur_words, 1                                   # bytes per record / states of the newest level
         passes = []
         found = None
@@ -291,8 +293,12 @@ def run_readme(args, dump_trace=None, seed=0):
                 kms += a["expand_ms"]
                 launches += 1
                 alg += 8.0 * cur_words + 8.0 * a["generated"] + 8.0 * a["n_new"] + 8.0 * a["record_words"]
+                split["stored"][0] += a["expand_ms"]
+                split["stored"][1] += 8.0 * cur_words + 8.0 * a["generated"] + 8.0 * a["n_new"] + 8.0 * a["record_words"]
+                split["stored"][2] += 1
                 cur_words = a["record_words"]
                 s_rec, n_prev = 8.0 * a["record_words"] / a["n_new"], a["n_new"]
+                n_base = a["n_new"]
                 t_mat, n_mat, mat_levels = time.perf_counter() - t0, mc.distinct, a["level"]
                 continue
             # a level that exists in the seen-set only.  Algorithmic bytes: SURVEY §8(d)'s B_alg = 2 S + 8 g + 8 per distinct state — every state
@@ -301,6 +307,17 @@ def run_readme(args, dump_trace=None, seed=0):
             if verify and want["fp_xor"] is not None and E["checksums"] and not seed:
                 assert ("%016x" % a["fp_xor"], "%016x" % a["fp_sum"]) == (want["fp_xor"], want["fp_sum"]), a["level"]
             alg += s_rec * n_prev + 8.0 * a["generated"] + 8.0 * a["n_new"] + s_rec * a["n_new"]
+            # per pass: a virtual level (first pass beyond the buffers) reads its parents and claims, writes no record; a later pass regenerates the levels
+            # between the base and its parents (their records written once more: the redundant work of this scheme), then inserts through a scratch buffer
+            first = a["materialize_ms"] == 0.0 and b is None
+            key_ = "virtual" if first else "insert_beyond"
+            split[key_][0] += a["expand_ms"]
+            split[key_][1] += s_rec * n_prev + 8.0 * a["generated"] + 8.0 * a["n_new"] + (0.0 if first else s_rec * a["n_new"])
+            split[key_][2] += 1 if first else (a["words_new"] & 0xFFFFFFFF)
+            if a["materialize_ms"]:
+                split["regenerate"][0] += a["materialize_ms"]
+                split["regenerate"][1] += s_rec * n_base + s_rec * n_prev      # the base level read, the level below the inserted one written (a two-level descent)
+                split["regenerate"][2] += a["words_new"] >> 32
             n_prev = a["n_new"]
             dms += a["expand_ms"] + a["materialize_ms"]
             launches += a["pending"]
@@ -310,6 +327,9 @@ def run_readme(args, dump_trace=None, seed=0):
                 gen += b["generated"]
                 alg += s_rec * n_prev + 8.0 * b["generated"]                 # the level below read, its successors looked up
                 dms += b["expand_ms"]
+                split["probe"][0] += b["expand_ms"]
+                split["probe"][1] += s_rec * n_prev + 8.0 * b["generated"]
+                split["probe"][2] += max(0, a["pending"] - (a["words_new"] >> 32) - (a["words_new"] & 0xFFFFFFFF))
                 row.update(probed_level=b["level"], probe_seconds=b["seconds"], probe_ms=b["expand_ms"])
                 if b["viol_mask"]:
                     found = b
@@ -363,6 +383,7 @@ def run_readme(args, dump_trace=None, seed=0):
             S["n_mat"], S["mat_levels"] = n_mat, mat_levels
             S["launches"] = launches
             S["deep"] = passes
+            S["split"] = split
 
     try:
         if seed:
@@ -421,7 +442,12 @@ def readme_object(args, elapsed, S):
                   "B_alg_per_state": round(alg_run / distinct, 1),
                   "sector_granular": sector_granular(alg_run, S["generated"] / k + distinct, kernel_ms / 1e3, distinct),
                   "kernel_ms_per_step": {"k_expand": round(kernel_ms, 3), "k_expand_materialised_levels": round(S["mat_ms"] / k, 3),
-                                         "k_expand_deep_passes": round(S["deep_ms"] / k, 3)}},
+                                         "k_expand_deep_passes": round(S["deep_ms"] / k, 3)},
+                  # the same roofline per KIND of pass = per instantiation of k_expand (one run, the last timed one): stored levels <313,1>, the virtual
+                  # level <313,4>, its regeneration from the claim bitmap <313,3>, the level inserted beyond the buffers <313,1> into scratch, the probe <313,2>
+                  "per_pass": {name: {"kernel_ms": round(v[0], 3), "launches": int(v[2]), "alg_bytes": round(v[1]),
+                                      "achieved": round(v[1] / max(v[0] / 1e3, 1e-12) / 1e9, 2), "frac": round(v[1] / max(v[0] / 1e3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5)}
+                               for name, v in S.get("split", {}).items() if v[0] > 0}},
         materialised=dict(levels=S["mat_levels"], distinct=S["n_mat"], seconds=round(S["mat_s"] / k, 4), states_per_s=round(S["n_mat"] / (S["mat_s"] / k), 1)),
         deep_passes=[{k_: (round(v, 4) if isinstance(v, float) else v) for k_, v in row.items()} for row in S["deep"]])
 
@@ -506,6 +532,62 @@ def run_config4(args):
                 distinct=g["distinct"], oracle_pinned_levels=len(g["levels"]), stored_levels=rows[-1][2], k_expand_ms_per_step=round(sum(r[1] for r in rows) / k, 3))
 
 
+def run_config5(args):
+    """BASELINE configs[4] (ReplicaCount=5, ClientCount=1, Values={v1,v2}, StartViewOnTimerLimit=2: the "288 GB/GPU FPSet sizing stress") on this ONE GPU as
+    deep as its HBM goes, through the automatic level scheme: every level the CPU oracle's fixture holds (tests/golden/oracle_levels_config5.json: 14 levels,
+    3 177 730 826 states) asserted — new states, successors in total and per action, deadlocks, largest bag, fingerprint checksums — then the probe of the
+    level after it (no CPU counterpart: 3.7e10 successors; GPU-sourced, labelled so), and the whole run once more under the audit seed.  Neither a violation
+    nor exhaustion is within one GPU's reach: the object is a rate and a depth, not a time-to-violation.  -> JSON fields"""
+    import torch
+    import vsr_tlaplus_amd as vt
+    torch.cuda.set_device(0)
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_config5.json")) as f:
+        g = json.load(f)
+    p = g["params"]
+    last = g["levels"][-1]["level"]
+    sums = g.get("fp_version") == FP_VERSION
+
+    def one(seed):
+        m = vt.Model.from_constants(R=p["R"], C_=p["C"], n=p["n"], L=p["L"])
+        if seed:
+            m.set_fp_seed(seed)
+        mc = vt.ModelChecker.auto(m, device=0)
+        try:
+            t0 = time.perf_counter()
+            kms, stored, probed = 0.0, 1, None
+            while mc.depth < last:
+                kind, a, b = mc.advance()
+                lv = g["levels"][a["level"] - 1]
+                assert (a["n_new"], a["generated"], a["deadlocks"], a["max_bag"], a["viol_mask"]) == (lv["new"], lv["generated"], lv["deadlocks"], lv["max_bag"], 0), a["level"]
+                assert [int(x) for x in a["act_generated"][1:16]] == lv["act_generated"][1:16], a["level"]
+                if sums and not seed:
+                    x, s_ = (mc.level_checksum()[:2]) if kind == "level" else (a["fp_xor"], a["fp_sum"])
+                    assert ("%016x" % x, "%016x" % s_) == (lv["fp_xor"], lv["fp_sum"]), a["level"]
+                kms += a["expand_ms"] + a["materialize_ms"] + (b["expand_ms"] if b is not None else 0.0)
+                stored += kind == "level"
+                if b is not None:
+                    probed = dict(level=b["level"], generated=b["generated"], deadlocks=b["deadlocks"], viol_mask=b["viol_mask"], seconds=round(b["seconds"], 3))
+            dt = time.perf_counter() - t0
+            assert mc.distinct == sum(lv["new"] for lv in g["levels"]) and mc.violation is None
+            return dict(seconds=dt, kernel_ms=kms, stored_levels=stored, probed=probed, distinct=mc.distinct,
+                        table_log2=int(mc.options.table_log2), load=round(mc.distinct / float(1 << int(mc.options.table_log2)), 3))
+        finally:
+            mc.close()
+
+    r0 = one(0)
+    r1 = one(AUDIT_SEED) if not args.no_verify else None
+    same = None if r1 is None else (r1["probed"] is not None and r0["probed"] is not None and
+                                    (r1["probed"]["level"], r1["probed"]["generated"], r1["probed"]["deadlocks"], r1["probed"]["viol_mask"]) ==
+                                    (r0["probed"]["level"], r0["probed"]["generated"], r0["probed"]["deadlocks"], r0["probed"]["viol_mask"]))
+    return dict(workload="VSR.tla BFS, ReplicaCount=5 ClientCount=1 Values={v1,v2} StartViewOnTimerLimit=2 (BASELINE configs[4], the FPSet sizing stress), VIEW+SYMMETRY, "
+                         "the %d levels the CPU oracle's fixture holds: %d distinct states, no violation; every level asserted; the level after them probed "
+                         "(GPU-sourced: no CPU counterpart)" % (last, r0["distinct"]),
+                value=round(r0["distinct"] / r0["seconds"], 1), unit="distinct states/s", steps=1, ms_per_step=round(1e3 * r0["seconds"], 3), depth=last,
+                distinct=r0["distinct"], oracle_pinned_levels=len(g["levels"]), stored_levels=r0["stored_levels"], k_expand_ms_per_step=round(r0["kernel_ms"], 3),
+                seen_set=dict(slots_log2=r0["table_log2"], load=r0["load"]), probed=r0["probed"], probed_source="gpu",
+                second_seed=None if r1 is None else dict(seed=hex(AUDIT_SEED), every_level_equal_to_the_fixture=True, probed=r1["probed"], probe_figures_equal=same))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -517,6 +599,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip the README configuration (takes the whole HBM): config 2 is the headline")
     ap.add_argument("--no-config2", action="store_true", help="skip the config-2 object")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 object (BASELINE configs[3] under assume_commit_number)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 object (BASELINE configs[4]: 14 oracle-pinned levels + the probe of level 15, two seeds)")
     ap.add_argument("--workload", choices=["auto", "readme", "config3", "config2"], default="auto",
                     help="auto (default): the README defect configuration (BASELINE configs[2], fits one MI355X) is the headline and config 2 "
                          "(BASELINE configs[1]) an object beside it; readme / config3: only the former; config2: only the latter")
@@ -527,7 +610,7 @@ def main():
         return sharded_bench.main(args, sys.modules[__name__])
     want_readme = args.workload in ("auto", "readme", "config3") and not args.no_config3
     want_c2 = args.workload in ("auto", "config2") and not args.no_config2
-    c2 = rd = c4 = None
+    c2 = rd = c4 = c5 = None
     audit = None
     if want_c2:
         elapsed, S, _ = run_single(args)
@@ -539,6 +622,8 @@ def main():
         rd = readme_object(args, elapsed, S)
     if args.workload == "auto" and not args.no_config4 and not args.no_config3:
         c4 = run_config4(args)
+    if args.workload == "auto" and not args.no_config5 and not args.no_config3:
+        c5 = run_config5(args)
     if not args.no_verify:
         # second-hash audit: the untimed verification runs once more under another member of the fingerprint family — every per-level count
         # (new states, generated, deadlocks, largest bag, per action) is asserted against the same oracle fixtures inside the runs
@@ -578,6 +663,8 @@ def main():
         out["config2"] = c2
     if c4 is not None:
         out["config4"] = c4
+    if c5 is not None:
+        out["config5"] = c5
     out["collision_audit"] = audit
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, cfg)

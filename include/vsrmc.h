@@ -195,6 +195,10 @@ typedef struct vsrmc_level_info {
   uint64_t phase_cycles[8];      /* k_expand shader clocks summed over blocks: stage, enumerate, sort, apply, tail */
   uint64_t fp_xor, fp_sum;       /* vsrmc_checker_probe2 / _probe3, the levels that are never stored: xor / sum (mod 2^64) of the level's
                                   * fingerprints (a stored level: vsrmc_checker_level_checksum) */
+  uint64_t limit_rechecked;      /* a probed level: instances outside the invariants' footprint (not applied by a probe pass) that sat in a tile with a record
+                                  * at a representation limit — bag within R - 1 entries of its capacity, a delivery count of 3.  Not 0: those passes were
+                                  * run AGAIN with every action applied, so a limit hit by such a successor is reported like anywhere else (round 5: it went
+                                  * unreported); 0 on every BASELINE configuration */
 } vsrmc_level_info;
 
 void vsrmc_options_default(vsrmc_options* o);
@@ -217,6 +221,10 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
 /* the states of the newest level in which at least one instance of an action of `action_mask` (bit a = action id a, the order of
  * `Next`, VSR.tla:896-918) is enabled — at most max_states of them, wire layout; *n_matching = how many there are in all
  * (≙ TLC's per-action coverage, as a filter) */
+/* MEASUREMENT (not a product path; tools/bench_layout.py): one staging pass of k_expand's tile loop over the newest stored level, layout 0 =
+ * the records as they are (refs + variable-length records), 1 = the same level as fixed-stride columns (SURVEY §8a row a1's SoA; a transposed copy is made
+ * first, untimed).  Both fill the same LDS tile and read it back once.  *ms_per_pass = HIP-event time of one pass (mean of `reps`), *bytes_per_pass = what it reads. */
+int32_t vsrmc_checker_bench_staging(vsrmc_checker* c, int32_t layout, int32_t reps, double* ms_per_pass, uint64_t* bytes_per_pass);
 int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t max_states, uint64_t* words, uint64_t cap_words,
                              uint64_t* off, uint64_t* n_states, uint64_t* n_matching);
 /* ≙ TLCTrace.getTrace: the path Init .. state `index` of the NEWEST level (level must be the current one); records in wire
@@ -453,6 +461,13 @@ int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t sto
  * is more than 85 % full — every rank learns it in the same call and all of them stop together ("incomplete at depth N"); loops over
  * vsrmc_shard_loop_advance ask before every call, vsrmc_shard_loop_run does */
 int32_t vsrmc_shard_loop_room(vsrmc_shard_loop* l, int32_t* state);
+/* ≙ TLC's checkpoints for a sharded run (collective; between two vsrmc_shard_loop_advance calls — also once the search has gone beyond the ranks' record
+ * buffers: the seen-set-only levels' descriptors and each rank's winner set travel in its shard file).  Every rank writes <prefix>.rank<r>of<w> (its checker:
+ * vsrmc_checker_save) and <prefix>.rank<r>of<w>.loop (the loop's own state), in two phases: a failure on any rank leaves the previous checkpoint whole.
+ * Recover: vsrmc_checker_load of the rank's own shard file, then vsrmc_shard_loop_restore over it (every rank must have loaded the same depth). */
+int32_t vsrmc_shard_loop_save(vsrmc_shard_loop* l, const char* prefix);
+int32_t vsrmc_shard_loop_restore(vsrmc_checker* c, const vsrmc_comm* comm, uint64_t cand_cap, uint64_t rec_cap, uint64_t rec_words_cap, const char* prefix,
+                                 vsrmc_shard_loop** out);
 /* vsrmc_checker_deepen / vsrmc_checker_advance for a sharded run (collective; figures over all ranks): levels beyond the ranks' record
  * buffers live in the ranks' seen-sets only and are regenerated from the newest stored level; every pass of the descent is the
  * protocol of a sharded level with other sources and targets (csrc/vsr_shard_loop.hpp).  advance: an ordinary sharded level while EVERY

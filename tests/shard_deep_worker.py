@@ -24,17 +24,29 @@ def main():
     import vsr_tlaplus_amd as vt
     from vsr_tlaplus_amd import sharded
     m = vt.Model.from_constants(R=R, C_=C_, n=n, L=L, invariant_mask=inv_mask, assume_commit_number=bool(int(os.environ.get("SHARD_ASSUME_COMMIT", "0"))))
-    if fw_log2:
-        eng = sharded.HipShardEngine(m, rank, world, device=0, table_log2=20, frontier_words=1 << fw_log2, frontier_states=1 << (fw_log2 - 5),
-                                     pending_entries=1 << 16, cand_cap=1 << 17, rec_cap=1 << 15, rec_words_cap=1 << 20, filter_log2=16, native_only=True)
+    def make_engine(recover=None):
+        if fw_log2:
+            return sharded.HipShardEngine(m, rank, world, device=0, table_log2=20, frontier_words=1 << fw_log2, frontier_states=1 << (fw_log2 - 5),
+                                          pending_entries=1 << 16, cand_cap=1 << 17, rec_cap=1 << 15, rec_words_cap=1 << 20, filter_log2=16, native_only=True,
+                                          recover=recover)
+        return sharded.HipShardEngine(m, rank, world, device=0, table_log2=0, frontier_words=0, frontier_states=0, pending_entries=0, cand_cap=0,
+                                      rec_cap=1 << 22, rec_words_cap=1 << 28, native_only=True, recover=recover)
+    # SHARD_SAVE_AT=<depth>: when the search has reached that depth it is checkpointed (vsrmc_shard_loop_save) and this process ends;
+    # SHARD_RECOVER=<prefix>: the run continues from such a checkpoint, in fresh processes
+    save_at, recover = int(os.environ.get("SHARD_SAVE_AT", "0")), os.environ.get("SHARD_RECOVER")
+    if recover:
+        sc = sharded.NativeShardedChecker.restore(recover, make_engine, sharded.TorchHostComm())
+        eng = sc.e
     else:
-        eng = sharded.HipShardEngine(m, rank, world, device=0, table_log2=0, frontier_words=0, frontier_states=0, pending_entries=0, cand_cap=0,
-                                     rec_cap=1 << 22, rec_words_cap=1 << 28, native_only=True)
-    sc = sharded.NativeShardedChecker(eng, sharded.TorchHostComm(), replicate_below=replicate_below)
-    sc.depth = sc.level
+        eng = make_engine()
+        sc = sharded.NativeShardedChecker(eng, sharded.TorchHostComm(), replicate_below=replicate_below)
+        sc.depth = sc.level
     rows = []
     probed = None
     while sc.depth < max_depth and sc.violation is None:
+        if save_at and sc.depth >= save_at:
+            sc.save(out + ".chk")
+            break
         kind, a, b = sc.advance()
         if a["n_new"] == 0:
             break

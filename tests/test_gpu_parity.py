@@ -219,6 +219,17 @@ def test_bfs_config3_prefix(vt, orc, exact):
     assert level == 11 and total == 80646 + 154410
 
 
+@pytest.mark.parametrize("params,depth,want", [((3, 1, 2, 2), 13, 163346 + 161457), ((3, 1, 3, 3), 11, 80646 + 154410), ((5, 1, 2, 2), 7, None)])
+def test_a_tile_that_overflows_the_work_list_is_taken_again_in_pieces(vt, orc, monkeypatch, params, depth, want):
+    """Round 6: the launch shape shortens k_expand's LDS work list until five blocks fit a CU, so a tile with more enabled instances than the list
+    holds must not be an error any more: the block takes the same records again in pieces of half the size (s_redo_*), nothing of the tile having
+    been applied when the counting sort finds out.  VSRMC_CCAP=256 makes nearly every tile of these prefixes overflow (4 instances per record; the
+    models' mean is 5 - 16), several times over: per-level fingerprint SETS, new / generated / deadlock counts = the oracle's, as without it."""
+    monkeypatch.setenv("VSRMC_CCAP", "256")
+    total, level = _compare_levels(vt, orc, params, depth)
+    assert level == depth and (want is None or total == want)
+
+
 def test_bfs_config5_prefix(vt, orc):
     total, level = _compare_levels(vt, orc, (5, 1, 2, 2), 7)                     # five replicas
     assert level == 7

@@ -58,3 +58,53 @@ def test_the_set_in_the_kernel_source_is_this_one():
     body = src[src.index("static VSR_HD u32 probe_actions()"):]
     body = body[:body.index("}")]
     assert set(re.findall(r"A_(\w+)", body)) == PROBE_ACTIONS
+
+
+@pytest.mark.gpu
+def test_a_probe_pass_beside_a_representation_limit_is_run_again_with_every_action(tmp_path):
+    """Round-5 review: a probe level applies only the footprint actions, so a representation limit (bag capacity, delivery count) hit by a successor
+    of ANOTHER action went unreported.  Now the kernel counts the instances it did not apply in tiles that hold a record at such a limit
+    (LevelCtl::limit_unchecked) and the host runs the pass again with every action applied; vsrmc_level_info.limit_rechecked says so.  No shipped
+    configuration comes near a limit, so the hooks library lowers the bag capacity (VSRMC_TEST_MAX_BAG) to the largest bag the space holds: the
+    probe of the level after the one that reaches it must be re-run, and must report what the unconstrained probe reports."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "limit_probe.py"
+    script.write_text("""
+import os, sys
+sys.path.insert(0, %r)
+import vsr_tlaplus_amd as vt
+kw = dict(device=0, table_log2=16, frontier_words=1 << 20, frontier_states=1 << 15, pending_entries=1 << 15)
+m = vt.Model.from_constants(R=2, C_=1, n=2, L=2)
+mc = vt.ModelChecker(m, **kw)
+bags = [0]
+while True:
+    d = mc.step()
+    if not d["n_new"]:
+        break
+    bags.append(d["max_bag"])
+B = max(bags)
+L = bags.index(B) + 1                       # the first level that holds a record with the largest bag (Init = level 1)
+assert 4 <= B < 40 and L < len(bags)
+def probe_at(model):
+    c = vt.ModelChecker(model, **kw)
+    while c.level < L:
+        c.step()
+    p = c.probe()
+    c.close()
+    return p
+p0 = probe_at(m)
+os.environ["VSRMC_TEST_MAX_BAG"] = str(B)
+m2 = vt.Model.from_constants(R=2, C_=1, n=2, L=2)
+assert m2.layout.max_bag == B, (m2.layout.max_bag, B)
+p1 = probe_at(m2)
+assert p0["limit_rechecked"] == 0 and p1["limit_rechecked"] > 0, (p0["limit_rechecked"], p1["limit_rechecked"])
+for k in ("level", "generated", "deadlocks", "viol_mask", "viol_fp", "pending"):
+    assert p0[k] == p1[k], (k, p0[k], p1[k])
+print("OK", B, L, p1["limit_rechecked"])
+""" % root)
+    hooks = os.path.join(root, "vsr_tlaplus_amd", "libvsrmc_hooks.so")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=dict(os.environ, VSRMC_LIB=hooks))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

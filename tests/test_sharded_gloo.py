@@ -248,6 +248,25 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
     assert "Recovered from checkpoint" in r.stdout and "Probe(19):" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert "Error: Invariant AcknowledgedWritesExistOnMajority is violated." in r.stdout
     assert "State 19: <" in r.stdout and "State 20: <" not in r.stdout and "109878 distinct states found" in r.stdout, r.stdout[-1500:]
+    # the AUTOMATIC scheme (C++ level loop) with -checkpoint / -recover, cut AFTER the search has gone beyond the ranks' record buffers (round 6:
+    # vsrmc_shard_loop_save / _restore): 1/1000 of the device each (282 MB: seen-set shards of 2^22 slots, 55-MB record buffers), the shipped constants —
+    # level 14 no longer fits, "Virtual(..)" lines follow; checkpointed before every unit of progress up to depth 16; recovered to depth 17
+    d4 = tmp_path / "c4"
+    d4.mkdir()
+    chk4 = str(d4 / "chk")
+    cfg4 = _cfg(d4)
+    def auto(*extra):
+        return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29674",
+                               "-m", "vsr_tlaplus_amd.sharded_cli", "-config", cfg4, "-noTLA", "-backend", "gloo"] + list(extra),
+                              capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1", VSRMC_AUTOSIZE_SHARE="1000"))
+    r = auto("-maxDepth", "16", "-checkpoint", chk4, "-checkpointMinutes", "0")
+    assert "Virtual(" in r.stdout and "Checkpointing of run %s completed (depth 15)." % chk4 in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert os.path.exists(chk4 + ".rank1of2") and os.path.exists(chk4 + ".rank0of2.loop")
+    r = auto("-recover", chk4, "-maxDepth", "17")
+    assert "Recovered from checkpoint %s: depth 15" % chk4 in r.stdout and "Virtual(16)" in r.stdout and "Virtual(17)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_config2.json")) as f:
+        lv2 = json.load(f)["levels"]
+    assert "%d distinct states found" % sum(l["new"] for l in lv2[:17]) in r.stdout, r.stdout[-1500:]
     # the shipped VSR.cfg constants: the run ends in the depth-28 violation of AcknowledgedWriteNotLost (319 M states)
     d2 = tmp_path / "c2"
     d2.mkdir()
@@ -369,6 +388,52 @@ def test_sharded_deep_levels_against_the_oracle(tmp_path, world, rb):
         assert nxt, "a state of the counter-example is not a successor of its predecessor"
         rec, bad = nxt[0]["words"], nxt[0]["inv"]
     assert bad == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,params,inv,fw,save_at,last", [(2, (3, 1, 2, 1), 2, 17, 13, 19), (2, (3, 1, 3, 3), 1, 18, 10, 12), (3, (3, 1, 2, 1), 2, 17, 15, 19)])
+def test_sharded_deep_search_is_checkpointed_and_recovered(tmp_path, world, params, inv, fw, save_at, last):
+    """Round 6 (the round-5 review's f4 remainder): a SHARDED search that has gone beyond its record buffers is checkpointed between two passes
+    (vsrmc_shard_loop_save: every rank its seen-set shard, its part of the stored base level, the descriptors of the seen-set-only levels, its winner
+    set; the loop's totals in a sidecar; two phases) and recovered by NEW processes (vsrmc_checker_load + vsrmc_shard_loop_restore), which make every
+    later pass as the uninterrupted run does: every level's figures and checksums against the CPU oracle before and after the cut, the violation and
+    its counter-example where the configuration has one.  (3,1,{v1,v2},1) with AcknowledgedWritesExistOnMajority on 2 / 3 ranks; the README defect
+    configuration (six permutations) on 2 ranks with 2 MB record buffers, cut at depth 10."""
+    from oracle import orc
+    first = run_deep_world(world, params, inv, last, tmp_path, 29705 + world, fw_log2=fw, SHARD_SAVE_AT=save_at)
+    assert first["violation"] is None and first["depth"] >= save_at and [lv["kind"] for lv in first["levels"]][-1] == "deep"
+    prefix = str(tmp_path / ("deep_w%d" % world)) + ".chk"
+    for r in range(world):
+        assert os.path.exists("%s.rank%dof%d" % (prefix, r, world)) and os.path.exists("%s.rank%dof%d.loop" % (prefix, r, world))
+    second = run_deep_world(world, params, inv, last, tmp_path, 29715 + world, fw_log2=fw, SHARD_RECOVER=prefix)
+    levels = first["levels"] + second["levels"]
+    assert [lv["level"] for lv in levels] == list(range(2, levels[-1]["level"] + 1)) and second["levels"], "the recovered run goes on where the first one stopped"
+    assert all(lv["kind"] == "deep" for lv in second["levels"])
+    P = orc.Params(*params, invariant_mask=inv)
+    ob = orc.Bfs(P)
+    for lv in levels:
+        n = ob.step()
+        assert (lv["level"], lv["n_new"], lv["generated"], lv["deadlocks"]) == (ob.info["depth"], n, ob.info["generated"], ob.info["deadlocks"]), lv["level"]
+        if lv["kind"] == "deep":
+            fps = ob.level_fps(lv["level"])
+            assert lv["fp_xor"] == "%016x" % int(np.bitwise_xor.reduce(fps)), lv["level"]
+            assert lv["fp_sum"] == "%016x" % (int(fps.astype(object).sum()) & ((1 << 64) - 1)), lv["level"]
+    assert second["distinct"] == ob.info["distinct"]
+    if inv == 2:                                                          # the violation at depth 19 is found by the recovered run's probe
+        ob.step()
+        words, off = ob.frontier()
+        viol = min(orc.fingerprint(P, words[int(off[i]): int(off[i + 1])])[0] for i in range(len(off) - 1)
+                   if orc.invariants(P, words[int(off[i]): int(off[i + 1])]))
+        assert second["violation"] == dict(level=19, fp="%016x" % viol, mask=2, probed=True)
+        path = [int(f, 16) for f in second["path"]]
+        rec = orc.init_record(P)
+        assert len(path) == 19 and orc.fingerprint(P, rec)[0] == path[0]
+        for f in path[1:]:
+            nxt = [s_ for s_ in orc.successors(P, rec) if s_["fp"] == f]
+            assert nxt, "a state of the counter-example is not a successor of its predecessor"
+            rec = nxt[0]["words"]
+    else:
+        assert second["violation"] is None and second["depth"] == last
 
 
 @pytest.mark.gpu

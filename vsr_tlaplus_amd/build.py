@@ -10,7 +10,10 @@ LIB = os.path.join(HERE, "libvsrmc.so")
 LIB_HOOKS = os.path.join(HERE, "libvsrmc_hooks.so")     # the same sources with -DVSRMC_TEST_HOOKS: test hooks the product library does not contain
 CLI = os.path.join(HERE, "vsrmc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# -disable-machine-licm (round 6): MachineLICM hoists the materialisation of constants (position salts, masks, small integers) out of k_expand's tile loop into
+# VGPRs that then live across the whole loop and get spilled — with it off the three hot instantiations compile to 107 / 119 / 120 VGPRs and NO scratch
+# (were 128 + 12 / 34 / 27 spilled, reloaded in the middle of every successor's hash chain): k_expand -4.4 % (config 2), -6.4 % (README); DESIGN.md §8.5
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm"]
 
 
 def _newer(target, srcs):

@@ -28,7 +28,7 @@ class LevelInfo(C.Structure):
                 ("max_bag", C.c_uint64), ("viol_fp", C.c_uint64), ("viol_index", C.c_uint64), ("viol_mask", C.c_int32),
                 ("reserved0", C.c_int32), ("seconds", C.c_double), ("expand_ms", C.c_double),
                 ("materialize_ms", C.c_double), ("act_generated", C.c_uint64 * 16), ("phase_cycles", C.c_uint64 * 8),
-                ("fp_xor", C.c_uint64), ("fp_sum", C.c_uint64)]
+                ("fp_xor", C.c_uint64), ("fp_sum", C.c_uint64), ("limit_rechecked", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("act_generated", "reserved0", "phase_cycles")}
@@ -125,6 +125,7 @@ SYMBOLS = {
     "vsrmc_checker_seen_batch": (C.c_int32, [V, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "vsrmc_checker_probe_violators": (C.c_int32, [V, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_probe_trace": (C.c_int32, [V, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vsrmc_checker_bench_staging": (C.c_int32, [V, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "vsrmc_checker_trace_to_violator": (C.c_int32, [V, C.c_uint64, V, C.c_uint64, V, V, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vsrmc_checker_save": (C.c_int32, [V, C.c_char_p]),
     "vsrmc_checker_status": (C.c_int32, [V, C.POINTER(LevelInfo)]),
@@ -150,6 +151,8 @@ SYMBOLS = {
     "vsrmc_shard_loop_step": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo)]),
     "vsrmc_shard_loop_run": (C.c_int32, [V, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(LevelInfo)]),
     "vsrmc_shard_loop_room": (C.c_int32, [V, C.POINTER(C.c_int32)]),
+    "vsrmc_shard_loop_save": (C.c_int32, [V, C.c_char_p]),
+    "vsrmc_shard_loop_restore": (C.c_int32, [V, V, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]),
     "vsrmc_shard_loop_status": (C.c_int32, [V, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]),

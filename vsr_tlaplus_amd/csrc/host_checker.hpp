@@ -66,6 +66,7 @@ struct vsrmc_checker {
   int probe_viol_level = 0;              // the probed level they belong to
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
   bool saw_violation = false;            // a committed level held a violating state (the caller went on): probe passes apply every action
+  bool probe_all_actions = false;        // ... and so does the second run of a probe pass whose first run left instances unapplied beside a representation limit
   // levels beyond the record buffers (vsr_deep.hpp): `deep` levels above `level` are complete in the seen-set and have no frontier
   int deep = 0;
   std::vector<DeepLevelRec> deep_lv;     // [i] = level + 1 + i
@@ -197,13 +198,27 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
   };
   f.blk = blk;
   size_t lds64 = 0, lds128 = 0;
-  const u32 ccap64 = M.R <= 3 ? (u32)VSR_CCAP64 : (u32)VSR_CAND_CAP;      // work-list entries per tile (24 resp. 32 per record)
+  u32 ccap64 = M.R <= 3 ? (u32)VSR_CCAP64 : (u32)VSR_CAND_CAP;            // work-list entries per tile (24 resp. 32 per record)
+  if (const char* e = std::getenv("VSRMC_CCAP"))                           // tests: a work list so short that tiles overflow it and are taken again in pieces (k_expand: s_redo_*)
+    ccap64 = (u32)std::max(256, std::min(2048, std::atoi(e))) & ~127u;
   const int occ64 = occupancy(64, ccap64, &lds64);
-  const int occ128 = M.R <= 3 ? occupancy(128, 1536u, &lds128) : 0;
+  // 128-record tiles: only the instantiations that are generic in the constants (compiled for two blocks per CU) ever have fewer than three 64-record
+  // tiles resident at R <= 3 — the specialised ones size their per-record LDS arrays for 64 (vsr_kernels.hpp: TILE_MAX)
+  const bool generic = kernel == (const void*)(ExpandKernel)k_expand<true, 0> || kernel == (const void*)(ExpandKernel)k_expand<true, 1000> ||
+                       kernel == (const void*)(ExpandKernel)k_expand<true, 2000>;
+  const int occ128 = (M.R <= 3 && generic) ? occupancy(128, 1536u, &lds128) : 0;
   if (M.R <= 3 && occ64 < 3 && occ128 >= 1) {
     f.tile = 128; f.ccap = 1536u; f.lds = lds128; f.blocks_per_cu = (unsigned)std::min(occ128, 2);
   } else {
-    f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, VSR_OCC));
+    f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, VSR_OCC + 1));   // (what the instantiation's registers and this LDS allow)
+    // An instantiation compiled for FIVE blocks per CU (expand_occ: the ordinary level's kernel of BASELINE configs[1]) gets them when a shorter work list
+    // fits the LDS five times: the largest multiple of 128 entries that does, 512 at the least (8 instances per record; the mean is 5).  A tile with more
+    // is taken again in halves by the kernel (s_redo_*), so the length of the list is a matter of speed, not of correctness.
+    if (M.R <= 3 && occ64 == VSR_OCC && ccap64 > 512u)
+      for (u32 cc = ccap64 - 128; cc >= 512u; cc -= 128) {
+        size_t l5 = 0;
+        if (occupancy(64, cc, &l5) > VSR_OCC) { f.ccap = cc; f.lds = l5; f.blocks_per_cu = (unsigned)(VSR_OCC + 1); break; }
+      }
   }
   if (const char* e = std::getenv("VSRMC_MAX_BPC"))            // diagnostic: fewer resident blocks per CU (occupancy sweeps)
     f.blocks_per_cu = (unsigned)std::max(1, std::min<int>((int)f.blocks_per_cu, std::atoi(e)));
@@ -582,7 +597,7 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
                          stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
                          c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, ichunk,
                          wchunk, tile, ccap, c->filter, c->fmask, c->cand_idx, cchunk,
-                         mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), (u64)0, (const WSet*)nullptr, 0u);
+                         mode | ((mode == MODE_PROBE && (c->saw_violation || c->probe_all_actions)) ? (int)MODE_NO_FOOTPRINT : 0), (u64)0, (const WSet*)nullptr, 0u);
     else
       hipLaunchKernelGGL(exact_kernel_for(M), dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
@@ -824,7 +839,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
                        io ? io->cand_send : nullptr, io ? io->cand_cap : (u64)0, (u32)VSR_CAND_CAP,
                        d_words, d_wcap, d_off, nx_cap, d_fp,
                        ichunk, wchunk, tile, ccap, !one_rank ? c->filter : (u64*)claim_bits, !one_rank ? c->fmask : claim_w, io ? c->cand_idx : nullptr, cchunk,
-                       mode | ((mode == MODE_PROBE && c->saw_violation) ? (int)MODE_NO_FOOTPRINT : 0), p_offset,
+                       mode | ((mode == MODE_PROBE && (c->saw_violation || c->probe_all_actions)) ? (int)MODE_NO_FOOTPRINT : 0), p_offset,
                        (const WSet*)((io && c->opt.world > 1) ? c->d_wset : nullptr), c->wepoch);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));

@@ -40,8 +40,8 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   if (!c || !path) return fail(VSRMC_E_ARG, "NULL argument");
   if (c->failed) return fail(VSRMC_E_STATE, "the checker stopped on an error");
   if (c->opt.world > 1 && c->opt.exact_ties) return fail(VSRMC_E_STATE, "checkpoints of sharded exact-mode checkers are not supported");
-  if (c->opt.world > 1 && c->deep) return fail(VSRMC_E_STATE, "a sharded search that has gone beyond its record buffers is not checkpointed (the level loop's own state — the run's totals, "
-                                                               "the ranks' shares of every seen-set-only level — lives outside this handle); unsharded checkers are");
+  // (a sharded search beyond its record buffers: the rank's winner set travels in a section of its own behind the frontier, the level loop's own state —
+  // the run's totals, the violation — in a sidecar the loop writes: vsrmc_shard_loop_save)
   HIPCHK(hipSetDevice(c->opt.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   const Model& M = c->model.M;
@@ -96,6 +96,31 @@ int32_t vsrmc_checker_save(vsrmc_checker* c, const char* path) {
   ok = ok && dev_to_file(f, c->words[c->cur], c->cur_w * 8, buf);
   ok = ok && dev_to_file(f, c->off[c->cur], c->n_frontier * 8, buf);
   ok = ok && dev_to_file(f, c->lvl_fp, c->n_frontier * 8, buf);
+  // optional section: the generator-side winner set of a sharded deep search, as (fingerprint, level) pairs
+  if (ok && c->opt.world > 1 && c->deep && c->d_wset) {
+    const u64 wslots = c->h_wset.mask + 1, wwin = std::min<u64>(wslots, (u64)1 << 26);
+    Slot* d_w = nullptr;
+    u64* d_wc = nullptr;
+    ok = hipMalloc((void**)&d_w, wwin * sizeof(Slot)) == hipSuccess && hipMalloc((void**)&d_wc, 8) == hipSuccess;
+    const u64 magic = 0x5445535754455357ull;                    // "WSETWSET"
+    const long at = std::ftell(f);
+    u64 head[2] = {magic, 0};
+    ok = ok && std::fwrite(head, 8, 2, f) == 2;
+    u64 wtotal = 0;
+    for (u64 first = 0; first < wslots && ok; first += wwin) {
+      u64 cnt = 0;
+      const u64 n = std::min<u64>(wwin, wslots - first);
+      ok = hipMemset(d_wc, 0, 8) == hipSuccess;
+      hipLaunchKernelGGL(k_wset_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64*)c->h_wset.fp, (const u32*)c->h_wset.epoch, first, n, d_w, wwin, d_wc);
+      ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(&cnt, d_wc, 8, hipMemcpyDeviceToHost) == hipSuccess;
+      ok = ok && dev_to_file(f, d_w, cnt * sizeof(Slot), buf);
+      wtotal += cnt;
+    }
+    if (d_w) (void)hipFree(d_w);
+    if (d_wc) (void)hipFree(d_wc);
+    head[1] = wtotal;
+    ok = ok && std::fseek(f, at, SEEK_SET) == 0 && std::fwrite(head, 8, 2, f) == 2 && std::fseek(f, 0, SEEK_END) == 0;
+  }
   h.table_entries = total;
   ok = ok && std::fseek(f, 0, SEEK_SET) == 0 && std::fwrite(&h, sizeof(h), 1, f) == 1;
   ok = (std::fclose(f) == 0) && ok;
@@ -189,6 +214,33 @@ int32_t vsrmc_checker_load(const vsrmc_model* m, const vsrmc_options* o_in, cons
   ok = ok && file_to_dev(f, c->words[c->cur], h.cur_w * 8, buf);
   ok = ok && file_to_dev(f, c->off[c->cur], h.n_frontier * 8, buf);
   ok = ok && file_to_dev(f, c->lvl_fp, h.n_frontier * 8, buf);
+  // optional section: the winner set of a sharded deep search (vsrmc_checker_save)
+  u64 whead[2] = {0, 0};
+  const bool has_wset = ok && std::fread(whead, 8, 2, f) == 2 && whead[0] == 0x5445535754455357ull;
+  if (ok && h.deep && o->world > 1 && !has_wset) ok = false;    // (a sharded search beyond its buffers cannot regenerate anything without it)
+  if (ok && has_wset) {
+    c->deep = (int)h.deep;                                       // (wset_ensure sizes nothing from it, but a set only exists for a deep search)
+    int wrc = wset_ensure(c);
+    u64 need = whead[1];
+    while (!wrc && (double)need > 0.6 * (double)(c->h_wset.mask + 1) && wset_grow(c) == 0) {}
+    Slot* d_w = nullptr;
+    u32* d_werr = nullptr;
+    const u64 wwin = (u64)1 << 24;
+    ok = !wrc && hipMalloc((void**)&d_w, wwin * sizeof(Slot)) == hipSuccess && hipMalloc((void**)&d_werr, 4) == hipSuccess && hipMemset(d_werr, 0, 4) == hipSuccess;
+    for (u64 done = 0; done < whead[1] && ok; done += wwin) {
+      const u64 k = std::min<u64>(wwin, whead[1] - done);
+      ok = file_to_dev(f, d_w, k * sizeof(Slot), buf);
+      hipLaunchKernelGGL(k_wset_import, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, (const WSet*)c->d_wset, (const Slot*)d_w, k, d_werr);
+      ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+    }
+    u32 werr = 0;
+    if (ok) ok = hipMemcpy(&werr, d_werr, 4, hipMemcpyDeviceToHost) == hipSuccess && werr == 0;
+    if (d_w) (void)hipFree(d_w);
+    if (d_werr) (void)hipFree(d_werr);
+    c->wset_used = true;
+    c->wset_dirty = false;
+    c->wepoch = 0;
+  }
   std::fclose(f);
   if (!ok) {
     vsrmc_checker_destroy(c);

@@ -26,6 +26,12 @@ void apply_test_hooks(Model& M) {
     const u64 fp = std::strtoull(e, &end, 16);
     if (end && *end == ':') { M.test_bad_fp = fp; M.test_bad_mask = (u32)std::strtoul(end + 1, nullptr, 0) & 31u; }
   }
+  // VSRMC_TEST_MAX_BAG=<n>: a smaller bag capacity — how tests/test_probe_footprint.py brings the records of a small space to a representation limit
+  // (LevelCtl::limit_unchecked: a probe pass must then be run again with every action applied)
+  if (const char* e = std::getenv("VSRMC_TEST_MAX_BAG")) {
+    const int n = std::atoi(e);
+    if (n >= 4 && n < M.max_bag) M.max_bag = n;
+  }
 #endif
 }
 

@@ -21,8 +21,16 @@ int32_t vsrmc_checker_probe(vsrmc_checker* c, vsrmc_level_info* info) {
   c->probe_viol_key.clear();
   c->probe_viol_level = 0;
   int rc = phase_expand(c, nullptr, MODE_PROBE);
+  u64 rechecked = 0;
+  if (!rc && c->h.limit_unchecked) {                            // (see LevelCtl::limit_unchecked: the pass once more with every action applied)
+    rechecked = c->h.limit_unchecked;
+    c->probe_all_actions = true;
+    rc = phase_expand(c, nullptr, MODE_PROBE);
+    c->probe_all_actions = false;
+  }
   if (rc) return rc;
   std::memset(info, 0, sizeof(*info));
+  info->limit_rechecked = rechecked;
   info->level = c->level + 1;
   info->frontier = c->n_frontier;
   info->generated = c->h.generated;

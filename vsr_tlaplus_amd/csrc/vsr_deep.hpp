@@ -241,6 +241,13 @@ int deep_probe(DeepRun& R, const PassDst& B, u64 n, int lv, u64 bag) {
   c->expand_ms = 0;
   if (R.err) return 0;
   int rc = expand_pass(c, B.words, B.off, n, 0, lv + 1, MODE_PROBE, bag);
+  if (!rc && c->h.limit_unchecked) {                            // a record at a representation limit beside instances the footprint filter skipped: once more, every action applied
+    R.prb.limit_rechecked += c->h.limit_unchecked;
+    c->probe_all_actions = true;
+    rc = expand_pass(c, B.words, B.off, n, 0, lv + 1, MODE_PROBE, bag);
+    c->probe_all_actions = false;
+    R.launches++;
+  }
   if (rc) return deep_local_fail(R, rc);
   R.launches++;
   deep_acc(&R.prb, c->h, c->expand_ms);

@@ -123,6 +123,10 @@ struct LevelCtl {   // device-resident counters of one BFS level
   u32 full;
   u32 full_pad_;
   u64 full_info;
+  // probe level with the footprint filter on: instances that were NOT applied although a record of their tile sits at a representation limit (a bag within
+  // R - 1 entries of its capacity, a delivery count of 3): a successor of theirs could have raised ERR_REP_* unseen.  Not 0: the host runs the pass again
+  // with every action applied (host_checker.hpp: expand_pass) — nothing goes unreported, and vsrmc_level_info.limit_rechecked says it happened.
+  u64 limit_unchecked;
 };
 
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
@@ -133,8 +137,8 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO
 #define VSR_BLOCK 256
 // per-phase shader clocks of k_expand (vsrmc_level_info.phase_cycles; tools/run_bfs.py prints the breakdown): every read is an
 // s_memtime that waits for the wave's outstanding LDS / scalar loads.  -DVSR_PHASE_CLOCKS=0 builds without them.
-#ifndef VSR_PHASE_CLOCKS
-#define VSR_PHASE_CLOCKS 1
+#ifndef VSR_PHASE_CLOCKS    // round 6: off in the product build (-0.6 %: twelve s_memtime per tile and 16 SGPRs); tools/phase_split.py wants a -DVSR_PHASE_CLOCKS=1 build
+#define VSR_PHASE_CLOCKS 0
 #endif
 #if VSR_PHASE_CLOCKS
 #define VSR_CLK() __builtin_readcyclecounter()
@@ -165,6 +169,25 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO
 #endif
 #ifndef VSR_NO_TAIL_SYNC    // EXPERIMENT: no barrier at the bottom of the tile loop (what follows the apply-closing barrier touches LDS words of wave 0 only)
 #define VSR_NO_TAIL_SYNC 0
+#endif
+#ifndef VSR_COPY8
+#define VSR_COPY8 0
+#endif
+#ifndef VSR_REDO            // a tile that overflows the work list is taken again in pieces (k_expand: s_redo_*); 0: ERR_FRONTIER_FULL as in rounds 1-5 (A/B; the experiments below need 0)
+#define VSR_REDO 1
+#endif
+#ifndef VSR_REFS_AHEAD
+#define VSR_REFS_AHEAD 0
+#endif
+#if (VSR_REFS_AHEAD || VSR_TAKE) && VSR_REDO
+#undef VSR_REDO
+#define VSR_REDO 0
+#endif
+#ifndef VSR_COOP_COPY       // wave-cooperative copy of the parent words of new states in the ordinary level's instantiation (see the apply loop); 0: the lane-serial copy everywhere
+#define VSR_COOP_COPY 1
+#endif
+#ifndef VSR_OCC_312         // five resident blocks per CU for the ordinary level's kernel of BASELINE configs[1] (expand_occ)
+#define VSR_OCC_312 1
 #endif
 #ifndef VSR_ROUND_REV       // EXPERIMENT: the second round of the apply loop runs on the block's LAST waves (wave 0 carries the serial sections already)
 #define VSR_ROUND_REV 0
@@ -477,9 +500,15 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
 // clients, values and permutations unroll without predicates and strides fold into addresses.
 // BLK = threads per block = 256: four waves share a tile of 64 (or 128) records, block barriers between the phases.  (One wave per block
 // with a 16-record tile of its own and 512-thread blocks were built and measured in round 3: 268 and 212 ms against 156 — DESIGN.md §5.)
+// Resident blocks per CU an instantiation is compiled for (= its register budget: 4 -> 128 VGPRs, 5 -> 96).  Round 6: with MachineLICM off (build.py) the
+// ordinary level's kernel of BASELINE configs[1] needs 107 registers and runs FIVE blocks per CU with 7 spilled ones at the top of the tile loop (k_expand
+// 139 -> 134.6 ms; with the cooperative copy 127.9); the README configuration's (six permutations: 119 registers) loses at five (28 spilled: 232 -> 257 ms).
+constexpr int expand_occ(bool fused, int spec, int plain) {
+  return !fused ? 3 : spec == 0 ? 2 : (VSR_OCC_312 && spec == 312 && plain == 1) ? 5 : VSR_OCC;
+}
 template <bool FUSED, int SPEC = 0, int PLAIN = 0, int BLK = VSR_BLOCK>
 // (hipcc turns the second bound into waves per SIMD as blocks * max(1, threads / 256): 4 = 128 VGPRs)
-__global__ void __launch_bounds__(BLK, (FUSED ? (SPEC ? VSR_OCC : 2) : 3) / (BLK > VSR_BLOCK ? BLK / VSR_BLOCK : 1))
+__global__ void __launch_bounds__(BLK, expand_occ(FUSED, SPEC, PLAIN) / (BLK > VSR_BLOCK ? BLK / VSR_BLOCK : 1))
 k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ fr_off, u64 n_parents, int level, int rank,
          Slot* table, u64 tmask, u64* pending, u64 pending_cap, LevelCtl* ctl, int stride, int world_arg, u64* cand_send,
          u64 cand_cap, u32 pchunk /* pending entries a block reserves per global atomic, >= ccap */,
@@ -522,8 +551,10 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
   u32* s_cand2 = s_cand + ccap;                        // the same, sorted by action
-  __shared__ u32 s_ncand, s_napply, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv;
-  constexpr int TILE_MAX = BLK >= VSR_BLOCK ? VSR_TILE_MAX : BLK / 2;
+  __shared__ u32 s_ncand, s_napply, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv, s_risky;
+  // (single-pass levels of a configuration with R <= 3 always run 64-record tiles: host_checker.hpp, fused_shape — 1.3 KB of LDS less, which five blocks per CU need)
+  constexpr int TILE_MAX = BLK < VSR_BLOCK ? BLK / 2 : (FUSED && SPEC % 1000 != 0 && (SPEC % 1000) / 100 <= 3) ? 64 : VSR_TILE_MAX;
+  constexpr bool COOP = VSR_COOP_COPY && FUSED && PLAIN == 1;
   __shared__ u32 s_alive[TILE_MAX];
   __shared__ u64 s_ref[TILE_MAX];
   __shared__ u64 s_pfp[TILE_MAX];                          // canonical fingerprint of every staged record (the parent part of its successors' keys)
@@ -579,12 +610,57 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   __shared__ u32 s_tile_n;
   u32 my_take = (u32)tile, my_n = 0, avg_q8 = 0;                // thread 0: records to draw next time / drawn with my_next / instances per record x 256
   if (tid == 0) { my_n = my_take; my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)my_take); }
+#elif VSR_REFS_AHEAD
+  // EXPERIMENT: the refs of a tile are fetched while the tile BEFORE it is staged (tiles are drawn two ahead), so staging starts with the record loads —
+  // one HBM round trip per tile instead of two dependent ones
+  __shared__ u64 s_tile_nxt;
+  __shared__ u64 s_ref2[TILE_MAX];
+  u64 my_next2 = 0;
+  if (tid == 0) {
+    my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+    my_next2 = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+    s_tile_nxt = my_next;
+  }
+  VSR_SYNC_G(0);
+  if (tid < tile) {
+    const u64 i0 = s_tile_nxt * (u64)tile + (u64)tid;
+    s_ref2[tid] = (s_tile_nxt < ntiles && i0 < n_parents) ? fr_off[i0] : 0;
+  }
+  VSR_SYNC_G(0);                                                // (thread 0 rewrites s_tile_nxt at the top of the loop)
 #else
   if (tid == 0) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
 #endif
+  // A tile whose enabled instances do not fit the work list (ccap entries: 12 .. 24 per record, the mean is 5 - 7) is not an error since round 6: nothing of it
+  // has been applied when the counting sort finds out, so the block takes the same records again in pieces of half the size (s_redo_*: a contiguous range of
+  // the frontier, worked off before the next tile is drawn; a piece that overflows again is halved again).  Only a SINGLE record with more instances than the
+  // list holds is ERR_FRONTIER_FULL.  This is what lets the launch shape shorten the list until five blocks fit a CU (host_checker.hpp: fused_shape).
+  __shared__ u64 s_redo_base;
+  __shared__ u32 s_redo_left, s_redo_step, s_redo_n, s_over;
+  if (tid == 0) { s_redo_left = 0; s_redo_step = 0; s_over = 0; }
   for (;;) {
+#if VSR_REDO
+    if (tid == 0 && s_redo_left) {
+      const u32 n = s_redo_step < s_redo_left ? s_redo_step : s_redo_left;
+      s_tile_cur = s_redo_base;
+      s_redo_n = n;
+      s_redo_base += n;
+      s_redo_left -= n;
+    } else
+#endif
     if (tid == 0) {
+#if VSR_REDO
+      s_tile_cur = my_next < ntiles ? my_next * (u64)tile : ~(u64)0;
+      s_redo_n = (u32)tile;
+#else
       s_tile_cur = my_next;
+#endif
+#if VSR_REFS_AHEAD
+      s_tile_nxt = my_next2;
+      my_next = my_next2;
+      if (my_next2 < ntiles) my_next2 = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+    }
+    if (0) {
+#endif
 #if VSR_TAKE
       s_tile_n = my_n;
       if (my_next < n_parents) { my_n = my_take; my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)my_take); }
@@ -593,7 +669,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
 #endif
     }
     const u64 t_0 = VSR_CLK();
-    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; s_nsurv = 0; }
+    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; s_nsurv = 0; s_over = 0; if (PLAIN != 1) s_risky = 0; }
     if (tid < tile) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
     VSR_SYNC_G(0);
@@ -602,10 +678,14 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     if (tile_i >= n_parents) break;
     const u64 p_base = tile_i;
     const int np_tile = (int)((n_parents - p_base) < (u64)s_tile_n ? (n_parents - p_base) : (u64)s_tile_n);
-#else
+#elif !VSR_REDO
     if (tile_i >= ntiles) break;
     const u64 p_base = tile_i * (u64)tile;
     const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
+#else
+    if (tile_i >= n_parents) break;                             // (s_tile_cur is the index of the tile's first record here: a drawn tile or a piece of one)
+    const u64 p_base = tile_i;
+    const int np_tile = (int)((n_parents - p_base) < (u64)s_redo_n ? (n_parents - p_base) : (u64)s_redo_n);
 #endif
     // PLAIN == 3 (regeneration by the claim bitmap): the bitmap IS the list of enabled instances that matter — the (parent, ordinal) pairs whose lane
     // made a state when the level was inserted.  The words of this thread's record (thread g of the record's G threads takes words g and g + G; the host
@@ -623,8 +703,19 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
 
     // ---- stage the tile.  Frontier refs are (word offset << 8 | length): one coalesced load of 64 refs, then 16 lanes per
     // record / 16 records per pass, all 16 loads of a thread issued before the first LDS store (one HBM latency per tile)
+#if VSR_REFS_AHEAD
+    u64 ref_pre = 0;                                            // wave 0: the refs of the NEXT tile, on their way while this one is staged
+    if (tid < tile) {
+      const u64 i1 = s_tile_nxt * (u64)tile + (u64)tid;
+      if (s_tile_nxt < ntiles && i1 < n_parents) ref_pre = fr_off[i1];
+    }
+#endif
     if (tid < np_tile) {
+#if VSR_REFS_AHEAD
+      const u64 ref = s_ref2[tid];
+#else
       const u64 ref = fr_off[p_base + tid];
+#endif
       s_ref[tid] = ref;
       if (ref) atomicMax(&s_maxbag, (u32)((int)(ref & 255) - M.fixed));
       if ((int)(ref & 255) > stride) raise_error(ctl, ERR_INTERNAL, (p_base + (u64)tid) << 16);   // LDS slots sized for shorter records
@@ -675,6 +766,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
           }
         }
       }
+#if VSR_REFS_AHEAD
+    if (tid < tile) s_ref2[tid] = ref_pre;                      // (read again at the top of the next tile, two barriers from here)
+#endif
     VSR_SYNC_G(2);
     if (tid < np_tile && s_ref[tid] != 0) {                     // the parent's own fingerprint, from the view hashes it carries
       const u64* r0 = s_rec + tid * stride;
@@ -785,6 +879,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
               const int r = m_dest(w);
               const u64 l = r == 1 ? lut[1] : r == 2 ? lut[2] : r == 3 ? lut[3] : r == 4 ? lut[4] : lut[5];
               pass = m_count(w) != 0 && ((l >> (w & 63)) & 1);
+              if (PLAIN != 1 && PLAIN != 3 && PLAIN != 4 && mode == MODE_PROBE && m_count(w) == 3) s_risky = 1;   // one more Send of this key would not fit the count field
             }
             const u64 bal = __ballot(pass);
             if (bal) {
@@ -857,7 +952,17 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     // ---- counting sort of the work list by action id: the lanes of a wave then run the same action (no divergence between
     // the 15 action bodies, only inside one)
     if (tid == 0) {
-      if (s_ncand >= 0x40000000u) raise_error(ctl, ERR_FRONTIER_FULL, p_base);
+      if (s_ncand >= 0x40000000u) {
+#if VSR_REDO
+        if (np_tile > 1) {                                       // the work list is too short for this tile: the same records again, half as many at a time
+          s_over = 1;
+          s_redo_left += (u32)np_tile;                           // (what was still queued starts right behind this piece: the range stays contiguous)
+          s_redo_base = p_base;
+          s_redo_step = (u32)np_tile / 2u;
+        } else
+#endif
+        raise_error(ctl, ERR_FRONTIER_FULL, p_base);
+      }
       u32 acc = 0;
       // probe level: an action outside the invariants' footprint cannot turn a passing parent into a violating successor (Ops::probe_actions):
       // its instances are counted and sorted behind the others, and the apply loop stops in front of them.  (Compiled into the mode-capable
@@ -871,12 +976,15 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
             acc += s_kcount[a];
           }
         s_napply = acc > ccap ? ccap : acc;
-        if (keep != ~0u)
+        if (keep != ~0u) {
           for (int a = 0; a < 16; a++)
             if (!((keep >> a) & 1u)) {
               s_kbase[a] = acc;
               acc += s_kcount[a];
             }
+          // the instances behind s_napply are not applied: is a record of this tile so close to a representation limit that one of them could have hit it?
+          if (s_risky || (int)s_maxbag + M.R - 1 > M.max_bag) s_acc[15] += acc - s_napply;
+        }
       } else {
         for (int a = 0; a < 16; a++) {
           s_kbase[a] = acc;
@@ -897,6 +1005,12 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     const u64 t_2 = VSR_CLK();
     VSR_SYNC_G(6);
     const u32 ncand = s_ncand;
+#if VSR_REDO
+    if (s_over) {                                               // (block-uniform) the tile is taken again in pieces: nothing of it has been applied or counted
+      VSR_SYNC_G(6);                                            // every wave has read the flag before thread 0 clears it at the top of the loop
+      continue;
+    }
+#endif
     for (u32 c = tid; c < ccap; c += BLK) {
       const u32 code = s_cand[c];
       if (code == ~0u) continue;
@@ -1104,38 +1218,82 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         const u64 a_3 = VSR_CLK();
         if (tid == 0) s_acc[12] += a_3 - a_2;
         u64 idx = 0;
-        if (do_write) {                                         // new state (or: possibly new, the owner decides): write it out
-          const int plen = (int)(s_ref[p] & 255);
-          const int clen = M.fixed + hdr_nmsg(D.hdr);
+        // Since round 6 the ordinary level's instantiation (PLAIN == 1) copies the parent words of the successors a wave writes in a round with the WHOLE wave —
+        // lane k moves word k of one record per instruction: one contiguous 350-byte store instead of twenty-two 16-byte stores of the claiming lane alone, and
+        // the LDS reads of different records are independent of each other (the lane-serial copy waits for its own LDS read in every trip).  The claiming lane
+        // then writes its patches on top (same wave, program order).  Lanes that left the body earlier (errors) take no part: the words are shared out over the
+        // lanes that are here.  (Config 2: k_expand -2.5 %, with five blocks per CU -8 %; the regenerating instantiation LOSES 13 % with it — every lane writes
+        // there — and keeps the lane-serial copy)
+        u64 dst = 0;
+        int plen = 0, clen = 0;
+        if (do_write) {                                         // new state (or: possibly new, the owner decides): room in the tile's reservation
+          plen = (int)(s_ref[p] & 255);
+          clen = M.fixed + hdr_nmsg(D.hdr);
           const u32 io = atomicAdd(&s_tile_icur, 1u);
           const u32 wo = atomicAdd(&s_tile_wcur, (u32)clen);
           idx = s_ich_base + s_tile_ibase + io;
-          const u64 dst = s_wch_base + s_tile_wbase + wo;
-          u64* out = nx_words + dst;
-          // parent from LDS, 16 bytes per store (records are 8-byte aligned), then the patches on top (same lane: ordered)
-          typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
-          int k = 0;
-          if (plen >= 2) {
-            u64x2_a8 cur;
-            cur.x = rec[0];
-            cur.y = rec[1];
-            for (; k + 3 < plen; k += 2) {
-              u64x2_a8 nxt;
-              nxt.x = rec[k + 2];
-              nxt.y = rec[k + 3];
-              *(u64x2_a8*)(out + k) = cur;
-              cur = nxt;
+          dst = s_wch_base + s_tile_wbase + wo;
+        }
+        if constexpr (COOP) {
+          const u64 act = __ballot(1);
+          u64 wm = __ballot(do_write);
+          const int nact = __popcll(act), rnk = __popcll(act & (((u64)1 << lane) - 1));
+          while (wm) {
+            const int l0 = __ffsll((long long)wm) - 1;
+            wm &= wm - 1;
+            const int l1 = wm ? __ffsll((long long)wm) - 1 : l0;   // two records per trip: their LDS reads are in flight together
+            wm &= wm - 1;
+            const int n0 = __builtin_amdgcn_readlane(plen, l0), n1 = l1 != l0 ? __builtin_amdgcn_readlane(plen, l1) : 0;
+            const u64* r0 = s_rec + __builtin_amdgcn_readlane(p, l0) * stride;
+            const u64* r1 = s_rec + __builtin_amdgcn_readlane(p, l1) * stride;
+            u64* o0 = nx_words + readlane64(dst, l0);
+            u64* o1 = nx_words + readlane64(dst, l1);
+            for (int k = rnk; k < n0 || k < n1; k += nact) {
+              const u64 v0 = k < n0 ? r0[k] : 0, v1 = k < n1 ? r1[k] : 0;
+              if (k < n0) o0[k] = v0;
+              if (k < n1) o1[k] = v1;
             }
-            *(u64x2_a8*)(out + k) = cur;
-            k += 2;
           }
-          for (; k + 1 < plen; k += 2) {
-            u64x2_a8 v2;
-            v2.x = rec[k];
-            v2.y = rec[k + 1];
-            *(u64x2_a8*)(out + k) = v2;
+        }
+        if (do_write) {
+          u64* out = nx_words + dst;
+          if constexpr (!COOP) {
+          // parent from LDS, 16 bytes per store (records are 8-byte aligned), then the patches on top (same lane: ordered)
+            typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+            int k = 0;
+#if VSR_COPY8
+            for (; k + 7 < plen; k += 8) {                        // EXPERIMENT: eight words per trip, four LDS reads in flight (round 3 lost registers to this; MachineLICM off leaves room)
+              u64x2_a8 a0, a1, a2, a3;
+              a0.x = rec[k]; a0.y = rec[k + 1]; a1.x = rec[k + 2]; a1.y = rec[k + 3];
+              a2.x = rec[k + 4]; a2.y = rec[k + 5]; a3.x = rec[k + 6]; a3.y = rec[k + 7];
+              *(u64x2_a8*)(out + k) = a0;
+              *(u64x2_a8*)(out + k + 2) = a1;
+              *(u64x2_a8*)(out + k + 4) = a2;
+              *(u64x2_a8*)(out + k + 6) = a3;
+            }
+#endif
+            if (plen - k >= 2) {
+              u64x2_a8 cur;
+              cur.x = rec[k];
+              cur.y = rec[k + 1];
+              for (; k + 3 < plen; k += 2) {
+                u64x2_a8 nxt;
+                nxt.x = rec[k + 2];
+                nxt.y = rec[k + 3];
+                *(u64x2_a8*)(out + k) = cur;
+                cur = nxt;
+              }
+              *(u64x2_a8*)(out + k) = cur;
+              k += 2;
+            }
+            for (; k + 1 < plen; k += 2) {
+              u64x2_a8 v2;
+              v2.x = rec[k];
+              v2.y = rec[k + 1];
+              *(u64x2_a8*)(out + k) = v2;
+            }
+            if (k < plen) out[k] = rec[k];
           }
-          if (k < plen) out[k] = rec[k];
           out[0] = D.hdr;
           u64* ob = out + 1 + (D.r - 1) * M.wpr;
           ob[0] = D.rep[0];
@@ -1261,6 +1419,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
       if (tid == 0) {
         if (s_acc[8]) atomicAdd((unsigned long long*)&ctl->ties, s_acc[8]);
+        if (PLAIN != 1 && s_acc[15]) atomicAdd((unsigned long long*)&ctl->limit_unchecked, s_acc[15]);
         if (s_acc[14]) atomicAdd((unsigned long long*)&ctl->n_written, s_acc[14]);
         if (s_acc[9]) atomicAdd((unsigned long long*)(mode == MODE_INSERT ? &ctl->n_new : &ctl->rec_words), s_acc[9]);
         if (s_maxbag_out) atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)s_maxbag_out);
@@ -1826,6 +1985,25 @@ __global__ void k_table_import(Slot* table, u64 tmask, const Slot* __restrict__ 
     return;
   }
   table[p.slot].meta = in[i].meta;
+}
+
+// the winner set of a sharded deep search as (fingerprint, level) pairs (checkpoint of a sharded search beyond its record buffers: host_checkpoint.hpp) ...
+__global__ void k_wset_export(const u64* __restrict__ fp, const u32* __restrict__ epoch, u64 first, u64 n, Slot* out, u64 out_cap, u64* counter) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  Slot s;
+  s.fp = 0;
+  s.meta = 0;
+  if (i < n) { s.fp = fp[first + i]; s.meta = (u64)(epoch[first + i] >> 23); }
+  if (s.fp != 0) {
+    const u64 k = wave_alloc(counter);
+    if (k < out_cap) out[k] = s;
+  }
+}
+// ... and back into an empty set (any size): the descent counter of every entry starts at 0 again, like the recovered checker's
+__global__ void k_wset_import(const WSet* w, const Slot* __restrict__ in, u64 n, u32* err) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!wset_insert(w, in[i].fp, (int)in[i].meta)) atomicExch(err, (u32)ERR_TABLE_FULL);
 }
 
 // Seed the search with the initial state (ModelChecker.doInit): record already in frontier slot 0.

@@ -684,7 +684,7 @@ int loop_deep_pass(void* ctx, const u64* sw, const u64* so, u64 n, u64 p_off, in
 // this rank's figures of the pass -> the level's (sums; largest bag; smallest violating fingerprint; masks or-ed; checksums xor / sum)
 int loop_deep_reduce(void* ctx, DeepRun* R) {
   vsrmc_shard_loop* l = (vsrmc_shard_loop*)ctx;
-  struct Row { u64 n_new, generated, deadlocks, probes, words, fx, fs, bag, viol, mask, frontier, act[16], p_gen, p_dead, p_probes, p_mask, p_act[16]; };
+  struct Row { u64 n_new, generated, deadlocks, probes, words, fx, fs, bag, viol, mask, frontier, act[16], p_gen, p_dead, p_probes, p_mask, p_lim, p_act[16]; };
   static_assert(sizeof(Row) <= 512, "one all-gather record");
   Row mine;
   std::memset(&mine, 0, sizeof(mine));
@@ -693,7 +693,7 @@ int loop_deep_reduce(void* ctx, DeepRun* R) {
   mine.n_new = a.n_new; mine.generated = a.generated; mine.deadlocks = a.deadlocks; mine.probes = a.probes; mine.words = a.record_words;
   mine.fx = a.fp_xor; mine.fs = a.fp_sum; mine.bag = a.max_bag; mine.viol = a.viol_fp; mine.mask = (u64)(u32)a.viol_mask; mine.frontier = a.frontier;
   for (int i = 0; i < 16; i++) { mine.act[i] = a.act_generated[i]; mine.p_act[i] = b.act_generated[i]; }
-  mine.p_gen = b.generated; mine.p_dead = b.deadlocks; mine.p_probes = b.probes; mine.p_mask = (u64)(u32)b.viol_mask;
+  mine.p_gen = b.generated; mine.p_dead = b.deadlocks; mine.p_probes = b.probes; mine.p_mask = (u64)(u32)b.viol_mask; mine.p_lim = b.limit_rechecked;
   std::vector<Row> all((size_t)l->world);
   const int rc = loop_allgather(l, &mine, all.data(), (u32)sizeof(Row));
   if (rc) return rc;
@@ -704,7 +704,7 @@ int loop_deep_reduce(void* ctx, DeepRun* R) {
     t.n_new += r.n_new; t.generated += r.generated; t.deadlocks += r.deadlocks; t.probes += r.probes; t.words += r.words;
     t.fx ^= r.fx; t.fs += r.fs; t.bag = std::max(t.bag, r.bag); t.frontier += r.frontier;
     if (r.viol < t.viol) t.viol = r.viol;
-    t.p_gen += r.p_gen; t.p_dead += r.p_dead; t.p_probes += r.p_probes; t.p_mask |= r.p_mask;
+    t.p_gen += r.p_gen; t.p_dead += r.p_dead; t.p_probes += r.p_probes; t.p_mask |= r.p_mask; t.p_lim += r.p_lim;
     for (int i = 0; i < 16; i++) { t.act[i] += r.act[i]; t.p_act[i] += r.p_act[i]; }
   }
   for (const Row& r : all)
@@ -713,7 +713,7 @@ int loop_deep_reduce(void* ctx, DeepRun* R) {
   vsrmc_level_info& B = R->prb;
   A.n_new = t.n_new; A.generated = t.generated; A.deadlocks = t.deadlocks; A.probes = t.probes; A.record_words = t.words;
   A.fp_xor = t.fx; A.fp_sum = t.fs; A.max_bag = t.bag; A.viol_fp = t.viol; A.viol_mask = (int32_t)t.mask; A.frontier = t.frontier;
-  B.generated = t.p_gen; B.deadlocks = t.p_dead; B.probes = t.p_probes; B.viol_mask = (int32_t)t.p_mask;
+  B.generated = t.p_gen; B.deadlocks = t.p_dead; B.probes = t.p_probes; B.viol_mask = (int32_t)t.p_mask; B.limit_rechecked = t.p_lim;
   for (int i = 0; i < 16; i++) { A.act_generated[i] = t.act[i]; B.act_generated[i] = t.p_act[i]; }
   R->viol_ins = t.viol; R->mask_ins = (u32)t.mask; R->mask_prb = (u32)t.p_mask;
   return 0;
@@ -861,6 +861,95 @@ int32_t vsrmc_shard_loop_advance(vsrmc_shard_loop* l, vsrmc_level_info* a, vsrmc
   }
   *what = 2;
   return vsrmc_shard_loop_deepen(l, a, b);
+}
+
+// ---- checkpoint / recover of a sharded run between two units of progress (≙ TLC's checkpoints, per worker; round 6: also of a search that has gone
+// beyond its record buffers) -------------------------------------------------------------------------------------------------------------------
+// Every rank writes <prefix>.rank<r>of<w> (vsrmc_checker_save: its seen-set shard, its part of the newest stored level, the descriptors of the levels
+// that live in the seen-sets only, its winner set) and <prefix>.rank<r>of<w>.loop (the level loop's own state: the run's totals, the violation — the
+// same on every rank).  Two phases, so that a failure on one rank cannot leave files of different depths under one prefix: (1) level-tagged names,
+// error codes gathered — on any failure the tagged files are removed and the previous checkpoint stays whole; (2) renames, gathered again.
+namespace {
+struct LoopChk {
+  char magic[8];                 // "VSRMCLP1"
+  int32_t world, rank, level, deep, replicated, has_violation, viol_mask, viol_level, viol_probed, pad_;
+  u64 distinct, n_frontier, moved, bytes_sent, viol_fp, probe_parent_fp, replicate_below;
+};
+}  // namespace
+
+int32_t vsrmc_shard_loop_save(vsrmc_shard_loop* l, const char* prefix) {
+  if (!l || !prefix) return fail(VSRMC_E_ARG, "NULL argument");
+  const std::string fin = std::string(prefix) + ".rank" + std::to_string(l->rank) + "of" + std::to_string(l->world);
+  const std::string tag = fin + ".D" + std::to_string(l->level + l->deep);
+  int rc = vsrmc_checker_save(l->c, tag.c_str());
+  if (!rc) {
+    LoopChk k;
+    std::memset(&k, 0, sizeof(k));
+    std::memcpy(k.magic, "VSRMCLP1", 8);
+    k.world = l->world; k.rank = l->rank; k.level = l->level; k.deep = l->deep; k.replicated = l->replicated ? 1 : 0;
+    k.has_violation = l->has_violation ? 1 : 0; k.viol_mask = l->viol_mask; k.viol_level = l->viol_level; k.viol_probed = l->viol_probed ? 1 : 0;
+    k.distinct = l->distinct; k.n_frontier = l->n_frontier; k.moved = l->moved; k.bytes_sent = l->bytes_sent; k.viol_fp = l->viol_fp;
+    k.probe_parent_fp = l->probe_parent_fp; k.replicate_below = l->replicate_below;
+    FILE* f = std::fopen((tag + ".loop").c_str(), "wb");
+    const bool ok = f && std::fwrite(&k, sizeof(k), 1, f) == 1;
+    if (f && std::fclose(f) != 0) rc = fail(VSRMC_E_CFG, "writing " + tag + ".loop failed");
+    if (!ok && !rc) rc = fail(VSRMC_E_CFG, "writing " + tag + ".loop failed");
+  }
+  u64 e = rc ? 1 : 0;
+  int crc = loop_deep_any(l, &e);                                // (also before the run is sharded: the replicated phase's ranks checkpoint together too)
+  if (crc || e) {
+    std::remove(tag.c_str());
+    std::remove((tag + ".loop").c_str());
+    return crc ? crc : (rc ? rc : fail(VSRMC_E_STATE, "checkpoint: another rank could not write its shard; the previous checkpoint stays whole"));
+  }
+  e = (std::rename(tag.c_str(), fin.c_str()) != 0 || std::rename((tag + ".loop").c_str(), (fin + ".loop").c_str()) != 0) ? 1 : 0;
+  crc = loop_deep_any(l, &e);
+  if (crc) return crc;
+  if (e) return fail(VSRMC_E_CFG, std::string("checkpoint: a rank could not move its shard into place under ") + prefix);
+  return 0;
+}
+
+// The loop of a run vsrmc_shard_loop_save wrote, over a checker vsrmc_checker_load has recovered from THIS rank's file of the same prefix (collective:
+// every rank must have loaded the same depth).
+int32_t vsrmc_shard_loop_restore(vsrmc_checker* c, const vsrmc_comm* comm, uint64_t cand_cap, uint64_t rec_cap, uint64_t rec_words_cap, const char* prefix,
+                                 vsrmc_shard_loop** out) {
+  if (!c || !comm || !out || !prefix || !comm->alltoallv || !comm->allgather) return fail(VSRMC_E_ARG, "NULL argument");
+  if (comm->world != c->opt.world || comm->rank != c->opt.rank) return fail(VSRMC_E_ARG, "the communicator and the checker disagree about rank / world");
+  if (c->opt.exact_ties) return fail(VSRMC_E_STATE, "the native level loop runs single-pass levels (exact_ties = 0)");
+  if (cand_cap < 1024) return fail(VSRMC_E_ARG, "cand_cap too small");
+  const std::string path = std::string(prefix) + ".rank" + std::to_string(comm->rank) + "of" + std::to_string(comm->world) + ".loop";
+  LoopChk k;
+  std::memset(&k, 0, sizeof(k));
+  FILE* f = std::fopen(path.c_str(), "rb");
+  bool ok = f && std::fread(&k, sizeof(k), 1, f) == 1 && std::memcmp(k.magic, "VSRMCLP1", 8) == 0;
+  if (f) std::fclose(f);
+  ok = ok && k.world == comm->world && k.rank == comm->rank && k.level == c->level && k.deep == c->deep;
+  HIPCHK(hipSetDevice(c->opt.device));
+  vsrmc_shard_loop* l = new vsrmc_shard_loop();
+  l->c = c; l->comm = *comm; l->rank = comm->rank; l->world = comm->world;
+  l->cand_cap = cand_cap; l->rec_cap = rec_cap; l->rec_words_cap = rec_words_cap;
+  // every rank says what it loaded: one checkpoint, or nobody goes on
+  struct Row { u64 ok, level, deep, distinct; } mine = {ok ? 1ull : 0ull, (u64)k.level, (u64)k.deep, k.distinct};
+  std::vector<Row> all((size_t)l->world);
+  const int crc = loop_allgather(l, &mine, all.data(), (u32)sizeof(Row));
+  bool same = crc == 0;
+  for (const Row& r : all) same = same && r.ok && r.level == mine.level && r.deep == mine.deep && r.distinct == mine.distinct;
+  if (!same) {
+    delete l;
+    return crc ? crc : fail(VSRMC_E_CFG, std::string(prefix) + ": the ranks' files are not one checkpoint of this run (missing, another world size, or different depths)");
+  }
+  const u64 w = (u64)l->world;
+  hipError_t e = hipMalloc((void**)&l->cand_send, w * cand_cap * 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&l->cand_recv, w * cand_cap * 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&l->verdict_out, w * cand_cap);
+  if (e == hipSuccess) e = hipMalloc((void**)&l->verdict_in, w * cand_cap);
+  if (e != hipSuccess) { vsrmc_shard_loop_destroy(l); return fail(VSRMC_E_HIP, std::string("hipMalloc of the exchange buffers: ") + hipGetErrorString(e)); }
+  l->level = k.level; l->deep = k.deep; l->replicated = k.replicated != 0; l->replicate_below = k.replicate_below;
+  l->distinct = k.distinct; l->n_frontier = k.n_frontier; l->moved = k.moved; l->bytes_sent = k.bytes_sent;
+  l->has_violation = k.has_violation != 0; l->viol_fp = k.viol_fp; l->viol_mask = k.viol_mask; l->viol_level = k.viol_level;
+  l->viol_probed = k.viol_probed != 0; l->probe_parent_fp = k.probe_parent_fp;
+  *out = l;
+  return 0;
 }
 
 // the fingerprints of the counter-example of a violation a probe pass found (collective): Init .. the violator's parent, then the violator

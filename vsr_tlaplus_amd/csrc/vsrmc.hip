@@ -110,3 +110,4 @@ extern "C" {
 #include "host_checkpoint.hpp"   // checkpoint / recover, accessors, traces, destroy
 #include "vsr_shard_loop.hpp"    // the sharded level loop in C++ over RCCL / host callbacks
 #include "host_tlcfp.hpp"        // TLC's FP64 as a mode
+#include "vsr_bench_layout.hpp"  // measurement: k_expand's staging over records vs over fixed-stride columns (tools/bench_layout.py)

@@ -892,6 +892,32 @@ class NativeShardedChecker:
         self.levels, self.violation = [], None
         self._sync()
 
+    def save(self, prefix):
+        """Checkpoint between two advance() calls (collective; vsrmc_shard_loop_save): every rank its shard — also of a search that has gone beyond its
+        record buffers — and the loop's state, in two phases."""
+        rc = capi.load().vsrmc_shard_loop_save(self._l, os.fsencode(prefix))
+        if rc != 0:
+            raise ShardError("checkpoint: %s" % capi.load().vsrmc_last_error().decode())
+
+    @classmethod
+    def restore(cls, prefix, make_engine, comm, cand_cap=None, rec_cap=None, rec_words_cap=None):
+        """Continue the run save() wrote (collective; same number of ranks): make_engine(path of this rank's shard file) -> HipShardEngine."""
+        self = cls.__new__(cls)
+        self.comm = comm
+        self.rank, self.world = comm.rank, comm.world
+        self.e = make_engine("%s.rank%dof%d" % (prefix, comm.rank, comm.world))
+        self._l = C.c_void_p()
+        rc = capi.load().vsrmc_shard_loop_restore(self.e._h, comm.ptr, int(cand_cap or self.e.cand_cap), int(rec_cap or self.e.rec_cap),
+                                                  int(rec_words_cap or self.e.rec_words_cap), os.fsencode(prefix), C.byref(self._l))
+        if rc != 0:
+            raise ShardError("recover: %s" % capi.load().vsrmc_last_error().decode())
+        self.levels, self.violation = [], None
+        self._sync()
+        info = capi.LevelInfo()
+        check(capi.load().vsrmc_checker_status(self.e._h, C.byref(info)))
+        self.depth = self.level + int(info.reserved0)           # levels beyond the newest stored one that live in the seen-sets only
+        return self
+
     def _sync(self):
         lv, rep, vm, vl = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         d, nf, vf, mv, bs = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -104,8 +104,8 @@ def main(argv=None):
         say("Error: %s" % e)
         return 1
     lay = m.layout
-    if not (opt["table_log2"] or opt["frontier_gib"] or opt["checkpoint"] or opt["recover"] or opt["exact"] or opt["probe_at"]):
-        return run_automatic(opt, m, rank, world, local_rank, say)
+    if not (opt["table_log2"] or opt["frontier_gib"] or opt["exact"] or opt["probe_at"]):
+        return run_automatic(opt, m, rank, world, local_rank, say)      # (with -checkpoint / -recover too, since round 6: vsrmc_shard_loop_save / _restore)
     opt["table_log2"] = opt["table_log2"] or 26
     opt["frontier_gib"] = opt["frontier_gib"] or 2.0
     words = int(opt["frontier_gib"] * (1 << 30) / 8)
@@ -210,28 +210,47 @@ def run_automatic(opt, m, rank, world, local_rank, say):
     lay = m.layout
     if opt["backend"] != "nccl":
         os.environ.setdefault("VSRMC_AUTOSIZE_SHARE", str(world))   # the ranks share device 0
+    def make_engine(recover=None):
+        return sharded.HipShardEngine(m, rank, world, device=local_rank, table_log2=0, frontier_words=0, frontier_states=0, pending_entries=0,
+                                      cand_cap=0, rec_cap=1 << 22, rec_words_cap=1 << 28, native_only=True, recover=recover)
     try:
         comm = sharded.RcclComm(local_rank) if opt["backend"] == "nccl" else sharded.TorchHostComm()   # before the checker sizes itself
-        eng = sharded.HipShardEngine(m, rank, world, device=local_rank, table_log2=0, frontier_words=0, frontier_states=0, pending_entries=0,
-                                     cand_cap=0, rec_cap=1 << 22, rec_words_cap=1 << 28, native_only=True)
-        sc = sharded.NativeShardedChecker(eng, comm, replicate_below=opt["replicate_below"])
+        if opt["recover"]:
+            sc = sharded.NativeShardedChecker.restore(opt["recover"], make_engine, comm)
+            eng = sc.e
+        else:
+            eng = make_engine()
+            sc = sharded.NativeShardedChecker(eng, comm, replicate_below=opt["replicate_below"])
+            sc.depth = sc.level
     except (sharded.ShardError, vt.VsrmcError, OSError) as e:
         say("Error: %s" % e)
         return 1
-    sc.depth = sc.level
     say("vsrmc: %s lowered: ReplicaCount=%d ClientCount=%d |Values|=%d StartViewOnTimerLimit=%d, %d permutation(s), invariant mask %d; "
         "%d rank(s), backend %s, C++ level loop; per rank: seen-set 2^%d slots, record buffers 2 x %.1f GiB, %d candidates per peer"
         % (["VSR.tla", "VR_STATE_TRANSFER.tla", "VR_APP_STATE.tla"][lay.module], lay.replica_count, lay.client_count, lay.value_count,
            lay.start_view_on_timer_limit, lay.permutations, lay.invariant_mask, world, opt["backend"], int(eng.options.table_log2),
            int(eng.options.frontier_words) * 8 / (1 << 30), int(eng.cand_cap)))
-    say("Finished computing initial states: 1 distinct state generated.")
-    t0 = time.time()
+    if opt["recover"]:
+        say("Recovered from checkpoint %s: depth %d (%d level(s) in the seen-sets only), %d distinct states found."
+            % (opt["recover"], sc.depth, sc.depth - sc.level, sc.distinct))
+    else:
+        say("Finished computing initial states: 1 distinct state generated.")
+    t0 = t_chk = time.time()
     total_generated, code, last, deadlocked, kind, incomplete = 0, 0, dict(n_new=1, deadlocks=0), False, "level", False
     try:
         while sc.depth < opt["max_depth"]:
             if sc.room() == 2:                                   # (collective: every rank stops here together)
                 incomplete = True
                 break
+            if opt["checkpoint"] and sc.depth > 1:
+                # rank 0's clock decides for everybody (a checkpoint is a collective); between two units of progress — also after Virtual(..) lines
+                due = torch.tensor([1 if (rank == 0 and time.time() - t_chk >= 60.0 * opt["checkpoint_minutes"]) else 0],
+                                   device=("cuda:%d" % local_rank) if opt["backend"] == "nccl" else "cpu")
+                dist.all_reduce(due, op=dist.ReduceOp.MAX)
+                if int(due.item()):
+                    sc.save(opt["checkpoint"])
+                    say("Checkpointing of run %s completed (depth %d)." % (opt["checkpoint"], sc.depth))
+                    t_chk = time.time()
             kind, d, b = sc.advance()
             last = d
             total_generated += d["generated"]
