@@ -435,7 +435,7 @@ def readme_object(args, elapsed, S):
         distinct=int(distinct), generated=int(S["generated"] / k), setup_s=round(S["setup_s"], 2), oracle_pinned_levels=S["oracle_levels"],
         violation_pinned_by=S["probe_source"], trace_equals_fixture=S["same_trace"], reference_trace_in_this_run=S.get("reference_trace"),
         sized_from_free_hbm=S["sizes"],
-        roofline={"bound": "hbm", "kernel": "k_expand (all launches of a run: PLAIN instantiation for the stored levels and the sub-slices of a streamed level, mode-capable one for the virtual / regenerated / probed passes)",
+        roofline={"bound": "hbm", "kernel": "k_expand (all launches of a run: PLAIN instantiation for the stored levels and the sub-slices of a streamed level, one-mode instantiations for the virtual / regenerated / probed passes)",
                   "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                   "traffic": tr["bytes_per_launch"], "traffic_source": tr["source"],
                   "avg_launch_ms": round(1e3 * avg_launch_s, 4), "launches": launches, "alg_bytes_per_launch": round(alg_run / launches),
@@ -444,7 +444,7 @@ def readme_object(args, elapsed, S):
                   "kernel_ms_per_step": {"k_expand": round(kernel_ms, 3), "k_expand_materialised_levels": round(S["mat_ms"] / k, 3),
                                          "k_expand_deep_passes": round(S["deep_ms"] / k, 3)},
                   # the same roofline per KIND of pass = per instantiation of k_expand (one run, the last timed one): stored levels <313,1>, the virtual
-                  # level <313,4>, its regeneration from the claim bitmap <313,3>, the level inserted beyond the buffers <313,1> into scratch, the probe <313,2>
+                  # level <313,4>, its regeneration from the claim bitmap <313,3>, the level inserted beyond the buffers <313,1> into scratch, the probe <313,6> (+ k_probe_resolve; <313,2> when a violation has been seen or a limit is re-checked)
                   "per_pass": {name: {"kernel_ms": round(v[0], 3), "launches": int(v[2]), "alg_bytes": round(v[1]),
                                       "achieved": round(v[1] / max(v[0] / 1e3, 1e-12) / 1e9, 2), "frac": round(v[1] / max(v[0] / 1e3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5)}
                                for name, v in S.get("split", {}).items() if v[0] > 0}},

@@ -223,7 +223,10 @@ int32_t vsrmc_checker_frontier(vsrmc_checker* c, uint64_t* words, uint64_t cap_w
  * (≙ TLC's per-action coverage, as a filter) */
 /* MEASUREMENT (not a product path; tools/bench_layout.py): one staging pass of k_expand's tile loop over the newest stored level, layout 0 =
  * the records as they are (refs + variable-length records), 1 = the same level as fixed-stride columns (SURVEY §8a row a1's SoA; a transposed copy is made
- * first, untimed).  Both fill the same LDS tile and read it back once.  *ms_per_pass = HIP-event time of one pass (mean of `reps`), *bytes_per_pass = what it reads. */
+ * first, untimed).  Both fill the same LDS tile and read it back once.  *ms_per_pass = HIP-event time of one pass (mean of `reps`), *bytes_per_pass = what it reads.
+ * Layouts 2-6 (round 6) are layout 0 with the tile loop software-pipelined / more resident blocks: 2 = refs one tile ahead, 3 = refs two and words one tile
+ * ahead, 4 = layout 0 at eight blocks per CU, 5 / 6 = 2 / 3 at eight blocks per CU, 7 / 10 = layout 0 drawing 4 / 16 tiles from the cursor at a time, 8 / 9 =
+ * 3 / 6 drawing 4 (csrc/vsr_bench_layout.hpp: k_stage_pipe). */
 int32_t vsrmc_checker_bench_staging(vsrmc_checker* c, int32_t layout, int32_t reps, double* ms_per_pass, uint64_t* bytes_per_pass);
 int32_t vsrmc_checker_select(vsrmc_checker* c, uint32_t action_mask, uint64_t max_states, uint64_t* words, uint64_t cap_words,
                              uint64_t* off, uint64_t* n_states, uint64_t* n_matching);
@@ -461,6 +464,11 @@ int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t sto
  * is more than 85 % full — every rank learns it in the same call and all of them stop together ("incomplete at depth N"); loops over
  * vsrmc_shard_loop_advance ask before every call, vsrmc_shard_loop_run does */
 int32_t vsrmc_shard_loop_room(vsrmc_shard_loop* l, int32_t* state);
+/* Since round 6 a sharded level of 2^20 states per rank or more runs in SLICES with the exchange overlapped: the all-to-all of slice k's (fp, key)
+ * candidates, the owners' claims, the verdict bytes and the withdrawal of the losers run on a second stream and a second set of buckets while k_expand of
+ * slice k + 1 runs (VSRMC_OVERLAP=0: the sequential level of rounds 2-5; VSRMC_OVERLAP_MIN_STATES / _MIN_SLICES: when and how finely).  What a level
+ * leaves does not depend on the slicing.  *levels / *slices: how many levels ran that way so far, in how many slices. */
+int32_t vsrmc_shard_loop_overlap_stats(vsrmc_shard_loop* l, uint64_t* levels, uint64_t* slices);
 /* ≙ TLC's checkpoints for a sharded run (collective; between two vsrmc_shard_loop_advance calls — also once the search has gone beyond the ranks' record
  * buffers: the seen-set-only levels' descriptors and each rank's winner set travel in its shard file).  Every rank writes <prefix>.rank<r>of<w> (its checker:
  * vsrmc_checker_save) and <prefix>.rank<r>of<w>.loop (the loop's own state), in two phases: a failure on any rank leaves the previous checkpoint whole.

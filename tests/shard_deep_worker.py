@@ -43,11 +43,18 @@ def main():
         sc.depth = sc.level
     rows = []
     probed = None
+    stopped = None
     while sc.depth < max_depth and sc.violation is None:
         if save_at and sc.depth >= save_at:
             sc.save(out + ".chk")
             break
+        if sc.room() == 2:                                      # (collective, as every loop over advance() asks: the seen-set shards — and it grows the winner sets)
+            stopped = "no room: " + getattr(sc, "room_note", "")
+            break
         kind, a, b = sc.advance()
+        if os.environ.get("SHARD_VERBOSE") and rank == 0:
+            print("level %d %s: new %d generated %d launches %s seconds %.3f overlap %s" % (a["level"], kind, a["n_new"], a["generated"], a["launches"], a["seconds"],
+                                                                                   sc.overlap_stats()), flush=True)
         if a["n_new"] == 0:
             break
         rows.append(dict(kind=kind, level=a["level"], n_new=a["n_new"], generated=a["generated"], deadlocks=a["deadlocks"], max_bag=a["max_bag"],
@@ -61,7 +68,7 @@ def main():
         viol = dict(level=sc.violation["level"], fp="%016x" % sc.violation["fp"], mask=sc.violation["mask"], probed=bool(sc.violation.get("probed")))
         path = ["%016x" % f for f in sc.violation_trace_fps()]
     with open("%s.rank%d.json" % (out, rank), "w") as f:
-        json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.depth, levels=rows, probed=probed, violation=viol, path=path,
+        json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.depth, levels=rows, probed=probed, violation=viol, path=path, stopped=stopped,
                        bytes_sent=sc.bytes_sent, sizes=dict(table_log2=int(eng.options.table_log2), frontier_words=int(eng.options.frontier_words),
                                                             cand_cap=int(eng.cand_cap))), f)
     sc.close()

@@ -105,7 +105,8 @@ def main():
         if sc.violation is not None:
             viol = dict(level=sc.violation["level"], fp="%016x" % sc.violation["fp"], mask=sc.violation["mask"])
         json.dump(dict(rank=rank, world=world, distinct=sc.distinct, depth=sc.level, levels=levels, walks=walks, violation=viol,
-                       bytes_sent=sc.x.bytes_sent, moved=sc.moved, probe=probe, restored=restored), f)
+                       bytes_sent=sc.x.bytes_sent, moved=sc.moved, probe=probe, restored=restored,
+                       overlap=list(sc.overlap_stats()) if hasattr(sc, "overlap_stats") else None), f)
     dist.barrier()
     dist.destroy_process_group()
 

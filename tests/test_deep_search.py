@@ -64,13 +64,17 @@ def test_rolling_deep_search_exhausts_a_small_space():
     mc.close()
 
 
-@pytest.mark.parametrize("base", [9, 12])
-def test_deep_search_finds_the_violation_many_levels_past_the_base(base):
+@pytest.mark.parametrize("base,probe_env", [(9, None), (12, None), (9, ("VSRMC_PROBE_CCAP", "32")), (11, ("VSRMC_NO_PROBE_KERNEL", "1"))])
+def test_deep_search_finds_the_violation_many_levels_past_the_base(base, probe_env, monkeypatch):
     """(3,1,{v1,v2},1) with AcknowledgedWritesExistOnMajority: violated at depth 19 after 109 878 states.  The base level is 9 / 12;
     levels beyond it are held against the oracle one by one, the violation is found by whichever pass reaches it — as a probed level
-    one pass before it would be inserted — and the counter-example is reconstructed through the seen-set."""
+    one pass before it would be inserted — and the counter-example is reconstructed through the seen-set.  The probe passes run the
+    probe-only instantiation (k_expand<.., 6> + k_probe_resolve, round 6); once with a work list of 32 entries, so that its tiles
+    overflow and are taken again in halves, and once without it (the mode-capable kernel, rounds 4-5)."""
     import vsr_tlaplus_amd as vt
     from oracle import orc
+    if probe_env:
+        monkeypatch.setenv(*probe_env)
     P = orc.Params(3, 1, 2, 1, invariant_mask=2)
     want, ob = _oracle_levels(orc, P, 19)
     assert want[-1]["viol"] == 2 and want[-1]["level"] == 19

@@ -198,6 +198,29 @@ def test_sharded_hip_engine_on_one_gpu(tmp_path, engine, world, params, depth, r
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,params,depth,rb,slices", [(2, (3, 1, 2, 2), 12, 0, 3), (3, (3, 1, 3, 3), 9, 50, 2), (2, (5, 1, 2, 2), 6, 0, 5), (4, (3, 1, 2, 2), 11, 100, 4)])
+def test_overlapped_exchange_in_slices(tmp_path, world, params, depth, rb, slices):
+    """Round 6 (the review's item 2): a sharded level runs in slices — the exchange of slice k (count all-gather, all-to-all of candidates, owners' claims,
+    verdict bytes, withdrawal of the losers; second stream, second set of buckets) while k_expand of slice k + 1 runs; the slices append to one next
+    frontier and add up in one control block.  Forced onto these small spaces (the default starts at 2^20 states per rank): every level in `slices` slices
+    or more — per-level fingerprint SETS over the ranks, new / generated / deadlock counts = the single-process oracle's; the trace walks replay; and the
+    sequential level (VSRMC_OVERLAP=0) leaves the same."""
+    ranks = run_world("native", world, params, depth, tmp_path, 29750 + world, rb, VSRMC_OVERLAP_MIN_STATES=8, VSRMC_OVERLAP_MIN_SLICES=slices)
+    check_against_oracle(ranks, params, depth)
+    replay_walks_with_oracle_gpu = [w for w in ranks[0]["walks"]]
+    assert all(r["walks"] == ranks[0]["walks"] for r in ranks) and replay_walks_with_oracle_gpu
+    lv, sl = ranks[0]["overlap"]
+    assert all(r["overlap"] == ranks[0]["overlap"] for r in ranks)                 # every rank cuts every level into the same number of slices
+    sharded_levels = sum(1 for x in ranks[0]["levels"][1:] if not x["replicated"])
+    assert lv >= sharded_levels - 4 and sl >= slices * lv, (lv, sl, sharded_levels)    # (the first levels hold fewer than 8 states per rank)
+    seq = run_world("native", world, params, depth, tmp_path, 29760 + world, rb, VSRMC_OVERLAP=0)
+    assert seq[0]["overlap"] == [0, 0]
+    for a, b in zip(ranks[0]["levels"], seq[0]["levels"]):
+        assert (a["level"], a["n_new"], a["generated"], a["deadlocks"]) == (b["level"], b["n_new"], b["generated"], b["deadlocks"])
+    assert sorted(f for r in ranks for f in r["levels"][-1]["fps"]) == sorted(f for r in seq for f in r["levels"][-1]["fps"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,rb", [(2, 0), (3, 500)])
 def test_sharded_hip_checkpoint_and_probe_level(tmp_path, world, rb):
     """the same legs over the HIP engine (ranks share device 0, gloo): vsrmc_checker_save / _load of a shard, vsrmc_checker_probe
@@ -249,8 +272,8 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
     assert "Error: Invariant AcknowledgedWritesExistOnMajority is violated." in r.stdout
     assert "State 19: <" in r.stdout and "State 20: <" not in r.stdout and "109878 distinct states found" in r.stdout, r.stdout[-1500:]
     # the AUTOMATIC scheme (C++ level loop) with -checkpoint / -recover, cut AFTER the search has gone beyond the ranks' record buffers (round 6:
-    # vsrmc_shard_loop_save / _restore): 1/1000 of the device each (282 MB: seen-set shards of 2^22 slots, 55-MB record buffers), the shipped constants —
-    # level 14 no longer fits, "Virtual(..)" lines follow; checkpointed before every unit of progress up to depth 16; recovered to depth 17
+    # vsrmc_shard_loop_save / _restore): 1/100 of the device each (2.8 GB: seen-set shards of 2^25 slots, 0.6-GB record buffers), the shipped constants —
+    # level 19 no longer fits, "Virtual(..)" lines follow; checkpointed before every unit of progress up to depth 21; recovered to depth 22
     d4 = tmp_path / "c4"
     d4.mkdir()
     chk4 = str(d4 / "chk")
@@ -258,15 +281,16 @@ def test_sharded_cli_two_ranks_on_one_gpu(tmp_path):
     def auto(*extra):
         return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29674",
                                "-m", "vsr_tlaplus_amd.sharded_cli", "-config", cfg4, "-noTLA", "-backend", "gloo"] + list(extra),
-                              capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1", VSRMC_AUTOSIZE_SHARE="1000"))
-    r = auto("-maxDepth", "16", "-checkpoint", chk4, "-checkpointMinutes", "0")
-    assert "Virtual(" in r.stdout and "Checkpointing of run %s completed (depth 15)." % chk4 in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+                              capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1", VSRMC_AUTOSIZE_SHARE="100"))
+    r = auto("-maxDepth", "21", "-checkpoint", chk4, "-checkpointMinutes", "0")
+    assert "Virtual(20)" in r.stdout and "Checkpointing of run %s completed (depth 20)." % chk4 in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.index("Virtual(") < r.stdout.index("completed (depth 20)")          # the last checkpoint was cut after the search had left its record buffers
     assert os.path.exists(chk4 + ".rank1of2") and os.path.exists(chk4 + ".rank0of2.loop")
-    r = auto("-recover", chk4, "-maxDepth", "17")
-    assert "Recovered from checkpoint %s: depth 15" % chk4 in r.stdout and "Virtual(16)" in r.stdout and "Virtual(17)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    r = auto("-recover", chk4, "-maxDepth", "22")
+    assert "Recovered from checkpoint %s: depth 20" % chk4 in r.stdout and "Virtual(21)" in r.stdout and "Virtual(22)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     with open(os.path.join(ROOT, "tests", "golden", "oracle_levels_config2.json")) as f:
         lv2 = json.load(f)["levels"]
-    assert "%d distinct states found" % sum(l["new"] for l in lv2[:17]) in r.stdout, r.stdout[-1500:]
+    assert "%d distinct states found" % sum(l["new"] for l in lv2[:22]) in r.stdout, r.stdout[-1500:]
     # the shipped VSR.cfg constants: the run ends in the depth-28 violation of AcknowledgedWriteNotLost (319 M states)
     d2 = tmp_path / "c2"
     d2.mkdir()
@@ -347,6 +371,7 @@ def run_deep_world(world, params, inv_mask, max_depth, tmp_path, port, fw_log2=0
     for r_ in ranks[1:]:                                                 # every figure is the level's, the same on every rank
         assert ([strip(x) for x in r_["levels"]], r_["probed"], r_["violation"], r_["path"], r_["distinct"]) == \
             ([strip(x) for x in ranks[0]["levels"]], ranks[0]["probed"], ranks[0]["violation"], ranks[0]["path"], ranks[0]["distinct"])
+    ranks[0]["stopped"] = [r_.get("stopped") for r_ in ranks]            # (why each rank's loop ended early, if it did)
     return ranks[0]
 
 
@@ -444,7 +469,7 @@ def test_readme_configuration_on_two_ranks(tmp_path, oracle_levels):
     g = oracle_levels["config3"]
     p = g["params"]
     got = run_deep_world(2, (p["R"], p["C"], p["n"], p["L"]), p["inv_mask"], 23, tmp_path, 29697)
-    assert len(got["levels"]) == 22 and "deep" in [lv["kind"] for lv in got["levels"]]
+    assert len(got["levels"]) == 22 and "deep" in [lv["kind"] for lv in got["levels"]], (got.get("stopped"), got["sizes"])
     for lv, want in zip(got["levels"], g["levels"][1:]):
         assert (lv["level"], lv["n_new"], lv["generated"], lv["deadlocks"], lv["max_bag"]) == \
             (want["level"], want["new"], want["generated"], want["deadlocks"], want["max_bag"]), want["level"]

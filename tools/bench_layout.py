@@ -24,9 +24,17 @@ for name, lay in (("records (AoS, the product's layout)", 0), ("fixed-stride col
     ms, nb = C.c_double(), C.c_uint64()
     capi.check(capi.load().vsrmc_checker_bench_staging(mc._h, lay, reps, C.byref(ms), C.byref(nb)))
     rows[name] = dict(ms_per_pass=round(ms.value, 4), bytes_read=int(nb.value), GBs=round(nb.value / ms.value / 1e6, 1))
+pipe = {}
+if os.environ.get("BENCH_LAYOUT_PIPE", "1") != "0":                # round 6: the tile loop of the records layout, software-pipelined / at eight blocks per CU
+    for name, lay in (("refs one tile ahead", 2), ("refs two, words one tile ahead", 3), ("as it is, 8 blocks per CU", 4), ("refs ahead, 8 blocks per CU", 5),
+                      ("refs and words ahead, 8 blocks per CU", 6), ("as it is, 4 tiles per draw from the cursor", 7), ("refs and words ahead, 4 tiles per draw", 8),
+                      ("refs and words ahead, 4 tiles per draw, 8 blocks per CU", 9), ("as it is, 16 tiles per draw", 10)):
+        ms, nb = C.c_double(), C.c_uint64()
+        capi.check(capi.load().vsrmc_checker_bench_staging(mc._h, lay, reps, C.byref(ms), C.byref(nb)))
+        pipe[name] = dict(ms_per_pass=round(ms.value, 4), GBs=round(nb.value / ms.value / 1e6, 1))
 a, b = rows["records (AoS, the product's layout)"], rows["fixed-stride columns (SoA)"]
 print(json.dumps(dict(workload="BASELINE configs[1], level %d: %d states, %.1f B per record on average, LDS stride %d words" %
                                (mc.level, d["n_new"], 8.0 * d["record_words"] / d["n_new"], (int(m.layout.fixed_words) + int(m.layout.permutations) + d["max_bag"]) | 1),
-                      k_expand_ms_of_this_level_for_scale=round(d["expand_ms"], 3), staging_pass=rows, soa_over_aos_time=round(b["ms_per_pass"] / a["ms_per_pass"], 3),
+                      k_expand_ms_of_this_level_for_scale=round(d["expand_ms"], 3), staging_pass=rows, records_pipelined=pipe, soa_over_aos_time=round(b["ms_per_pass"] / a["ms_per_pass"], 3),
                       note="the columns' padding (stride x states words) is allocated but never fetched; a stored SoA frontier would hold 1.16 x the bytes")))
 mc.close()

@@ -32,6 +32,12 @@ done
 rm -f $OUT/${TAG}_*.db
 one sq_counters_a "--workload config2" --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 one sq_counters_b "--workload config2" --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
+# the same two passes over the README run: one row per INSTANTIATION of k_expand (<313,1> stored levels and the level inserted beyond the buffers, <313,4> the
+# virtual level, <313,3> its regeneration from the claim bitmap, <313,6> the probe) — 45 % of that run is not the plain instantiation
+one sq_counters_readme_a "--workload readme" --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
+one sq_counters_readme_b "--workload readme" --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU
+# registers, spills, scratch and code size of every instantiation in the shipped library (from the code object's notes)
+$R/tools/kernel_resources.sh $R/vsr_tlaplus_amd/libvsrmc.so k_expandILb1ELi31 > $OUT/${TAG}_kernel_resources.txt 2>&1
 rm -f $OUT/${TAG}_*.db
 # the driver-style line last: its roofline.traffic comes from the request counters measured above on the same sources
 python $R/bench.py --steps 5 --warmup 1 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err

@@ -151,6 +151,7 @@ SYMBOLS = {
     "vsrmc_shard_loop_step": (C.c_int32, [V, C.POINTER(LevelInfo), C.POINTER(LevelInfo)]),
     "vsrmc_shard_loop_run": (C.c_int32, [V, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(LevelInfo)]),
     "vsrmc_shard_loop_room": (C.c_int32, [V, C.POINTER(C.c_int32)]),
+    "vsrmc_shard_loop_overlap_stats": (C.c_int32, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vsrmc_shard_loop_save": (C.c_int32, [V, C.c_char_p]),
     "vsrmc_shard_loop_restore": (C.c_int32, [V, V, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]),
     "vsrmc_shard_loop_status": (C.c_int32, [V, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32),

@@ -53,8 +53,12 @@ struct vsrmc_checker {
   // the single-pass kernel of this model (a specialised instantiation when there is one) and its launch shape
   void* fused_kernel = nullptr;
   void* plain_kernel = nullptr;          // the same without modes / sharding, when the configuration has one (ordinary unsharded levels)
+  u64* redo_buf[2] = {nullptr, nullptr}; // the lists of tiles that overflowed the LDS work list of an ordinary launch (LevelCtl::redo_out), 65536 entries each
+  void* plain5_kernel = nullptr;         // ... compiled for FIVE resident blocks per CU (96 VGPRs), when the configuration has one (BASELINE configs[1]): fused_shape picks it
+                                         // for the launches whose LDS fits five times
   void* modes_kernel = nullptr;          // the same without sharding (expand_pass: the passes of vsrmc_checker_probe / _probe2 / _probe3), or null
   void* regen_bits_kernel = nullptr, *insert_kernel = nullptr;   // ... with ONE mode compiled in (k_expand: PLAIN == 3 / 4), or null
+  void* probe_kernel = nullptr;          // ... the probe pass alone, five blocks per CU, failing successors resolved afterwards (PLAIN == 6; k_probe_resolve), or null
   u64 cur_max_bag = 0;                   // largest bag among the records of the newest level (LDS slot size of the next launch)
   bool bag_known = true;                 // false after a checkpoint was loaded or records arrived from other ranks: use the capacity
   // vsrmc_checker_probe / _probe2: where the reported violator's counter-example is walked from — the fingerprint of the deepest
@@ -66,6 +70,7 @@ struct vsrmc_checker {
   int probe_viol_level = 0;              // the probed level they belong to
   int host_frontier = 0;                 // bit b: record buffer b lives in pinned host memory (zero-copy over PCIe)
   bool saw_violation = false;            // a committed level held a violating state (the caller went on): probe passes apply every action
+  u64 extra_launches = 0;                // k_expand launches of the last pass beyond its first one: the lists of overflowed tiles taken again (redo_overflowed_tiles), a probe pass run again
   bool probe_all_actions = false;        // ... and so does the second run of a probe pass whose first run left instances unapplied beside a representation limit
   // levels beyond the record buffers (vsr_deep.hpp): `deep` levels above `level` are complete in the seen-set and have no frontier
   int deep = 0;
@@ -135,6 +140,10 @@ ExpandKernel plain_kernel_for(const Model& M) {               // unsharded ordin
     default: return nullptr;
   }
 }
+ExpandKernel plain5_kernel_for(const Model& M) {              // the ordinary level at five blocks per CU: pays where the kernel fits 96 registers (two permutations: 107 -> 7 spilled)
+  if (M.model_id != 0 || std::getenv("VSRMC_NO_OCC5")) return nullptr;
+  return (M.R * 100 + M.C * 10 + M.n) == 312 ? k_expand<true, 312, 5> : nullptr;
+}
 ExpandKernel modes_kernel_for(const Model& M) {               // unsharded passes with a mode (probe / virtual / regenerated / streamed levels)
   if (M.model_id != 0) return nullptr;
   switch (M.R * 100 + M.C * 10 + M.n) {
@@ -151,6 +160,15 @@ ExpandKernel one_mode_kernel_for(const Model& M, int which) {
     case 312: return which == MODE_REGEN ? k_expand<true, 312, 3> : k_expand<true, 312, 4>;
     case 313: return which == MODE_REGEN ? k_expand<true, 313, 3> : k_expand<true, 313, 4>;
     case 512: return which == MODE_REGEN ? k_expand<true, 512, 3> : k_expand<true, 512, 4>;
+    default: return nullptr;
+  }
+}
+ExpandKernel probe_kernel_for(const Model& M) {
+  if (M.model_id != 0 || std::getenv("VSRMC_NO_PROBE_KERNEL")) return nullptr;
+  switch (M.R * 100 + M.C * 10 + M.n) {
+    case 312: return k_expand<true, 312, 6>;
+    case 313: return k_expand<true, 313, 6>;
+    case 512: return k_expand<true, 512, 6>;
     default: return nullptr;
   }
 }
@@ -183,6 +201,7 @@ struct FusedShape {
   int stride;
   size_t lds;
   unsigned blocks_per_cu;
+  const void* kernel;       // the instantiation this shape is for (plain launches: the four- or the five-block one)
 };
 FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = false) {
   const Model& M = c->model.M;
@@ -211,14 +230,23 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
     f.tile = 128; f.ccap = 1536u; f.lds = lds128; f.blocks_per_cu = (unsigned)std::min(occ128, 2);
   } else {
     f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, VSR_OCC + 1));   // (what the instantiation's registers and this LDS allow)
-    // An instantiation compiled for FIVE blocks per CU (expand_occ: the ordinary level's kernel of BASELINE configs[1]) gets them when a shorter work list
-    // fits the LDS five times: the largest multiple of 128 entries that does, 512 at the least (8 instances per record; the mean is 5).  A tile with more
-    // is taken again in halves by the kernel (s_redo_*), so the length of the list is a matter of speed, not of correctness.
-    if (M.R <= 3 && occ64 == VSR_OCC && ccap64 > 512u)
-      for (u32 cc = ccap64 - 128; cc >= 512u; cc -= 128) {
-        size_t l5 = 0;
-        if (occupancy(64, cc, &l5) > VSR_OCC) { f.ccap = cc; f.lds = l5; f.blocks_per_cu = (unsigned)(VSR_OCC + 1); break; }
-      }
+  }
+  f.kernel = kernel;
+  // FIVE blocks per CU: the configuration has an ordinary-level instantiation compiled for 96 registers (plain5_kernel), and this launch's tile plus a
+  // work list of 896 entries (14 instances per record; the mean is 5 — a tile with more is written down and launched again in halves:
+  // redo_overflowed_tiles) fits the LDS five times.  The runtime's occupancy query is necessary, not sufficient: 32.3 KB per block (1024 entries) runs as FOUR
+  // resident blocks although the query says five — 31.3 KB (896) is the largest size measured at five (VSRMC_LDS5 / VSRMC_CCAP5: the sweep of DESIGN.md §8.5:
+  // config 2 k_expand 132.7 / 132.9 / 132.5 / 131.2 / 141.2 ms at 512 / 640 / 768 / 896 / 1024 entries, 137.1 with the four-block instantiation).
+  if (plain && c->plain5_kernel && M.R <= 3 && f.tile == 64) {
+    static const u32 cc5 = std::getenv("VSRMC_CCAP5") ? (u32)std::max(256, std::atoi(std::getenv("VSRMC_CCAP5"))) & ~127u : 896u;
+    static const size_t lds5 = std::getenv("VSRMC_LDS5") ? (size_t)std::atoll(std::getenv("VSRMC_LDS5")) : (size_t)31744;
+    hipFuncAttributes at;
+    size_t dyn = (size_t)64 * f.stride * 8 + 2 * (size_t)cc5 * 4;
+    int nb5 = 0;
+    if (hipFuncGetAttributes(&at, c->plain5_kernel) == hipSuccess && dyn + at.sharedSizeBytes <= lds5 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb5, c->plain5_kernel, blk, dyn) == hipSuccess && nb5 >= VSR_OCC + 1) {
+      f.kernel = c->plain5_kernel; f.ccap = cc5; f.lds = dyn; f.blocks_per_cu = (unsigned)(VSR_OCC + 1);
+    }
   }
   if (const char* e = std::getenv("VSRMC_MAX_BPC"))            // diagnostic: fewer resident blocks per CU (occupancy sweeps)
     f.blocks_per_cu = (unsigned)std::max(1, std::min<int>((int)f.blocks_per_cu, std::atoi(e)));
@@ -491,6 +519,8 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o_in, vs
   if (e == hipSuccess) e = hipMalloc((void**)&c->pending, o->pending_entries * 24);   // (slot, key, parent index) entries of the exact scheme
   if (e == hipSuccess) e = hipMalloc((void**)&c->ctl, sizeof(LevelCtl));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_find, 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->redo_buf[0], (size_t)65536 * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->redo_buf[1], (size_t)65536 * 8);
   if (e != hipSuccess) {
     vsrmc_checker_destroy(c);
     return fail(VSRMC_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -498,9 +528,11 @@ int32_t vsrmc_checker_create(const vsrmc_model* m, const vsrmc_options* o_in, vs
   c->fused_kernel = (void*)fused_kernel_for(M);
   c->modes_kernel = (void*)modes_kernel_for(M);
   c->plain_kernel = (void*)plain_kernel_for(M);
+  c->plain5_kernel = (void*)plain5_kernel_for(M);
   if (!std::getenv("VSRMC_NO_MODE_KERNELS")) {                   // (A/B knob: the run-time-switched instantiation for every pass, as in rounds 3-4)
     c->regen_bits_kernel = (void*)one_mode_kernel_for(M, MODE_REGEN);
     c->insert_kernel = (void*)one_mode_kernel_for(M, MODE_INSERT);
+    c->probe_kernel = (void*)probe_kernel_for(M);
   }
   rc = checker_seed(c);
   if (rc) { vsrmc_checker_destroy(c); return rc; }
@@ -535,6 +567,45 @@ int level_error(vsrmc_checker* c, const LevelCtl& h, int new_level) {
   return fail(h.err < ERR_REP_RANGE ? VSRMC_E_EVAL : VSRMC_E_REP, msg);
 }
 
+// The tiles an ordinary single-pass launch wrote down because their enabled instances did not fit the LDS work list (k_expand: s_over; c->h.n_redo of
+// them at c->h.redo_out as first record | size << 48): launched again — ONE launch over the list, every entry as two tiles of half its size, with the long
+// work list — into the same destination: the level counters in the control block run on (only the tile cursor and the list start over), so the launches
+// add up to what one launch with a longer list would have left.  Repeats while tiles are written down (a tile of 64 records is halved at most six
+// times); a single record that does not fit is ERR_FRONTIER_FULL.
+int redo_overflowed_tiles(vsrmc_checker* c, const void* kern, const u64* src_words, const u64* src_off, int level, int stride, u64* d_words, u64 d_wcap,
+                          u64* d_off, u64 nx_cap, u64* d_fp, u32 ichunk, u32 wchunk, unsigned grid_cap /* the first launch's grid: its chunks fit the destination */,
+                          int mode = MODE_NORMAL, u32 ccap_same = 0 /* the probe-only instantiation: the same short list — half a tile has half the instances */) {
+  const Model& M = c->model.M;
+  const u32 ccap = ccap_same ? ccap_same : M.R <= 3 ? (u32)VSR_CCAP64 : (u32)VSR_CAND_CAP;   // the long list (the short one is the five-block shape's)
+  for (int round = 0; c->h.n_redo && !c->h.err && round < 8; round++) {   // (2^6 = a tile: the seventh round takes single records)
+    const u64 n = c->h.n_redo;
+    if (n > c->h.redo_cap) return fail(VSRMC_E_REP, "more tiles overflowed the work list of one launch than the list of them holds (65536)");
+    const int in = (c->h.redo_out == (u64)(uintptr_t)c->redo_buf[0]) ? 0 : 1;      // what the last launch wrote is this one's input; it writes the other list
+    LevelCtl patch = c->h;
+    patch.n_redo = 0; patch.tile_cursor = 0; patch.redo_out = (u64)(uintptr_t)c->redo_buf[in ^ 1];
+    HIPCHK(hipMemcpyAsync(&c->ctl->n_redo, &patch.n_redo, 3 * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(&c->ctl->tile_cursor, 0, 8, c->stream));
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    const int tile = 64;
+    const size_t lds = (size_t)tile * stride * 8 + 2 * (size_t)ccap * 4;
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(std::min<u64>(2 * n, (u64)c->num_cus * 3), (u64)grid_cap));
+    c->extra_launches++;
+    hipLaunchKernelGGL((ExpandKernel)kern, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, 2 * n * (u64)tile, level,
+                       c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, stride, 1, (u64*)nullptr, (u64)0, (u32)VSR_CAND_CAP,
+                       d_words, d_wcap, d_off, nx_cap, d_fp, ichunk, wchunk, tile, ccap, (u64*)nullptr, (u64)0, (u64*)nullptr, 0u, mode | (int)MODE_REDO_LIST,
+                       (u64)(uintptr_t)c->redo_buf[in], (const WSet*)nullptr, 0u);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->expand_ms += ms;
+  }
+  if (!c->h.err && c->h.n_redo) { c->h.err = ERR_FRONTIER_FULL; c->h.err_info = 0; }
+  return 0;
+}
+
 // phase 1: k_expand over the current frontier.  io == nullptr: unsharded.
 int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NORMAL) {
   const Model& M = c->model.M;
@@ -543,9 +614,13 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
   c->t_level0 = now_s();
   c->expand_ms = c->materialize_ms = 0;
   std::memset(&c->h, 0, sizeof(c->h));
-  c->h.viol_fp = ~(u64)0;
+  c->h.viol_fp = ~(u64)0; c->h.redo_out = (u64)(uintptr_t)c->redo_buf[0]; c->h.redo_cap = 65536;
   HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
   c->level_fused = !c->opt.exact_ties;
+  const void* redo_kern = nullptr;                               // set for an ordinary (plain) launch: the instantiation that writes overflowed tiles down
+  int redo_stride = 0;
+  u32 redo_ichunk = 0, redo_wchunk = 0;
+  unsigned redo_grid = 1;
   if (c->n_frontier > 0) {
     // 128 records per tile when the work list has room for them (about 4 successors per record at R <= 3), else 64
     const bool fused = !c->opt.exact_ties;                       // sharded (io != nullptr) or not
@@ -590,8 +665,9 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
       ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(8192, nx_cap / (4 * (u64)grid)));
       wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(262144, c->words_cap(nxt) / (4 * (u64)grid)));
     }
+    if (fused && use_plain) { redo_kern = fs.kernel; redo_stride = stride; redo_ichunk = ichunk; redo_wchunk = wchunk; redo_grid = grid; }
     if (fused)
-      hipLaunchKernelGGL((ExpandKernel)(use_plain ? c->plain_kernel : c->fused_kernel), dim3(grid),
+      hipLaunchKernelGGL((ExpandKernel)(use_plain ? fs.kernel : c->fused_kernel), dim3(grid),
                          dim3(VSR_BLOCK), lds, c->stream, M, c->words[c->cur], c->off[c->cur],
                          c->n_frontier, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
                          stride, io ? c->opt.world : 1, io ? io->cand_send : nullptr, io ? io->cand_cap : 0, pchunk, c->words[nxt],
@@ -613,6 +689,12 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->expand_ms = ms;
   }
+  if (redo_kern && c->h.n_redo && !c->h.err) {                 // tiles that overflowed the (short) work list of an ordinary level: again, in halves
+    const int nxt = c->cur ^ 1;
+    const int rrc = redo_overflowed_tiles(c, redo_kern, c->words[c->cur], c->off[c->cur], c->level + 1, redo_stride, c->words[nxt], c->words_cap(nxt), c->off[nxt],
+                                          c->opt.frontier_states, c->lvl_fp, redo_ichunk, redo_wchunk, redo_grid);
+    if (rrc) return rrc;
+  }
   c->nx_n = c->nx_w = 0;
   c->full_recoverable = false;
   if (!c->h.err && c->h.full) {                                // the record buffers ran out (LevelCtl::full): reported as before ..
@@ -633,6 +715,64 @@ int phase_expand(vsrmc_checker* c, const vsrmc_shard_io* io, int mode = MODE_NOR
                                  "vsrmc_options.exact_ties = 1");
     }
   }
+  return 0;
+}
+
+// phase 1 in SLICES (round 6: the overlapped exchange of vsr_shard_loop.hpp): k_expand over parents [first, first + n) of the current frontier of a sharded
+// single-pass level, announcing into the caller's buckets (one of two sets) and APPENDING to the next frontier — the level counters in the control block
+// run on from slice to slice (only the tile cursor and the bucket fills start over), so that the slices of a level add up to what one launch would have left.
+// Asynchronous: the launch is queued on the checker's stream between two events and the call returns; expand_slice_wait() collects it.
+// A block leaves a partly used index and word chunk behind per launch: chunks are smaller here (2048 indices, 64 K words) than for a whole level.
+int expand_slice_launch(vsrmc_checker* c, const vsrmc_shard_io* io, u64* cand_idx, u64 first, u64 n, bool first_slice) {
+  const Model& M = c->model.M;
+  HIPCHK(hipSetDevice(c->opt.device));
+  if (first_slice) {
+    if (c->level + 1 >= 511) return fail(VSRMC_E_REP, "more than 510 BFS levels");
+    c->t_level0 = now_s();
+    c->expand_ms = c->materialize_ms = 0;
+    std::memset(&c->h, 0, sizeof(c->h));
+    c->h.viol_fp = ~(u64)0; c->h.redo_out = (u64)(uintptr_t)c->redo_buf[0]; c->h.redo_cap = 65536;
+    HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
+    c->level_fused = true;
+    c->nx_n = c->nx_w = 0;
+    c->full_recoverable = false;
+  } else {
+    HIPCHK(hipMemsetAsync(&c->ctl->tile_cursor, 0, sizeof(u64), c->stream));
+    HIPCHK(hipMemsetAsync(c->ctl->cand_cnt, 0, sizeof(c->ctl->cand_cnt), c->stream));
+  }
+  HIPCHK(hipEventRecord(c->ev[0], c->stream));
+  if (n > 0) {
+    const FusedShape fs = fused_shape(c, c->bag_known ? c->cur_max_bag : (u64)M.max_bag, false);
+    const int nxt = c->cur ^ 1;
+    const u64 nx_cap = c->opt.frontier_states;
+    const u64 ntiles = (n + fs.tile - 1) / fs.tile;
+    unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)c->num_cus * fs.blocks_per_cu);
+    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, std::min<u64>(nx_cap / (4 * (u64)VSR_CAND_CAP), c->words_cap(nxt) / (4 * 16384))));
+    const u64 wmin = std::max<u64>(16384, (u64)fs.ccap * (u64)(fs.stride + 5));
+    grid = (unsigned)std::max<u64>(1, std::min<u64>(grid, c->words_cap(nxt) / (4 * wmin)));
+    const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(2048, nx_cap / (4 * (u64)grid)));
+    const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, c->words_cap(nxt) / 2), std::min<u64>(65536, c->words_cap(nxt) / (4 * (u64)grid)));
+    const u32 cchunk = (u32)std::max<u64>(16, std::min<u64>(512, io->cand_cap / (4 * (u64)c->num_cus * 2)));
+    hipLaunchKernelGGL((ExpandKernel)c->fused_kernel, dim3(grid), dim3(VSR_BLOCK), fs.lds, c->stream, M, c->words[c->cur], c->off[c->cur] + first,
+                       n, c->level + 1, c->opt.rank, c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl,
+                       fs.stride, c->opt.world, io->cand_send, io->cand_cap, (u32)VSR_CAND_CAP, c->words[nxt],
+                       c->words_cap(nxt), c->off[nxt], nx_cap, c->lvl_fp, ichunk, wchunk, fs.tile, fs.ccap, c->filter, c->fmask, cand_idx, cchunk,
+                       (int)MODE_NORMAL, (u64)0, (const WSet*)nullptr, 0u);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+// ... the slice has run: its kernel time, its errors, how many candidates it left in each owner's bucket
+int expand_slice_wait(vsrmc_checker* c, u64* cand_counts) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->expand_ms += ms;
+  for (int o = 0; o < c->opt.world; o++) cand_counts[o] = c->h.cand_cnt[o];
+  if (!c->h.err && c->h.full) { c->h.err = ERR_FRONTIER_FULL; c->h.err_info = c->h.full_info << 16; }
+  if (c->h.err) return level_error(c, c->h, c->level + 1);
   return 0;
 }
 
@@ -783,14 +923,37 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
                 u32* claim_bits = nullptr, u64 claim_w = 0 /* unsharded MODE_INSERT / MODE_REGEN over the stored base: the claim bitmap (vsr_deep.hpp) */) {
   const Model& M = c->model.M;
   std::memset(&c->h, 0, sizeof(c->h));
-  c->h.viol_fp = ~(u64)0;
+  c->h.viol_fp = ~(u64)0; c->h.redo_out = (u64)(uintptr_t)c->redo_buf[0]; c->h.redo_cap = 65536;
   HIPCHK(hipMemcpyAsync(c->ctl, &c->h, sizeof(c->h), hipMemcpyHostToDevice, c->stream));
+  c->extra_launches = 0;
+  u32 probe_ccap = 256u;
+  bool use_probe = false;                                        // the probe-only instantiation ran: its failing successors are (parent, ordinal) entries still to be resolved
+  const void* redo_kern = nullptr;                               // (see phase_expand)
+  int redo_stride = 0;
+  u32 redo_ichunk = 0, redo_wchunk = 0;
+  unsigned redo_grid = 1;
+  u64 *redo_words = nullptr, *redo_off = nullptr, *redo_fp = nullptr, redo_wcap = 0, redo_cap = 0;
   if (n_parents > 0) {
     // an ordinary level into other buffers (the streamed level's sub-slices) runs the plain instantiation: the code of a stored level
     static const bool plain_normal = std::getenv("VSRMC_STREAM_MODES_KERNEL") == nullptr;
     const bool one_rank = !io || c->opt.world == 1;                // (world 1 through the level loop: nothing is remote — the unsharded instantiations)
     const bool use_plain = one_rank && mode == MODE_NORMAL && plain_normal && c->plain_kernel;
-    const FusedShape fs = fused_shape(c, src_max_bag, use_plain);
+    FusedShape fs = fused_shape(c, src_max_bag, use_plain);
+    // a probe pass (nothing seen to violate so far, no limit re-check): the probe-only instantiation at five blocks per CU when its tile — a work list of 256
+    // entries: only the footprint's instances are listed — fits the LDS five times (same measured bound as the five-block ordinary level: fused_shape)
+    if (one_rank && mode == MODE_PROBE && c->probe_kernel && !c->saw_violation && !c->probe_all_actions && fs.tile == 64) {
+      hipFuncAttributes at;
+      const u32 pcap = std::getenv("VSRMC_PROBE_CCAP") ? (u32)std::max(32, std::min(256, std::atoi(std::getenv("VSRMC_PROBE_CCAP")))) : 256u;   // (tests: a list that overflows; 32 = one bag entry per record and batch of the enumeration)
+      const size_t dyn = (size_t)64 * fs.stride * 8 + 2 * (size_t)pcap * 4;
+      static const size_t lds5 = std::getenv("VSRMC_LDS5") ? (size_t)std::atoll(std::getenv("VSRMC_LDS5")) : (size_t)31744;
+      int nb5 = 0;
+      if (hipFuncGetAttributes(&at, c->probe_kernel) == hipSuccess && dyn + at.sharedSizeBytes <= lds5 &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb5, c->probe_kernel, VSR_BLOCK, dyn) == hipSuccess && nb5 >= VSR_OCC + 1) {
+        use_probe = true;
+        probe_ccap = pcap;
+        fs.kernel = c->probe_kernel; fs.ccap = pcap; fs.lds = dyn; fs.blocks_per_cu = (unsigned)(VSR_OCC + 1);
+      }
+    }
     u32 cchunk = 0;
     if (io) {
       if (c->cand_idx_cap < (u64)c->opt.world * io->cand_cap) {   // per announced candidate: where it was written / what regenerates it
@@ -824,7 +987,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     const u32 ichunk = (u32)std::max<u64>(VSR_CAND_CAP, std::min<u64>(ichunk_max, nx_cap / (4 * (u64)grid)));
     const u32 wchunk = (u32)std::max<u64>(std::min<u64>(wmin, d_wcap / 2), std::min<u64>(262144, d_wcap / (4 * (u64)grid)));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    const void* kern = !one_rank ? c->fused_kernel : use_plain ? c->plain_kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
+    const void* kern = !one_rank ? c->fused_kernel : (use_plain || use_probe) ? fs.kernel : (c->modes_kernel ? c->modes_kernel : c->fused_kernel);
     // the claim bitmap of the first seen-set-only level (vsr_deep.hpp): written by the pass that inserts it, read by every pass that regenerates it — both
     // expand the stored base (level c->level), slice by slice, p_offset = the slice's first parent
     if (!claim_bits && c->claim_bits && one_rank && level == c->level + 1 && (mode == MODE_INSERT || mode == MODE_REGEN) &&
@@ -834,6 +997,7 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
       else if (mode == MODE_INSERT && c->insert_kernel) kern = c->insert_kernel;
     }
     if (claim_bits && kern != c->regen_bits_kernel && kern != c->insert_kernel) { claim_bits = nullptr; claim_w = 0; }   // (only those two know the bitmap)
+    if (use_plain || use_probe) { redo_kern = kern; redo_stride = fs.stride; redo_ichunk = ichunk; redo_wchunk = wchunk; redo_words = d_words; redo_off = d_off; redo_fp = d_fp; redo_wcap = d_wcap; redo_cap = nx_cap; redo_grid = grid; }
     hipLaunchKernelGGL((ExpandKernel)kern, dim3(grid), dim3(VSR_BLOCK), lds, c->stream, M, src_words, src_off, n_parents, level, c->opt.rank,
                        c->table, c->tmask, c->pending, c->opt.pending_entries, c->ctl, fs.stride, io ? c->opt.world : 1,
                        io ? io->cand_send : nullptr, io ? io->cand_cap : (u64)0, (u32)VSR_CAND_CAP,
@@ -850,6 +1014,43 @@ int expand_pass(vsrmc_checker* c, const u64* src_words, const u64* src_off, u64 
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->expand_ms += ms;
+  }
+  if (redo_kern && !use_probe && c->h.n_redo && !c->h.err) {   // tiles that overflowed the work list of an ordinary pass: again, in halves
+    const int rrc = redo_overflowed_tiles(c, redo_kern, src_words, src_off, level, redo_stride, redo_words, redo_wcap, redo_off, redo_cap, redo_fp, redo_ichunk, redo_wchunk, redo_grid);
+    if (rrc) return rrc;
+  }
+  if (use_probe && c->h.n_redo > c->h.redo_cap && !c->h.err) c->h.err = ERR_FRONTIER_FULL;   // (more such tiles than the list holds: the general kernel, below)
+  if (use_probe && c->h.n_redo && !c->h.err) {                 // tiles with more footprint instances than the short list holds: again, in halves, by the same kernel
+    const int rrc = redo_overflowed_tiles(c, c->probe_kernel, src_words, src_off, level, redo_stride, redo_words, redo_wcap, redo_off, redo_cap, redo_fp, redo_ichunk, redo_wchunk,
+                                          redo_grid, MODE_PROBE, probe_ccap);
+    if (rrc) return rrc;
+  }
+  if (use_probe && c->h.err == ERR_FRONTIER_FULL) {            // a tile with more footprint instances than the short work list holds: the pass again with the general probe kernel
+    void* const pk = c->probe_kernel;
+    const u64 before = c->extra_launches + 1;
+    c->probe_kernel = nullptr;
+    const int rrc = expand_pass(c, src_words, src_off, n_parents, p_offset, level, mode, src_max_bag, dst, io, claim_bits, claim_w);
+    c->probe_kernel = pk;
+    c->extra_launches += before;
+    return rrc;
+  }
+  if (use_probe && c->h.n_pending && !c->h.err) {              // the failing successors the probe-only pass wrote down: fingerprinted and looked up now (k_probe_resolve)
+    const u64 n = c->h.n_pending;
+    if (n > c->opt.pending_entries) return fail(VSRMC_E_REP, "more violating successors in the probed level than the pending list holds (pending_entries)");
+    u64* d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_out, n * 16));
+    struct FreeOut { u64* p; ~FreeOut() { (void)hipFree(p); } } free_out{d_out};
+    u64 zero = 0, kept = 0;
+    HIPCHK(hipMemcpyAsync(c->d_find, &zero, 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_probe_resolve<0>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, M, src_words, src_off, (const u64*)c->pending, n, (const Slot*)c->table,
+                       c->tmask, level, d_out, n, (unsigned long long*)c->d_find, c->ctl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&kept, c->d_find, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (kept) HIPCHK(hipMemcpyAsync(c->pending, d_out, kept * 16, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->ctl->n_pending, &kept, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
   }
   if (!c->h.err && c->h.full) {                                // a pass into buffers that ran out (LevelCtl::full): an error here — the caller sized the slice
     c->h.err = ERR_FRONTIER_FULL;

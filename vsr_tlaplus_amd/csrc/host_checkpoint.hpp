@@ -531,6 +531,7 @@ void vsrmc_checker_destroy(vsrmc_checker* c) {
   if (c->pending) (void)hipFree(c->pending);
   if (c->ctl) (void)hipFree(c->ctl);
   if (c->d_find) (void)hipFree(c->d_find);
+  for (u64* q : c->redo_buf) if (q) (void)hipFree(q);
   if (c->rslot) (void)hipFree(c->rslot);
   if (c->filter) (void)hipFree(c->filter);
   if (c->cand_idx) (void)hipFree(c->cand_idx);

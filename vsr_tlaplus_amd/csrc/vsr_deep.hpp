@@ -197,6 +197,7 @@ void deep_acc(vsrmc_level_info* t, const LevelCtl& h, double ms) {
 }
 
 int deep_run_pass(DeepRun& R, const u64* sw, const u64* so, u64 n, u64 p_off, int level, int mode, u64 bag, const PassDst* dst) {
+  R.c->extra_launches = 0;
   if (R.io) return R.io->pass(R.io->ctx, sw, so, n, p_off, level, mode, bag, dst);
   return expand_pass(R.c, sw, so, n, p_off, level, mode, bag, dst);   // (expand_pass finds the claim bitmap of the first seen-set-only level by itself)
 }
@@ -241,12 +242,13 @@ int deep_probe(DeepRun& R, const PassDst& B, u64 n, int lv, u64 bag) {
   c->expand_ms = 0;
   if (R.err) return 0;
   int rc = expand_pass(c, B.words, B.off, n, 0, lv + 1, MODE_PROBE, bag);
+  R.launches += c->extra_launches;
   if (!rc && c->h.limit_unchecked) {                            // a record at a representation limit beside instances the footprint filter skipped: once more, every action applied
     R.prb.limit_rechecked += c->h.limit_unchecked;
     c->probe_all_actions = true;
     rc = expand_pass(c, B.words, B.off, n, 0, lv + 1, MODE_PROBE, bag);
     c->probe_all_actions = false;
-    R.launches++;
+    R.launches += 1 + c->extra_launches;
   }
   if (rc) return deep_local_fail(R, rc);
   R.launches++;
@@ -301,7 +303,7 @@ int deep_descend(DeepRun& R, const u64* src_words, const u64* src_off, u64 n_idx
     c->expand_ms = 0;
     rc = deep_run_pass(R, src_words, src_off + a, n, (R.io && c->opt.world > 1) ? 0 : a, lv + 1, regen ? MODE_REGEN : MODE_NORMAL, src_bag, &B);
     if (rc) return rc;
-    if (n) R.launches++;
+    if (n) R.launches += 1 + c->extra_launches;
     a += n;
     if (n) (k == 0 ? R.n_slices : R.n_subs)++;
     const u64 part = c->h.n_new;                               // index range written (holes included)
@@ -418,7 +420,7 @@ int deep_first_pass(vsrmc_checker* c, vsrmc_level_info* ins, const DeepIo* io = 
     rc = deep_run_pass(R, c->words[c->cur], c->off[c->cur] + a, n, (io && c->opt.world > 1) ? 0 : a, c->level + 1, MODE_INSERT, bagL, nullptr);
     if (rc) break;
     a += n;
-    if (n) R.launches++;
+    if (n) R.launches += 1 + c->extra_launches;
     deep_acc(&R.ins, c->h, c->expand_ms);
     R.ins.n_new += c->h.n_new;
     R.ins.max_bag = std::max<u64>(R.ins.max_bag, c->h.max_bag);

@@ -127,12 +127,16 @@ struct LevelCtl {   // device-resident counters of one BFS level
   // R - 1 entries of its capacity, a delivery count of 3): a successor of theirs could have raised ERR_REP_* unseen.  Not 0: the host runs the pass again
   // with every action applied (host_checker.hpp: expand_pass) — nothing goes unreported, and vsrmc_level_info.limit_rechecked says it happened.
   u64 limit_unchecked;
+  // ordinary single-pass levels: the tiles whose enabled instances did not fit the LDS work list (k_expand: s_over) — n_redo of them written to the list at
+  // redo_out (a device pointer the host puts here, redo_cap entries: first record | size << 48); the host launches them again in halves (redo_overflowed_tiles)
+  u64 n_redo, redo_out, redo_cap;
 };
 
 // owner rank of a fingerprint: high bits, so that the table index (low bits) stays uniform inside a shard
 __host__ __device__ __forceinline__ int owner_of(u64 fp, int world) { return (int)(((fp >> 40) & 0xFFFFFF) % (u64)world); }
 
-enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO_FOOTPRINT = 0x100 /* flag, or-ed to MODE_PROBE */ };
+enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO_FOOTPRINT = 0x100 /* flag, or-ed to MODE_PROBE */,
+       MODE_REDO_LIST = 0x200 /* flag of an ordinary launch: the tiles come from the list of overflowed tiles at p_offset (host_checker.hpp: redo_overflowed_tiles) */ };
 #define VSR_TILE_MAX 128     // frontier records staged per block iteration: 64 or 128 (kernel parameter `tile`)
 #define VSR_BLOCK 256
 // per-phase shader clocks of k_expand (vsrmc_level_info.phase_cycles; tools/run_bfs.py prints the breakdown): every read is an
@@ -164,14 +168,17 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO
 #ifndef VSR_SPEC_CAS
 #define VSR_SPEC_CAS 0
 #endif
-#ifndef VSR_DIRECT_REFS     // EXPERIMENT: every thread fetches the refs of the four records it stages itself (no barrier between the ref load and the record loads)
-#define VSR_DIRECT_REFS 0
+#ifndef VSR_DIRECT_REFS     // every thread fetches the refs of the four records it stages itself (no barrier between the ref load and the record loads)
+#define VSR_DIRECT_REFS 1   // (round 6, with the next switch: config 2 k_expand 130.7 -> 129.5 ms, README 1 091 -> 1 078 ms per step; 0: refs through LDS, as in rounds 1-5)
 #endif
-#ifndef VSR_NO_TAIL_SYNC    // EXPERIMENT: no barrier at the bottom of the tile loop (what follows the apply-closing barrier touches LDS words of wave 0 only)
-#define VSR_NO_TAIL_SYNC 0
+#ifndef VSR_NO_TAIL_SYNC    // no barrier at the bottom of the tile loop (what follows the apply-closing barrier touches LDS words of wave 0 only)
+#define VSR_NO_TAIL_SYNC 1
 #endif
 #ifndef VSR_COPY8
 #define VSR_COPY8 0
+#endif
+#ifndef VSR_TILE_BATCH      // tiles a block draws from the cursor at a time (k_expand: s_tile_left); 1 = rounds 1-5
+#define VSR_TILE_BATCH 4
 #endif
 #ifndef VSR_REDO            // a tile that overflows the work list is taken again in pieces (k_expand: s_redo_*); 0: ERR_FRONTIER_FULL as in rounds 1-5 (A/B; the experiments below need 0)
 #define VSR_REDO 1
@@ -186,9 +193,7 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO
 #ifndef VSR_COOP_COPY       // wave-cooperative copy of the parent words of new states in the ordinary level's instantiation (see the apply loop); 0: the lane-serial copy everywhere
 #define VSR_COOP_COPY 1
 #endif
-#ifndef VSR_OCC_312         // five resident blocks per CU for the ordinary level's kernel of BASELINE configs[1] (expand_occ)
-#define VSR_OCC_312 1
-#endif
+
 #ifndef VSR_ROUND_REV       // EXPERIMENT: the second round of the apply loop runs on the block's LAST waves (wave 0 carries the serial sections already)
 #define VSR_ROUND_REV 0
 #endif
@@ -504,7 +509,7 @@ __device__ __forceinline__ void specialise(Model& M, const Model& Marg) {
 // ordinary level's kernel of BASELINE configs[1] needs 107 registers and runs FIVE blocks per CU with 7 spilled ones at the top of the tile loop (k_expand
 // 139 -> 134.6 ms; with the cooperative copy 127.9); the README configuration's (six permutations: 119 registers) loses at five (28 spilled: 232 -> 257 ms).
 constexpr int expand_occ(bool fused, int spec, int plain) {
-  return !fused ? 3 : spec == 0 ? 2 : (VSR_OCC_312 && spec == 312 && plain == 1) ? 5 : VSR_OCC;
+  return !fused ? 3 : spec == 0 ? 2 : (plain == 5 || plain == 6) ? VSR_OCC + 1 : VSR_OCC;
 }
 template <bool FUSED, int SPEC = 0, int PLAIN = 0, int BLK = VSR_BLOCK>
 // (hipcc turns the second bound into waves per SIMD as blocks * max(1, threads / 256): 4 = 128 VGPRs)
@@ -539,10 +544,16 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   // MODE_INSERT (a virtual level: no successor write; leaves the claim bitmap).  The mode-capable instantiation carries every mode behind a run-time switch
   // and pays for it in registers (its README build spills 27 VGPRs; one more branch took that to 93, and every pass 10 % with it): a pass that knows its mode
   // runs leaner code.  (A probe-only instantiation was built too and lost to the run-time-switched one — 88 spilled VGPRs: DESIGN.md §8.5.)
-  const int mode = PLAIN == 1 ? (int)MODE_NORMAL : PLAIN == 3 ? (int)MODE_REGEN : PLAIN == 4 ? (int)MODE_INSERT : (mode_arg & 0xFF);
+  constexpr bool IS_PLAIN = PLAIN == 1 || PLAIN == 5;          // the ordinary level's instantiation (5: the same compiled for five blocks per CU)
+  // PLAIN == 6 (round 6): the PROBE pass of the deep search and nothing else, compiled for FIVE blocks per CU.  A probe pass stages and enumerates every
+  // parent but applies 2 % of the instances (the actions inside the invariants' footprint) and fingerprints only a successor that FAILS an invariant — 8 of
+  // 3.8e9 on the README configuration.  Here that rare successor is not fingerprinted at all: its (parent, ordinal) goes to the `pending` list and a small
+  // kernel of its own (k_probe_resolve) hashes it and looks it up after the pass; and the instances outside the footprint are counted, not listed.  Without
+  // the hash of six permutations and the seen-set code the kernel fits 96 registers, and with a work list of 256 entries its tile fits the LDS five times.
+  const int mode = IS_PLAIN ? (int)MODE_NORMAL : PLAIN == 3 ? (int)MODE_REGEN : PLAIN == 4 ? (int)MODE_INSERT : PLAIN == 6 ? (int)MODE_PROBE : (mode_arg & 0xFF);
   // MODE_NO_FOOTPRINT: the probe pass applies every action — the caller has seen a violating state among the parents' levels (a search that
   // went on after a reported violation), and a violating parent hands its verdict to successors of actions outside the footprint
-  const bool no_footprint = PLAIN != 1 && (mode_arg & MODE_NO_FOOTPRINT) != 0;
+  const bool no_footprint = !IS_PLAIN && PLAIN != 6 && (mode_arg & MODE_NO_FOOTPRINT) != 0;
   const int world = PLAIN ? 1 : world_arg;
   Model M = Marg;
   specialise<SPEC>(M, Marg);
@@ -551,10 +562,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   u64* s_rec = smem;                                           // tile * stride words
   u32* s_cand = (u32*)(smem + tile * stride);                  // ccap entries: action << 18 | record << 11 | ordinal
   u32* s_cand2 = s_cand + ccap;                        // the same, sorted by action
-  __shared__ u32 s_ncand, s_napply, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv, s_risky;
+  __shared__ u32 s_ncand, s_napply, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv, s_risky, s_ntotal;
   // (single-pass levels of a configuration with R <= 3 always run 64-record tiles: host_checker.hpp, fused_shape — 1.3 KB of LDS less, which five blocks per CU need)
   constexpr int TILE_MAX = BLK < VSR_BLOCK ? BLK / 2 : (FUSED && SPEC % 1000 != 0 && (SPEC % 1000) / 100 <= 3) ? 64 : VSR_TILE_MAX;
-  constexpr bool COOP = VSR_COOP_COPY && FUSED && PLAIN == 1;
+  constexpr bool COOP = VSR_COOP_COPY && FUSED && IS_PLAIN;
+  constexpr bool REDO_OK = VSR_REDO && FUSED && (IS_PLAIN || PLAIN == 6);   // a tile that overflows the work list goes to the host's list (LevelCtl::n_redo) instead of failing the launch
   __shared__ u32 s_alive[TILE_MAX];
   __shared__ u64 s_ref[TILE_MAX];
   __shared__ u64 s_pfp[TILE_MAX];                          // canonical fingerprint of every staged record (the parent part of its successors' keys)
@@ -628,32 +640,23 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   }
   VSR_SYNC_G(0);                                                // (thread 0 rewrites s_tile_nxt at the top of the loop)
 #else
-  if (tid == 0) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+  // Round 6: VSR_TILE_BATCH consecutive tiles per draw.  Atomics on ONE address are served one after the other — 13 - 15 ns each on this part (the staging
+  // micro-benchmark: 65 - 75 tiles per microsecond whatever the layout, the occupancy or the prefetch depth, tools/bench_layout.py) — and a pass that only
+  // stages and enumerates (the probe pass: 65 tiles per microsecond) ran AT that rate: the cursor, not the HBM, was its bound.
+  __shared__ u32 s_tile_left;                                    // tiles left of the drawn batch after my_next (thread 0's)
+  const u32 tbatch = ntiles >= (u64)gridDim.x * 16 ? (u32)VSR_TILE_BATCH : 1u;   // (the same in every block of the launch; a small level keeps single tiles: every block gets work)
+  if (tid == 0) { my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull) * (u64)tbatch; s_tile_left = tbatch - 1; }
 #endif
-  // A tile whose enabled instances do not fit the work list (ccap entries: 12 .. 24 per record, the mean is 5 - 7) is not an error since round 6: nothing of it
-  // has been applied when the counting sort finds out, so the block takes the same records again in pieces of half the size (s_redo_*: a contiguous range of
-  // the frontier, worked off before the next tile is drawn; a piece that overflows again is halved again).  Only a SINGLE record with more instances than the
-  // list holds is ERR_FRONTIER_FULL.  This is what lets the launch shape shorten the list until five blocks fit a CU (host_checker.hpp: fused_shape).
-  __shared__ u64 s_redo_base;
-  __shared__ u32 s_redo_left, s_redo_step, s_redo_n, s_over;
-  if (tid == 0) { s_redo_left = 0; s_redo_step = 0; s_over = 0; }
+  // A tile whose enabled instances do not fit the work list (ccap entries: 12 .. 24 per record, the mean is 5 - 7) is not an error for the ordinary level's
+  // instantiations since round 6: nothing of it has been applied when the counting sort finds out, so the block writes the tile down (its first record and
+  // its size, in the `pending` list an ordinary single-pass level has no other use for) and goes on; the host launches the listed tiles again in halves
+  // (host_checker.hpp: redo_overflowed_tiles).  Only a SINGLE record with more instances than the list holds is ERR_FRONTIER_FULL.  This is what lets the
+  // launch shape shorten the list until five blocks fit a CU (fused_shape) without betting correctness on it.
+  __shared__ u32 s_over;
+  if (tid == 0) s_over = 0;
   for (;;) {
-#if VSR_REDO
-    if (tid == 0 && s_redo_left) {
-      const u32 n = s_redo_step < s_redo_left ? s_redo_step : s_redo_left;
-      s_tile_cur = s_redo_base;
-      s_redo_n = n;
-      s_redo_base += n;
-      s_redo_left -= n;
-    } else
-#endif
     if (tid == 0) {
-#if VSR_REDO
-      s_tile_cur = my_next < ntiles ? my_next * (u64)tile : ~(u64)0;
-      s_redo_n = (u32)tile;
-#else
       s_tile_cur = my_next;
-#endif
 #if VSR_REFS_AHEAD
       s_tile_nxt = my_next2;
       my_next = my_next2;
@@ -665,27 +668,43 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       s_tile_n = my_n;
       if (my_next < n_parents) { my_n = my_take; my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)my_take); }
 #else
-      if (my_next < ntiles) my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull);
+      if (my_next < ntiles) {
+        const u32 left = s_tile_left;
+        if (left) { my_next++; s_tile_left = left - 1; }
+        else { my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, 1ull) * (u64)tbatch; s_tile_left = tbatch - 1; }
+      }
 #endif
     }
     const u64 t_0 = VSR_CLK();
-    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; s_nsurv = 0; s_over = 0; if (PLAIN != 1) s_risky = 0; }
+    if (tid == 0) { s_ncand = 0; s_dead = 0; s_maxbag = 0; s_wneed = 0; s_skip = 0; s_nsurv = 0; s_over = 0; if (!IS_PLAIN) s_risky = 0; }
     if (tid < tile) s_alive[tid] = 0;
     if (tid < 16) s_kcount[tid] = 0;
     VSR_SYNC_G(0);
-    const u64 tile_i = s_tile_cur;
+    u64 tile_i = s_tile_cur;
+    tile_i = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tile_i >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)tile_i);   // (block-uniform: scalar)
 #if VSR_TAKE
     if (tile_i >= n_parents) break;
     const u64 p_base = tile_i;
     const int np_tile = (int)((n_parents - p_base) < (u64)s_tile_n ? (n_parents - p_base) : (u64)s_tile_n);
-#elif !VSR_REDO
-    if (tile_i >= ntiles) break;
-    const u64 p_base = tile_i * (u64)tile;
-    const int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
 #else
-    if (tile_i >= n_parents) break;                             // (s_tile_cur is the index of the tile's first record here: a drawn tile or a piece of one)
-    const u64 p_base = tile_i;
-    const int np_tile = (int)((n_parents - p_base) < (u64)s_redo_n ? (n_parents - p_base) : (u64)s_redo_n);
+    if (tile_i >= ntiles) break;
+    u64 p_base = tile_i * (u64)tile;
+    int np_tile = (int)((n_parents - p_base) < (u64)tile ? (n_parents - p_base) : (u64)tile);
+    if constexpr (REDO_OK) {
+      // a launch over the LIST of tiles an earlier launch could not fit into its work list (MODE_REDO_LIST: p_offset = the list, n_parents = 2 x entries x
+      // tile): tile 2 k / 2 k + 1 = the two halves of entry k
+      if (mode_arg & MODE_REDO_LIST) {
+        const u64 e = ((const u64*)p_offset)[tile_i >> 1];
+        const int cnt = (int)(e >> 48);
+        int half = 1;
+        while (half * 2 < cnt) half *= 2;
+        p_base = (e & (((u64)1 << 48) - 1)) + ((tile_i & 1) ? (u64)half : 0);
+        np_tile = (tile_i & 1) ? cnt - half : half;
+      }
+      // (block-uniform values that came out of LDS / memory: into scalar registers, not three VGPRs live across the whole tile)
+      p_base = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(p_base >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)p_base);
+      np_tile = __builtin_amdgcn_readfirstlane(np_tile);
+    }
 #endif
     // PLAIN == 3 (regeneration by the claim bitmap): the bitmap IS the list of enabled instances that matter — the (parent, ordinal) pairs whose lane
     // made a state when the level was inserted.  The words of this thread's record (thread g of the record's G threads takes words g and g + G; the host
@@ -802,7 +821,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       // in a register, no atomics, no cross-lane traffic inside the slot loop; the entries beyond 256*PRIV are a shared
       // overflow area (atomic cursor) for the rare thread that finds more.  Unused entries hold ~0; the counting sort below
       // skips them.
-      const u32 PRIV = (ccap - (u32)BLK) / BLK;               // 5 at ccap 1536, 7 at 2048
+      const u32 PRIV = PLAIN == 6 ? 0u : (ccap - (u32)BLK) / BLK;   // 5 at ccap 1536, 7 at 2048; the probe-only instantiation lists 2 % of the instances: one shared region
       const u32 shared0 = PRIV * BLK;
       for (u32 k = tid; k < ccap; k += BLK) s_cand[k] = ~0u;
       VSR_SYNC_G(3);
@@ -816,6 +835,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         // instances of a record are evaluated as one bit mask per replica by the record's threads (thread g takes replicas g+1, g+1+G, ..).
         auto emit = [&](int kind, int p, int ord) {
           atomicAdd(&s_kcount[kind], 1u);
+          if constexpr (PLAIN == 6) {                               // the probe-only instantiation lists what it will apply; the rest is counted
+            if (!((Ops::probe_actions() >> kind) & 1u)) { s_alive[p] = 1; return; }
+          }
           u32 idx;
           if (nmine < PRIV) idx = (u32)tid * PRIV + nmine;
           else idx = shared0 + atomicAdd(&s_ncand, 1u);
@@ -879,7 +901,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
               const int r = m_dest(w);
               const u64 l = r == 1 ? lut[1] : r == 2 ? lut[2] : r == 3 ? lut[3] : r == 4 ? lut[4] : lut[5];
               pass = m_count(w) != 0 && ((l >> (w & 63)) & 1);
-              if (PLAIN != 1 && PLAIN != 3 && PLAIN != 4 && mode == MODE_PROBE && m_count(w) == 3) s_risky = 1;   // one more Send of this key would not fit the count field
+              if (!IS_PLAIN && PLAIN != 3 && PLAIN != 4 && mode == MODE_PROBE && m_count(w) == 3) s_risky = 1;   // one more Send of this key would not fit the count field
             }
             const u64 bal = __ballot(pass);
             if (bal) {
@@ -953,22 +975,21 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     // the 15 action bodies, only inside one)
     if (tid == 0) {
       if (s_ncand >= 0x40000000u) {
-#if VSR_REDO
-        if (np_tile > 1) {                                       // the work list is too short for this tile: the same records again, half as many at a time
-          s_over = 1;
-          s_redo_left += (u32)np_tile;                           // (what was still queued starts right behind this piece: the range stays contiguous)
-          s_redo_base = p_base;
-          s_redo_step = (u32)np_tile / 2u;
-        } else
-#endif
-        raise_error(ctl, ERR_FRONTIER_FULL, p_base);
+        bool listed = false;
+        if constexpr (REDO_OK) {
+          if (np_tile > 1) {                                     // the work list is too short for this tile: written down for the host, which launches it again in halves
+            const u64 k = atomicAdd((unsigned long long*)&ctl->n_redo, 1ull);
+            if (k < ctl->redo_cap) { ((u64*)ctl->redo_out)[k] = p_base | ((u64)np_tile << 48); listed = true; s_over = 1; }
+          }
+        }
+        if (!listed) raise_error(ctl, ERR_FRONTIER_FULL, p_base);
       }
       u32 acc = 0;
       // probe level: an action outside the invariants' footprint cannot turn a passing parent into a violating successor (Ops::probe_actions):
       // its instances are counted and sorted behind the others, and the apply loop stops in front of them.  (Compiled into the mode-capable
       // kernels only: the plain kernels sit on a register-allocation cliff — one more LDS word here cost the README configuration's 20
       // stored levels 22 ms.)
-      if constexpr (PLAIN != 1 && FUSED && VSR_PROBE_FOOTPRINT) {
+      if constexpr (!IS_PLAIN && FUSED && VSR_PROBE_FOOTPRINT) {
         const u32 keep = (mode == MODE_PROBE && !no_footprint) ? Ops::probe_actions() : ~0u;
         for (int a = 0; a < 16; a++)
           if ((keep >> a) & 1u) {
@@ -983,7 +1004,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
               acc += s_kcount[a];
             }
           // the instances behind s_napply are not applied: is a record of this tile so close to a representation limit that one of them could have hit it?
-          if (s_risky || (int)s_maxbag + M.R - 1 > M.max_bag) s_acc[15] += acc - s_napply;
+          if (!s_over && (s_risky || (int)s_maxbag + M.R - 1 > M.max_bag)) s_acc[15] += acc - s_napply;   // (an overflowed tile is counted when it is taken again)
         }
       } else {
         for (int a = 0; a < 16; a++) {
@@ -992,6 +1013,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         }
       }
       s_ncand = acc > ccap ? ccap : acc;
+      if constexpr (PLAIN == 6) { s_ntotal = acc; s_ncand = s_napply; }   // (listed = the footprint's instances; every instance counts as generated)
 #if VSR_TAKE
       {
         const u32 q8 = (acc << 8) / (u32)np_tile;
@@ -1005,12 +1027,12 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
     const u64 t_2 = VSR_CLK();
     VSR_SYNC_G(6);
     const u32 ncand = s_ncand;
-#if VSR_REDO
-    if (s_over) {                                               // (block-uniform) the tile is taken again in pieces: nothing of it has been applied or counted
-      VSR_SYNC_G(6);                                            // every wave has read the flag before thread 0 clears it at the top of the loop
-      continue;
+    if constexpr (REDO_OK) {
+      if (s_over) {                                             // (block-uniform) the tile goes to the host's list: nothing of it has been applied or counted
+        VSR_SYNC_G(6);                                          // every wave has read the flag before thread 0 clears it at the top of the loop
+        continue;
+      }
     }
-#endif
     for (u32 c = tid; c < ccap; c += BLK) {
       const u32 code = s_cand[c];
       if (code == ~0u) continue;
@@ -1070,7 +1092,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
       VSR_SYNC_G(6);
     }
-    const u32 ncand_apply = s_skip ? 0u : ((PLAIN != 1 && FUSED && VSR_PROBE_FOOTPRINT) ? s_napply : ncand);                // s_skip: the tile was refused (see the word-chunk reservation)
+    const u32 ncand_apply = s_skip ? 0u : ((!IS_PLAIN && FUSED && VSR_PROBE_FOOTPRINT) ? s_napply : ncand);                // s_skip: the tile was refused (see the word-chunk reservation)
     constexpr bool dd_on = false;
     if (tid == 0) { s_tile_base = s_chunk_used; s_tile_cursor = 0; }
     VSR_SYNC_G(6);
@@ -1099,12 +1121,19 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
         raise_error(ctl, D.err, ((p_base + (u64)p) << 16) | (u64)ord);
         continue;
       }
+      if constexpr (PLAIN == 6) {                                 // probe-only: a successor that fails an invariant is written down for k_probe_resolve, nothing else happens here
+        if (Ops::invariants(M, rec, D) != 0) {
+          const u64 i = atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
+          if (i < pending_cap) { pending[2 * i] = origin_make(p_base + (u64)p, ord); pending[2 * i + 1] = 0; }   // (p_offset is 0 for this instantiation, or the tile list)
+        }
+        continue;
+      }
       const u64 a_1 = VSR_CLK();
       // Probe level: nothing is inserted, so the fingerprint and the seen-set matter only for a successor that VIOLATES an invariant — it is
       // reported unless it is a state of an earlier level.  Invariants first, then (for the handful that fail) hash and lookup: the README
       // configuration's level 24 has 3.8e9 successors of which 8 violate; hashing them under six permutations and fetching a 128-byte line
       // of the seen-set for each was a third of that run.
-      if (PLAIN != 1 && fused && mode == MODE_PROBE && Ops::invariants(M, rec, D) == 0) continue;
+      if (!IS_PLAIN && fused && mode == MODE_PROBE && Ops::invariants(M, rec, D) == 0) continue;
       u64 Hc[6];
       Ops::hash_child_(M, rec, D, Hc);
       u64 fp;
@@ -1380,9 +1409,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       } else {
         s_chunk_used += s_tile_cursor;
       }
-      s_acc[0] += s_ncand;
+      s_acc[0] += PLAIN == 6 ? s_ntotal : s_ncand;
       s_acc[1] += s_dead;
-      s_acc[2] += ncand_apply;                                   // one home-slot probe per applied candidate
+      if (PLAIN != 6) s_acc[2] += ncand_apply;                   // one home-slot probe per applied candidate
       const u64 t_5 = VSR_CLK();
       s_acc[3] += t_1 - t_0;
       s_acc[4] += t_2 - t_1;
@@ -1419,11 +1448,11 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       }
       if (tid == 0) {
         if (s_acc[8]) atomicAdd((unsigned long long*)&ctl->ties, s_acc[8]);
-        if (PLAIN != 1 && s_acc[15]) atomicAdd((unsigned long long*)&ctl->limit_unchecked, s_acc[15]);
+        if (!IS_PLAIN && s_acc[15]) atomicAdd((unsigned long long*)&ctl->limit_unchecked, s_acc[15]);
         if (s_acc[14]) atomicAdd((unsigned long long*)&ctl->n_written, s_acc[14]);
         if (s_acc[9]) atomicAdd((unsigned long long*)(mode == MODE_INSERT ? &ctl->n_new : &ctl->rec_words), s_acc[9]);
         if (s_maxbag_out) atomicMax((unsigned long long*)&ctl->max_bag, (unsigned long long)s_maxbag_out);
-        if (PLAIN != 1 && (s_fxs[0] | s_fxs[1])) {
+        if (!IS_PLAIN && (s_fxs[0] | s_fxs[1])) {
           atomicXor((unsigned long long*)&ctl->fp_xor, s_fxs[0]);
           atomicAdd((unsigned long long*)&ctl->fp_sum, s_fxs[1]);
         }
@@ -1433,6 +1462,9 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
       const u64 base = s_chunk_base;
       for (u32 k = used + tid; k < pchunk; k += BLK) pending[3 * (base + k) + 1] = ~(u64)0;
     }
+#if VSR_NO_FLUSH     // EXPERIMENT (timing only: the level's reported figures are wrong): how much of a launch is the drain of the per-block statistics?
+    if (tid >= 0) return;
+#endif
     if (tid == 0) {
       if (s_acc[0]) atomicAdd((unsigned long long*)&ctl->generated, s_acc[0]);
       if (s_acc[1]) atomicAdd((unsigned long long*)&ctl->deadlocks, s_acc[1]);
@@ -1985,6 +2017,38 @@ __global__ void k_table_import(Slot* table, u64 tmask, const Slot* __restrict__ 
     return;
   }
   table[p.slot].meta = in[i].meta;
+}
+
+// The failing successors a probe-only pass (k_expand<.., 6>) wrote down as (parent index, ordinal): fingerprinted and looked up here, after the pass — the ones
+// that are states of an earlier level are dropped, the rest become the (fingerprint, key) pairs the probe passes of rounds 3-5 produced inside k_expand, in
+// `out` (out_n counts them; viol_fp / viol_mask of the control block as before).  A handful of entries per pass (README: 8 of 3.8e9 successors): one lane each,
+// records read from HBM, the model's constants at run time.
+template <int MODEL>
+__global__ void k_probe_resolve(Model M, const u64* __restrict__ src_words, const u64* __restrict__ src_off, const u64* __restrict__ list, u64 n, const Slot* table,
+                                u64 tmask, int level, u64* out, u64 out_cap, unsigned long long* out_n, LevelCtl* ctl) {
+  typedef ModelOps<MODEL> Ops;
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 origin = list[2 * i];
+  const u64 ref = src_off[origin_pidx(origin)];
+  const u64* rec = src_words + (ref >> 8);
+  Delta D;
+  if (!Ops::template gen_<false>(M, rec, origin_ord(origin), D) || D.err) { raise_error(ctl, D.err ? D.err : (int)ERR_INTERNAL, origin); return; }
+  const int bad = Ops::invariants(M, rec, D);
+  if (!bad) return;
+  u64 Hc[6];
+  Ops::hash_child_(M, rec, D, Hc);
+  u64 fp, pfp;
+  u32 ak, pak;
+  canonical_fp(M, D.hdr, Hc, &fp, &ak);
+  canonical_fp(M, rec[0], rec + M.h0, &pfp, &pak);
+  u64 m = META_EMPTY;
+  u32 np = 0;
+  if (probe_lookup(table, tmask, fp, &m, CntReg{&np}) && meta_level(m) < level) return;      // a state of an earlier level: TLC drops it as seen
+  const u64 k = atomicAdd(out_n, 1ull);
+  if (k < out_cap) { out[2 * k] = fp; out[2 * k + 1] = meta_make(level, ak, pfp); }
+  atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
+  atomicOr(&ctl->viol_mask, (u32)bad);
 }
 
 // the winner set of a sharded deep search as (fingerprint, level) pairs (checkpoint of a sharded search beyond its record buffers: host_checkpoint.hpp) ...

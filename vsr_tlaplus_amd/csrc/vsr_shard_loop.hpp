@@ -156,6 +156,10 @@ struct vsrmc_shard_loop {
   char* h_send = nullptr;
   char* h_recv = nullptr;
   u64 h_cap = 0;
+  // the overlapped exchange (round 6): a second set of buckets and a second stream — the all-to-all, the owners' claims, the verdicts and their application
+  // of slice k run on `stream2` while k_expand of slice k + 1 runs on the checker's stream
+  hipStream_t stream2 = nullptr;           // (the two sets of buckets are the two HALVES of the loop's buffers: a slice is sized for half a bucket, no extra memory)
+  u64 overlap_levels = 0, overlap_slices = 0;
 };
 
 namespace {
@@ -173,10 +177,12 @@ int loop_stage_cap(vsrmc_shard_loop* l, u64 bytes) {
 }
 
 // all-to-all-v of device buffers through the loop's transport (element offsets / counts; nothing is sent to oneself)
-int loop_alltoallv(vsrmc_shard_loop* l, const void* d_send, const u64* scnt, const u64* soff, void* d_recv, const u64* rcnt, const u64* roff, u32 eb) {
+int loop_alltoallv(vsrmc_shard_loop* l, const void* d_send, const u64* scnt, const u64* soff, void* d_recv, const u64* rcnt, const u64* roff, u32 eb,
+                   hipStream_t stream = nullptr) {
+  if (!stream) stream = l->c->stream;
   for (int p = 0; p < l->world; p++)
     if (p != l->rank) l->bytes_sent += scnt[p] * eb;
-  if (!l->comm.host_buffers) return l->comm.alltoallv(l->comm.ctx, d_send, scnt, soff, d_recv, rcnt, roff, eb, (void*)l->c->stream);
+  if (!l->comm.host_buffers) return l->comm.alltoallv(l->comm.ctx, d_send, scnt, soff, d_recv, rcnt, roff, eb, (void*)stream);
   // host transport: pack the non-empty buckets contiguously on the host, exchange, unpack
   std::vector<u64> hs(l->world, 0), hr(l->world, 0);
   u64 st = 0, rt = 0;
@@ -187,23 +193,141 @@ int loop_alltoallv(vsrmc_shard_loop* l, const void* d_send, const u64* scnt, con
   int rc = loop_stage_cap(l, std::max<u64>(1, std::max(st, rt)) * eb);
   if (rc) return rc;
   for (int p = 0; p < l->world; p++)
-    if (p != l->rank && scnt[p] && hipMemcpyAsync(l->h_send + hs[p] * eb, (const char*)d_send + soff[p] * eb, scnt[p] * eb, hipMemcpyDeviceToHost, l->c->stream) != hipSuccess)
+    if (p != l->rank && scnt[p] && hipMemcpyAsync(l->h_send + hs[p] * eb, (const char*)d_send + soff[p] * eb, scnt[p] * eb, hipMemcpyDeviceToHost, stream) != hipSuccess)
       return fail(VSRMC_E_HIP, "staging copy (device to host)");
-  if (hipStreamSynchronize(l->c->stream) != hipSuccess) return fail(VSRMC_E_HIP, "stream synchronisation");
+  if (hipStreamSynchronize(stream) != hipSuccess) return fail(VSRMC_E_HIP, "stream synchronisation");
   std::vector<u64> sc(scnt, scnt + l->world), rcv(rcnt, rcnt + l->world);
   sc[l->rank] = rcv[l->rank] = 0;
   rc = l->comm.alltoallv(l->comm.ctx, l->h_send, sc.data(), hs.data(), l->h_recv, rcv.data(), hr.data(), eb, nullptr);
   if (rc) return rc > 0 ? fail(VSRMC_E_HIP, "the caller's all-to-all-v failed") : rc;
   for (int p = 0; p < l->world; p++)
-    if (p != l->rank && rcnt[p] && hipMemcpyAsync((char*)d_recv + roff[p] * eb, l->h_recv + hr[p] * eb, rcnt[p] * eb, hipMemcpyHostToDevice, l->c->stream) != hipSuccess)
+    if (p != l->rank && rcnt[p] && hipMemcpyAsync((char*)d_recv + roff[p] * eb, l->h_recv + hr[p] * eb, rcnt[p] * eb, hipMemcpyHostToDevice, stream) != hipSuccess)
       return fail(VSRMC_E_HIP, "staging copy (host to device)");
-  if (hipStreamSynchronize(l->c->stream) != hipSuccess) return fail(VSRMC_E_HIP, "stream synchronisation");
+  if (hipStreamSynchronize(stream) != hipSuccess) return fail(VSRMC_E_HIP, "stream synchronisation");
   return 0;
 }
 
 int loop_allgather(vsrmc_shard_loop* l, const void* mine, void* all, u32 bytes) {
   const int rc = l->comm.allgather(l->comm.ctx, mine, all, bytes);
   return rc > 0 ? fail(VSRMC_E_HIP, "the caller's all-gather failed") : rc;
+}
+
+// ---- the overlapped exchange (round 6) ---------------------------------------------------------------------------------------------------------
+// Rounds 2-5 ran a sharded level strictly in sequence: k_expand over the whole frontier, THEN the candidates to their owners, the owners' claims, the verdict
+// bytes back, the losers withdrawn — the fabric idle while the kernel runs and the CUs idle while the fabric does.  Here the frontier is cut into `nb` slices
+// (the same number on every rank: every slice has its collectives) and the exchange of slice k — count all-gather, all-to-all of (fp, key), k_claim_batch_fused,
+// all-to-all of the verdict bytes, k_apply_verdict, on `stream2` and a second set of buckets — runs while k_expand of slice k + 1 runs on the checker's stream.
+// The slices of a level append to one next frontier and add up in one control block (host_checker.hpp: expand_slice_launch); the seen-set is claimed by the
+// lanes of k_expand and by k_claim_batch_fused concurrently, both with the same compare-and-swap / min-merge, so a state is inserted by exactly one of them
+// and its key is the minimum over every candidate whichever slice carried it.  What a level leaves — new states, counts, keys — does not depend on nb.
+int loop_overlap_buffers(vsrmc_shard_loop* l) {
+  vsrmc_checker* c = l->c;
+  if (!l->stream2 && hipStreamCreateWithFlags(&l->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return fail(VSRMC_E_HIP, "overlapped exchange: second stream"); }
+  // the two sets of buckets are the two halves of the loop's exchange buffers (and of the checker's "where was it written" array): a slice announces at most
+  // 0.45 of half a bucket per owner, so the overlap costs no memory — what autosize_options set aside for the winner set and the scratch buffers of the deep
+  // search stays theirs (a second set of full-size buckets, 15 GB per rank on the README configuration at world 2, took exactly that)
+  if (c->cand_idx_cap < (u64)l->world * l->cand_cap) {
+    if (c->cand_idx) (void)hipFree(c->cand_idx);
+    c->cand_idx = nullptr;
+    c->cand_idx_cap = 0;
+    if (hipMalloc((void**)&c->cand_idx, (u64)l->world * l->cand_cap * 8) != hipSuccess) { (void)hipGetLastError(); return fail(VSRMC_E_HIP, "hipMalloc of the candidate index array failed"); }
+    c->cand_idx_cap = (u64)l->world * l->cand_cap;
+  }
+  return 0;
+}
+
+// the exchange of one slice on stream2: counts gathered, candidates out, claims, verdicts back, losers withdrawn.  *rc: this rank's local error (it keeps
+// taking part in the collectives: their sizes are fixed by the counts); return value: a failed collective (nobody can go on).
+int loop_exchange_slice(vsrmc_shard_loop* l, int set, const u64* counts, int* rc) {
+  vsrmc_checker* c = l->c;
+  const int w = l->world, me = l->rank;
+  const u64 hcap = l->cand_cap / 2;                               // set 0 / 1 = the first / second half of every buffer, [owner][hcap] each
+  u64* cand_send = l->cand_send + (u64)set * (u64)w * hcap * 2;
+  u64* cand_recv = l->cand_recv + (u64)set * (u64)w * hcap * 2;
+  uint8_t* verdict_out = l->verdict_out + (u64)set * (u64)w * hcap;
+  uint8_t* verdict_in = l->verdict_in + (u64)set * (u64)w * hcap;
+  u64* cand_idx = c->cand_idx + (u64)set * (u64)w * hcap;
+  struct CountRow { u64 cnt[8]; u64 err; } mine, zero;
+  std::memset(&zero, 0, sizeof(zero));
+  mine = zero;
+  for (int p = 0; p < w; p++) mine.cnt[p] = (p == me || *rc) ? 0 : std::min<u64>(counts[p], hcap);
+  mine.err = *rc ? (u64)(*rc < 0 ? -*rc : *rc) : 0;
+  std::vector<CountRow> all((size_t)w, zero);
+  const int crc = loop_allgather(l, &mine, all.data(), (u32)sizeof(CountRow));
+  if (crc) return crc;
+  u64 worst = 0;
+  for (const CountRow& r : all) worst = std::max(worst, r.err);
+  if (worst) return *rc ? *rc : fail(VSRMC_E_STATE, "level " + std::to_string(l->level + 1) + ", phase expand (a slice): error " + std::to_string((long long)worst) + " on another rank");
+  u64 scnt[8], soff[8], rcnt[8], roff[8], n_recv = 0;
+  for (int p = 0; p < w; p++) {
+    scnt[p] = mine.cnt[p];
+    soff[p] = (u64)p * hcap;
+    rcnt[p] = p == me ? 0 : all[(size_t)p].cnt[me];
+    roff[p] = n_recv;
+    n_recv += rcnt[p];
+  }
+  if (n_recv > (u64)w * hcap) return fail(VSRMC_E_REP, "more candidates received than the exchange buffer holds");
+  int xrc = loop_alltoallv(l, cand_send, scnt, soff, cand_recv, rcnt, roff, 16, l->stream2);
+  if (!*rc) *rc = xrc;
+  if (!*rc && n_recv) {
+    hipLaunchKernelGGL(k_claim_batch_fused, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, l->stream2, c->table, c->tmask, cand_recv, n_recv, c->level + 1, verdict_out, c->ctl);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(l->stream2) != hipSuccess) *rc = fail(VSRMC_E_HIP, "overlapped exchange: claim kernel");
+  }
+  xrc = loop_alltoallv(l, verdict_out, rcnt, roff, verdict_in, scnt, soff, 1, l->stream2);
+  if (!*rc) *rc = xrc;
+  const int nxt = c->cur ^ 1;
+  for (int o = 0; o < w && !*rc; o++) {
+    if (o == me || scnt[o] == 0) continue;
+    hipLaunchKernelGGL(k_apply_verdict, dim3((unsigned)((scnt[o] + 255) / 256)), dim3(256), 0, l->stream2, cand_send + 2 * (u64)o * hcap,
+                       cand_idx + (u64)o * hcap, verdict_in + (u64)o * hcap, scnt[o], c->off[nxt], c->lvl_fp, c->ctl, (const WSet*)nullptr, 0);
+    if (hipGetLastError() != hipSuccess) *rc = fail(VSRMC_E_HIP, "overlapped exchange: verdict kernel");
+  }
+  if (hipStreamSynchronize(l->stream2) != hipSuccess && !*rc) *rc = fail(VSRMC_E_HIP, "overlapped exchange: stream");
+  return 0;
+}
+
+// steps 1-5 of a sharded level in nb >= 2 slices; leaves the checker as vsrmc_shard_materialize does (c->h, nx_n, nx_w)
+int loop_level_head_overlapped(vsrmc_shard_loop* l, int nb, int* rc) {
+  vsrmc_checker* c = l->c;
+  *rc = loop_overlap_buffers(l);
+  const u64 n = c->n_frontier;
+  u64 counts[2][8];
+  std::memset(counts, 0, sizeof(counts));
+  for (int k = 0; k <= nb; k++) {
+    // (1) slice k onto the checker's stream — its buckets are set k & 1, free since the exchange of slice k - 2 ended (it ended inside iteration k - 1)
+    bool launched = false;
+    if (k < nb && !*rc) {
+      const u64 a = n * (u64)k / (u64)nb, b = n * (u64)(k + 1) / (u64)nb;
+      const u64 hcap = l->cand_cap / 2;
+      vsrmc_shard_io io;
+      io.cand_send = l->cand_send + (u64)(k & 1) * (u64)l->world * hcap * 2;
+      io.cand_cap = hcap;
+      *rc = expand_slice_launch(c, &io, c->cand_idx + (u64)(k & 1) * (u64)l->world * hcap, a, b - a, k == 0);
+      launched = !*rc;
+    }
+    // (2) meanwhile: the exchange of slice k - 1 (every rank takes part, whatever its own state)
+    if (k >= 1) {
+      const int crc = loop_exchange_slice(l, (k - 1) & 1, counts[(k - 1) & 1], rc);
+      if (crc) { if (launched) (void)hipStreamSynchronize(c->stream); return crc; }
+    }
+    // (3) slice k has run
+    if (launched) {
+      const int wrc = expand_slice_wait(c, counts[k & 1]);
+      if (!*rc) *rc = wrc;
+    } else if (k < nb) {
+      std::memset(counts[k & 1], 0, sizeof(counts[0]));
+    }
+  }
+  l->overlap_levels++;
+  l->overlap_slices += (u64)nb;
+  if (!*rc) {
+    if (hipMemcpy(&c->h, c->ctl, sizeof(c->h), hipMemcpyDeviceToHost) != hipSuccess) *rc = fail(VSRMC_E_HIP, "overlapped level: control block");
+    else if (c->h.err) *rc = level_error(c, c->h, c->level + 1);
+    else if (c->h.full) { c->h.err = ERR_FRONTIER_FULL; c->h.err_info = c->h.full_info << 16; *rc = level_error(c, c->h, c->level + 1); }
+    else if (c->h.ties) { c->failed = 1; *rc = fail(VSRMC_E_STATE, "two successors of one level share a VIEW fingerprint but differ in the aux variables (SURVEY F2): create the checker with vsrmc_options.exact_ties = 1"); }
+    else { c->nx_n = c->h.n_new; c->nx_w = c->h.words_new; }
+  }
+  return 0;
 }
 
 }  // namespace
@@ -290,6 +414,7 @@ void vsrmc_shard_loop_destroy(vsrmc_shard_loop* l) {
   for (void* p : {(void*)l->cand_send, (void*)l->cand_recv, (void*)l->verdict_out, (void*)l->verdict_in, (void*)l->mv_words, (void*)l->mv_off,
                   (void*)l->mv_fp, (void*)l->rv_words, (void*)l->rv_off, (void*)l->rv_fp})
     if (p) (void)hipFree(p);
+  if (l->stream2) (void)hipStreamDestroy(l->stream2);
   if (l->h_send) (void)hipHostFree(l->h_send);
   if (l->h_recv) (void)hipHostFree(l->h_recv);
   delete l;
@@ -322,21 +447,45 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
     }
     return 0;
   }
-  // ---- 1. expand; candidates owned by other ranks are bucketed per owner
+  // ---- 0. in slices with the exchange overlapped (round 6)?  Every rank must cut its frontier into the SAME number of slices: the largest any rank wants —
+  // enough that a slice's announcements fill at most 0.45 of an owner's bucket, at least VSRMC_OVERLAP_MIN_SLICES (default 2) once a rank holds 2^20 states
+  // (below that a level is a millisecond of kernel: nothing to hide an exchange behind), at most 8.  VSRMC_OVERLAP=0: the sequential level of rounds 2-5.
   vsrmc_shard_io io;
   io.cand_send = l->cand_send;
   io.cand_cap = l->cand_cap;
+  int rc = 0, crc = 0;
+  u64 worst = 0;
+  bool head_done = false;
+  static const bool overlap_on = !(std::getenv("VSRMC_OVERLAP") && std::atoi(std::getenv("VSRMC_OVERLAP")) == 0);
+  if (w > 1 && overlap_on) {
+    static const u64 min_slices = std::getenv("VSRMC_OVERLAP_MIN_SLICES") ? (u64)std::max(1, std::atoi(std::getenv("VSRMC_OVERLAP_MIN_SLICES"))) : 2;
+    static const u64 min_states = std::getenv("VSRMC_OVERLAP_MIN_STATES") ? (u64)std::atoll(std::getenv("VSRMC_OVERLAP_MIN_STATES")) : ((u64)1 << 20);
+    const u64 per_slice = std::max<u64>(4096, (u64)(0.45 * (double)(l->cand_cap / 2) * (double)w / (double)std::max<u64>(2, c->g_last)));   // (as deep_cand_bound, for HALF a bucket: 1 / w of a parent's successors go to each owner)
+    u64 want = c->n_frontier >= min_states ? std::max<u64>(min_slices, (c->n_frontier + per_slice - 1) / per_slice) : 1;
+    want = std::min<u64>(want, 8);                              // (every slice leaves a partly used index and word chunk per block behind: next_level_fits has margin for about that many)
+    u64 all_want[8] = {0};
+    crc = loop_allgather(l, &want, all_want, 8);
+    if (crc) return crc;
+    for (int p = 0; p < w; p++) want = std::max(want, all_want[p]);
+    if (want >= 2) {
+      crc = loop_level_head_overlapped(l, (int)want, &rc);
+      if (crc) return crc;
+      head_done = true;
+    }
+  }
+  if (!head_done) {
+  // ---- 1. expand; candidates owned by other ranks are bucketed per owner
   uint64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int rc = vsrmc_shard_expand(c, &io, counts);
+  rc = vsrmc_shard_expand(c, &io, counts);
   struct CountRow { u64 cnt[8]; u64 err; } mine, zero;
   std::memset(&zero, 0, sizeof(zero));
   mine = zero;
   for (int p = 0; p < w; p++) mine.cnt[p] = (p == me || rc) ? 0 : std::min<u64>(counts[p], l->cand_cap);
   mine.err = rc ? (u64)(rc < 0 ? -rc : rc) : 0;
   std::vector<CountRow> all(w, zero);
-  int crc = loop_allgather(l, &mine, all.data(), (u32)sizeof(CountRow));
+  crc = loop_allgather(l, &mine, all.data(), (u32)sizeof(CountRow));
   if (crc) return crc;
-  u64 worst = 0;
+  worst = 0;
   for (const CountRow& r : all) worst = std::max(worst, r.err);
   if (worst) return rc ? rc : fail(VSRMC_E_STATE, "level " + std::to_string(l->level + 1) + ", phase expand: error " + std::to_string((long long)worst) + " on another rank");
   // ---- 2. candidates to their owners
@@ -360,6 +509,7 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
   }
   // ---- 5. withdraw the announced successors that lost
   if (!rc) rc = vsrmc_shard_materialize(c, &io, l->verdict_in);
+  }   // (!head_done)
   // ---- 6. compare the frontier sizes; move records where they are missing (rare)
   u64 valid = 0, range = 0;
   if (!rc) rc = vsrmc_shard_count(c, &valid, &range);
@@ -485,13 +635,27 @@ int32_t vsrmc_shard_loop_advance(vsrmc_shard_loop* l, vsrmc_level_info* a, vsrmc
 int32_t vsrmc_shard_loop_room(vsrmc_shard_loop* l, int32_t* state) {
   if (!l || !state) return fail(VSRMC_E_ARG, "NULL argument");
   u64 full = (double)(l->c->deep ? l->c->deep_distinct : l->c->distinct) > 0.85 * (double)(l->c->tmask + 1) ? 1 : 0;
+  std::string why;                                              // (what vsrmc_last_error() says after an answer of 2: which set, how full)
+  if (full) why = "seen-set shard: " + std::to_string((unsigned long long)(l->c->deep ? l->c->deep_distinct : l->c->distinct)) + " states in " +
+                  std::to_string((unsigned long long)(l->c->tmask + 1)) + " slots";
   // the winner set of the deep search (round-5 advice): it fills with the rank's share of every level beyond the base, long before the seen-set shard does —
   // grown between two passes while the device has the memory, else the run stops here, cleanly, instead of ERR_TABLE_FULL inside a pass
   if (l->c->d_wset && l->c->deep) {
     const u64 held = wset_count(l->c);
-    const u64 next = l->c->deep_lv.empty() ? 0 : 2 * l->c->deep_lv.back().n_local;   // the next level's share: growth below 2 from level to level
+    // the next level's share: this rank's share of the newest level times the last growth factor (these models' levels grow by less from level to level)
+    const size_t nd = l->c->deep_lv.size();
+    const double grow = nd >= 2 && l->c->deep_lv[nd - 2].n_local ? std::min(2.0, (double)l->c->deep_lv[nd - 1].n_local / (double)l->c->deep_lv[nd - 2].n_local) : 2.0;
+    const u64 next = nd ? (u64)(grow * (double)l->c->deep_lv.back().n_local) : 0;
     while ((double)(held + next) > 0.6 * (double)(l->c->h_wset.mask + 1) && wset_grow(l->c) == 0) {}
-    if ((double)(held + next) > 0.7 * (double)(l->c->h_wset.mask + 1)) full = 1;
+    // (linear probing, 65 536 steps at most: a set that cannot grow is used as long as the next level can fit at all — the README run at world 2 with both
+    // ranks on ONE GPU ends at 0.91 of rank 1's 2^30 slots (the ranks' shares differ: 533 M against 479 M states before the last level), and the estimate
+    // of the next level — the last growth factor again — overshoots, these models' levels grow by less every level.  A set that does run full is
+    // ERR_TABLE_FULL inside the pass, an error and never a wrong count)
+    if ((double)(held + next) > 0.98 * (double)(l->c->h_wset.mask + 1)) {
+      full = 1;
+      why = "winner set: " + std::to_string((unsigned long long)held) + " states held + " + std::to_string((unsigned long long)next) + " expected of the next level in " +
+            std::to_string((unsigned long long)(l->c->h_wset.mask + 1)) + " slots, and the device has no memory for twice as many";
+    }
   }
   if (!l->replicated) {
     u64 all[8] = {0};
@@ -500,6 +664,7 @@ int32_t vsrmc_shard_loop_room(vsrmc_shard_loop* l, int32_t* state) {
     for (int p = 0; p < l->world; p++) full = std::max(full, all[p]);
   }
   *state = full ? 2 : 0;
+  if (full) (void)fail(0, why.empty() ? std::string("another rank's seen-set shard or winner set is full") : "rank " + std::to_string(l->rank) + ": " + why);
   return 0;
 }
 
@@ -534,6 +699,14 @@ int32_t vsrmc_shard_loop_status(vsrmc_shard_loop* l, int32_t* level, uint64_t* d
   if (viol_level) *viol_level = l->viol_level;
   if (moved) *moved = l->moved;
   if (bytes_sent) *bytes_sent = l->bytes_sent;
+  return 0;
+}
+
+// how many sharded levels ran in slices with the exchange overlapped (vsrmc_shard_loop_step), and how many slices in all
+int32_t vsrmc_shard_loop_overlap_stats(vsrmc_shard_loop* l, uint64_t* levels, uint64_t* slices) {
+  if (!l || !levels || !slices) return fail(VSRMC_E_ARG, "NULL argument");
+  *levels = l->overlap_levels;
+  *slices = l->overlap_slices;
   return 0;
 }
 

@@ -981,12 +981,20 @@ class NativeShardedChecker:
             self.violation["probed"] = bool(db["level"] and db["viol_mask"] and not da["viol_mask"])
         return "deep", da, (db if db["level"] else None)
 
+    def overlap_stats(self):
+        """(sharded levels that ran in slices with the exchange overlapped, slices in all)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(capi.load().vsrmc_shard_loop_overlap_stats(self._l, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def room(self):
         """the seen-set shards before the next advance() (collective): 0 = room on every rank, 2 = some rank's shard is more than 85 % full"""
         st = C.c_int32()
         rc = capi.load().vsrmc_shard_loop_room(self._l, C.byref(st))
         if rc != 0:
             raise ShardError("seen-set check: %s" % capi.load().vsrmc_last_error().decode())
+        if st.value == 2:
+            self.room_note = capi.load().vsrmc_last_error().decode()       # which set is full on this rank, and how full
         return st.value
 
     def run(self, max_depth=None, stop_on_violation=True):

@@ -16,6 +16,8 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0
 XGMI_LINK_GBS = 153.0        # one xGMI link of an MI355X, one direction (7 links per GPU: a fully connected 8-GPU node gives every pair its own)
+XGMI_ACHIEVABLE = 0.70       # ASSUMPTION (no multi-GPU node was available to measure it): the share of a link's peak grouped ncclSend / ncclRecv of 16-byte
+                             # candidates sustain — the modelled critical path below prices the exchange at 107 GB/s per link, not at peak
 # levels with fewer new states than this are explored by every rank on its own (no collectives): a level of a million states
 # is under a millisecond of kernel time, less than the exchanges of one sharded level
 REPLICATE_BELOW = int(os.environ.get("VSR_BENCH_REPLICATE_BELOW", 1 << 20))
@@ -63,8 +65,11 @@ def main(args, bench):
         t0 = time.perf_counter()
         s_rec, n_prev = 8.0 * (int(m.layout.fixed_words) + int(m.layout.permutations)), 1
         alg, kms, dms, launches, stored, passes, found = 0.0, 0.0, 0.0, 0, 0, [], None
+        units = []                                              # per unit of progress: (rank 0's kernel seconds, rank 0's bytes sent)
         while found is None:
+            sent0 = sc.bytes_sent
             kind, a, b = sc.advance()
+            units.append(((a["expand_ms"] + a["materialize_ms"] + (b["expand_ms"] if b is not None else 0.0)) / 1e3, sc.bytes_sent - sent0))
             assert a["n_new"], "the search is exhausted before the violation"
             want = want_levels[a["level"] - 1]
             assert (a["n_new"], a["generated"]) == (want["n_new"], want["generated"]), (a["level"], a["n_new"], a["generated"])
@@ -107,6 +112,8 @@ def main(args, bench):
         assert expect["probe_generated"] is None or kind == "level" or b is None or not b["viol_mask"] or b["generated"] == expect["probe_generated"]
         S["moved"] = sc.moved
         S["sent"] += sc.bytes_sent
+        S["units"] = units
+        S["overlap"] = sc.overlap_stats()
         sc.close()
         if record:
             S["distinct"] += sc.distinct
@@ -161,6 +168,17 @@ def main(args, bench):
                                         "note": "a regenerated level costs no exchange since round 5 (generator-side winner set): what is left are the (fp, key) "
                                                 "announcements of the levels that are inserted, their verdict bytes and the small all-gathers"})(
                 S["sent"] / max(1, args.steps + args.warmup), kernel_ms / 1e3 / max(1, args.steps)),
+            # the modelled critical path of one run (the last timed one), unit of progress by unit: rank 0's kernel time against its bytes over the links to its
+            # N - 1 peers at an ACHIEVABLE rate (XGMI_ACHIEVABLE of link peak: an assumption, stated, not a measurement).  sequential = kernel + exchange
+            # (rounds 2-5); overlapped = the larger of the two per unit (round 6: the exchange of slice k runs under k_expand of slice k + 1)
+            "exchange_model": (lambda units, rate: {
+                "achievable_link_GBs": round(XGMI_LINK_GBS * XGMI_ACHIEVABLE, 1), "links_used": max(1, min(world - 1, 7)), "assumption": "%.0f %% of link peak" % (100 * XGMI_ACHIEVABLE),
+                "kernel_s": round(sum(k_ for k_, _ in units), 4), "exchange_s": round(sum(x / rate for _, x in units), 4),
+                "critical_path_sequential_s": round(sum(k_ + x / rate for k_, x in units), 4),
+                "critical_path_overlapped_s": round(sum(max(k_, x / rate) for k_, x in units), 4),
+                "units_bound_by_exchange": sum(1 for k_, x in units if x / rate > k_), "units": len(units),
+                "levels_run_in_slices": S.get("overlap", (0, 0))[0], "slices": S.get("overlap", (0, 0))[1]})(
+                S.get("units", []), XGMI_LINK_GBS * XGMI_ACHIEVABLE * 1e9 * max(1, min(world - 1, 7))),
             "records_moved_by_rebalancing_rank0": S["moved"],
             "deep_passes": S["passes"],
             "roofline": {"bound": "hbm", "kernel": "k_expand (rank 0; the job's algorithmic bytes / N over rank 0's kernel time)", "achieved": round(achieved, 2),
