@@ -231,6 +231,13 @@ FusedShape fused_shape(vsrmc_checker* c, u64 max_bag_of_source, bool plain = fal
   } else {
     f.tile = 64; f.ccap = ccap64; f.lds = lds64; f.blocks_per_cu = (unsigned)std::max(1, std::min(occ64, VSR_OCC + 1));   // (what the instantiation's registers and this LDS allow)
   }
+#if VSR_TILE128
+  if (plain && M.R <= 3) {                                       // EXPERIMENT: 128-record tiles, a work list of 1024 (8 per record; overflow goes to the host's list), three blocks per CU
+    size_t l128 = 0;
+    const int o128 = occupancy(128, 1024u, &l128);
+    if (o128 >= 3) { f.tile = 128; f.ccap = 1024u; f.lds = l128; f.blocks_per_cu = 3; f.kernel = kernel; return f; }
+  }
+#endif
   f.kernel = kernel;
   // FIVE blocks per CU: the configuration has an ordinary-level instantiation compiled for 96 registers (plain5_kernel), and this launch's tile plus a
   // work list of 896 entries (14 instances per record; the mean is 5 — a tile with more is written down and launched again in halves:

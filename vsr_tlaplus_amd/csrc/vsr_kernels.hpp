@@ -177,6 +177,12 @@ enum { MODE_NORMAL = 0, MODE_PROBE = 1, MODE_INSERT = 2, MODE_REGEN = 3, MODE_NO
 #ifndef VSR_COPY8
 #define VSR_COPY8 0
 #endif
+#ifndef VSR_TILE128         // EXPERIMENT: tiles of 128 records (three blocks per CU) for the ordinary levels of the specialised instantiations too: the fixed cost per tile over twice the records
+#define VSR_TILE128 0
+#endif
+#ifndef VSR_TAKE_BATCH      // -DVSR_TAKE: records per draw from the cursor
+#define VSR_TAKE_BATCH 512
+#endif
 #ifndef VSR_TILE_BATCH      // tiles a block draws from the cursor at a time (k_expand: s_tile_left); 1 = rounds 1-5
 #define VSR_TILE_BATCH 4
 #endif
@@ -564,7 +570,7 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   u32* s_cand2 = s_cand + ccap;                        // the same, sorted by action
   __shared__ u32 s_ncand, s_napply, s_dead, s_maxbag, s_maxbag_out, s_skip, s_nsurv, s_risky, s_ntotal;
   // (single-pass levels of a configuration with R <= 3 always run 64-record tiles: host_checker.hpp, fused_shape — 1.3 KB of LDS less, which five blocks per CU need)
-  constexpr int TILE_MAX = BLK < VSR_BLOCK ? BLK / 2 : (FUSED && SPEC % 1000 != 0 && (SPEC % 1000) / 100 <= 3) ? 64 : VSR_TILE_MAX;
+  constexpr int TILE_MAX = BLK < VSR_BLOCK ? BLK / 2 : (!VSR_TILE128 && FUSED && SPEC % 1000 != 0 && (SPEC % 1000) / 100 <= 3) ? 64 : VSR_TILE_MAX;
   constexpr bool COOP = VSR_COOP_COPY && FUSED && IS_PLAIN;
   constexpr bool REDO_OK = VSR_REDO && FUSED && (IS_PLAIN || PLAIN == 6);   // a tile that overflows the work list goes to the host's list (LevelCtl::n_redo) instead of failing the launch
   __shared__ u32 s_alive[TILE_MAX];
@@ -621,7 +627,13 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
   // expected to yield VSR_TAKE instances (smoothed instances per record of the block's own tiles); the cursor counts records, not tiles.
   __shared__ u32 s_tile_n;
   u32 my_take = (u32)tile, my_n = 0, avg_q8 = 0;                // thread 0: records to draw next time / drawn with my_next / instances per record x 256
-  if (tid == 0) { my_n = my_take; my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)my_take); }
+  // (the cursor is drawn VSR_TAKE_BATCH records at a time — see VSR_TILE_BATCH below — and the block cuts its batch into tiles)
+  __shared__ u64 s_take_end;                                     // end of the drawn batch (thread 0's)
+  if (tid == 0) {
+    my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)VSR_TAKE_BATCH);
+    s_take_end = my_next + VSR_TAKE_BATCH;
+    my_n = my_take;
+  }
 #elif VSR_REFS_AHEAD
   // EXPERIMENT: the refs of a tile are fetched while the tile BEFORE it is staged (tiles are drawn two ahead), so staging starts with the record loads —
   // one HBM round trip per tile instead of two dependent ones
@@ -666,7 +678,12 @@ k_expand(Model Marg, const u64* __restrict__ fr_words, const u64* __restrict__ f
 #endif
 #if VSR_TAKE
       s_tile_n = my_n;
-      if (my_next < n_parents) { my_n = my_take; my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)my_take); }
+      if (my_next < n_parents) {
+        const u64 end = s_take_end;
+        my_next += my_n;
+        if (my_next >= end) { my_next = atomicAdd((unsigned long long*)&ctl->tile_cursor, (unsigned long long)VSR_TAKE_BATCH); s_take_end = my_next + VSR_TAKE_BATCH; my_n = my_take; }
+        else { const u64 room = end - my_next; my_n = (room < (u64)my_take + 8 && room <= (u64)tile) ? (u32)room : my_take; }   // (a remainder of fewer than 8 records rides with the last tile)
+      }
 #else
       if (my_next < ntiles) {
         const u32 left = s_tile_left;
