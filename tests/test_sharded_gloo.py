@@ -532,7 +532,7 @@ def test_violation_of_any_mask_on_a_remotely_owned_successor_is_reported(tmp_pat
         assert r["violation"] == dict(level=8, fp=target, mask=28), r["violation"]
 
 
-@pytest.mark.parametrize("world,rb,deep_at", [(2, 0, 8), (3, 200, 10), (8, 200, 11)])
+@pytest.mark.parametrize("world,rb,deep_at", [(2, 0, 8), (3, 200, 12), (8, 200, 13)])
 def test_sharded_deep_protocol_on_the_cpu_stand_in(tmp_path, world, rb, deep_at):
     """The protocol of the levels beyond the ranks' record buffers (virtual level: announce -> first inserter wins -> winners counted;
     regenerated level: local — a rank rebuilds the states of that level its own candidates inserted (winner set: fingerprint -> level, last
