@@ -462,7 +462,9 @@ int32_t vsrmc_shard_loop_step(vsrmc_shard_loop* l, vsrmc_level_info* global, vsr
 int32_t vsrmc_shard_loop_run(vsrmc_shard_loop* l, int32_t max_depth, int32_t stop_on_violation, int32_t* stop_reason, vsrmc_level_info* last);
 /* the seen-set shards before the next vsrmc_shard_loop_advance (collective once the run is sharded): *state = 0 room on every rank, 2 = some rank's shard
  * is more than 85 % full — every rank learns it in the same call and all of them stop together ("incomplete at depth N"); loops over
- * vsrmc_shard_loop_advance ask before every call, vsrmc_shard_loop_run does */
+ * vsrmc_shard_loop_advance ask before every call, vsrmc_shard_loop_run does.  Round 6: the winner set of a sharded deep search counts too — it is re-hashed
+ * into twice the slots here when the next level is expected to take it past 60 % (while the device has the memory) and answers 2 when that level cannot fit;
+ * after an answer of 2 vsrmc_last_error() names the set and its fill on this rank (the call itself returns 0) */
 int32_t vsrmc_shard_loop_room(vsrmc_shard_loop* l, int32_t* state);
 /* Since round 6 a sharded level of 2^20 states per rank or more runs in SLICES with the exchange overlapped: the all-to-all of slice k's (fp, key)
  * candidates, the owners' claims, the verdict bytes and the withdrawal of the losers run on a second stream and a second set of buckets while k_expand of

@@ -2061,7 +2061,9 @@ __global__ void k_probe_resolve(Model M, const u64* __restrict__ src_words, cons
   canonical_fp(M, rec[0], rec + M.h0, &pfp, &pak);
   u64 m = META_EMPTY;
   u32 np = 0;
-  if (probe_lookup(table, tmask, fp, &m, CntReg{&np}) && meta_level(m) < level) return;      // a state of an earlier level: TLC drops it as seen
+  const bool old_state = probe_lookup(table, tmask, fp, &m, CntReg{&np}) && meta_level(m) < level;
+  if (np) atomicAdd((unsigned long long*)&ctl->probes, (unsigned long long)np);             // (the few lookups a probe level makes: vsrmc_level_info.probes)
+  if (old_state) return;                                        // a state of an earlier level: TLC drops it as seen
   const u64 k = atomicAdd(out_n, 1ull);
   if (k < out_cap) { out[2 * k] = fp; out[2 * k + 1] = meta_make(level, ak, pfp); }
   atomicMin((unsigned long long*)&ctl->viol_fp, (unsigned long long)fp);
